@@ -1,0 +1,463 @@
+"""CPU oracle for GCPNet's geometry-complete message-passing hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain-PyTorch (CPU, fp32) restatement of the reference algorithm for
+the path named by BASELINE.json.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it, and only as the checker / reported baseline -- never as a product path.
+
+Pinning: the reference holds no golden vectors for this path, so the oracle is pinned
+against outputs of the reference itself, run in the authoring container through ``tests/golden/ref_stubs.py``
+and committed as ``tests/golden/*.npz`` by ``tests/golden/gen_fixtures.py``;
+``tests/test_oracle_golden.py`` checks every function here against those fixtures.
+
+Style: functional.  Every block takes a flat ``params`` mapping with the reference's state_dict key names
+(e.g. ``interaction.message_fusion.0.scalar_out.weight``) plus a ``prefix``; shapes are inferred from the
+weights.  Citations are ``file:line`` relative to ``/root/reference/src/models``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Mapping[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# third-party arithmetic restated: torch_scatter.scatter (pytorch-scatter 2.0.9; call sites
+# components/__init__.py:179,197,316,369 and components/gcpnet.py:946,1105,1153)
+# ----------------------------------------------------------------------------------------------------------
+def scatter(src: Tensor, index: Tensor, dim_size: Optional[int] = None, reduce: str = "sum") -> Tensor:
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() else 0
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype).index_add(0, index, src)
+    if reduce in ("sum", "add"):
+        return out
+    if reduce != "mean":
+        raise NotImplementedError(reduce)
+    cnt = torch.zeros(dim_size, dtype=src.dtype).index_add(0, index, torch.ones(index.shape[0], dtype=src.dtype))
+    return out / cnt.clamp(min=1).reshape((-1,) + (1,) * (src.dim() - 1))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# small pieces
+# ----------------------------------------------------------------------------------------------------------
+def nonlinearity(name: Optional[str], x: Tensor, slope: float = 1e-2) -> Tensor:
+    """models/__init__.py:42-57 (get_nonlinearity)."""
+    if name is None:
+        return x
+    key = name.lower().strip()
+    if key == "relu":
+        return F.relu(x)
+    if key == "leakyrelu":
+        return F.leaky_relu(x, negative_slope=slope)
+    if key == "selu":
+        return F.selu(x)
+    if key == "silu":
+        return F.silu(x)
+    if key == "sigmoid":
+        return torch.sigmoid(x)
+    raise NotImplementedError(f"The nonlinearity {name} is currently not implemented.")
+
+
+def safe_norm(x: Tensor, dim: int = -1, eps: float = 1e-8, keepdim: bool = False, sqrt: bool = True) -> Tensor:
+    """components/__init__.py:382-392."""
+    n = (x * x).sum(dim=dim, keepdim=keepdim)
+    if sqrt:
+        n = torch.sqrt(n + eps)
+    return n + eps
+
+
+def flatten_sv(s: Tensor, v: Tensor) -> Tensor:
+    """ScalarVector.flatten, components/__init__.py:61-63: [s | V x 3 row-major]."""
+    return torch.cat((s, v.reshape(v.shape[0], -1)), dim=-1)
+
+
+def recover_sv(x: Tensor, vdim: int) -> Tuple[Tensor, Tensor]:
+    """ScalarVector.recover, components/__init__.py:65-69."""
+    return x[..., : x.shape[-1] - 3 * vdim], x[..., x.shape[-1] - 3 * vdim:].reshape(x.shape[0], vdim, 3)
+
+
+def centralize(x: Tensor, batch_index: Tensor) -> Tuple[Tensor, Tensor]:
+    """components/__init__.py:195-200 (unmasked branch)."""
+    c = scatter(x, batch_index, reduce="mean")
+    return c, x - c[batch_index]
+
+
+def decentralize(x: Tensor, batch_index: Tensor, centroid: Tensor) -> Tensor:
+    """components/__init__.py:215-217 (unmasked branch)."""
+    return x + centroid[batch_index]
+
+
+def localize(x: Tensor, edge_index: Tensor, norm_x_diff: bool = True) -> Tensor:
+    """components/__init__.py:221-269 (unmasked branch): frame rows [x_diff; x_cross; x_vertical]."""
+    xi, xj = x[edge_index[0]], x[edge_index[1]]
+    d = xi - xj
+    c = torch.cross(xi, xj, dim=-1)
+    if norm_x_diff:
+        d = d / (d.pow(2).sum(1, keepdim=True).sqrt() + 1)
+        c = c / (c.pow(2).sum(1, keepdim=True).sqrt() + 1)
+    vert = torch.cross(d, c, dim=-1)
+    return torch.stack((d, c, vert), dim=1)
+
+
+def scalarize(vec: Tensor, edge_index: Tensor, frames: Tensor, node_inputs: bool, e3: bool, dim_size: int) -> Tensor:
+    """components/__init__.py:273-325 (unmasked).  ``vec`` is [rows, 3 channels, 3 xyz]; the result is
+    [rows, 9] with entry 3*channel + frame_row = <frame_row, channel vector>."""
+    row = edge_index[0]
+    src = vec[row] if node_inputs else vec
+    local = torch.einsum("ead,ekd->eka", frames, src)
+    if e3:
+        local = torch.cat((local[..., :1], local[..., 1:2].abs(), local[..., 2:]), dim=-1)
+    flat = local.reshape(local.shape[0], 9)
+    return scatter(flat, row, dim_size=dim_size, reduce="mean") if node_inputs else flat
+
+
+def vectorize(gate: Tensor, edge_index: Tensor, frames: Tensor, node_inputs: bool, dim_size: int) -> Tensor:
+    """components/__init__.py:329-378 (unmasked): 9 gate scalars -> 3 vectors sum_a g[3c+a] * frame_row_a."""
+    row = edge_index[0]
+    g = gate[row] if node_inputs else gate
+    out = torch.einsum("eca,ead->ecd", g.reshape(-1, 3, 3), frames)
+    return scatter(out, row, dim_size=dim_size, reduce="mean") if node_inputs else out
+
+
+def gcp_layer_norm(P: Params, pre: str, s: Tensor, v: Optional[Tensor], eps: float = 1e-8):
+    """GCPLayerNorm, components/__init__.py:138-167.  nn.LayerNorm (eps 1e-5, affine) on scalars; vectors divided
+    by sqrt(mean_channels(clamp(|v|^2, eps)))."""
+    if s.shape[0] == 0:
+        return s, v
+    d = s.shape[-1]
+    s_out = F.layer_norm(s, (d,), P[pre + "scalar_norm.weight"], P[pre + "scalar_norm.bias"], 1e-5)
+    if v is None or v.shape[1] == 0:
+        return s_out, v
+    vn = torch.clamp((v * v).sum(-1, keepdim=True), min=eps)
+    vn = torch.sqrt(vn.mean(dim=-2, keepdim=True))
+    return s_out, v / vn
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GCP2 -- components/gcpnet.py:252-468
+# ----------------------------------------------------------------------------------------------------------
+def gcp2(
+    P: Params,
+    pre: str,
+    s: Tensor,
+    v: Optional[Tensor],
+    edge_index: Tensor,
+    frames: Tensor,
+    node_inputs: bool = False,
+    nonlinearities: Sequence[Optional[str]] = ("relu", "sigmoid"),
+    vector_gate: bool = True,
+    frame_gate: bool = False,
+    vector_residual: bool = False,
+    ablate_frame_updates: bool = False,
+    ablate_scalars: bool = False,
+    ablate_vectors: bool = False,
+    enable_e3_equivariance: bool = False,
+    vector_output_dim: Optional[int] = None,
+    slope: float = 1e-2,
+):
+    """One geometry-complete perceptron.  Returns (s_out, v_out) or just s_out when there is no vector output.
+
+    Dims are read off the weights: ``vector_down`` [H, V_in], ``scalar_out`` [s_out, s_in + H + 9],
+    ``vector_down_frames`` [3, V_in], ``vector_up`` [V_out, H], ``vector_out_scale`` [V_out, s_out]
+    (gcpnet.py:298-324)."""
+    if nonlinearities is None:
+        nonlinearities = (None, None)
+    act_s, act_v = nonlinearities
+    has_vin = (pre + "vector_down.weight") in P
+    has_vout = (pre + "vector_up.weight") in P
+    W_s, b_s = P[pre + "scalar_out.weight"], P[pre + "scalar_out.bias"]
+
+    vh = None
+    if has_vin:  # gcpnet.py:414-436
+        if ablate_scalars:
+            s = torch.zeros_like(s)
+        if ablate_vectors:
+            v = torch.zeros_like(v)
+        vh = torch.einsum("rcd,hc->rdh", v, P[pre + "vector_down.weight"])  # [rows, xyz, H]
+        merged = torch.cat((s, safe_norm(vh, dim=-2)), dim=-1)
+        if not ablate_frame_updates:
+            vf = torch.einsum("rcd,kc->rkd", v, P[pre + "vector_down_frames.weight"])  # [rows, 3 ch, xyz]
+            sh = scalarize(vf, edge_index, frames, node_inputs, enable_e3_equivariance, vf.shape[0])
+            merged = torch.cat((merged, sh), dim=-1)
+    else:
+        merged = s
+
+    s_pre = merged @ W_s.t() + b_s  # gcpnet.py:441
+
+    if not has_vout and not vector_output_dim:  # gcpnet.py:443-446
+        if ablate_scalars:
+            s_pre = torch.zeros_like(s_pre)
+        return nonlinearity(act_s, s_pre, slope)
+    if not has_vin:  # gcpnet.py:447-449
+        v_out = torch.zeros(s_pre.shape[0], vector_output_dim, 3, dtype=s_pre.dtype)
+    else:  # gcpnet.py:334-391
+        vu = torch.einsum("rdh,oh->rdo", vh, P[pre + "vector_up.weight"])
+        if vector_residual:
+            vu = vu + v.transpose(-1, -2)
+        v_out = vu.transpose(-1, -2)  # [rows, V_out, xyz]
+        if frame_gate and not ablate_frame_updates:
+            g = nonlinearity(act_v, s_pre, slope) @ P[pre + "vector_out_scale_frames.weight"].t() \
+                + P[pre + "vector_out_scale_frames.bias"]
+            gv = vectorize(g, edge_index, frames, node_inputs, s_pre.shape[0])  # [rows, 3, xyz]
+            gvr = torch.einsum("rkd,ok->rod", gv, P[pre + "vector_up_frames.weight"])
+            v_out = v_out * nonlinearity(act_v, safe_norm(gvr, dim=-1, keepdim=True), slope)
+        elif vector_gate:
+            g = nonlinearity(act_v, s_pre, slope) @ P[pre + "vector_out_scale.weight"].t() \
+                + P[pre + "vector_out_scale.bias"]
+            v_out = v_out * torch.sigmoid(g).unsqueeze(-1)
+        elif act_v is not None:
+            v_out = v_out * nonlinearity(act_v, safe_norm(v_out, dim=-1, keepdim=True), slope)
+
+    s_out = nonlinearity(act_s, s_pre, slope)  # gcpnet.py:465-468
+    if ablate_scalars:
+        s_out = torch.zeros_like(s_out)
+    if ablate_vectors:
+        v_out = torch.zeros_like(v_out)
+    return s_out, v_out
+
+
+def _gcp_kwargs(cfg: Mapping, **over) -> Dict:
+    """What get_GCP_with_custom_cfg (gcpnet.py:826-835) forwards that GCP2 actually reads."""
+    kw = dict(
+        nonlinearities=tuple(cfg["nonlinearities"]),
+        vector_gate=cfg["vector_gate"],
+        frame_gate=cfg["frame_gate"],
+        vector_residual=cfg["vector_residual"],
+        ablate_frame_updates=cfg["ablate_frame_updates"],
+        ablate_scalars=cfg["ablate_scalars"],
+        ablate_vectors=cfg["ablate_vectors"],
+        enable_e3_equivariance=cfg["enable_e3_equivariance"],
+    )
+    kw.update(over)
+    if kw["nonlinearities"] is None:
+        kw["nonlinearities"] = (None, None)
+    return kw
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GCPEmbedding -- components/gcpnet.py:703-823
+# ----------------------------------------------------------------------------------------------------------
+def gcp_embedding(
+    P: Params,
+    pre: str,
+    h: Tensor,
+    chi: Tensor,
+    e: Tensor,
+    xi: Tensor,
+    edge_index: Tensor,
+    frames: Tensor,
+    cfg: Mapping,
+    nonlinearities: Sequence[Optional[str]] = (None, None),
+    pre_norm: bool = True,
+):
+    if (pre + "atom_embedding.weight") in P:  # gcpnet.py:785-788
+        h = P[pre + "atom_embedding.weight"][h]
+    kw = dict(
+        vector_gate=cfg["vector_gate"],
+        frame_gate=cfg["frame_gate"],
+        ablate_frame_updates=cfg["ablate_frame_updates"],
+        ablate_scalars=cfg["ablate_scalars"],
+        ablate_vectors=cfg["ablate_vectors"],
+        enable_e3_equivariance=cfg["enable_e3_equivariance"],
+    )
+    if pre_norm:  # gcpnet.py:800-802
+        e, xi = gcp_layer_norm(P, pre + "edge_normalization.", e, xi)
+        h, chi = gcp_layer_norm(P, pre + "node_normalization.", h, chi)
+    edge_rep = gcp2(P, pre + "edge_embedding.", e, xi, edge_index, frames, node_inputs=False,
+                    nonlinearities=nonlinearities, **kw)
+    node_rep = gcp2(P, pre + "node_embedding.", h, chi, edge_index, frames, node_inputs=True,
+                    nonlinearities=(None, None), **kw)
+    if not pre_norm:  # gcpnet.py:819-821
+        edge_rep = gcp_layer_norm(P, pre + "edge_normalization.", *edge_rep)
+        node_rep = gcp_layer_norm(P, pre + "node_normalization.", *node_rep)
+    return node_rep, edge_rep
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GCPMessagePassing -- components/gcpnet.py:838-960
+# ----------------------------------------------------------------------------------------------------------
+def _soft_cfg(cfg: Mapping) -> Dict:
+    c = dict(cfg)  # gcpnet.py:867-868
+    c["bottleneck"], c["vector_residual"] = cfg["default_bottleneck"], cfg["default_vector_residual"]
+    return c
+
+
+def message_passing(
+    P: Params,
+    pre: str,
+    h: Tensor,
+    chi: Tensor,
+    e: Tensor,
+    xi: Tensor,
+    edge_index: Tensor,
+    frames: Tensor,
+    cfg: Mapping,
+    mp_cfg: Mapping,
+    reduce_function: str = "mean",
+    return_messages: bool = False,
+):
+    row, col = edge_index[0], edge_index[1]
+    n_msg = mp_cfg["num_message_layers"]
+    soft = _soft_cfg(cfg)
+    ms = torch.cat((h[row], e, h[col]), dim=-1)  # gcpnet.py:917
+    mv = torch.cat((chi[row], xi, chi[col]), dim=1)
+
+    first = _gcp_kwargs(soft, nonlinearities=tuple(cfg["nonlinearities"]) if n_msg > 1 else None)
+    mid = _gcp_kwargs(cfg)
+    last = _gcp_kwargs(soft, nonlinearities=(None, None))
+    kws = [first] + [mid] * (n_msg - 2) + ([last] if n_msg > 1 else [])
+
+    if mp_cfg["use_residual_message_gcp"]:  # gcpnet.py:919-924
+        ms, mv = gcp2(P, f"{pre}message_fusion.0.", ms, mv, edge_index, frames, **kws[0])
+        for k in range(1, len(kws)):
+            ds, dv = gcp2(P, f"{pre}message_fusion.{k}.", ms, mv, edge_index, frames, **kws[k])
+            ms, mv = ms + ds, mv + dv
+    else:
+        for k in range(len(kws)):
+            ms, mv = gcp2(P, f"{pre}message_fusion.{k}.", ms, mv, edge_index, frames, **kws[k])
+
+    if (pre + "scalar_message_attention.0.weight") in P:  # gcpnet.py:932-934
+        att = torch.sigmoid(ms @ P[pre + "scalar_message_attention.0.weight"].t()
+                            + P[pre + "scalar_message_attention.0.bias"])
+        ms = ms * att
+    msg = flatten_sv(ms, mv)
+    agg = scatter(msg, col, dim_size=h.shape[0], reduce=reduce_function)  # gcpnet.py:939-947
+    out = recover_sv(agg, mv.shape[1])
+    return (out, msg) if return_messages else out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GCPInteractions -- components/gcpnet.py:963-1262 (non-autoregressive, unmasked)
+# ----------------------------------------------------------------------------------------------------------
+def gcp_interactions(
+    P: Params,
+    pre: str,
+    h: Tensor,
+    chi: Tensor,
+    e: Tensor,
+    xi: Tensor,
+    edge_index: Tensor,
+    frames: Tensor,
+    cfg: Mapping,
+    layer_cfg: Mapping,
+    node_pos: Optional[Tensor] = None,
+    nonlinearities: Optional[Sequence[Optional[str]]] = None,
+):
+    """Eval-mode (dropout = identity) forward.  Returns (h, chi) or ((h, chi), node_pos)."""
+    if nonlinearities is None:
+        nonlinearities = cfg["nonlinearities"]
+    pre_norm = layer_cfg["pre_norm"]
+    n_ff = layer_cfg["num_feedforward_layers"]
+    updating = (pre + "node_position_update_network.0.scalar_out.weight") in P
+
+    if pre_norm:  # gcpnet.py:1188-1189
+        h, chi = gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
+    rs, rv = message_passing(P, pre + "interaction.", h, chi, e, xi, edge_index, frames, cfg, layer_cfg["mp_cfg"])
+    h, chi = h + rs, chi + rv  # gcpnet.py:1220
+    h, chi = gcp_layer_norm(P, pre + ("gcp_norm.1." if pre_norm else "gcp_norm.0."), h, chi)
+
+    no_res = dict(cfg)
+    no_res["vector_residual"] = False  # gcpnet.py:1003-1004
+    ff_cfg = dict(cfg)
+    ff_cfg["nonlinearities"] = nonlinearities  # gcpnet.py:1001-1002
+    kws = [_gcp_kwargs(no_res, nonlinearities=None if n_ff == 1 else tuple(cfg["nonlinearities"]))]
+    kws += [_gcp_kwargs(ff_cfg)] * (n_ff - 2)
+    if n_ff > 1:
+        kws.append(_gcp_kwargs(no_res, nonlinearities=(None, None)))
+    fs, fv = h, chi
+    for k, kw in enumerate(kws):  # gcpnet.py:1229-1239
+        fs, fv = gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, edge_index, frames, node_inputs=True, **kw)
+    h, chi = h + fs, chi + fv  # gcpnet.py:1242
+    if not pre_norm:
+        h, chi = gcp_layer_norm(P, pre + "gcp_norm.1.", h, chi)
+
+    if not updating:
+        return h, chi
+    # derive_x_update, gcpnet.py:1119-1158 (force term ablated in every shipped config)
+    _, xv = gcp2(P, pre + "node_position_update_network.0.", h, chi, edge_index, frames, node_inputs=True,
+                 **_gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])))
+    upd = xv.squeeze(1)
+    if (pre + "phi_force_i.weight") in P:
+        row, col = edge_index[0], edge_index[1]
+        hi = h[row] @ P[pre + "phi_force_i.weight"].t() + P[pre + "phi_force_i.bias"]
+        hj = h[col] @ P[pre + "phi_force_j.weight"].t() + P[pre + "phi_force_j.bias"]
+        coef = nonlinearity(cfg["nonlinearities"][0], hi + hj, layer_cfg["nonlinearity_slope"]) \
+            @ P[pre + "phi_force_ij.1.weight"].t()
+        force = torch.einsum("ea,ead->ed", coef, frames)
+        upd = upd + scatter(force, col, reduce="mean")
+    upd = (upd * cfg.get("node_positions_weight", 1.0)).clamp(min=-100, max=100)
+    return (h, chi), node_pos + upd
+
+
+# ----------------------------------------------------------------------------------------------------------
+# task-level forwards: gcpnet_nms_module.py:127-151, gcpnet_lba_module.py:155-186
+# ----------------------------------------------------------------------------------------------------------
+def nms_forward(P: Params, batch: Mapping[str, Tensor], cfg: Mapping, layer_cfg: Mapping, num_layers: int):
+    bidx, ei = batch["batch"], batch["edge_index"]
+    centroid, x = centralize(batch["x"], bidx)
+    f_ij = localize(x, ei, norm_x_diff=cfg["norm_x_diff"])
+    (h, chi), (e, xi) = gcp_embedding(P, "gcp_embedding.", batch["h"], batch["chi"], batch["e"], batch["xi"], ei,
+                                      f_ij, cfg)
+    for i in range(num_layers):
+        (h, chi), x = gcp_interactions(P, f"interaction_layers.{i}.", h, chi, e, xi, ei, f_ij, cfg, layer_cfg,
+                                       node_pos=x)
+    return dict(h=h, chi=chi, e=e, xi=xi, f_ij=f_ij, x=decentralize(x, bidx, centroid))
+
+
+def lba_forward(P: Params, batch: Mapping[str, Tensor], cfg: Mapping, layer_cfg: Mapping, num_layers: int):
+    bidx, ei = batch["batch"], batch["edge_index"]
+    _, x = centralize(batch["x"], bidx)
+    f_ij = localize(x, ei, norm_x_diff=cfg["norm_x_diff"])
+    (h, chi), (e, xi) = gcp_embedding(P, "gcp_embedding.", batch["h"], batch["chi"], batch["e"], batch["xi"], ei,
+                                      f_ij, cfg)
+    for i in range(num_layers):
+        h, chi = gcp_interactions(P, f"interaction_layers.{i}.", h, chi, e, xi, ei, f_ij, cfg, layer_cfg)
+    s, v = gcp_layer_norm(P, "invariant_node_projection.0.", h, chi)  # gcpnet_lba_module.py:176-184
+    out = gcp2(P, "invariant_node_projection.1.", s, v, ei, f_ij, node_inputs=True,
+               nonlinearities=tuple(cfg["nonlinearities"]), vector_gate=cfg["vector_gate"],
+               frame_gate=cfg["frame_gate"], ablate_frame_updates=cfg["ablate_frame_updates"],
+               enable_e3_equivariance=cfg["enable_e3_equivariance"])
+    out = scatter(out, bidx, reduce="mean")
+    out = F.relu(out @ P["dense.0.weight"].t() + P["dense.0.bias"])
+    out = out @ P["dense.3.weight"].t() + P["dense.3.bias"]
+    return dict(h=h, chi=chi, pred=out.squeeze())
+
+
+# ----------------------------------------------------------------------------------------------------------
+# reference-default configs (values of configs/model/module_cfg/gcp_module_nms.yaml etc.), as plain dicts
+# ----------------------------------------------------------------------------------------------------------
+def default_module_cfg(**over) -> Dict:
+    cfg = dict(
+        norm_x_diff=True, scalar_gate=0, vector_gate=True, vector_residual=False, vector_frame_residual=False,
+        frame_gate=False, sigma_frame_gate=False, scalar_nonlinearity="relu", vector_nonlinearity=None,
+        nonlinearities=("relu", None), bottleneck=4, default_vector_residual=False, default_bottleneck=4,
+        node_positions_weight=1.0, ablate_frame_updates=False, ablate_scalars=False, ablate_vectors=False,
+        ablate_x_force_update=True, enable_e3_equivariance=False,
+    )
+    cfg.update(over)
+    return cfg
+
+
+def default_layer_cfg(**over) -> Dict:
+    mp = dict(num_message_layers=8, self_message=True, use_residual_message_gcp=True)
+    cfg = dict(pre_norm=False, num_feedforward_layers=2, dropout=0.1, nonlinearity_slope=1e-2, mp_cfg=mp)
+    for k, v in over.items():
+        (mp if k in mp else cfg)[k] = v
+    return cfg
+
+
+def random_rotation(seed: int = 0) -> Tensor:
+    """Proper rotation from a seeded QR (tests/test_gcpnet_equivariance.py uses scipy's Rotation.random)."""
+    g = torch.Generator().manual_seed(seed)
+    q, r = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.to(torch.float32)
+
+
+__all__ = [n for n in dir() if not n.startswith("_") and n not in ("math", "torch", "F", "annotations")]

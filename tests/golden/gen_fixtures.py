@@ -1,0 +1,295 @@
+"""Generate golden input/output vectors by running the REAL reference (imported from /root/reference through
+``ref_stubs``) on seeded inputs.  Authoring-container only; the outputs (``*.npz`` next to this file) are the
+committed fixtures that pin ``oracle/gcp_oracle.py``.
+
+    python tests/golden/gen_fixtures.py
+
+Each fixture stores ``p/<state_dict key>``, ``i/<input>``, ``o/<output>``, ``g/<grad of input or weight>``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+comp, gn, ref_models = ref_stubs.load_reference()
+SV = comp.ScalarVector
+
+
+def save(name, params=None, inputs=None, outputs=None, grads=None, meta=None):
+    blob = {}
+    for tag, d in (("p", params), ("i", inputs), ("o", outputs), ("g", grads)):
+        for k, v in (d or {}).items():
+            blob[f"{tag}/{k}"] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    for k, v in (meta or {}).items():
+        blob[f"m/{k}"] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(blob)} arrays")
+
+
+def rand_graph(n, e, seed, no_self=True):
+    g = torch.Generator().manual_seed(seed)
+    row = torch.randint(0, n, (e,), generator=g)
+    col = torch.randint(0, n, (e,), generator=g)
+    if no_self:
+        col = torch.where(col == row, (col + 1) % n, col)
+    x = torch.randn(n, 3, generator=g)
+    return torch.stack((row, col)), x
+
+
+def randn(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def sq_loss(*ts):
+    return sum((t * t).mean() for t in ts if t is not None and t.numel())
+
+
+# ------------------------------------------------------------------------------------------------------------
+def fx_geometry():
+    ei, x = rand_graph(20, 64, 1)
+    f = comp.localize(x, ei, norm_x_diff=True)
+    f_raw = comp.localize(x, ei, norm_x_diff=False)
+    vec_e = randn(64, 3, 3, seed=2)
+    vec_n = randn(20, 3, 3, seed=3)
+    bidx = torch.tensor([0] * 7 + [1] * 8 + [2] * 5)
+    bag = ref_stubs.Bag(x=x)
+    cen, xc = comp.centralize(bag, "x", bidx)
+    bag2 = ref_stubs.Bag(x=xc)
+    back = comp.decentralize(bag2, "x", bidx, cen)
+    gate_e, gate_n = randn(64, 9, seed=4), randn(20, 9, seed=5)
+    save("geometry",
+         inputs=dict(x=x, edge_index=ei, vec_e=vec_e, vec_n=vec_n, batch=bidx, gate_e=gate_e, gate_n=gate_n),
+         outputs=dict(
+             frames=f, frames_raw=f_raw,
+             scalarize_edge=comp.scalarize(vec_e, ei, f, False, False, 64),
+             scalarize_node=comp.scalarize(vec_n, ei, f, True, False, 20),
+             scalarize_edge_e3=comp.scalarize(vec_e, ei, f, False, True, 64),
+             vectorize_edge=comp.vectorize(gate_e, ei, f, False, 64),
+             vectorize_node=comp.vectorize(gate_n, ei, f, True, 20),
+             centroid=cen, x_centered=xc, x_back=back,
+             safe_norm=comp.safe_norm(vec_e, dim=-2),
+         ))
+
+
+def run_gcp2(name, in_dims, out_dims, rows_are_nodes, seed, n=20, e=64, **kw):
+    torch.manual_seed(seed)
+    mod = gn.GCP2(SV(*in_dims), SV(*out_dims), **kw)
+    ei, x = rand_graph(n, e, seed + 100)
+    frames = comp.localize(x, ei)
+    rows = n if rows_are_nodes else e
+    s = randn(rows, in_dims[0], seed=seed + 1).requires_grad_()
+    if in_dims[1]:
+        v = randn(rows, in_dims[1], 3, seed=seed + 2).requires_grad_()
+        out = mod((s, v), ei, frames, node_inputs=rows_are_nodes)
+    else:
+        v = None
+        out = mod(s, ei, frames, node_inputs=rows_are_nodes)
+    outs = dict(s=out[0], v=out[1]) if isinstance(out, tuple) else dict(s=out)
+    loss = sq_loss(*outs.values())
+    loss.backward()
+    grads = {"s": s.grad}
+    if v is not None:
+        grads["v"] = v.grad
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            grads["w." + k] = p.grad
+    ins = dict(s=s, edge_index=ei, frames=frames)
+    if v is not None:
+        ins["v"] = v
+    meta = dict(node_inputs=int(rows_are_nodes), in_dims=in_dims, out_dims=out_dims)
+    save(name, params=mod.state_dict(), inputs=ins, outputs=outs, grads=grads, meta=meta)
+
+
+def fx_gcp2():
+    relu_none = ("relu", None)
+    run_gcp2("gcp2_edge_msg0", (160, 36), (64, 16), False, 10, nonlinearities=relu_none, bottleneck=4)
+    run_gcp2("gcp2_edge_res", (64, 16), (64, 16), False, 11, nonlinearities=relu_none, bottleneck=4)
+    run_gcp2("gcp2_node_ff0", (64, 16), (256, 32), True, 12, nonlinearities=relu_none, bottleneck=4)
+    run_gcp2("gcp2_node_ff1", (256, 32), (64, 16), True, 13, nonlinearities=(None, None), bottleneck=4)
+    run_gcp2("gcp2_node_scalar_only", (100, 16), (100, 0), True, 14, nonlinearities=relu_none)
+    run_gcp2("gcp2_no_vector_in", (12, 0), (8, 3), False, 15, nonlinearities=relu_none)
+    run_gcp2("gcp2_node_posupd", (64, 16), (64, 1), True, 16, nonlinearities=relu_none, bottleneck=4)
+    run_gcp2("gcp2_silu_sigmoid", (24, 8), (24, 8), False, 17, nonlinearities=("silu", "sigmoid"), bottleneck=2)
+    run_gcp2("gcp2_selfgate", (24, 8), (20, 6), False, 18, nonlinearities=("silu", "sigmoid"), vector_gate=False)
+    run_gcp2("gcp2_vres_e3", (24, 8), (24, 8), True, 19, nonlinearities=("leakyrelu", None), bottleneck=4,
+             vector_residual=True, enable_e3_equivariance=True)
+    run_gcp2("gcp2_frame_gate", (24, 8), (16, 4), True, 20, nonlinearities=("silu", "silu"), bottleneck=2,
+             frame_gate=True)
+    run_gcp2("gcp2_frame_gate_edge", (24, 8), (16, 4), False, 21, nonlinearities=("relu", "sigmoid"), frame_gate=True)
+    run_gcp2("gcp2_ablate_frames", (24, 8), (16, 4), False, 22, nonlinearities=("relu", None), bottleneck=4,
+             ablate_frame_updates=True)
+
+
+def fx_layernorm():
+    torch.manual_seed(30)
+    ln = comp.GCPLayerNorm(SV(64, 16))
+    with torch.no_grad():
+        ln.scalar_norm.weight.uniform_(0.5, 1.5)
+        ln.scalar_norm.bias.uniform_(-0.5, 0.5)
+    s = randn(40, 64, seed=31).requires_grad_()
+    v = randn(40, 16, 3, seed=32).requires_grad_()
+    so, vo = ln(SV(s, v))
+    sq_loss(so * randn(40, 64, seed=33), vo * randn(40, 16, 3, seed=34)).backward()
+    save("layernorm", params=ln.state_dict(), inputs=dict(s=s, v=v), outputs=dict(s=so, v=vo),
+         grads={"s": s.grad, "v": v.grad, "w.scalar_norm.weight": ln.scalar_norm.weight.grad,
+                "w.scalar_norm.bias": ln.scalar_norm.bias.grad})
+
+
+def nms_like_batch(n_graphs, n_body, seed, h_dim=1, chi_dim=3, e_dim=17, xi_dim=1, int_h=False, n_types=9):
+    """Batch of fully-connected n-body graphs (block-diagonal collation as PyG does), seeded random features."""
+    g = torch.Generator().manual_seed(seed)
+    rows, cols, bidx = [], [], []
+    for k in range(n_graphs):
+        idx = torch.arange(n_body)
+        r, c = torch.meshgrid(idx, idx, indexing="ij")
+        keep = r != c
+        rows.append(r[keep] + k * n_body)
+        cols.append(c[keep] + k * n_body)
+        bidx += [k] * n_body
+    ei = torch.stack((torch.cat(rows), torch.cat(cols)))
+    n, e = n_graphs * n_body, ei.shape[1]
+    h = torch.randint(0, n_types, (n,), generator=g) if int_h else torch.randn(n, h_dim, generator=g)
+    return dict(
+        h=h, chi=torch.randn(n, chi_dim, 3, generator=g), e=torch.randn(e, e_dim, generator=g),
+        xi=torch.randn(e, xi_dim, 3, generator=g), x=torch.randn(n, 3, generator=g) * 2 + 1.5,
+        edge_index=ei, batch=torch.tensor(bidx),
+    )
+
+
+def fx_embedding():
+    cfg = ref_stubs.make_cfg()
+    for name, node_in, edge_in, hid_n, hid_e, int_h in (
+        ("embedding_nms", (1, 3), (17, 1), (64, 16), (32, 4), False),
+        ("embedding_lba", (9, 2), (16, 1), (100, 16), (32, 4), True),
+    ):
+        torch.manual_seed(40)
+        emb = gn.GCPEmbedding(SV(*edge_in), SV(*node_in), SV(*hid_e), SV(*hid_n),
+                              num_atom_types=9 if int_h else 0, cfg=cfg)
+        b = nms_like_batch(3, 5, 41, h_dim=node_in[0], chi_dim=node_in[1], e_dim=edge_in[0], xi_dim=edge_in[1],
+                           int_h=int_h)
+        f = comp.localize(b["x"], b["edge_index"])
+        bag = ref_stubs.Bag(**b, f_ij=f)
+        (h, chi), (e, xi) = emb(bag)
+        save(name, params=emb.state_dict(), inputs=dict(**b, frames=f), outputs=dict(h=h, chi=chi, e=e, xi=xi))
+
+
+def fx_interactions():
+    cfg, lc = ref_stubs.make_cfg(), ref_stubs.make_layer_cfg()
+    nd, ed = SV(64, 16), SV(32, 4)
+    ei, x = rand_graph(24, 96, 50)
+    frames = comp.localize(x, ei)
+    # message passing alone
+    torch.manual_seed(51)
+    mp = gn.GCPMessagePassing(nd, nd, ed, cfg=cfg, mp_cfg=lc.mp_cfg)
+    h, chi = randn(24, 64, seed=52).requires_grad_(), randn(24, 16, 3, seed=53).requires_grad_()
+    e, xi = randn(96, 32, seed=54).requires_grad_(), randn(96, 4, 3, seed=55).requires_grad_()
+    msg = mp.message(SV(h, chi), SV(e, xi), ei, frames)
+    out = mp(SV(h, chi), SV(e, xi), ei, frames)
+    sq_loss(out[0], out[1]).backward()
+    grads = dict(h=h.grad, chi=chi.grad, e=e.grad, xi=xi.grad)
+    grads.update({"w." + k: p.grad for k, p in mp.named_parameters()})
+    save("message_passing", params=mp.state_dict(), inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames),
+         outputs=dict(s=out[0], v=out[1], messages=msg), grads=grads)
+
+    # full interaction layer, with and without position update
+    for name, upd in (("interactions", False), ("interactions_posupd", True)):
+        torch.manual_seed(56)
+        layer = gn.GCPInteractions(nd, ed, cfg=cfg, layer_cfg=lc, dropout=0.0, updating_node_positions=upd)
+        layer.eval()
+        for t in (h, chi, e, xi):
+            t.grad = None
+        if upd:
+            (ho, co), xo = layer((h, chi), (e, xi), ei, frames, node_pos=x)
+            outs = dict(h=ho, chi=co, x=xo)
+        else:
+            ho, co = layer((h, chi), (e, xi), ei, frames)
+            outs = dict(h=ho, chi=co)
+        sq_loss(*outs.values()).backward()
+        grads = dict(h=h.grad, chi=chi.grad, e=e.grad, xi=xi.grad)
+        grads.update({"w." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+        save(name, params=layer.state_dict(),
+             inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames, x=x), outputs=outs, grads=grads)
+
+    # pre-norm ordering, 3 message layers / 3 FF layers, small dims
+    lc2 = ref_stubs.make_layer_cfg(pre_norm=True, num_feedforward_layers=3, num_message_layers=3)
+    cfg2 = ref_stubs.make_cfg(scalar_nonlinearity="silu", vector_nonlinearity="silu")
+    torch.manual_seed(57)
+    layer = gn.GCPInteractions(SV(16, 4), SV(8, 4), cfg=cfg2, layer_cfg=lc2, dropout=0.0)
+    layer.eval()
+    h2, chi2 = randn(24, 16, seed=58), randn(24, 4, 3, seed=59)
+    e2, xi2 = randn(96, 8, seed=60), randn(96, 4, 3, seed=61)
+    ho, co = layer((h2, chi2), (e2, xi2), ei, frames)
+    save("interactions_prenorm_silu", params=layer.state_dict(),
+         inputs=dict(h=h2, chi=chi2, e=e2, xi=xi2, edge_index=ei, frames=frames), outputs=dict(h=ho, chi=co))
+
+
+def fx_models():
+    """The LitModules cannot be imported (no Lightning here); their forwards (gcpnet_nms_module.py:127-151,
+    gcpnet_lba_module.py:155-186) are driven step by step with the real reference components."""
+    cfg, lc = ref_stubs.make_cfg(), ref_stubs.make_layer_cfg(num_message_layers=4)
+    # --- NMS-style: (1,3)/(17,1) -> (32,8)/(16,4), 2 layers, 3 x 5-body
+    torch.manual_seed(70)
+    nd, ed = SV(32, 8), SV(16, 4)
+    emb = gn.GCPEmbedding(SV(17, 1), SV(1, 3), ed, nd, num_atom_types=0, cfg=cfg)
+    layers = torch.nn.ModuleList(
+        gn.GCPInteractions(nd, ed, cfg=cfg, layer_cfg=lc, dropout=0.0, updating_node_positions=True)
+        for _ in range(2))
+    b = nms_like_batch(3, 5, 71)
+    bag = ref_stubs.Bag(**b)
+    cen, bag.x = comp.centralize(bag, "x", bag.batch)
+    bag.f_ij = comp.localize(bag.x, bag.edge_index, norm_x_diff=True)
+    (h, chi), (e, xi) = emb(bag)
+    for layer in layers:
+        (h, chi), bag.x = layer((h, chi), (e, xi), bag.edge_index, bag.f_ij, node_pos=bag.x)
+    x_out = comp.decentralize(bag, "x", bag.batch, cen)
+    params = {"gcp_embedding." + k: v for k, v in emb.state_dict().items()}
+    params.update({"interaction_layers." + k: v for k, v in layers.state_dict().items()})
+    save("model_nms_small", params=params, inputs=b, outputs=dict(h=h, chi=chi, e=e, xi=xi, x=x_out, f_ij=bag.f_ij),
+         meta=dict(num_layers=2, num_message_layers=4))
+
+    # --- LBA-style: int atom types -> (20,4)/(8,4), 2 layers, readout
+    torch.manual_seed(72)
+    nd, ed = SV(20, 4), SV(8, 4)
+    emb = gn.GCPEmbedding(SV(16, 1), SV(9, 2), ed, nd, num_atom_types=9, cfg=cfg)
+    layers = torch.nn.ModuleList(gn.GCPInteractions(nd, ed, cfg=cfg, layer_cfg=lc, dropout=0.0) for _ in range(2))
+    proj_norm = comp.GCPLayerNorm(nd)
+    proj = gn.GCP2(nd, (nd.scalar, 0), nonlinearities=tuple(cfg.nonlinearities), scalar_gate=cfg.scalar_gate,
+                   vector_gate=cfg.vector_gate, frame_gate=cfg.frame_gate, sigma_frame_gate=cfg.sigma_frame_gate,
+                   vector_frame_residual=cfg.vector_frame_residual, ablate_frame_updates=cfg.ablate_frame_updates,
+                   enable_e3_equivariance=cfg.enable_e3_equivariance, node_inputs=True)
+    dense = torch.nn.Sequential(torch.nn.Linear(20, 40), torch.nn.ReLU(), torch.nn.Dropout(0.1),
+                                torch.nn.Linear(40, 1)).eval()
+    b = nms_like_batch(4, 6, 73, chi_dim=2, e_dim=16, xi_dim=1, int_h=True)
+    bag = ref_stubs.Bag(**b)
+    _, bag.x = comp.centralize(bag, "x", bag.batch)
+    bag.f_ij = comp.localize(bag.x, bag.edge_index, norm_x_diff=True)
+    (h, chi), (e, xi) = emb(bag)
+    for layer in layers:
+        (h, chi) = layer((h, chi), (e, xi), bag.edge_index, bag.f_ij)
+    out = proj_norm(SV(h, chi))
+    out = proj(out, bag.edge_index, bag.f_ij, node_inputs=True)
+    from torch_scatter import scatter
+    pred = dense(scatter(out, bag.batch, dim=0, reduce="mean")).squeeze()
+    params = {"gcp_embedding." + k: v for k, v in emb.state_dict().items()}
+    params.update({"interaction_layers." + k: v for k, v in layers.state_dict().items()})
+    params.update({"invariant_node_projection.0." + k: v for k, v in proj_norm.state_dict().items()})
+    params.update({"invariant_node_projection.1." + k: v for k, v in proj.state_dict().items()})
+    params.update({"dense." + k: v for k, v in dense.state_dict().items()})
+    save("model_lba_small", params=params, inputs=b, outputs=dict(h=h, chi=chi, pred=pred),
+         meta=dict(num_layers=2, num_message_layers=4))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    fx_geometry()
+    fx_gcp2()
+    fx_layernorm()
+    fx_embedding()
+    fx_interactions()
+    fx_models()

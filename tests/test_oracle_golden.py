@@ -1,0 +1,166 @@
+"""Pins the CPU oracle (oracle/gcp_oracle.py) to golden vectors produced by the real reference
+(tests/golden/gen_fixtures.py).  CPU only."""
+import pytest
+import torch
+
+from oracle import gcp_oracle as O
+from tests.helpers import Fixture, close
+
+TOL = dict(atol=2e-6, rtol=2e-5)
+
+
+def _grads(loss, tensors):
+    return torch.autograd.grad(loss, tensors, allow_unused=True)
+
+
+def sq_loss(*ts):
+    return sum((t * t).mean() for t in ts if t is not None and t.numel())
+
+
+def test_geometry():
+    f = Fixture("geometry")
+    x, ei = f.i["x"], f.i["edge_index"]
+    fr = O.localize(x, ei, True)
+    close(fr, f.o["frames"], **TOL)
+    close(O.localize(x, ei, False), f.o["frames_raw"], **TOL)
+    close(O.scalarize(f.i["vec_e"], ei, fr, False, False, 64), f.o["scalarize_edge"], **TOL)
+    close(O.scalarize(f.i["vec_n"], ei, fr, True, False, 20), f.o["scalarize_node"], **TOL)
+    close(O.scalarize(f.i["vec_e"], ei, fr, False, True, 64), f.o["scalarize_edge_e3"], **TOL)
+    close(O.vectorize(f.i["gate_e"], ei, fr, False, 64), f.o["vectorize_edge"], **TOL)
+    close(O.vectorize(f.i["gate_n"], ei, fr, True, 20), f.o["vectorize_node"], **TOL)
+    c, xc = O.centralize(x, f.i["batch"])
+    close(c, f.o["centroid"], **TOL)
+    close(xc, f.o["x_centered"], **TOL)
+    close(O.decentralize(xc, f.i["batch"], c), f.o["x_back"], **TOL)
+    close(O.safe_norm(f.i["vec_e"], dim=-2), f.o["safe_norm"], **TOL)
+
+
+GCP2_CASES = {
+    "gcp2_edge_msg0": dict(nonlinearities=("relu", None)),
+    "gcp2_edge_res": dict(nonlinearities=("relu", None)),
+    "gcp2_node_ff0": dict(nonlinearities=("relu", None)),
+    "gcp2_node_ff1": dict(nonlinearities=(None, None)),
+    "gcp2_node_scalar_only": dict(nonlinearities=("relu", None)),
+    "gcp2_no_vector_in": dict(nonlinearities=("relu", None), vector_output_dim=3),
+    "gcp2_node_posupd": dict(nonlinearities=("relu", None)),
+    "gcp2_silu_sigmoid": dict(nonlinearities=("silu", "sigmoid")),
+    "gcp2_selfgate": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False),
+    "gcp2_vres_e3": dict(nonlinearities=("leakyrelu", None), vector_residual=True, enable_e3_equivariance=True),
+    "gcp2_frame_gate": dict(nonlinearities=("silu", "silu"), frame_gate=True),
+    "gcp2_frame_gate_edge": dict(nonlinearities=("relu", "sigmoid"), frame_gate=True),
+    "gcp2_ablate_frames": dict(nonlinearities=("relu", None), ablate_frame_updates=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GCP2_CASES))
+def test_gcp2(name):
+    f = Fixture(name)
+    kw = GCP2_CASES[name]
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    s = f.i["s"].clone().requires_grad_()
+    v = f.i["v"].clone().requires_grad_() if "v" in f.i else None
+    out = O.gcp2(P, "", s, v, f.i["edge_index"], f.i["frames"], node_inputs=bool(f.m["node_inputs"]), **kw)
+    outs = dict(s=out[0], v=out[1]) if isinstance(out, tuple) else dict(s=out)
+    for k in outs:
+        close(outs[k], f.o[k], **TOL)
+    loss = sq_loss(*outs.values())
+    names = ["s"] + (["v"] if v is not None else []) + ["w." + k for k in P]
+    tens = [s] + ([v] if v is not None else []) + list(P.values())
+    for n, g in zip(names, _grads(loss, tens)):
+        if n in f.g:
+            close(g, f.g[n], atol=2e-6, rtol=1e-4)
+        else:
+            assert g is None or float(g.abs().max()) == 0.0
+
+
+def test_layernorm():
+    f = Fixture("layernorm")
+    so, vo = O.gcp_layer_norm(f.p, "", f.i["s"], f.i["v"])
+    close(so, f.o["s"], **TOL)
+    close(vo, f.o["v"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["embedding_nms", "embedding_lba"])
+def test_embedding(name):
+    f = Fixture(name)
+    i = f.i
+    (h, chi), (e, xi) = O.gcp_embedding(f.p, "", i["h"], i["chi"], i["e"], i["xi"], i["edge_index"], i["frames"],
+                                        O.default_module_cfg())
+    for k, t in dict(h=h, chi=chi, e=e, xi=xi).items():
+        close(t, f.o[k], **TOL)
+
+
+def test_message_passing():
+    f = Fixture("message_passing")
+    i = f.i
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    ins = {k: i[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    cfg, lc = O.default_module_cfg(), O.default_layer_cfg()
+    (s, v), msg = O.message_passing(P, "", ins["h"], ins["chi"], ins["e"], ins["xi"], i["edge_index"], i["frames"],
+                                    cfg, lc["mp_cfg"], return_messages=True)
+    close(msg, f.o["messages"], atol=5e-6, rtol=5e-5)
+    close(s, f.o["s"], atol=5e-6, rtol=5e-5)
+    close(v, f.o["v"], atol=5e-6, rtol=5e-5)
+    names = list(ins) + ["w." + k for k in P]
+    for n, g in zip(names, _grads(sq_loss(s, v), list(ins.values()) + list(P.values()))):
+        close(g, f.g[n], atol=5e-6, rtol=5e-4)
+
+
+@pytest.mark.parametrize("name", ["interactions", "interactions_posupd"])
+def test_interactions(name):
+    f = Fixture(name)
+    i = f.i
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    ins = {k: i[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    cfg, lc = O.default_module_cfg(), O.default_layer_cfg()
+    out = O.gcp_interactions(P, "", ins["h"], ins["chi"], ins["e"], ins["xi"], i["edge_index"], i["frames"], cfg, lc,
+                             node_pos=i["x"] if name.endswith("posupd") else None)
+    outs = dict(h=out[0][0], chi=out[0][1], x=out[1]) if name.endswith("posupd") else dict(h=out[0], chi=out[1])
+    for k, t in outs.items():
+        close(t, f.o[k], atol=5e-6, rtol=5e-5)
+    names = list(ins) + ["w." + k for k in P]
+    gr = _grads(sq_loss(*outs.values()), list(ins.values()) + list(P.values()))
+    for n, g in zip(names, gr):
+        if n in f.g:
+            close(g, f.g[n], atol=5e-6, rtol=1e-3)
+
+
+def test_interactions_prenorm_silu():
+    f = Fixture("interactions_prenorm_silu")
+    i = f.i
+    cfg = O.default_module_cfg(scalar_nonlinearity="silu", vector_nonlinearity="silu", nonlinearities=("silu", "silu"))
+    lc = O.default_layer_cfg(pre_norm=True, num_feedforward_layers=3, num_message_layers=3)
+    h, chi = O.gcp_interactions(f.p, "", i["h"], i["chi"], i["e"], i["xi"], i["edge_index"], i["frames"], cfg, lc)
+    close(h, f.o["h"], atol=5e-6, rtol=5e-5)
+    close(chi, f.o["chi"], atol=5e-6, rtol=5e-5)
+
+
+def test_model_nms():
+    f = Fixture("model_nms_small")
+    out = O.nms_forward(f.p, f.i, O.default_module_cfg(), O.default_layer_cfg(num_message_layers=4), 2)
+    for k in ("h", "chi", "e", "xi", "x", "f_ij"):
+        close(out[k], f.o[k], atol=1e-5, rtol=1e-4)
+
+
+def test_model_lba():
+    f = Fixture("model_lba_small")
+    out = O.lba_forward(f.p, f.i, O.default_module_cfg(), O.default_layer_cfg(num_message_layers=4), 2)
+    for k in ("h", "chi", "pred"):
+        close(out[k], f.o[k], atol=1e-5, rtol=1e-4)
+
+
+def test_oracle_equivariance():
+    """The property the reference's (disabled) tests assert, tests/test_gcpnet_equivariance.py:1773-1881."""
+    f = Fixture("interactions_posupd")
+    i = f.i
+    cfg, lc = O.default_module_cfg(), O.default_layer_cfg()
+    Q = O.random_rotation(3)
+    x = i["x"]
+    fr = O.localize(x, i["edge_index"])
+    (h0, c0), x0 = O.gcp_interactions(f.p, "", i["h"], i["chi"], i["e"], i["xi"], i["edge_index"], fr, cfg, lc, node_pos=x)
+    xr = x @ Q.t()
+    (h1, c1), x1 = O.gcp_interactions(f.p, "", i["h"], i["chi"] @ Q.t(), i["e"], i["xi"] @ Q.t(), i["edge_index"],
+                                      O.localize(xr, i["edge_index"]), cfg, lc, node_pos=xr)
+    close(h1, h0, atol=1e-5, rtol=1e-4)
+    close(c1, c0 @ Q.t(), atol=1e-5, rtol=1e-4)
+    close(x1, x0 @ Q.t(), atol=1e-5, rtol=1e-4)
