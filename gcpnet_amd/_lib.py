@@ -1,0 +1,103 @@
+"""ctypes binding of libgcpnet_hip.so (the C ABI declared in include/gcpnet_hip.h).
+
+There is deliberately no CPU fallback: if the library is missing the product path raises.  PyTorch is used for
+device memory, the current HIP stream and autograd plumbing only.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgcpnet_hip.so")
+
+ACT = {None: 0, "relu": 1, "leakyrelu": 2, "selu": 3, "silu": 4, "sigmoid": 5}
+VMODE_NONE, VMODE_SCALAR_GATE, VMODE_SELF_GATE = 0, 1, 2
+MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
+
+EXPORTS = [
+    "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
+    "gcpnet_gcp2_backward", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_segment_reduce", "gcpnet_gather_rows",
+    "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_axpy_clamp",
+]
+
+
+class Concat(C.Structure):
+    _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * MAX_SEG), ("idx", C.c_void_p * MAX_SEG), ("dim", C.c_int * MAX_SEG)]
+
+
+class Gcp2Weights(C.Structure):
+    _fields_ = [
+        ("si", C.c_int), ("vi", C.c_int), ("so", C.c_int), ("vo", C.c_int), ("hidden", C.c_int), ("use_frames", C.c_int),
+        ("w_down", C.c_void_p), ("w_frames", C.c_void_p), ("w_up", C.c_void_p), ("w_scalar", C.c_void_p),
+        ("b_scalar", C.c_void_p), ("w_gate", C.c_void_p), ("b_gate", C.c_void_p), ("pack", C.c_void_p),
+    ]
+
+
+class Gcp2Opts(C.Structure):
+    _fields_ = [("act_s", C.c_int), ("act_v", C.c_int), ("slope", C.c_float), ("vmode", C.c_int),
+                ("vector_residual", C.c_int), ("e3", C.c_int), ("fused_residual", C.c_int)]
+
+
+class BwdScratch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ds_pre", "dgate", "ext", "dvu", "dvhf", "vh", "vt")]
+
+
+class Operand(C.Structure):
+    _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * TN_MAX_SEG), ("idx", C.c_void_p * TN_MAX_SEG),
+                ("dim", C.c_int * TN_MAX_SEG), ("ld", C.c_int * TN_MAX_SEG), ("act", C.c_int), ("slope", C.c_float),
+                ("ones", C.c_int)]
+
+
+class TnProblem(C.Structure):
+    _fields_ = [("rows", C.c_int), ("a", Operand), ("b", Operand), ("out", C.c_void_p), ("out_sm", C.c_int64),
+                ("out_sn", C.c_int64), ("partial", C.c_void_p), ("splits", C.c_int)]
+
+
+class GcpnetHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GcpnetHipError(
+            f"{LIB_PATH} is missing: build it with `python -m gcpnet_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950).  gcpnet_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    P = C.POINTER
+    lib.gcpnet_abi_version.restype = i32
+    lib.gcpnet_gcp2_pack_floats.restype = i64
+    lib.gcpnet_gcp2_pack_floats.argtypes = [i32] * 6
+    lib.gcpnet_pack_gcp2_weights.argtypes = [P(Gcp2Weights), vp, vp]
+    lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
+                                        vp, vp]
+    lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
+                                         vp, P(BwdScratch), vp]
+    lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]
+    lib.gcpnet_tn_splits.argtypes = [i32, i32, i32]
+    lib.gcpnet_segment_reduce.argtypes = [i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp]
+    lib.gcpnet_gather_rows.argtypes = [i32, vp, vp, i64, i32, vp, vp, i64, vp]
+    lib.gcpnet_localize.argtypes = [i32, vp, vp, vp, i32, vp, vp]
+    lib.gcpnet_layernorm_forward.argtypes = [i32, i32, i32] + [vp] * 12
+    lib.gcpnet_layernorm_backward.argtypes = [i32, i32, i32] + [vp] * 11
+    lib.gcpnet_axpy_clamp.argtypes = [i64, vp, vp, f32, i32, f32, f32, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("gcpnet_gcp2_pack_floats",):
+            fn.restype = i32
+    if lib.gcpnet_abi_version() != 1:
+        raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape"}.get(rc, f"hipError {rc}")
+        raise GcpnetHipError(f"{what} failed: {kind}")

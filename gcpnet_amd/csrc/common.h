@@ -1,0 +1,99 @@
+// Device-side helpers shared by the gfx950 kernels of libgcpnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gcpnet_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GCP_WAVE 64
+#define GCP_TILE_ROWS 32  // rows (edges or nodes) owned by one wavefront: the N dimension of v_mfma_f32_32x32x2_f32
+
+// ---- activations (models/__init__.py:42-57) and their derivatives w.r.t. the pre-activation ----------------
+#define GCP_SELU_ALPHA 1.6732632423543772f
+#define GCP_SELU_SCALE 1.0507009873554805f
+
+__device__ __forceinline__ float gcp_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float gcp_act(int act, float x, float slope) {
+    switch (act) {
+        case GCP_ACT_RELU: return x > 0.f ? x : 0.f;
+        case GCP_ACT_LEAKYRELU: return x > 0.f ? x : slope * x;
+        case GCP_ACT_SELU: return GCP_SELU_SCALE * (x > 0.f ? x : GCP_SELU_ALPHA * (__expf(x) - 1.0f));
+        case GCP_ACT_SILU: return x * gcp_sigmoid(x);
+        case GCP_ACT_SIGMOID: return gcp_sigmoid(x);
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float gcp_act_grad(int act, float x, float slope) {
+    switch (act) {
+        case GCP_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case GCP_ACT_LEAKYRELU: return x > 0.f ? 1.f : slope;
+        case GCP_ACT_SELU: return GCP_SELU_SCALE * (x > 0.f ? 1.f : GCP_SELU_ALPHA * __expf(x));
+        case GCP_ACT_SILU: {
+            float s = gcp_sigmoid(x);
+            return s * (1.f + x * (1.f - s));
+        }
+        case GCP_ACT_SIGMOID: {
+            float s = gcp_sigmoid(x);
+            return s * (1.f - s);
+        }
+        default: return 1.f;
+    }
+}
+
+// Row index inside a 32x32 MFMA C/D tile held by (register r, lane half hi): the column is lane & 31.
+__device__ __forceinline__ int gcp_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__host__ __device__ __forceinline__ int gcp_round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ __forceinline__ int gcp_cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int gcp_odd(int x) { return x | 1; }
+
+// ---- derived shape constants of one GCP2 block, shared by host packing code and kernels ---------------------
+struct GcpShape {
+    int si, vi, so, vo, H, nf;  // nf = 9 frame scalars or 0
+    int K;    // merged width  = si (+ H + nf when vi > 0)
+    int KP;   // K rounded up to 8 (MFMA k-pairs, 4-deep software pipeline)
+    int KK;   // KP / 2 forward steps
+    int NTG;  // 32-wide output tiles per accumulator group (1, 2 or 4)
+    int NG;   // output groups
+    int NUG;  // 32-wide tiles of the merged axis per backward accumulator group
+    int NGK;  // merged-axis groups
+    int NS;   // backward-data reduction steps = NG * NTG * 16
+    int NOT;  // 16-wide tiles of the vector-gate outputs
+    int NJ4;  // gate forward steps (4 scalar columns each) = NG * NTG * 8
+    int NOO;  // gate backward steps (2 gate outputs each), padded to a multiple of 2
+    int64_t offA, offB, offC, offD, total;  // section offsets (floats) inside the packed image
+};
+
+__host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, int H, int use_frames) {
+    GcpShape s;
+    s.si = si; s.vi = vi; s.so = so; s.vo = vo; s.H = vi > 0 ? H : 0;
+    s.nf = (vi > 0 && use_frames) ? 9 : 0;
+    s.K = si + s.H + s.nf;
+    s.KP = gcp_round_up(s.K, 8);
+    s.KK = s.KP / 2;
+    s.NTG = so <= 32 ? 1 : (so <= 64 ? 2 : 4);
+    s.NG = gcp_cdiv(gcp_cdiv(so, 32), s.NTG);
+    s.NUG = s.K <= 32 ? 1 : (s.K <= 64 ? 2 : 4);
+    s.NGK = gcp_cdiv(gcp_cdiv(s.K, 32), s.NUG);
+    s.NS = s.NG * s.NTG * 16;
+    s.NOT = gcp_cdiv(vo, 16);
+    s.NJ4 = s.NG * s.NTG * 8;
+    s.NOO = gcp_round_up(gcp_cdiv(vo, 2), 2);
+    s.offA = 0;
+    s.offB = s.offA + (int64_t)s.NG * s.KK * 64 * s.NTG;
+    s.offC = s.offB + (int64_t)s.NGK * s.NS * 64 * s.NUG;
+    s.offD = s.offC + (int64_t)s.NOT * s.NJ4 * 64;
+    s.total = s.offD + (int64_t)s.NOO * s.NG * 64 * s.NTG;
+    return s;
+}
+
+#define GCP_HIP_CHECK_LAUNCH()                         \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)

@@ -1,0 +1,514 @@
+// GCP2 backward (data path) on gfx950.  There is no reference code for this: the reference gets it from autograd
+// over src/models/components/gcpnet.py:394-468; this kernel is the hand-derived adjoint of gcp2_fwd.hip.
+//
+// Same wave-autonomous tiling as the forward (32 rows per wavefront, no inter-wave barriers).  The two GEMM-shaped
+// steps run on v_mfma_f32_32x32x2_f32 in transposed form:
+//   * gate adjoint      ds_pre_gate^T[so, rows] = Wg^T[so, vo]  x dgate^T[vo, rows]   (B from LDS)
+//   * scalar_out adjoint dmerged^T[K, rows]     = W^T[K, so]    x ds_pre^T[so, rows]
+//     where the B operand is the ds_pre accumulator tile ITSELF: a 32x32 C/D register (t, r) of lane half `hi` holds
+//     column j = 32t + (r&3) + 8(r>>2) + 4hi of row lane&31, so using it as the B fragment of a k-pair step whose two
+//     reduction indices are (j0, j0+4) needs no data movement at all; the packed A image is built for that pairing.
+// Weight gradients are reductions over rows and are left to gcpnet_tn_gemm, fed by the per-row scratch written here.
+#include "common.h"
+
+namespace {
+
+struct BwdParams {
+    int rows;
+    gcp_concat_t v_in;
+    const float* frames;
+    gcp2_weights_t w;
+    gcp2_opts_t o;
+    const float* s_pre;
+    const float* gate;
+    const float* d_s_out;
+    const float* d_v_out;
+    float* d_s_in;
+    float* d_v_in;
+    gcp2_bwd_scratch_t sc;
+    GcpShape sh;
+};
+
+struct BwdLds {
+    int VS, HS, NS_, US, GS2, DS, FS;
+    int o_vt, o_vht, o_rn, o_dvut, o_dgt, o_dext, o_dvhf, o_fr, total;
+};
+
+__host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
+    BwdLds l;
+    l.VS = gcp_odd(3 * s.vi);
+    l.HS = gcp_odd(3 * s.H);
+    l.NS_ = gcp_odd(s.H);
+    l.US = gcp_odd(3 * s.vo);
+    l.GS2 = gcp_odd(2 * s.NOO);
+    l.DS = gcp_odd(s.H + 9);
+    l.FS = gcp_odd(3 * (s.H + 3));
+    l.o_vt = 0;
+    l.o_vht = l.o_vt + 32 * l.VS;
+    l.o_rn = l.o_vht + 32 * l.HS;
+    l.o_dvut = l.o_rn + 32 * l.NS_;
+    l.o_dgt = l.o_dvut + 32 * l.US;
+    l.o_dext = l.o_dgt + 32 * l.GS2;
+    l.o_dvhf = l.o_dext + 32 * l.DS;
+    l.o_fr = l.o_dvhf + 32 * l.FS;
+    l.total = l.o_fr + 32 * 9;
+    return l;
+}
+
+__device__ __forceinline__ void load_concat_tile(const gcp_concat_t& c, int mult, int r0, int rows, float* tile,
+                                                 int stride, int lane) {
+    int coff = 0;
+    for (int sg = 0; sg < c.n; ++sg) {
+        const float* base = c.ptr[sg];
+        const int32_t* idx = c.idx[sg];
+        const int dim = c.dim[sg] * mult;
+#pragma unroll 4
+        for (int e = 0; e < GCP_TILE_ROWS; ++e) {
+            const int r = r0 + e;
+            float* dst = tile + e * stride + coff;
+            if (r < rows) {
+                const int64_t src = idx ? (int64_t)idx[r] : (int64_t)r;
+                const float* rowp = base + src * dim;
+                for (int j = lane; j < dim; j += GCP_WAVE) dst[j] = rowp[j];
+            } else {
+                for (int j = lane; j < dim; j += GCP_WAVE) dst[j] = 0.f;
+            }
+        }
+        coff += dim;
+    }
+}
+
+// 4 consecutive columns j0..j0+3 of row `row` of a [rows, ld] matrix (zeros outside).
+__device__ __forceinline__ float4 load4(const float* base, int64_t row, int ld, int j0, bool ok, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok) return v;
+    const float* p = base + row * ld + j0;
+    if (vec && j0 + 3 < ld) return *reinterpret_cast<const float4*>(p);
+    if (j0 + 0 < ld) v.x = p[0];
+    if (j0 + 1 < ld) v.y = p[1];
+    if (j0 + 2 < ld) v.z = p[2];
+    if (j0 + 3 < ld) v.w = p[3];
+    return v;
+}
+
+__device__ __forceinline__ void store4(float* base, int64_t row, int ld, int j0, float4 v, bool ok, bool vec) {
+    if (!ok) return;
+    float* p = base + row * ld + j0;
+    if (vec && j0 + 3 < ld) { *reinterpret_cast<float4*>(p) = v; return; }
+    if (j0 + 0 < ld) p[0] = v.x;
+    if (j0 + 1 < ld) p[1] = v.y;
+    if (j0 + 2 < ld) p[2] = v.z;
+    if (j0 + 3 < ld) p[3] = v.w;
+}
+
+template <int N>
+struct WFragB;
+template <>
+struct WFragB<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
+};
+template <>
+struct WFragB<2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float* p) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <>
+struct WFragB<4> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+template <int NTG, int NUG>
+__global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GcpShape& S = p.sh;
+    const BwdLds L = bwd_lds(S);
+    const int lane = threadIdx.x;
+    const int e = lane & 31, hi = lane >> 5;
+    const int r0 = blockIdx.x * GCP_TILE_ROWS;
+    const int rows = p.rows;
+    const int row = r0 + e;
+    const bool row_ok = row < rows;
+    float* vt = lds + L.o_vt;
+    float* vht = lds + L.o_vht;
+    float* rn = lds + L.o_rn;
+    float* dvut = lds + L.o_dvut;
+    float* dgt = lds + L.o_dgt;
+    float* dext = lds + L.o_dext;
+    float* dvhf = lds + L.o_dvhf;
+    float* fr = lds + L.o_fr;
+    const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H, HF = S.H + 3;
+    const float slope = p.o.slope;
+    const bool scalar_gate = (p.o.vmode == GCP_VMODE_SCALAR_GATE) && vo > 0 && vi > 0;
+    const bool has_vec = vi > 0;
+    const bool has_vout = has_vec && vo > 0;
+
+    // ---- 1. stage vectors / frames, recompute vh, its norms and the frame scalars ---------------------------
+    if (has_vec) {
+        load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
+        if (S.nf)
+            for (int i = lane; i < 32 * 9; i += GCP_WAVE) {
+                int rr = r0 + i / 9;
+                fr[i] = rr < rows ? p.frames[(int64_t)rr * 9 + (i % 9)] : 0.f;
+            }
+    }
+    for (int i = hi; i < 2 * S.NOO; i += 2) dgt[e * L.GS2 + i] = 0.f;
+    __syncthreads();
+    if (has_vec) {
+        const float* vrow = vt + e * L.VS;
+        for (int h = hi; h < H; h += 2) {
+            const float* wd = p.w.w_down + h * vi;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int c = 0; c < vi; ++c) {
+                const float w = wd[c];
+                a0 = fmaf(w, vrow[3 * c + 0], a0);
+                a1 = fmaf(w, vrow[3 * c + 1], a1);
+                a2 = fmaf(w, vrow[3 * c + 2], a2);
+            }
+            vht[e * L.HS + 3 * h + 0] = a0;
+            vht[e * L.HS + 3 * h + 1] = a1;
+            vht[e * L.HS + 3 * h + 2] = a2;
+            const float nr = sqrtf(a0 * a0 + a1 * a1 + a2 * a2 + 1e-8f);
+            rn[e * L.NS_ + h] = 1.0f / nr;
+            if (row_ok) {
+                p.sc.ext[(int64_t)row * (H + S.nf) + h] = nr + 1e-8f;
+                p.sc.vh[((int64_t)row * 3 + 0) * H + h] = a0;
+                p.sc.vh[((int64_t)row * 3 + 1) * H + h] = a1;
+                p.sc.vh[((int64_t)row * 3 + 2) * H + h] = a2;
+            }
+        }
+        if (S.nf) {
+            const float* f = fr + e * 9;
+            for (int k = hi; k < 3; k += 2) {
+                const float* wf = p.w.w_frames + k * vi;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                for (int c = 0; c < vi; ++c) {
+                    const float w = wf[c];
+                    a0 = fmaf(w, vrow[3 * c + 0], a0);
+                    a1 = fmaf(w, vrow[3 * c + 1], a1);
+                    a2 = fmaf(w, vrow[3 * c + 2], a2);
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float pr = f[3 * a + 0] * a0 + f[3 * a + 1] * a1 + f[3 * a + 2] * a2;
+                    if (p.o.e3 && a == 1) {
+                        // remember the sign for the adjoint of |.| in the dvhf tile's spare slot
+                        dvhf[e * L.FS + 0 * HF + H + k] = pr < 0.f ? -1.f : 1.f;
+                        pr = fabsf(pr);
+                    }
+                    if (row_ok) p.sc.ext[(int64_t)row * (H + 9) + H + 3 * k + a] = pr;
+                }
+            }
+        }
+        // transposed copy of the inputs for the vector_down weight gradients: vt_out[(row, d), c]
+        if (row_ok)
+            for (int c = hi; c < vi; c += 2)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) p.sc.vt[((int64_t)row * 3 + d) * vi + c] = vrow[3 * c + d];
+    }
+    __syncthreads();
+
+    // ---- 2. adjoint of the vector epilogue (gcpnet.py:364-391) ------------------------------------------------
+    if (has_vout) {
+        for (int oc = hi; oc < vo; oc += 2) {
+            const float* wu = p.w.w_up + oc * H;
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+            for (int h = 0; h < H; ++h) {
+                const float w = wu[h];
+                u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
+                u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
+                u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
+            }
+            if (p.o.vector_residual) {
+                u0 += vt[e * L.VS + 3 * oc + 0];
+                u1 += vt[e * L.VS + 3 * oc + 1];
+                u2 += vt[e * L.VS + 3 * oc + 2];
+            }
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (row_ok) {
+                const float* gp = p.d_v_out + ((int64_t)row * vo + oc) * 3;
+                g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
+            }
+            float du0 = g0, du1 = g1, du2 = g2;
+            const float dot = g0 * u0 + g1 * u1 + g2 * u2;
+            if (scalar_gate) {
+                const float sg = row_ok ? p.gate[(int64_t)row * vo + oc] : 0.f;
+                du0 = g0 * sg; du1 = g1 * sg; du2 = g2 * sg;
+                const float dg = dot * sg * (1.f - sg);
+                dgt[e * L.GS2 + oc] = dg;
+                if (row_ok) p.sc.dgate[(int64_t)row * vo + oc] = dg;
+            } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
+                const float rs = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
+                const float n = rs + 1e-8f;
+                const float a = gcp_act(p.o.act_v, n, slope), da = gcp_act_grad(p.o.act_v, n, slope);
+                const float coef = dot * da / rs;
+                du0 = g0 * a + coef * u0; du1 = g1 * a + coef * u1; du2 = g2 * a + coef * u2;
+            }
+            dvut[e * L.US + 3 * oc + 0] = du0;
+            dvut[e * L.US + 3 * oc + 1] = du1;
+            dvut[e * L.US + 3 * oc + 2] = du2;
+            if (row_ok) {
+                p.sc.dvu[((int64_t)row * 3 + 0) * vo + oc] = du0;
+                p.sc.dvu[((int64_t)row * 3 + 1) * vo + oc] = du1;
+                p.sc.dvu[((int64_t)row * 3 + 2) * vo + oc] = du2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. ds_pre = d_s_out * act_s'(s_pre) + act_v'(s_pre) * (Wg^T dgate)  (per output group) ----------------
+    // ---- 4. dmerged = W^T ds_pre, accumulated over the output groups, per merged-axis group ---------------------
+    const bool vec_so = (so & 3) == 0, vec_si = (si & 3) == 0;
+    const bool single = S.NG == 1;
+    f32x16 dsr[NTG];
+    for (int ug = 0; ug < S.NGK; ++ug) {
+        f32x16 acc2[NUG];
+#pragma unroll
+        for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
+        for (int g = 0; g < S.NG; ++g) {
+            if (ug == 0) {  // first pass over this output group: build ds_pre and keep a copy in HBM
+                f32x16 gacc[NTG];
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
+                if (scalar_gate) {
+                    const float* wg = p.w.pack + S.offD + ((int64_t)g * 64 + lane) * NTG;
+                    for (int oo = 0; oo < S.NOO; ++oo) {
+                        WFragB<NTG> a;
+                        a.load(wg + (int64_t)oo * S.NG * 64 * NTG);
+                        const float b = dgt[e * L.GS2 + 2 * oo + hi];
+#pragma unroll
+                        for (int t = 0; t < NTG; ++t)
+                            gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b, gacc[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
+                        const float4 sp = load4(p.s_pre, row, so, j0, row_ok, vec_so);
+                        const float4 dy = load4(p.d_s_out, row, so, j0, row_ok, vec_so);
+                        float4 d;
+                        d.x = dy.x * gcp_act_grad(p.o.act_s, sp.x, slope);
+                        d.y = dy.y * gcp_act_grad(p.o.act_s, sp.y, slope);
+                        d.z = dy.z * gcp_act_grad(p.o.act_s, sp.z, slope);
+                        d.w = dy.w * gcp_act_grad(p.o.act_s, sp.w, slope);
+                        if (scalar_gate) {
+                            d.x += gcp_act_grad(p.o.act_v, sp.x, slope) * gacc[t][4 * q + 0];
+                            d.y += gcp_act_grad(p.o.act_v, sp.y, slope) * gacc[t][4 * q + 1];
+                            d.z += gcp_act_grad(p.o.act_v, sp.z, slope) * gacc[t][4 * q + 2];
+                            d.w += gcp_act_grad(p.o.act_v, sp.w, slope) * gacc[t][4 * q + 3];
+                        }
+                        if (!row_ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                        dsr[t][4 * q + 0] = d.x; dsr[t][4 * q + 1] = d.y;
+                        dsr[t][4 * q + 2] = d.z; dsr[t][4 * q + 3] = d.w;
+                        store4(p.sc.ds_pre, row, so, j0, d, row_ok, vec_so);
+                    }
+            } else if (!single) {  // later merged-axis groups: re-read this lane's own ds_pre stores
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
+                        const float4 d = load4(p.sc.ds_pre, row, so, j0, row_ok, vec_so);
+                        dsr[t][4 * q + 0] = d.x; dsr[t][4 * q + 1] = d.y;
+                        dsr[t][4 * q + 2] = d.z; dsr[t][4 * q + 3] = d.w;
+                    }
+            }
+            // scalar_out adjoint for this (merged group, output group): 16 * NTG k-pair steps
+            const float* wq = p.w.pack + S.offB + (((int64_t)ug * S.NS + (int64_t)g * NTG * 16) * 64 + lane) * NUG;
+            {
+                WFragB<NUG> an[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) an[u].load(wq + (int64_t)u * 64 * NUG);
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        WFragB<NUG> a[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a[u] = an[u];
+                        if (!(t == NTG - 1 && rb == 3)) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) an[u].load(wq + (int64_t)((t * 4 + rb + 1) * 4 + u) * 64 * NUG);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int uu = 0; uu < NUG; ++uu)
+                                acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[uu], dsr[t][rb * 4 + u], acc2[uu], 0, 0, 0);
+                    }
+            }
+        }
+        // epilogue of this merged-axis group: d_s_in columns go to HBM, the vector extras to LDS
+#pragma unroll
+        for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
+                if (k0 + 3 < si) {
+                    float4 v = make_float4(acc2[uu][4 * q], acc2[uu][4 * q + 1], acc2[uu][4 * q + 2], acc2[uu][4 * q + 3]);
+                    if (p.o.fused_residual) {
+                        const float4 dy = load4(p.d_s_out, row, so, k0, row_ok, vec_so);
+                        v.x += dy.x; v.y += dy.y; v.z += dy.z; v.w += dy.w;
+                    }
+                    store4(p.d_s_in, row, si, k0, v, row_ok, vec_si);
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int k = k0 + x;
+                        float val = acc2[uu][4 * q + x];
+                        if (k < si) {
+                            if (p.o.fused_residual && row_ok) val += p.d_s_out[(int64_t)row * so + k];
+                            if (row_ok) p.d_s_in[(int64_t)row * si + k] = val;
+                        } else if (k < S.K) {
+                            dext[e * L.DS + (k - si)] = val;
+                        }
+                    }
+                }
+            }
+    }
+    if (!has_vec) return;
+    __syncthreads();
+
+    // ---- 5. adjoint of the vector prologue: d vh, d vf, then d v_in --------------------------------------------
+    for (int h = hi; h < H; h += 2) {
+        const float dn = dext[e * L.DS + h] * rn[e * L.NS_ + h];
+        const float* wu = p.w.w_up;  // [vo, H]
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (has_vout)
+            for (int oc = 0; oc < vo; ++oc) {
+                const float w = wu[oc * H + h];
+                a0 = fmaf(w, dvut[e * L.US + 3 * oc + 0], a0);
+                a1 = fmaf(w, dvut[e * L.US + 3 * oc + 1], a1);
+                a2 = fmaf(w, dvut[e * L.US + 3 * oc + 2], a2);
+            }
+        dvhf[e * L.FS + 0 * HF + h] = a0 + dn * vht[e * L.HS + 3 * h + 0];
+        dvhf[e * L.FS + 1 * HF + h] = a1 + dn * vht[e * L.HS + 3 * h + 1];
+        dvhf[e * L.FS + 2 * HF + h] = a2 + dn * vht[e * L.HS + 3 * h + 2];
+    }
+    for (int k = hi; k < 3; k += 2) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (S.nf) {
+            const float* f = fr + e * 9;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float ds = dext[e * L.DS + H + 3 * k + a];
+                if (p.o.e3 && a == 1) ds *= dvhf[e * L.FS + 0 * HF + H + k];
+                a0 = fmaf(f[3 * a + 0], ds, a0);
+                a1 = fmaf(f[3 * a + 1], ds, a1);
+                a2 = fmaf(f[3 * a + 2], ds, a2);
+            }
+        }
+        dvhf[e * L.FS + 0 * HF + H + k] = a0;
+        dvhf[e * L.FS + 1 * HF + H + k] = a1;
+        dvhf[e * L.FS + 2 * HF + H + k] = a2;
+    }
+    __syncthreads();
+    if (row_ok) {
+        for (int i = hi; i < 3 * HF; i += 2) p.sc.dvhf[(int64_t)row * 3 * HF + i] = dvhf[e * L.FS + i];
+        for (int c = hi; c < vi; c += 2) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int h = 0; h < H; ++h) {
+                const float w = p.w.w_down[h * vi + c];
+                a0 = fmaf(w, dvhf[e * L.FS + 0 * HF + h], a0);
+                a1 = fmaf(w, dvhf[e * L.FS + 1 * HF + h], a1);
+                a2 = fmaf(w, dvhf[e * L.FS + 2 * HF + h], a2);
+            }
+            if (S.nf)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float w = p.w.w_frames[k * vi + c];
+                    a0 = fmaf(w, dvhf[e * L.FS + 0 * HF + H + k], a0);
+                    a1 = fmaf(w, dvhf[e * L.FS + 1 * HF + H + k], a1);
+                    a2 = fmaf(w, dvhf[e * L.FS + 2 * HF + H + k], a2);
+                }
+            if (p.o.vector_residual && has_vout) {
+                a0 += dvut[e * L.US + 3 * c + 0];
+                a1 += dvut[e * L.US + 3 * c + 1];
+                a2 += dvut[e * L.US + 3 * c + 2];
+            }
+            if (p.o.fused_residual) {
+                const float* gp = p.d_v_out + ((int64_t)row * vo + c) * 3;
+                a0 += gp[0]; a1 += gp[1]; a2 += gp[2];
+            }
+            float* dp = p.d_v_in + ((int64_t)row * vi + c) * 3;
+            dp[0] = a0; dp[1] = a1; dp[2] = a2;
+        }
+    }
+}
+
+template <int NTG, int NUG>
+int launch(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
+    static size_t cur_max = 64 * 1024;
+    if (lds_bytes > cur_max) {
+        hipError_t err = hipFuncSetAttribute((const void*)gcp2_bwd_kernel<NTG, NUG>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return (int)err;
+        cur_max = lds_bytes;
+    }
+    hipLaunchKernelGGL((gcp2_bwd_kernel<NTG, NUG>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
+                       lds_bytes, st, p);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NTG>
+int launch_ntg(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
+    switch (p.sh.NUG) {
+        case 1: return launch<NTG, 1>(p, lds_bytes, st);
+        case 2: return launch<NTG, 2>(p, lds_bytes, st);
+        default: return launch<NTG, 4>(p, lds_bytes, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
+                                    const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* s_pre,
+                                    const float* gate, const float* d_s_out, const float* d_v_out, float* d_s_in,
+                                    float* d_v_in, const gcp2_bwd_scratch_t* sc, void* stream) {
+    (void)s_in;
+    if (rows < 0 || !w || !opts || !sc || !s_pre || !d_s_out || !d_s_in || !w->pack || !sc->ds_pre) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    const bool has_vec = w->vi > 0;
+    if (has_vec) {
+        if (!v_in || v_in->n < 1 || !w->w_down || !d_v_in || !sc->ext || !sc->vh || !sc->vt || !sc->dvhf) return GCPNET_E_BADARG;
+        if (w->use_frames && (!frames || !w->w_frames)) return GCPNET_E_BADARG;
+        if (w->vo > 0 && (!d_v_out || !w->w_up || !sc->dvu)) return GCPNET_E_BADARG;
+    }
+    if (w->vo > 64) return GCPNET_E_UNSUPPORTED;
+    if (opts->fused_residual && (w->si != w->so || w->vi != w->vo)) return GCPNET_E_BADARG;
+    BwdParams p;
+    p.rows = rows;
+    if (has_vec) p.v_in = *v_in; else p.v_in.n = 0;
+    p.frames = frames;
+    p.w = *w;
+    p.o = *opts;
+    if (!has_vec) p.o.vmode = GCP_VMODE_NONE;
+    if (p.o.vmode == GCP_VMODE_SCALAR_GATE && w->vo > 0 && has_vec && (!gate || !sc->dgate || !w->w_gate)) return GCPNET_E_BADARG;
+    p.s_pre = s_pre; p.gate = gate; p.d_s_out = d_s_out; p.d_v_out = d_v_out;
+    p.d_s_in = d_s_in; p.d_v_in = d_v_in;
+    p.sc = *sc;
+    p.sh = gcp_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames);
+    const BwdLds L = bwd_lds(p.sh);
+    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.sh.NTG) {
+        case 1: return launch_ntg<1>(p, lds_bytes, st);
+        case 2: return launch_ntg<2>(p, lds_bytes, st);
+        default: return launch_ntg<4>(p, lds_bytes, st);
+    }
+}

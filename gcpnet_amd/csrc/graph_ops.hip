@@ -1,0 +1,317 @@
+// HBM-bound graph kernels on gfx950: segmented reductions over CSR-sorted edges, row gathers, frame construction,
+// GCPLayerNorm (+ residual) and a clamp/axpy.  Every kernel is a pure stream: the design goal is coalesced 16-byte
+// accesses and enough loads in flight per CU; reductions are wavefront-segmented (one 64-lane wave per node), so no
+// atomics are needed for scatter-add over variable-degree nodes.
+#include "common.h"
+
+namespace {
+
+// ---- segment reduce: replaces torch_scatter.scatter(sum|mean) on sorted segments --------------------------------
+// (reference call sites: components/gcpnet.py:946 aggregate, components/__init__.py:197 centroids, :316 node scalarize)
+template <bool VEC4>
+__global__ __launch_bounds__(256) void segment_reduce_kernel(int n_seg, const int32_t* __restrict__ seg_ptr,
+                                                             const int32_t* __restrict__ perm,
+                                                             const float* __restrict__ x, int64_t ldx, int D, int mean,
+                                                             float* __restrict__ out, int64_t ldo, int accumulate) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n_seg) return;
+    const int beg = seg_ptr[wave], end = seg_ptr[wave + 1];
+    const float scale = mean ? 1.0f / (float)max(end - beg, 1) : 1.0f;
+    if (VEC4) {
+        for (int d0 = lane * 4; d0 < D; d0 += 256) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            int p = beg;
+            for (; p + 3 < end; p += 4) {
+                const int64_t i0 = perm ? perm[p] : p, i1 = perm ? perm[p + 1] : p + 1;
+                const int64_t i2 = perm ? perm[p + 2] : p + 2, i3 = perm ? perm[p + 3] : p + 3;
+                const float4 v0 = *reinterpret_cast<const float4*>(x + i0 * ldx + d0);
+                const float4 v1 = *reinterpret_cast<const float4*>(x + i1 * ldx + d0);
+                const float4 v2 = *reinterpret_cast<const float4*>(x + i2 * ldx + d0);
+                const float4 v3 = *reinterpret_cast<const float4*>(x + i3 * ldx + d0);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; p < end; ++p) {
+                const int64_t i0 = perm ? perm[p] : p;
+                const float4 v0 = *reinterpret_cast<const float4*>(x + i0 * ldx + d0);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            }
+            float4 r;
+            r.x = ((a0.x + a1.x) + (a2.x + a3.x)) * scale;
+            r.y = ((a0.y + a1.y) + (a2.y + a3.y)) * scale;
+            r.z = ((a0.z + a1.z) + (a2.z + a3.z)) * scale;
+            r.w = ((a0.w + a1.w) + (a2.w + a3.w)) * scale;
+            float4* o = reinterpret_cast<float4*>(out + (int64_t)wave * ldo + d0);
+            if (accumulate) { const float4 t = *o; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+            *o = r;
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) {
+            float a0 = 0.f, a1 = 0.f;
+            int p = beg;
+            for (; p + 1 < end; p += 2) {
+                const int64_t i0 = perm ? perm[p] : p, i1 = perm ? perm[p + 1] : p + 1;
+                a0 += x[i0 * ldx + d];
+                a1 += x[i1 * ldx + d];
+            }
+            if (p < end) a0 += x[(int64_t)(perm ? perm[p] : p) * ldx + d];
+            float r = (a0 + a1) * scale;
+            float* o = out + (int64_t)wave * ldo + d;
+            if (accumulate) r += *o;
+            *o = r;
+        }
+    }
+}
+
+// ---- gather rows (adjoint of the segment reduce; also plain index_select) ---------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gather_rows_kernel(int rows, const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ x, int64_t ldx, int D,
+                                                          const float* __restrict__ scale, float* __restrict__ out,
+                                                          int64_t ldo) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const int64_t src = idx ? idx[r] : r;
+    const float s = scale ? scale[src] : 1.0f;
+    if (VEC4) {
+        for (int d0 = lane * 4; d0 < D; d0 += 256) {
+            float4 v = *reinterpret_cast<const float4*>(x + src * ldx + d0);
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            *reinterpret_cast<float4*>(out + (int64_t)r * ldo + d0) = v;
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) out[(int64_t)r * ldo + d] = x[src * ldx + d] * s;
+    }
+}
+
+// ---- localize: components/__init__.py:221-269 (unmasked) ---------------------------------------------------------
+__global__ __launch_bounds__(256) void localize_kernel(int n_edges, const int32_t* __restrict__ row,
+                                                       const int32_t* __restrict__ col, const float* __restrict__ x,
+                                                       int norm_x_diff, float* __restrict__ frames) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const float* xi = x + (int64_t)row[e] * 3;
+    const float* xj = x + (int64_t)col[e] * 3;
+    const float ax = xi[0], ay = xi[1], az = xi[2], bx = xj[0], by = xj[1], bz = xj[2];
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    if (norm_x_diff) {
+        const float dn = sqrtf(dx * dx + dy * dy + dz * dz) + 1.0f;
+        const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1.0f;
+        dx = dx / dn; dy = dy / dn; dz = dz / dn;
+        cx = cx / cn; cy = cy / cn; cz = cz / cn;
+    }
+    const float vx = dy * cz - dz * cy, vy = dz * cx - dx * cz, vz = dx * cy - dy * cx;
+    float* f = frames + (int64_t)e * 9;
+    f[0] = dx; f[1] = dy; f[2] = dz;
+    f[3] = cx; f[4] = cy; f[5] = cz;
+    f[6] = vx; f[7] = vy; f[8] = vz;
+}
+
+// ---- GCPLayerNorm (+ residual add): components/__init__.py:138-167 ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int rows, int sdim, int vdim, const float* __restrict__ s_a,
+                                                            const float* __restrict__ s_b,
+                                                            const float* __restrict__ v_a,
+                                                            const float* __restrict__ v_b,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ s_out,
+                                                            float* __restrict__ v_out, float* __restrict__ stats,
+                                                            float* __restrict__ s_sum, float* __restrict__ v_sum) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const int64_t so = (int64_t)r * sdim;
+    float acc = 0.f;
+    for (int j = lane; j < sdim; j += 64) {
+        float x = s_a[so + j];
+        if (s_b) x += s_b[so + j];
+        s_sum[so + j] = x;
+        acc += x;
+    }
+    const float mean = wave_sum(acc) / (float)sdim;
+    float var = 0.f;
+    for (int j = lane; j < sdim; j += 64) {
+        const float d = s_sum[so + j] - mean;
+        var += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)sdim + 1e-5f);
+    for (int j = lane; j < sdim; j += 64) s_out[so + j] = (s_sum[so + j] - mean) * rstd * gamma[j] + beta[j];
+    float vn = 1.f;
+    if (vdim > 0) {
+        const int64_t vo = (int64_t)r * vdim * 3;
+        float q = 0.f;
+        for (int c = lane; c < vdim; c += 64) {
+            float x0 = v_a[vo + 3 * c], x1 = v_a[vo + 3 * c + 1], x2 = v_a[vo + 3 * c + 2];
+            if (v_b) { x0 += v_b[vo + 3 * c]; x1 += v_b[vo + 3 * c + 1]; x2 += v_b[vo + 3 * c + 2]; }
+            v_sum[vo + 3 * c] = x0; v_sum[vo + 3 * c + 1] = x1; v_sum[vo + 3 * c + 2] = x2;
+            q += fmaxf(x0 * x0 + x1 * x1 + x2 * x2, 1e-8f);
+        }
+        vn = sqrtf(wave_sum(q) / (float)vdim);
+        const float inv = 1.0f / vn;
+        for (int i = lane; i < 3 * vdim; i += 64) v_out[vo + i] = v_sum[vo + i] * inv;
+    }
+    if (lane == 0) { stats[(int64_t)r * 3] = mean; stats[(int64_t)r * 3 + 1] = rstd; stats[(int64_t)r * 3 + 2] = vn; }
+}
+
+#define LN_MAX_PER_LANE 16  // sdim <= 1024
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, int vdim,
+                                                            const float* __restrict__ s_sum,
+                                                            const float* __restrict__ v_sum,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ d_s_out,
+                                                            const float* __restrict__ d_v_out, float* __restrict__ d_s,
+                                                            float* __restrict__ d_v, float* __restrict__ d_gamma,
+                                                            float* __restrict__ d_beta) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float dg[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int r = wave; r < rows; r += nwaves) {
+        const int64_t so = (int64_t)r * sdim;
+        const float mean = stats[(int64_t)r * 3], rstd = stats[(int64_t)r * 3 + 1], vn = stats[(int64_t)r * 3 + 2];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int j = lane + 64 * i;
+            if (j < sdim) {
+                const float dy = d_s_out[so + j], xh = (s_sum[so + j] - mean) * rstd, g = dy * gamma[j];
+                s1 += g; s2 += g * xh;
+                dg[i] += dy * xh; db[i] += dy;
+            }
+        }
+        s1 = wave_sum(s1) / (float)sdim;
+        s2 = wave_sum(s2) / (float)sdim;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int j = lane + 64 * i;
+            if (j < sdim) {
+                const float xh = (s_sum[so + j] - mean) * rstd;
+                d_s[so + j] = rstd * (d_s_out[so + j] * gamma[j] - s1 - xh * s2);
+            }
+        }
+        if (vdim > 0) {
+            const int64_t vo = (int64_t)r * vdim * 3;
+            float dot = 0.f;
+            for (int i = lane; i < 3 * vdim; i += 64) dot += d_v_out[vo + i] * v_sum[vo + i];
+            dot = wave_sum(dot);
+            const float inv = 1.0f / vn;
+            const float coef = dot * inv * inv * inv / (float)vdim;
+            for (int c = lane; c < vdim; c += 64) {
+                const float x0 = v_sum[vo + 3 * c], x1 = v_sum[vo + 3 * c + 1], x2 = v_sum[vo + 3 * c + 2];
+                const float m = (x0 * x0 + x1 * x1 + x2 * x2) > 1e-8f ? coef : 0.f;  // clamp(min=eps) passes no gradient below eps
+                d_v[vo + 3 * c] = d_v_out[vo + 3 * c] * inv - m * x0;
+                d_v[vo + 3 * c + 1] = d_v_out[vo + 3 * c + 1] * inv - m * x1;
+                d_v[vo + 3 * c + 2] = d_v_out[vo + 3 * c + 2] * inv - m * x2;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int j = lane + 64 * i;
+        if (j < sdim) { atomicAdd(d_gamma + j, dg[i]); atomicAdd(d_beta + j, db[i]); }
+    }
+}
+
+__global__ void axpy_clamp_kernel(int64_t n, const float* __restrict__ a, const float* __restrict__ b, float alpha,
+                                  int clamp, float lo, float hi, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float u = alpha * b[i];
+        if (clamp) u = fminf(fmaxf(u, lo), hi);
+        y[i] = (a ? a[i] : 0.f) + u;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int gcpnet_segment_reduce(int n_seg, const int32_t* seg_ptr, const int32_t* perm, const float* x, int64_t ldx,
+                                     int D, int mean, float* out, int64_t ldo, int accumulate, void* stream) {
+    if (n_seg < 0 || D <= 0 || !seg_ptr || !x || !out) return GCPNET_E_BADARG;
+    if (n_seg == 0) return 0;
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+    const dim3 grid((unsigned)gcp_cdiv(n_seg, 4)), block(256);
+    if (vec)
+        hipLaunchKernelGGL(segment_reduce_kernel<true>, grid, block, 0, (hipStream_t)stream, n_seg, seg_ptr, perm, x, ldx,
+                           D, mean, out, ldo, accumulate);
+    else
+        hipLaunchKernelGGL(segment_reduce_kernel<false>, grid, block, 0, (hipStream_t)stream, n_seg, seg_ptr, perm, x,
+                           ldx, D, mean, out, ldo, accumulate);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_gather_rows(int rows, const int32_t* idx, const float* x, int64_t ldx, int D, const float* scale,
+                                  float* out, int64_t ldo, void* stream) {
+    if (rows < 0 || D <= 0 || !x || !out) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+    const dim3 grid((unsigned)gcp_cdiv(rows, 4)), block(256);
+    if (vec)
+        hipLaunchKernelGGL(gather_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, rows, idx, x, ldx, D, scale, out, ldo);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, rows, idx, x, ldx, D, scale, out, ldo);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_localize(int n_edges, const int32_t* row, const int32_t* col, const float* x, int norm_x_diff,
+                               float* frames, void* stream) {
+    if (n_edges < 0 || !row || !col || !x || !frames) return GCPNET_E_BADARG;
+    if (n_edges == 0) return 0;
+    hipLaunchKernelGGL(localize_kernel, dim3((unsigned)gcp_cdiv(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, n_edges,
+                       row, col, x, norm_x_diff, frames);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_layernorm_forward(int rows, int sdim, int vdim, const float* s_a, const float* s_b, const float* v_a,
+                                        const float* v_b, const float* gamma, const float* beta, float* s_out,
+                                        float* v_out, float* stats, float* s_sum, float* v_sum, void* stream) {
+    if (rows < 0 || sdim <= 0 || vdim < 0 || !s_a || !gamma || !beta || !s_out || !stats || !s_sum) return GCPNET_E_BADARG;
+    if (vdim > 0 && (!v_a || !v_out || !v_sum)) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)gcp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows,
+                       sdim, vdim, s_a, s_b, v_a, v_b, gamma, beta, s_out, v_out, stats, s_sum, v_sum);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const float* s_sum, const float* v_sum,
+                                         const float* stats, const float* gamma, const float* d_s_out,
+                                         const float* d_v_out, float* d_s, float* d_v, float* d_gamma, float* d_beta,
+                                         void* stream) {
+    if (rows < 0 || sdim <= 0 || vdim < 0 || !s_sum || !stats || !gamma || !d_s_out || !d_s || !d_gamma || !d_beta)
+        return GCPNET_E_BADARG;
+    if (sdim > 64 * LN_MAX_PER_LANE) return GCPNET_E_UNSUPPORTED;
+    if (vdim > 0 && (!v_sum || !d_v_out || !d_v)) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    const int blocks = min(gcp_cdiv(rows, 4), 512);  // d_gamma / d_beta must be zeroed by the caller
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, sdim, vdim, s_sum,
+                       v_sum, stats, gamma, d_s_out, d_v_out, d_s, d_v, d_gamma, d_beta);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi,
+                                 float* y, void* stream) {
+    if (n < 0 || !b || !y) return GCPNET_E_BADARG;
+    if (n == 0) return 0;
+    const int64_t nb = (n + 255) / 256;
+    const int blocks = (int)(nb < 2048 ? nb : 2048);
+    hipLaunchKernelGGL(axpy_clamp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b, alpha, clamp, lo, hi, y);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}

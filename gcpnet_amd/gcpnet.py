@@ -1,0 +1,389 @@
+"""Host-side mirror of the reference's `src/models/components/gcpnet.py` hot path:
+GCP2, GCPEmbedding, get_GCP_with_custom_cfg, GCPMessagePassing, GCPInteractions.
+
+Same constructor / forward signatures, same parameter (state_dict) names, same config keys, same Python error
+behaviour; the arithmetic is launched on the MI355X through gcpnet_amd.ops.  Citations are file:line in
+/root/reference/src/models/components/gcpnet.py.
+"""
+from __future__ import annotations
+
+from copy import copy
+from functools import partial
+from typing import Any, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import VMODE_NONE, VMODE_SCALAR_GATE, VMODE_SELF_GATE
+from .components import GCPDropout, GCPLayerNorm, ScalarVector, canonical_act
+from .config import to_container
+from .ops import GatherPlan, Gcp2Spec, GraphPlan
+
+NUM_ATOM_TYPES = 9  # src/datamodules/components/atom3d_dataset.py:20-33
+
+
+def _sv_add(a, b) -> "ScalarVector":
+    return ScalarVector(ops.axpy(a[0], b[0], 1.0), ops.axpy(a[1], b[1], 1.0))
+
+
+def _unsupported(what: str):
+    raise NotImplementedError(f"{what} is not on the MI355X path yet (SURVEY.md section 8, rows f2/f3)")
+
+
+class GCP2(nn.Module):
+    """Geometry-complete perceptron, :252-468.  Parameters are created in the reference's order so that the same
+    seed yields the same initial weights."""
+
+    def __init__(
+        self,
+        input_dims,
+        output_dims,
+        nonlinearities: Tuple[Optional[str]] = ("relu", "sigmoid"),
+        scalar_gate: int = 0,
+        vector_gate: bool = True,
+        frame_gate: bool = False,
+        sigma_frame_gate: bool = False,
+        bottleneck: int = 1,
+        vector_residual: bool = False,
+        vector_frame_residual: bool = False,
+        ablate_frame_updates: bool = False,
+        ablate_scalars: bool = False,
+        ablate_vectors: bool = False,
+        enable_e3_equivariance: bool = False,
+        scalarization_vectorization_output_dim: int = 3,
+        **kwargs,
+    ):
+        super().__init__()
+        if nonlinearities is None:
+            nonlinearities = (None, None)
+        self.scalar_input_dim, self.vector_input_dim = input_dims
+        self.scalar_output_dim, self.vector_output_dim = output_dims
+        self.act_s, self.act_v = canonical_act(nonlinearities[0]), canonical_act(nonlinearities[1])
+        self.scalar_gate, self.vector_gate, self.frame_gate, self.sigma_frame_gate = (
+            scalar_gate, vector_gate, frame_gate, sigma_frame_gate)
+        self.vector_residual, self.vector_frame_residual = vector_residual, vector_frame_residual
+        self.ablate_frame_updates = ablate_frame_updates
+        self.ablate_scalars, self.ablate_vectors = ablate_scalars, ablate_vectors
+        self.enable_e3_equivariance = enable_e3_equivariance
+        self.slope = 1e-2
+        if scalarization_vectorization_output_dim != 3:
+            _unsupported("scalarization_vectorization_output_dim != 3")
+
+        if self.scalar_gate > 0:  # created but never used by the reference's GCP2.forward (:290-291)
+            self.norm = nn.LayerNorm(self.scalar_output_dim)
+
+        self.hidden_dim = 0
+        if self.vector_input_dim:
+            assert self.vector_input_dim % bottleneck == 0, (
+                f"Input channel of vector ({self.vector_input_dim}) must be divisible with bottleneck factor ({bottleneck})")
+            self.hidden_dim = (self.vector_input_dim // bottleneck if bottleneck > 1
+                               else max(self.vector_input_dim, self.vector_output_dim))
+            frame_dim = 9 if not ablate_frame_updates else 0
+            self.vector_down = nn.Linear(self.vector_input_dim, self.hidden_dim, bias=False)
+            self.scalar_out = nn.Linear(self.hidden_dim + self.scalar_input_dim + frame_dim, self.scalar_output_dim)
+            if not ablate_frame_updates:
+                self.vector_down_frames = nn.Linear(self.vector_input_dim, 3, bias=False)
+            if self.vector_output_dim:
+                self.vector_up = nn.Linear(self.hidden_dim, self.vector_output_dim, bias=False)
+                if not ablate_frame_updates and self.frame_gate:
+                    self.vector_out_scale_frames = nn.Linear(self.scalar_output_dim, 9)
+                    self.vector_up_frames = nn.Linear(3, self.vector_output_dim, bias=False)
+                elif self.vector_gate:
+                    self.vector_out_scale = nn.Linear(self.scalar_output_dim, self.vector_output_dim)
+        else:
+            self.scalar_out = nn.Linear(self.scalar_input_dim, self.scalar_output_dim)
+        self._pack_cache: dict = {}
+
+    # ---- kernel dispatch ------------------------------------------------------------------------------------
+    def _vmode(self) -> int:
+        if not (self.vector_input_dim and self.vector_output_dim):
+            return VMODE_NONE
+        if self.frame_gate and not self.ablate_frame_updates:
+            _unsupported("GCP2(frame_gate=True) (vectorize path)")
+        if self.vector_gate:
+            return VMODE_SCALAR_GATE
+        return VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
+
+    def _weights(self):
+        g = lambda name: getattr(self, name).weight if hasattr(self, name) else None
+        gate = getattr(self, "vector_out_scale", None)
+        return (self.scalar_out.weight, self.scalar_out.bias, g("vector_down"), g("vector_down_frames"), g("vector_up"),
+                None if gate is None else gate.weight, None if gate is None else gate.bias)
+
+    def apply_rows(self, s_sources: Sequence[torch.Tensor], s_plans: Sequence[Optional[GatherPlan]],
+                   v_sources: Sequence[torch.Tensor], v_plans: Sequence[Optional[GatherPlan]],
+                   row_frames: Optional[torch.Tensor], residual: bool = False):
+        """Runs the block on rows whose inputs are concatenations of (optionally gathered) sources.  `row_frames`
+        holds one frame per row.  With `residual` the result is x + GCP(x) for the single source x (ResGCP)."""
+        use_frames = bool(self.vector_input_dim) and not self.ablate_frame_updates
+        spec = Gcp2Spec(
+            si=self.scalar_input_dim, vi=self.vector_input_dim, so=self.scalar_output_dim, vo=self.vector_output_dim,
+            hidden=self.hidden_dim, use_frames=use_frames, act_s=self.act_s, act_v=self.act_v, slope=self.slope,
+            vmode=self._vmode(), vector_residual=bool(self.vector_residual) and bool(self.vector_input_dim),
+            e3=bool(self.enable_e3_equivariance), s_plans=list(s_plans), v_plans=list(v_plans), residual=residual,
+            pack_cache=self._pack_cache)
+        return ops.gcp2(spec, s_sources, v_sources, row_frames if use_frames else None, self._weights())
+
+    def forward(self, s_maybe_v, edge_index, frames, node_inputs: bool = False, node_mask=None):
+        """:394-468.  Returns ScalarVector, or a Tensor when the block has no vector output."""
+        if node_mask is not None:
+            _unsupported("GCP2.forward(node_mask=...)")
+        if self.vector_input_dim:
+            s, v = s_maybe_v
+            if self.ablate_scalars:
+                s = torch.zeros_like(s)
+            if self.ablate_vectors:
+                v = torch.zeros_like(v)
+            row_frames = None
+            if not self.ablate_frame_updates:
+                if node_inputs:
+                    if self.enable_e3_equivariance:
+                        _unsupported("enable_e3_equivariance with node_inputs=True")
+                    row_frames = GraphPlan.get(edge_index, s.shape[0]).node_frames(frames)
+                else:
+                    row_frames = frames
+            out = self.apply_rows([s], [None], [v], [None], row_frames)
+        else:
+            out = self.apply_rows([s_maybe_v], [None], [], [], None)
+        if not self.vector_output_dim:
+            return torch.zeros_like(out) if self.ablate_scalars else out
+        s_out, v_out = out
+        if self.ablate_scalars:
+            s_out = torch.zeros_like(s_out)
+        if self.ablate_vectors:
+            v_out = torch.zeros_like(v_out)
+        return ScalarVector(s_out, v_out)
+
+
+def get_GCP_with_custom_cfg(input_dims, output_dims, cfg, **kwargs):
+    """:826-835 -- the whole module_cfg is forwarded; unknown keys are swallowed by GCP2's **kwargs."""
+    cfg_dict = copy(to_container(cfg))
+    cfg_dict["nonlinearities"] = cfg.nonlinearities
+    del cfg_dict["scalar_nonlinearity"]
+    del cfg_dict["vector_nonlinearity"]
+    for key in kwargs:
+        cfg_dict[key] = kwargs[key]
+    return cfg.selected_GCP(input_dims, output_dims, **cfg_dict)
+
+
+class GCPEmbedding(nn.Module):
+    """:703-823"""
+
+    def __init__(self, edge_input_dims, node_input_dims, edge_hidden_dims, node_hidden_dims,
+                 num_atom_types: int = NUM_ATOM_TYPES, nonlinearities: Tuple[Optional[str]] = (None, None),
+                 num_lig_flags: int = 2, cfg=None, pre_norm: bool = True):
+        super().__init__()
+        edge_input_dims, node_input_dims = ScalarVector(*edge_input_dims), ScalarVector(*node_input_dims)
+        self.atom_embedding = nn.Embedding(num_atom_types, num_atom_types) if num_atom_types > 0 else None
+        self.concatenate_lig_flag = getattr(cfg, "concatenate_lig_flag", None)
+        if self.concatenate_lig_flag:
+            node_input_dims = ScalarVector(node_input_dims[0] + num_lig_flags, node_input_dims[1])
+            self.lig_flag_embedding = nn.Embedding(num_lig_flags, num_lig_flags)
+        self.pre_norm = pre_norm
+        if pre_norm:
+            self.edge_normalization = GCPLayerNorm(edge_input_dims)
+            self.node_normalization = GCPLayerNorm(node_input_dims)
+        else:
+            self.edge_normalization = GCPLayerNorm(edge_hidden_dims)
+            self.node_normalization = GCPLayerNorm(node_hidden_dims)
+        common = dict(
+            scalar_gate=cfg.scalar_gate, vector_gate=cfg.vector_gate, frame_gate=cfg.frame_gate,
+            sigma_frame_gate=cfg.sigma_frame_gate, vector_frame_residual=cfg.vector_frame_residual,
+            ablate_frame_updates=cfg.ablate_frame_updates, ablate_scalars=cfg.ablate_scalars,
+            ablate_vectors=cfg.ablate_vectors, enable_e3_equivariance=cfg.enable_e3_equivariance)
+        self.edge_embedding = cfg.selected_GCP(edge_input_dims, edge_hidden_dims, nonlinearities=nonlinearities, **common)
+        self.node_embedding = cfg.selected_GCP(node_input_dims, node_hidden_dims, nonlinearities=(None, None), **common)
+
+    def forward(self, batch):
+        h = self.atom_embedding(batch.h) if self.atom_embedding is not None else batch.h
+        if self.concatenate_lig_flag:
+            h = torch.cat((h, self.lig_flag_embedding(batch.lig_flag.long())), dim=-1)
+        node_rep = ScalarVector(h, batch.chi)
+        edge_rep = ScalarVector(batch.e, batch.xi)
+        edge_rep = edge_rep.scalar if not self.edge_embedding.vector_input_dim else edge_rep
+        node_rep = node_rep.scalar if not self.node_embedding.vector_input_dim else node_rep
+        mask = getattr(batch, "mask", None)
+        if self.pre_norm:
+            edge_rep = self.edge_normalization(edge_rep)
+            node_rep = self.node_normalization(node_rep)
+        edge_rep = self.edge_embedding(edge_rep, batch.edge_index, batch.f_ij, node_inputs=False, node_mask=mask)
+        node_rep = self.node_embedding(node_rep, batch.edge_index, batch.f_ij, node_inputs=True, node_mask=mask)
+        if not self.pre_norm:
+            edge_rep = self.edge_normalization(edge_rep)
+            node_rep = self.node_normalization(node_rep)
+        return node_rep, edge_rep
+
+
+class GCPMessagePassing(nn.Module):
+    """:838-960"""
+
+    def __init__(self, input_dims, output_dims, edge_dims, cfg, mp_cfg, reduce_function: str = "mean",
+                 use_scalar_message_attention: bool = False, aggregate_with_row: bool = False):
+        super().__init__()
+        input_dims, output_dims, edge_dims = ScalarVector(*input_dims), ScalarVector(*output_dims), ScalarVector(*edge_dims)
+        self.scalar_input_dim, self.vector_input_dim = input_dims
+        self.scalar_output_dim, self.vector_output_dim = output_dims
+        self.edge_scalar_dim, self.edge_vector_dim = edge_dims
+        self.conv_cfg = mp_cfg
+        self.self_message = self.conv_cfg.self_message
+        self.use_residual_message_gcp = self.conv_cfg.use_residual_message_gcp
+        self.reduce_function = reduce_function
+        self.use_scalar_message_attention = use_scalar_message_attention
+        self.aggregate_with_row = aggregate_with_row
+        if reduce_function not in ("mean", "sum", "add"):
+            raise NotImplementedError(reduce_function)
+        if use_scalar_message_attention:
+            _unsupported("GCPMessagePassing(use_scalar_message_attention=True)")
+
+        scalars_in_dim = 2 * self.scalar_input_dim + self.edge_scalar_dim
+        vectors_in_dim = 2 * self.vector_input_dim + self.edge_vector_dim
+
+        soft_cfg = copy(cfg)  # :867-868
+        soft_cfg.bottleneck, soft_cfg.vector_residual = cfg.default_bottleneck, cfg.default_vector_residual
+        primary = partial(get_GCP_with_custom_cfg, cfg=soft_cfg)
+        secondary = partial(get_GCP_with_custom_cfg, cfg=cfg)
+        n_layers = self.conv_cfg.num_message_layers
+        modules = [primary((scalars_in_dim, vectors_in_dim), output_dims,
+                           nonlinearities=cfg.nonlinearities if n_layers > 1 else None,
+                           enable_e3_equivariance=cfg.enable_e3_equivariance)]
+        for _ in range(n_layers - 2):
+            modules.append(secondary(output_dims, output_dims, enable_e3_equivariance=cfg.enable_e3_equivariance))
+        if n_layers > 1:
+            modules.append(primary(output_dims, output_dims, nonlinearities=(None, None),
+                                   enable_e3_equivariance=cfg.enable_e3_equivariance))
+        self.message_fusion = nn.ModuleList(modules)
+
+    def _messages(self, node_rep, edge_rep, edge_index, frames) -> ScalarVector:
+        h, chi = node_rep
+        e, xi = edge_rep
+        plan = GraphPlan.get(edge_index, h.shape[0])
+        first = self.message_fusion[0]
+        # message = [h_row | e | h_col], [chi_row | xi | chi_col] (:907-917): gathered inside the kernel's tile loader
+        m = first.apply_rows([h, e, h], [plan.row, None, plan.col], [chi, xi, chi], [plan.row, None, plan.col], frames)
+        m = ScalarVector(*m)
+        for module in self.message_fusion[1:]:
+            same = (module.scalar_input_dim == module.scalar_output_dim
+                    and module.vector_input_dim == module.vector_output_dim)
+            if self.use_residual_message_gcp and same:  # ResGCP (:921-924), residual add fused into the kernel
+                m = ScalarVector(*module.apply_rows([m[0]], [None], [m[1]], [None], frames, residual=True))
+            elif self.use_residual_message_gcp:
+                m = _sv_add(m, module.apply_rows([m[0]], [None], [m[1]], [None], frames))
+            else:
+                m = ScalarVector(*module.apply_rows([m[0]], [None], [m[1]], [None], frames))
+        return m
+
+    def message(self, node_rep, edge_rep, edge_index, frames, node_mask=None):
+        if node_mask is not None:
+            _unsupported("GCPMessagePassing(node_mask=...)")
+        return self._messages(ScalarVector(*node_rep), ScalarVector(*edge_rep), edge_index, frames).flatten()
+
+    def aggregate(self, message, edge_index, dim_size: int):
+        plan = GraphPlan.get(edge_index, dim_size)
+        side = plan.row if self.aggregate_with_row else plan.col
+        return ops.segment_reduce(message, side, mean=self.reduce_function == "mean")
+
+    def forward(self, node_rep, edge_rep, edge_index, frames, node_mask=None) -> ScalarVector:
+        if node_mask is not None:
+            _unsupported("GCPMessagePassing(node_mask=...)")
+        node_rep, edge_rep = ScalarVector(*node_rep), ScalarVector(*edge_rep)
+        m = self._messages(node_rep, edge_rep, edge_index, frames)
+        n = node_rep[0].shape[0]
+        plan = GraphPlan.get(edge_index, n)
+        side = plan.row if self.aggregate_with_row else plan.col
+        mean = self.reduce_function == "mean"
+        # scatter(message, col, reduce) (:939-947) as wavefront-segmented reductions over the CSR segments
+        agg_s = ops.segment_reduce(m[0], side, mean)
+        agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], -1), side, mean).reshape(n, self.vector_output_dim, 3)
+        return ScalarVector(agg_s, agg_v)
+
+
+class GCPInteractions(nn.Module):
+    """:963-1262 (non-autoregressive, unmasked call paths)."""
+
+    def __init__(self, node_dims, edge_dims, cfg, layer_cfg, dropout: float = 0.1, autoregressive: bool = False,
+                 nonlinearities: Optional[Tuple[Any, Any]] = None, updating_node_positions: bool = False):
+        super().__init__()
+        node_dims, edge_dims = ScalarVector(*node_dims), ScalarVector(*edge_dims)
+        if nonlinearities is None:
+            nonlinearities = cfg.nonlinearities
+        self.pre_norm = layer_cfg.pre_norm
+        self.updating_node_positions = updating_node_positions
+        self.ablate_x_force_update = getattr(cfg, "ablate_x_force_update", True)
+        self.node_positions_weight = getattr(cfg, "node_positions_weight", 1.0)
+        reduce_function = "add" if autoregressive else "mean"
+
+        self.interaction = GCPMessagePassing(node_dims, node_dims, edge_dims, reduce_function=reduce_function, cfg=cfg,
+                                             mp_cfg=layer_cfg.mp_cfg)
+
+        ff_cfg = copy(cfg)  # :1001-1004
+        ff_cfg.nonlinearities = nonlinearities
+        ff_without_res_cfg = copy(cfg)
+        ff_without_res_cfg.vector_residual = False
+        ff_GCP = partial(get_GCP_with_custom_cfg, cfg=ff_cfg)
+        ff_without_res_GCP = partial(get_GCP_with_custom_cfg, cfg=ff_without_res_cfg)
+
+        self.gcp_norm = nn.ModuleList([GCPLayerNorm(node_dims) for _ in range(2)])
+        self.gcp_dropout = nn.ModuleList([GCPDropout(dropout) for _ in range(2)])
+
+        n_ff = layer_cfg.num_feedforward_layers
+        # the reference's un-parenthesised conditional (:1014) evaluates to this tuple
+        hidden_dims = (node_dims if n_ff == 1 else 4 * node_dims.scalar), 2 * node_dims.vector
+        ff = [ff_without_res_GCP(node_dims, hidden_dims, nonlinearities=None if n_ff == 1 else cfg.nonlinearities,
+                                 enable_e3_equivariance=cfg.enable_e3_equivariance)]
+        ff.extend(ff_GCP(hidden_dims, hidden_dims, enable_e3_equivariance=cfg.enable_e3_equivariance)
+                  for _ in range(n_ff - 2))
+        if n_ff > 1:
+            ff.append(ff_without_res_GCP(hidden_dims, node_dims, nonlinearities=(None, None),
+                                         enable_e3_equivariance=cfg.enable_e3_equivariance))
+        self.feedforward_network = nn.ModuleList(ff)
+
+        if updating_node_positions:
+            self.node_position_update_network = nn.ModuleList([
+                ff_without_res_GCP(node_dims, (node_dims.scalar, 1), nonlinearities=cfg.nonlinearities,
+                                   enable_e3_equivariance=cfg.enable_e3_equivariance)])
+            if not self.ablate_x_force_update:
+                _unsupported("GCPInteractions with ablate_x_force_update=False (force update)")
+            self.phi_force_i = self.phi_force_j = self.phi_force_ij = None
+
+    def derive_x_update(self, node_rep, edge_index, f_ij, node_mask=None):
+        """:1119-1158 with the force term ablated (every shipped config).  Returns the un-weighted vector update;
+        the weight and clamp are applied together with the position add."""
+        h_v, chi_v = node_rep
+        for gcp in self.node_position_update_network:
+            h_v, chi_v = gcp((h_v, chi_v), edge_index, f_ij, node_inputs=True, node_mask=node_mask)
+        return chi_v.reshape(chi_v.shape[0], 3)
+
+    def forward(self, node_rep, edge_rep, edge_index, frames, node_rep_regressive=None, node_mask=None, node_pos=None):
+        if node_rep_regressive is not None:
+            _unsupported("GCPInteractions autoregressive forward")
+        if node_mask is not None:
+            _unsupported("GCPInteractions(node_mask=...)")
+        node_rep = ScalarVector(node_rep[0], node_rep[1])
+        edge_rep = ScalarVector(edge_rep[0], edge_rep[1])
+
+        if self.pre_norm:
+            node_rep = self.gcp_norm[0](node_rep)
+        hidden = self.interaction(node_rep, edge_rep, edge_index, frames)
+        if self.gcp_dropout[0].active:
+            hidden = self.gcp_dropout[0](hidden)
+        if self.pre_norm:  # :1220-1226
+            node_rep = self.gcp_norm[1](node_rep, residual=hidden)
+        else:
+            node_rep = self.gcp_norm[0](node_rep, residual=hidden)
+
+        hidden = node_rep
+        for module in self.feedforward_network:
+            hidden = module(hidden, edge_index, frames, node_inputs=True)
+        if self.gcp_dropout[1].active:
+            hidden = self.gcp_dropout[1](hidden)
+        if self.pre_norm:  # :1242-1246
+            node_rep = _sv_add(node_rep, hidden)
+        else:
+            node_rep = self.gcp_norm[1](node_rep, residual=hidden)
+
+        if not self.updating_node_positions:
+            return node_rep
+        upd = self.derive_x_update(node_rep, edge_index, frames)
+        node_pos = ops.axpy_clamp(node_pos, upd, float(self.node_positions_weight), -100.0, 100.0)  # :1156-1158,1258
+        return node_rep, node_pos

@@ -1,0 +1,510 @@
+"""Operators of the hot path: thin autograd wrappers that launch the HIP kernels through the C ABI.
+
+Every function here requires CUDA(HIP) tensors and libgcpnet_hip.so; nothing falls back to PyTorch arithmetic.
+PyTorch provides device allocations, the current stream and the autograd graph -- plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (ACT, BwdScratch, Concat, Gcp2Opts, Gcp2Weights, Operand, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
+                   VMODE_SELF_GATE, check)
+
+Tensor = torch.Tensor
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise _lib.GcpnetHipError(f"{name} must live on the GPU: gcpnet_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ==============================================================================================================
+# graph plans (host-side preprocessing; sorting/counting is data preparation)
+# ==============================================================================================================
+class GatherPlan:
+    """Index structure for `out[r] = src[idx[r]]` and its adjoint (segmented sum over rows sharing idx)."""
+
+    def __init__(self, idx: Tensor, n_src: int):
+        idx64 = idx.long()
+        self.n_src = int(n_src)
+        self.rows = int(idx64.shape[0])
+        self.idx = idx64.to(torch.int32).contiguous()
+        if self.rows > 1 and not bool((idx64[1:] >= idx64[:-1]).all()):
+            order = torch.argsort(idx64, stable=True)
+            self.perm: Optional[Tensor] = order.to(torch.int32).contiguous()
+        else:
+            self.perm = None
+        counts = torch.bincount(idx64, minlength=self.n_src)
+        ptr = torch.zeros(self.n_src + 1, dtype=torch.int64, device=idx.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        self.seg_ptr = ptr.to(torch.int32).contiguous()
+        self.inv_count = (1.0 / counts.clamp(min=1).to(torch.float32)).contiguous()
+
+
+class GraphPlan:
+    """Per-batch preprocessing of `edge_index` ([2, E], row = source, col = target), cached on the caller's
+    tensor: int32 copies, CSR by col (aggregation), CSR by row (node scalarize), and the per-node mean frame."""
+
+    _cache: dict = {}
+
+    def __init__(self, edge_index: Tensor, n_nodes: int):
+        self.n_nodes, self.n_edges = int(n_nodes), int(edge_index.shape[1])
+        self.row = GatherPlan(edge_index[0], n_nodes)
+        self.col = GatherPlan(edge_index[1], n_nodes)
+        self._fbar_key = None
+        self._fbar = None
+
+    @classmethod
+    def get(cls, edge_index: Tensor, n_nodes: int) -> "GraphPlan":
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), int(n_nodes), edge_index._version, str(edge_index.device))
+        hit = cls._cache.get(key)
+        if hit is not None and hit[0]() is edge_index:
+            return hit[1]
+        import weakref
+
+        plan = cls(edge_index, n_nodes)
+        if len(cls._cache) > 64:
+            cls._cache.clear()
+        cls._cache[key] = (weakref.ref(edge_index), plan)
+        return plan
+
+    def node_frames(self, frames: Tensor) -> Tensor:
+        """Mean frame over each node's out-edges (row == node); zero for nodes without out-edges.
+        scalarize(node_inputs=True) (components/__init__.py:286,302,314-323) is linear in the frame, so the
+        gather-by-row / project / scatter-mean-by-row sequence equals one projection onto this mean frame."""
+        key = (frames.data_ptr(), frames._version)
+        if self._fbar_key != key:
+            with torch.no_grad():
+                flat = _req(frames, "frames").reshape(self.n_edges, 9)
+                self._fbar = segment_reduce(flat, self.row, mean=True).reshape(self.n_nodes, 3, 3)
+            self._fbar_key = key
+        return self._fbar
+
+
+# ==============================================================================================================
+# segment reduce / gather
+# ==============================================================================================================
+def _segment_reduce_raw(x: Tensor, col0: int, D: int, ld: int, plan: GatherPlan, mean: bool) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((plan.n_src, D), dtype=torch.float32, device=x.device)
+    check(lib.gcpnet_segment_reduce(plan.n_src, _p(plan.seg_ptr), _p(plan.perm), C.c_void_p(x.data_ptr() + 4 * col0), ld,
+                                    D, int(mean), _p(out), D, 0, _stream()), "segment_reduce")
+    return out
+
+
+def _gather_rows_raw(x: Tensor, plan: GatherPlan, scale: Optional[Tensor]) -> Tensor:
+    lib = _lib.load()
+    D = x.shape[1]
+    out = torch.empty((plan.rows, D), dtype=torch.float32, device=x.device)
+    check(lib.gcpnet_gather_rows(plan.rows, _p(plan.idx), _p(x), D, D, _p(scale), _p(out), D, _stream()), "gather_rows")
+    return out
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, mean):
+        ctx.plan, ctx.mean = plan, mean
+        return _segment_reduce_raw(x, 0, x.shape[1], x.shape[1], plan, mean)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _req(g, "grad")
+        return _gather_rows_raw(g, ctx.plan, ctx.plan.inv_count if ctx.mean else None), None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        return _gather_rows_raw(x, plan, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _req(g, "grad")
+        return _segment_reduce_raw(g, 0, g.shape[1], g.shape[1], ctx.plan, False), None
+
+
+def segment_reduce(x: Tensor, plan: GatherPlan, mean: bool) -> Tensor:
+    """torch_scatter.scatter(x, plan.idx, dim=0, dim_size=plan.n_src, reduce='mean'|'sum') for 2-D x."""
+    x = _req(x, "x")
+    assert x.dim() == 2 and x.shape[0] == plan.rows
+    return _SegmentReduce.apply(x, plan, bool(mean))
+
+
+def gather_rows(x: Tensor, plan: GatherPlan) -> Tensor:
+    x = _req(x, "x")
+    assert x.dim() == 2 and x.shape[0] == plan.n_src
+    return _GatherRows.apply(x, plan)
+
+
+# ==============================================================================================================
+# frames
+# ==============================================================================================================
+def localize(x: Tensor, plan: GraphPlan, norm_x_diff: bool = True) -> Tensor:
+    lib = _lib.load()
+    x = _req(x.detach(), "x")
+    frames = torch.empty((plan.n_edges, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib.gcpnet_localize(plan.n_edges, _p(plan.row.idx), _p(plan.col.idx), _p(x), int(norm_x_diff), _p(frames),
+                              _stream()), "localize")
+    return frames
+
+
+# ==============================================================================================================
+# GCPLayerNorm (+ residual)
+# ==============================================================================================================
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s_a, s_b, v_a, v_b, gamma, beta):
+        lib = _lib.load()
+        rows, sdim = s_a.shape
+        vdim = 0 if v_a is None else v_a.shape[1]
+        s_out, s_sum = torch.empty_like(s_a), torch.empty_like(s_a)
+        v_out = torch.empty_like(v_a) if vdim else None
+        v_sum = torch.empty_like(v_a) if vdim else None
+        stats = torch.empty((rows, 3), dtype=torch.float32, device=s_a.device)
+        check(lib.gcpnet_layernorm_forward(rows, sdim, vdim, _p(s_a), _p(s_b), _p(v_a), _p(v_b), _p(gamma), _p(beta),
+                                           _p(s_out), _p(v_out), _p(stats), _p(s_sum), _p(v_sum), _stream()), "layernorm")
+        ctx.save_for_backward(s_sum, v_sum, stats, gamma)
+        ctx.has_b = (s_b is not None, v_b is not None)
+        ctx.vdim = vdim
+        if vdim:
+            return s_out, v_out
+        ctx.mark_non_differentiable()
+        return s_out, None
+
+    @staticmethod
+    def backward(ctx, d_s, d_v):
+        lib = _lib.load()
+        s_sum, v_sum, stats, gamma = ctx.saved_tensors
+        rows, sdim = s_sum.shape
+        vdim = ctx.vdim
+        d_s = _req(d_s, "grad") if d_s is not None else torch.zeros_like(s_sum)
+        if vdim:
+            d_v = _req(d_v, "grad") if d_v is not None else torch.zeros_like(v_sum)
+        gs = torch.empty_like(s_sum)
+        gv = torch.empty_like(v_sum) if vdim else None
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(gamma)
+        check(lib.gcpnet_layernorm_backward(rows, sdim, vdim, _p(s_sum), _p(v_sum), _p(stats), _p(gamma), _p(d_s),
+                                            _p(d_v) if vdim else None, _p(gs), _p(gv), _p(dgamma), _p(dbeta), _stream()),
+              "layernorm_backward")
+        return gs, (gs if ctx.has_b[0] else None), gv, (gv if ctx.has_b[1] else None), dgamma, dbeta
+
+
+def layernorm(s_a: Tensor, v_a: Optional[Tensor], gamma: Tensor, beta: Tensor, s_b: Optional[Tensor] = None,
+              v_b: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """GCPLayerNorm((s_a + s_b), (v_a + v_b)) -- components/__init__.py:138-167 with the residual add fused in."""
+    s_a = _req(s_a, "s")
+    s_b = _req(s_b, "s_b") if s_b is not None else None
+    if v_a is not None and v_a.shape[1] == 0:
+        v_a, v_b = None, None
+    v_a = _req(v_a, "v") if v_a is not None else None
+    v_b = _req(v_b, "v_b") if v_b is not None else None
+    return _LayerNorm.apply(s_a, s_b, v_a, v_b, _req(gamma, "gamma"), _req(beta, "beta"))
+
+
+# ==============================================================================================================
+# position update:  y = a + clamp(alpha * b, lo, hi)   (components/gcpnet.py:1156-1158,1258)
+# ==============================================================================================================
+class _AxpyClamp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, clamp, lo, hi):
+        lib = _lib.load()
+        y = torch.empty_like(b)
+        check(lib.gcpnet_axpy_clamp(b.numel(), _p(a), _p(b), float(alpha), int(clamp), float(lo), float(hi), _p(y),
+                                    _stream()), "axpy_clamp")
+        ctx.save_for_backward(b)
+        ctx.cfg = (alpha, clamp, lo, hi)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (b,) = ctx.saved_tensors
+        alpha, clamp, lo, hi = ctx.cfg
+        gb = g * alpha
+        if clamp:  # tiny [N, 3] host-glue mask for the clamp's adjoint
+            u = b * alpha
+            gb = gb * ((u >= lo) & (u <= hi)).to(g.dtype)
+        return g, gb, None, None, None, None
+
+
+def axpy_clamp(a: Tensor, b: Tensor, alpha: float, lo: float = -100.0, hi: float = 100.0) -> Tensor:
+    """a + clamp(alpha * b, lo, hi)"""
+    return _AxpyClamp.apply(_req(a, "a"), _req(b, "b"), alpha, True, lo, hi)
+
+
+def axpy(a: Tensor, b: Tensor, alpha: float) -> Tensor:
+    """a + alpha * b"""
+    return _AxpyClamp.apply(_req(a, "a"), _req(b, "b"), alpha, False, 0.0, 0.0)
+
+
+# ==============================================================================================================
+# GCP2
+# ==============================================================================================================
+@dataclass
+class Gcp2Spec:
+    """Static description of one GCP2 application (dims, options, gather plans of the concatenated inputs)."""
+    si: int
+    vi: int
+    so: int
+    vo: int
+    hidden: int
+    use_frames: bool
+    act_s: Optional[str]
+    act_v: Optional[str]
+    slope: float
+    vmode: int
+    vector_residual: bool
+    e3: bool
+    s_plans: List[Optional[GatherPlan]] = field(default_factory=list)
+    v_plans: List[Optional[GatherPlan]] = field(default_factory=list)
+    residual: bool = False  # out = x + GCP(x) with x the single ungathered source (ResGCP)
+    pack_cache: Optional[dict] = None
+
+    @property
+    def K(self):
+        return self.si + ((self.hidden + (9 if self.use_frames else 0)) if self.vi > 0 else 0)
+
+
+def _concat(tensors: Sequence[Tensor], plans: Sequence[Optional[GatherPlan]], vec: bool) -> Concat:
+    c = Concat()
+    c.n = len(tensors)
+    for k, (t, pl) in enumerate(zip(tensors, plans)):
+        c.ptr[k] = t.data_ptr()
+        c.idx[k] = pl.idx.data_ptr() if pl is not None else None
+        c.dim[k] = t.shape[1]
+    return c
+
+
+def _weights_struct(spec: Gcp2Spec, w, pack: Tensor) -> Gcp2Weights:
+    w_scalar, b_scalar, w_down, w_frames, w_up, w_gate, b_gate = w
+    ws = Gcp2Weights()
+    ws.si, ws.vi, ws.so, ws.vo, ws.hidden, ws.use_frames = spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames)
+    ws.w_down, ws.w_frames, ws.w_up = (t.data_ptr() if t is not None else None for t in (w_down, w_frames, w_up))
+    ws.w_scalar, ws.b_scalar = w_scalar.data_ptr(), b_scalar.data_ptr()
+    ws.w_gate = w_gate.data_ptr() if w_gate is not None else None
+    ws.b_gate = b_gate.data_ptr() if b_gate is not None else None
+    ws.pack = pack.data_ptr()
+    return ws
+
+
+def _opts_struct(spec: Gcp2Spec, fused_residual: bool = False) -> Gcp2Opts:
+    o = Gcp2Opts()
+    o.act_s, o.act_v, o.slope = ACT[spec.act_s], ACT[spec.act_v], float(spec.slope)
+    o.vmode, o.vector_residual, o.e3 = spec.vmode, int(spec.vector_residual), int(spec.e3)
+    o.fused_residual = int(fused_residual)
+    return o
+
+
+def _pack(spec: Gcp2Spec, w) -> Tensor:
+    lib = _lib.load()
+    w_scalar, w_gate = w[0], w[5]
+    key = (w_scalar.data_ptr(), w_scalar._version, None if w_gate is None else (w_gate.data_ptr(), w_gate._version))
+    cache = spec.pack_cache
+    if cache is not None and cache.get("key") == key:
+        return cache["pack"]
+    n = lib.gcpnet_gcp2_pack_floats(spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames))
+    pack = torch.empty(int(n), dtype=torch.float32, device=w_scalar.device)
+    ws = _weights_struct(spec, w, pack)
+    check(lib.gcpnet_pack_gcp2_weights(C.byref(ws), _p(pack), _stream()), "pack_gcp2_weights")
+    if cache is not None:
+        cache["key"], cache["pack"] = key, pack
+    return pack
+
+
+class _Gcp2(torch.autograd.Function):
+    """inputs: spec, frames, then n_s scalar sources, n_v vector sources, res_s, res_v, 7 weights."""
+
+    @staticmethod
+    def forward(ctx, spec: Gcp2Spec, frames, *tensors):
+        lib = _lib.load()
+        n_s, n_v = len(spec.s_plans), len(spec.v_plans)
+        s_src = list(tensors[:n_s])
+        v_src = list(tensors[n_s:n_s + n_v])
+        res_s, res_v = tensors[n_s + n_v], tensors[n_s + n_v + 1]
+        w = tuple(tensors[n_s + n_v + 2:])
+        rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_src[0].shape[0]
+        dev = s_src[0].device
+        pack = _pack(spec, w)
+        ws = _weights_struct(spec, w, pack)
+        opts = _opts_struct(spec)
+        sc = _concat(s_src, spec.s_plans, False)
+        vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
+        if spec.residual:
+            res_s, res_v = s_src[0], (v_src[0] if n_v else None)
+        need_grad = any(ctx.needs_input_grad)
+        s_out = torch.empty((rows, spec.so), dtype=torch.float32, device=dev)
+        v_out = torch.empty((rows, spec.vo, 3), dtype=torch.float32, device=dev) if spec.vo else None
+        s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
+        gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
+        gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
+        check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts), _p(res_s),
+                                      _p(res_v), _p(s_out), _p(v_out), _p(s_pre), _p(gate), _stream()), "gcp2_forward")
+        if need_grad:
+            ctx.spec, ctx.rows, ctx.n_s, ctx.n_v = spec, rows, n_s, n_v
+            ctx.frames = frames
+            ctx.has_res = (tensors[n_s + n_v] is not None, tensors[n_s + n_v + 1] is not None)
+            ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate)
+        if spec.vo:
+            return s_out, v_out
+        return s_out
+
+    @staticmethod
+    def backward(ctx, d_s_out, d_v_out=None):
+        lib = _lib.load()
+        spec, rows, n_s, n_v = ctx.spec, ctx.rows, ctx.n_s, ctx.n_v
+        saved = ctx.saved_tensors
+        s_src, v_src = list(saved[:n_s]), list(saved[n_s:n_s + n_v])
+        w = tuple(saved[n_s + n_v:n_s + n_v + 7])
+        pack, s_pre, gate = saved[n_s + n_v + 7:]
+        w_scalar, b_scalar, w_down, w_frames, w_up, w_gate, b_gate = w
+        dev = s_pre.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_s_out = _req(d_s_out, "grad") if d_s_out is not None else torch.zeros((rows, spec.so), **f32)
+        if spec.vo:
+            d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
+        H, vi, vo, so, si = spec.hidden, spec.vi, spec.vo, spec.so, spec.si
+        nf = 9 if (spec.use_frames and vi > 0) else 0
+        has_vec, has_vout = vi > 0, vi > 0 and vo > 0
+        gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
+
+        d_s_in = torch.empty((rows, si), **f32)
+        d_v_in = torch.empty((rows, vi, 3), **f32) if has_vec else None
+        scr = BwdScratch()
+        ds_pre = torch.empty((rows, so), **f32)
+        scr.ds_pre = ds_pre.data_ptr()
+        ext = dvhf = vh = vt = dvu = dgate = None
+        if has_vec:
+            ext = torch.empty((rows, H + nf), **f32)
+            dvhf = torch.empty((rows * 3, H + 3), **f32)
+            vh = torch.empty((rows * 3, H), **f32)
+            vt = torch.empty((rows * 3, vi), **f32)
+            scr.ext, scr.dvhf, scr.vh, scr.vt = ext.data_ptr(), dvhf.data_ptr(), vh.data_ptr(), vt.data_ptr()
+            if has_vout:
+                dvu = torch.empty((rows * 3, vo), **f32)
+                scr.dvu = dvu.data_ptr()
+            if gated:
+                dgate = torch.empty((rows, vo), **f32)
+                scr.dgate = dgate.data_ptr()
+        ws = _weights_struct(spec, w, pack)
+        opts = _opts_struct(spec, fused_residual=spec.residual)
+        sc = _concat(s_src, spec.s_plans, False)
+        vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
+        check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(ctx.frames), C.byref(ws), C.byref(opts),
+                                       _p(s_pre), _p(gate), _p(d_s_out), _p(d_v_out) if spec.vo else None, _p(d_s_in),
+                                       _p(d_v_in), C.byref(scr), _stream()), "gcp2_backward")
+
+        # ---- weight gradients: TN GEMMs over the row axis ------------------------------------------------------
+        wgrads = [None] * 7
+        need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:]
+        if any(need_w):
+            probs, keep = [], []
+
+            def operand(segs, act=None, ones=False):
+                op = Operand()
+                op.n = len(segs)
+                for k, (t, pl, dim, ld) in enumerate(segs):
+                    op.ptr[k], op.dim[k], op.ld[k] = t.data_ptr(), dim, ld
+                    op.idx[k] = pl.idx.data_ptr() if pl is not None else None
+                op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
+                return op
+
+            def problem(R, a, M, b, N, out, sm, sn):
+                pr = TnProblem()
+                pr.rows, pr.a, pr.b = R, a, b
+                pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
+                pr.splits = lib.gcpnet_tn_splits(R, M, N)
+                part = torch.empty((pr.splits, M, N), **f32)
+                keep.append(part)
+                pr.partial = part.data_ptr()
+                probs.append(pr)
+
+            K = spec.K
+            W1 = torch.empty((so, K + 1), **f32)
+            bsegs = [(t, pl, t.shape[1], t.shape[1]) for t, pl in zip(s_src, spec.s_plans)]
+            if has_vec:
+                bsegs.append((ext, None, H + nf, H + nf))
+            problem(rows, operand([(ds_pre, None, so, so)]), so, operand(bsegs, ones=True), K + 1, W1, K + 1, 1)
+            W2 = W3 = W4 = None
+            if gated:
+                W2 = torch.empty((so + 1, vo), **f32)
+                problem(rows, operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
+                        operand([(dgate, None, vo, vo)]), vo, W2, vo, 1)
+            if has_vout:
+                W3 = torch.empty((vo, H), **f32)
+                problem(rows * 3, operand([(dvu, None, vo, vo)]), vo, operand([(vh, None, H, H)]), H, W3, H, 1)
+            if has_vec:
+                W4 = torch.empty((vi, H + 3), **f32)
+                problem(rows * 3, operand([(vt, None, vi, vi)]), vi, operand([(dvhf, None, H + 3, H + 3)]), H + 3, W4,
+                        H + 3, 1)
+            arr = (TnProblem * len(probs))(*probs)
+            check(lib.gcpnet_tn_gemm(len(probs), arr, _stream()), "tn_gemm")
+            wgrads[0] = W1[:, :K].contiguous()
+            wgrads[1] = W1[:, K].contiguous()
+            if has_vec:
+                wgrads[2] = W4[:, :H].t().contiguous()
+                if nf:
+                    wgrads[3] = W4[:, H:].t().contiguous()
+            if has_vout:
+                wgrads[4] = W3
+            if gated:
+                wgrads[5] = W2[:so].t().contiguous()
+                wgrads[6] = W2[so].contiguous()
+
+        # ---- input gradients: un-concatenate, scatter-add the gathered sources back to their rows -----------------
+        grads_s: List[Optional[Tensor]] = []
+        off = 0
+        for t, pl in zip(s_src, spec.s_plans):
+            dim = t.shape[1]
+            if pl is not None:
+                grads_s.append(_segment_reduce_raw(d_s_in, off, dim, si, pl, False))
+            else:
+                grads_s.append(d_s_in if n_s == 1 else d_s_in[:, off:off + dim])
+            off += dim
+        grads_v: List[Optional[Tensor]] = []
+        off = 0
+        for t, pl in zip(v_src, spec.v_plans):
+            ch = t.shape[1]
+            if pl is not None:
+                grads_v.append(_segment_reduce_raw(d_v_in, 3 * off, 3 * ch, 3 * vi, pl, False).reshape(pl.n_src, ch, 3))
+            else:
+                grads_v.append(d_v_in if n_v == 1 else d_v_in[:, off:off + ch, :])
+            off += ch
+        g_res_s = d_s_out if ctx.has_res[0] else None
+        g_res_v = d_v_out if ctx.has_res[1] else None
+        wgrads = [g if need else None for g, need in zip(wgrads, need_w)]
+        return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
+
+
+def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor], frames: Optional[Tensor], weights,
+         res_s: Optional[Tensor] = None, res_v: Optional[Tensor] = None):
+    """Applies one GCP2 block.  `weights` = (scalar_out.weight, scalar_out.bias, vector_down.weight,
+    vector_down_frames.weight, vector_up.weight, vector_out_scale.weight, vector_out_scale.bias), None where absent."""
+    assert len(s_sources) == len(spec.s_plans) and len(v_sources) == len(spec.v_plans)
+    assert sum(t.shape[1] for t in s_sources) == spec.si and sum(t.shape[1] for t in v_sources) == spec.vi
+    s_sources = [_req(t, "scalar input") for t in s_sources]
+    v_sources = [_req(t, "vector input") for t in v_sources]
+    if frames is not None:
+        frames = _req(frames.detach(), "frames")
+    weights = tuple(None if t is None else _req(t, "weight") for t in weights)
+    if res_s is not None:
+        res_s = _req(res_s, "residual")
+    if res_v is not None:
+        res_v = _req(res_v, "residual")
+    return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights)

@@ -1,0 +1,177 @@
+/*
+ * gcpnet_hip.h -- C ABI of libgcpnet_hip.so: MI355X (gfx950) kernels for GCPNet's geometry-complete
+ * message-passing hot path.
+ *
+ * The reference (BioinfoMachineLearning/GCPNet) has no native boundary for this path: it is a Python nn.Module
+ * API.  The drop-in boundary is therefore the Python package `gcpnet_amd`, which mirrors
+ * the reference classes; every arithmetic step those classes perform is one of the entry points below.  Each
+ * entry point cites the reference code it replaces (paths relative to /root/reference/src/models).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all float tensors are contiguous fp32 row-major device memory,
+ *     index arrays are int32 device memory;
+ *   - scalar features are [rows, dim]; vector features are [rows, channels, 3]; frames are [rows, 3, 3]
+ *     with frame row a in {x_diff, x_cross, x_vertical} (components/__init__.py:268);
+ *   - no ownership transfer; kernels are launched on the caller's `stream` (a hipStream_t) and return
+ *     immediately; return value 0 = launched, > 0 = hipError_t, < 0 = invalid argument (GCPNET_E_*);
+ *   - nothing here allocates device memory.
+ */
+#ifndef GCPNET_HIP_H
+#define GCPNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCPNET_ABI_VERSION 1
+
+#define GCPNET_E_BADARG (-1)
+#define GCPNET_E_UNSUPPORTED (-2)
+
+/* activation codes: models/__init__.py:42-57 (get_nonlinearity) */
+enum { GCP_ACT_NONE = 0, GCP_ACT_RELU = 1, GCP_ACT_LEAKYRELU = 2, GCP_ACT_SELU = 3, GCP_ACT_SILU = 4, GCP_ACT_SIGMOID = 5 };
+
+/* vector-gating mode of a GCP2 block: components/gcpnet.py:369-389 */
+enum { GCP_VMODE_NONE = 0, GCP_VMODE_SCALAR_GATE = 1 /* vector_gate */, GCP_VMODE_SELF_GATE = 2 /* sigma(norm) */ };
+
+#define GCP_MAX_SEG 3
+
+/* A row-wise concatenation of up to 3 sources, each optionally gathered by an index array:
+ * column block k of row r is ptr[k][(idx[k] ? idx[k][r] : r) * dim[k] ...].  This is how
+ * GCPMessagePassing.message builds [h_row | e | h_col] and [chi_row | xi | chi_col]
+ * (components/gcpnet.py:907-917) without materialising the concatenation. */
+typedef struct {
+    int n;
+    const float* ptr[GCP_MAX_SEG];
+    const int32_t* idx[GCP_MAX_SEG];
+    int dim[GCP_MAX_SEG]; /* scalars: floats per row; vectors: channels per row */
+} gcp_concat_t;
+
+/* Weights of one GCP2 block (components/gcpnet.py:298-324), reference layouts, plus packed MFMA operand images
+ * produced by gcpnet_pack_gcp2_weights(). */
+typedef struct {
+    int si, vi, so, vo, hidden; /* scalar in/out, vector in/out channels, hidden vector channels H */
+    int use_frames;             /* !ablate_frame_updates: 9 frame scalars appended to the merged input */
+    const float* w_down;        /* vector_down.weight        [H, vi]            (NULL when vi == 0) */
+    const float* w_frames;      /* vector_down_frames.weight [3, vi]            (NULL unless use_frames) */
+    const float* w_up;          /* vector_up.weight          [vo, H]            (NULL when vo == 0) */
+    const float* w_scalar;      /* scalar_out.weight         [so, si + H + 9]                       */
+    const float* b_scalar;      /* scalar_out.bias           [so]                                   */
+    const float* w_gate;        /* vector_out_scale.weight   [vo, so]           (NULL unless scalar gate) */
+    const float* b_gate;        /* vector_out_scale.bias     [vo]                                   */
+    const float* pack;          /* packed images, layout private to the library; size from gcpnet_gcp2_pack_floats() */
+} gcp2_weights_t;
+
+typedef struct {
+    int act_s, act_v;     /* nonlinearities (scalar, vector) */
+    float slope;          /* leaky-relu slope */
+    int vmode;            /* GCP_VMODE_* */
+    int vector_residual;  /* components/gcpnet.py:341-342,365-366 */
+    int e3;               /* enable_e3_equivariance: |.| on the x_cross projections (components/__init__.py:305-309) */
+    int fused_residual;   /* backward only: the block was applied as x + GCP(x) (ResGCP, components/gcpnet.py:921-924),
+                             so d(x) = d(out) + GCP^T d(out); the add is done in the kernel epilogue */
+} gcp2_opts_t;
+
+/* ---- weight packing ------------------------------------------------------------------------------------ */
+/* Number of floats gcpnet_pack_gcp2_weights() writes for these dims. */
+int64_t gcpnet_gcp2_pack_floats(int si, int vi, int so, int vo, int hidden, int use_frames);
+/* Packs scalar_out / vector_out_scale into MFMA operand order (forward, backward-data, gate, gate-backward). */
+int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out, void* stream);
+
+/* ---- GCP2 forward: replaces GCP2.forward (components/gcpnet.py:394-468) on `rows` rows --------------------
+ * s_in/v_in: concatenated inputs; frames: per-row frames [rows,3,3] (per-edge frames for edge rows; the
+ * out-edge frame mean for node rows, which is what scalarize(node_inputs=True) reduces to:
+ * components/__init__.py:286,314-323).  res_s/res_v (optional) are added to the outputs (ResGCP,
+ * components/gcpnet.py:921-924).  s_pre [rows,so] and gate [rows,vo] (sigmoid of the vector gate) are saved
+ * for the backward when non-NULL. */
+int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
+                        const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* res_s, const float* res_v,
+                        float* s_out, float* v_out, float* s_pre, float* gate, void* stream);
+
+/* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
+ * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
+ * concatenated layout, plus the per-row quantities the weight-gradient GEMMs consume (all row-major):
+ *   ds_pre [rows, so], dgate [rows, vo], ext [rows, H+9] (= [|vh| norms | frame scalars]),
+ *   dvu [rows, 3, vo], dvhf [rows, 3, H+3] (= [d vh | d vf]), vh [rows, 3, H], vt [rows, 3, vi]. */
+typedef struct {
+    float* ds_pre;
+    float* dgate;
+    float* ext;
+    float* dvu;
+    float* dvhf;
+    float* vh;
+    float* vt;
+} gcp2_bwd_scratch_t;
+
+int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
+                         const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* s_pre, const float* gate,
+                         const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in,
+                         const gcp2_bwd_scratch_t* scratch, void* stream);
+
+/* ---- weight-gradient GEMM: out[m, n] (+)= sum_r A[r, m] * B[r, n] -------------------------------------------
+ * A and B are row-wise concatenations (gcp_concat_t with per-segment leading dimension), optionally passed
+ * through an activation, optionally extended by a column of ones (bias gradients).  Used for
+ * d scalar_out.weight = ds_pre^T [s | norms | frame scalars], d vector_out_scale.weight, d vector_up.weight,
+ * d vector_down(.frames).weight. */
+#define GCP_TN_MAX_SEG 4
+typedef struct {
+    int n;
+    const float* ptr[GCP_TN_MAX_SEG];
+    const int32_t* idx[GCP_TN_MAX_SEG];
+    int dim[GCP_TN_MAX_SEG];
+    int ld[GCP_TN_MAX_SEG];
+    int act;       /* activation applied on load */
+    float slope;
+    int ones;      /* append a column of ones */
+} gcp_operand_t;
+
+typedef struct {
+    int rows;          /* reduction length */
+    gcp_operand_t a;   /* [rows, M]  (M = sum dims + ones) */
+    gcp_operand_t b;   /* [rows, N] */
+    float* out;        /* out[m * out_sm + n * out_sn] += ... */
+    int64_t out_sm, out_sn;
+    float* partial;    /* scratch [splits, M, N] */
+    int splits;
+} gcp_tn_problem_t;
+
+#define GCP_TN_MAX_PROBLEMS 8
+int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream);
+/* scratch floats a problem of this shape needs (splits * M * N) and the split count the library will use */
+int gcpnet_tn_splits(int rows, int M, int N);
+
+/* ---- segment reductions: torch_scatter.scatter(reduce=sum|mean) over sorted segments ------------------------
+ * out[s, 0:D] = reduce_{p in [seg_ptr[s], seg_ptr[s+1])} x[(perm ? perm[p] : p) * ldx + 0:D]
+ * (components/gcpnet.py:939-947 aggregate; components/__init__.py:195-198 centroids; :314-323 node scalarize). */
+int gcpnet_segment_reduce(int n_seg, const int32_t* seg_ptr, const int32_t* perm, const float* x, int64_t ldx, int D,
+                          int mean, float* out, int64_t ldo, int accumulate, void* stream);
+/* out[r, 0:D] = x[idx[r] * ldx + 0:D] * (scale ? scale[idx[r]] : 1)  (backward of the above; gathers) */
+int gcpnet_gather_rows(int rows, const int32_t* idx, const float* x, int64_t ldx, int D, const float* scale,
+                       float* out, int64_t ldo, void* stream);
+
+/* ---- frames: localize (components/__init__.py:221-269, unmasked) ---------------------------------------------*/
+int gcpnet_localize(int n_edges, const int32_t* row, const int32_t* col, const float* x, int norm_x_diff,
+                    float* frames, void* stream);
+
+/* ---- GCPLayerNorm (components/__init__.py:138-167) fused with the residual add in front of it
+ * (components/gcpnet.py:1220-1226,1242-1246): (s, v) = norm((s_a + s_b), (v_a + v_b)); s_b/v_b may be NULL. */
+int gcpnet_layernorm_forward(int rows, int sdim, int vdim, const float* s_a, const float* s_b, const float* v_a,
+                             const float* v_b, const float* gamma, const float* beta, float* s_out, float* v_out,
+                             float* stats /* [rows,3]: mean, rstd, vnorm */, float* s_sum, float* v_sum, void* stream);
+int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const float* s_sum, const float* v_sum,
+                              const float* stats, const float* gamma, const float* d_s_out, const float* d_v_out,
+                              float* d_s, float* d_v, float* d_gamma, float* d_beta, void* stream);
+
+/* ---- small elementwise pieces ---------------------------------------------------------------------------------
+ * y = a + alpha * b, clamped to [lo, hi] when clamp != 0 (position update, components/gcpnet.py:1156-1158,1258) */
+int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi, float* y,
+                      void* stream);
+
+int gcpnet_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCPNET_HIP_H */

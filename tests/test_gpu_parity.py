@@ -1,0 +1,321 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors of the reference and against the CPU
+oracle on seeded inputs.  Tolerances: forward 1e-5 absolute on O(1) activations (north_star), gradients 1e-4
+relative (+1e-5 absolute) -- fp32 everywhere, only the summation order differs (MFMA k-ordered fma chain vs BLAS)."""
+import pytest
+import torch
+
+from oracle import gcp_oracle as O
+from tests.helpers import Fixture, close, rand_graph
+
+pytestmark = pytest.mark.gpu
+
+FWD = dict(atol=1e-5, rtol=1e-5)
+GRAD = dict(atol=1e-5, rtol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gcpnet_amd
+
+    return gcpnet_amd
+
+
+def dev(t):
+    return t.cuda() if torch.is_tensor(t) else t
+
+
+def sq_loss(*ts):
+    return sum((t * t).mean() for t in ts if t is not None and t.numel())
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_geometry(G):
+    f = Fixture("geometry")
+    x, ei = f.i["x"].cuda(), f.i["edge_index"].cuda()
+    close(G.localize(x, ei, True).cpu(), f.o["frames"], **FWD)
+    close(G.localize(x, ei, False).cpu(), f.o["frames_raw"], **FWD)
+    bag = G.Batch(x=x)
+    cen, xc = G.centralize(bag, "x", f.i["batch"].cuda())
+    close(cen.cpu(), f.o["centroid"], **FWD)
+    close(xc.cpu(), f.o["x_centered"], **FWD)
+    back = G.decentralize(G.Batch(x=xc), "x", f.i["batch"].cuda(), cen)
+    close(back.cpu(), f.o["x_back"], **FWD)
+
+
+@pytest.mark.parametrize("n_src,rows,D,sort", [(50, 700, 176, True), (50, 700, 176, False), (7, 33, 9, False),
+                                                (300, 1000, 50, False), (10, 0, 8, True)])
+def test_segment_reduce_and_gather(G, n_src, rows, D, sort):
+    from gcpnet_amd import ops
+
+    g = torch.Generator().manual_seed(rows + D)
+    idx = torch.randint(0, n_src, (rows,), generator=g)
+    if sort:
+        idx = torch.sort(idx).values
+    x = torch.randn(rows, D, generator=g).requires_grad_()
+    for mean in (True, False):
+        want = O.scatter(x, idx, n_src, "mean" if mean else "sum")
+        gw, = torch.autograd.grad((want * want).sum(), x)
+        xg = x.detach().cuda().requires_grad_()
+        plan = ops.GatherPlan(idx.cuda(), n_src)
+        got = ops.segment_reduce(xg, plan, mean)
+        close(got.detach().cpu(), want.detach(), atol=1e-5, rtol=1e-5)
+        gg, = torch.autograd.grad((got * got).sum(), xg)
+        close(gg.cpu(), gw, atol=1e-5, rtol=1e-4)
+    src = torch.randn(n_src, D, generator=g)
+    plan = ops.GatherPlan(idx.cuda(), n_src)
+    close(ops.gather_rows(src.cuda(), plan).cpu(), src[idx], atol=0, rtol=0)
+
+
+def test_layernorm(G):
+    f = Fixture("layernorm")
+    ln = G.GCPLayerNorm((64, 16)).cuda()
+    ln.load_state_dict(f.p)
+    s, v = f.i["s"].cuda().requires_grad_(), f.i["v"].cuda().requires_grad_()
+    so, vo = ln(G.ScalarVector(s, v))
+    close(so.detach().cpu(), f.o["s"], **FWD)
+    close(vo.detach().cpu(), f.o["v"], **FWD)
+    g1 = torch.Generator().manual_seed(33)
+    w1 = torch.randn(40, 64, generator=g1)
+    w2 = torch.randn(40, 16, 3, generator=torch.Generator().manual_seed(34))
+    sq_loss(so * w1.cuda(), vo * w2.cuda()).backward()
+    close(s.grad.cpu(), f.g["s"], **GRAD)
+    close(v.grad.cpu(), f.g["v"], **GRAD)
+    close(ln.scalar_norm.weight.grad.cpu(), f.g["w.scalar_norm.weight"], **GRAD)
+    close(ln.scalar_norm.bias.grad.cpu(), f.g["w.scalar_norm.bias"], **GRAD)
+
+
+def test_layernorm_residual_vs_oracle(G):
+    g = torch.Generator().manual_seed(5)
+    s, sb = torch.randn(37, 100, generator=g), torch.randn(37, 100, generator=g)
+    v, vb = torch.randn(37, 16, 3, generator=g), torch.randn(37, 16, 3, generator=g)
+    ln = G.GCPLayerNorm((100, 16)).cuda()
+    P = {k: t.cpu() for k, t in ln.state_dict().items()}
+    ws, wv = O.gcp_layer_norm(P, "", s + sb, v + vb)
+    gs, gv = ln(G.ScalarVector(s.cuda(), v.cuda()), residual=(sb.cuda(), vb.cuda()))
+    close(gs.cpu(), ws, **FWD)
+    close(gv.cpu(), wv, **FWD)
+
+
+# ------------------------------------------------------------------------------------------------------------
+GCP2_CASES = {
+    "gcp2_edge_msg0": dict(nonlinearities=("relu", None), bottleneck=4),
+    "gcp2_edge_res": dict(nonlinearities=("relu", None), bottleneck=4),
+    "gcp2_node_ff0": dict(nonlinearities=("relu", None), bottleneck=4),
+    "gcp2_node_ff1": dict(nonlinearities=(None, None), bottleneck=4),
+    "gcp2_node_scalar_only": dict(nonlinearities=("relu", None)),
+    "gcp2_no_vector_in": dict(nonlinearities=("relu", None)),
+    "gcp2_node_posupd": dict(nonlinearities=("relu", None), bottleneck=4),
+    "gcp2_silu_sigmoid": dict(nonlinearities=("silu", "sigmoid"), bottleneck=2),
+    "gcp2_selfgate": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False),
+    "gcp2_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GCP2_CASES))
+def test_gcp2_golden(G, name):
+    f = Fixture(name)
+    mod = G.GCP2(tuple(int(d) for d in f.m["in_dims"]), tuple(int(d) for d in f.m["out_dims"]), **GCP2_CASES[name]).cuda()
+    mod.load_state_dict(f.p)
+    s = f.i["s"].cuda().requires_grad_()
+    ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
+    node_inputs = bool(f.m["node_inputs"])
+    if "v" in f.i:
+        v = f.i["v"].cuda().requires_grad_()
+        out = mod((s, v), ei, fr, node_inputs=node_inputs)
+    else:
+        v = None
+        out = mod(s, ei, fr, node_inputs=node_inputs)
+    outs = dict(s=out[0], v=out[1]) if isinstance(out, tuple) else dict(s=out)
+    for k, t in outs.items():
+        close(t.detach().cpu(), f.o[k], **FWD)
+    sq_loss(*outs.values()).backward()
+    close(s.grad.cpu(), f.g["s"], **GRAD)
+    if v is not None:
+        close(v.grad.cpu(), f.g["v"], **GRAD)
+    for k, p in mod.named_parameters():
+        if "w." + k in f.g:
+            assert p.grad is not None, k
+            close(p.grad.cpu(), f.g["w." + k], **GRAD)
+
+
+def test_gcp2_e3_edge_vs_oracle(G):
+    """enable_e3_equivariance on edge rows + vector_residual + leakyrelu, against the oracle."""
+    torch.manual_seed(3)
+    mod = G.GCP2((24, 8), (24, 8), nonlinearities=("leakyrelu", None), bottleneck=4, vector_residual=True,
+                 enable_e3_equivariance=True).cuda()
+    ei, x = rand_graph(20, 70, 9)
+    fr = O.localize(x, ei)
+    g = torch.Generator().manual_seed(4)
+    s, v = torch.randn(70, 24, generator=g).requires_grad_(), torch.randn(70, 8, 3, generator=g).requires_grad_()
+    P = {k: t.detach().cpu().clone().requires_grad_() for k, t in mod.state_dict().items()}
+    ws, wv = O.gcp2(P, "", s, v, ei, fr, nonlinearities=("leakyrelu", None), vector_residual=True,
+                    enable_e3_equivariance=True)
+    sg, vg = s.detach().cuda().requires_grad_(), v.detach().cuda().requires_grad_()
+    gs, gv = mod((sg, vg), ei.cuda(), fr.cuda())
+    close(gs.detach().cpu(), ws.detach(), **FWD)
+    close(gv.detach().cpu(), wv.detach(), **FWD)
+    sq_loss(ws, wv).backward()
+    sq_loss(gs, gv).backward()
+    close(sg.grad.cpu(), s.grad, **GRAD)
+    close(vg.grad.cpu(), v.grad, **GRAD)
+    for k, p in mod.named_parameters():
+        close(p.grad.cpu(), P[k].grad, **GRAD)
+
+
+@pytest.mark.parametrize("rows,dims_in,dims_out,bott", [(1, (5, 3), (7, 2), 1), (33, (100, 16), (100, 16), 4),
+                                                         (97, (40, 12), (300, 24), 4), (64, (530, 8), (36, 4), 2),
+                                                         (1000, (128, 16), (128, 16), 4), (50, (33, 4), (65, 5), 1)])
+def test_gcp2_ragged_vs_oracle(G, rows, dims_in, dims_out, bott):
+    """Odd sizes: partial tiles, widths that are not multiples of 4 / 32, several output and k groups."""
+    torch.manual_seed(rows)
+    mod = G.GCP2(dims_in, dims_out, nonlinearities=("silu", None), bottleneck=bott).cuda()
+    g = torch.Generator().manual_seed(rows + 1)
+    ei = torch.stack((torch.arange(rows), torch.arange(rows)))
+    fr = torch.randn(rows, 3, 3, generator=g)
+    s = torch.randn(rows, dims_in[0], generator=g).requires_grad_()
+    v = torch.randn(rows, dims_in[1], 3, generator=g).requires_grad_()
+    P = {k: t.detach().cpu().clone().requires_grad_() for k, t in mod.state_dict().items()}
+    ws, wv = O.gcp2(P, "", s, v, ei, fr, nonlinearities=("silu", None))
+    sg, vg = s.detach().cuda().requires_grad_(), v.detach().cuda().requires_grad_()
+    gs, gv = mod((sg, vg), ei.cuda(), fr.cuda())
+    close(gs.detach().cpu(), ws.detach(), atol=2e-5, rtol=2e-5)
+    close(gv.detach().cpu(), wv.detach(), atol=2e-5, rtol=2e-5)
+    sq_loss(ws, wv).backward()
+    sq_loss(gs, gv).backward()
+    close(sg.grad.cpu(), s.grad, **GRAD)
+    close(vg.grad.cpu(), v.grad, **GRAD)
+    for k, p in mod.named_parameters():
+        close(p.grad.cpu(), P[k].grad, atol=2e-5, rtol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["embedding_nms", "embedding_lba"])
+def test_embedding_golden(G, name):
+    f = Fixture(name)
+    lba = name.endswith("lba")
+    emb = G.GCPEmbedding((16, 1) if lba else (17, 1), (9, 2) if lba else (1, 3), (32, 4), (100, 16) if lba else (64, 16),
+                         num_atom_types=9 if lba else 0, cfg=G.default_module_cfg()).cuda()
+    emb.load_state_dict(f.p)
+    b = G.Batch(**{k: v.cuda() for k, v in f.i.items()})
+    b.f_ij = b.frames
+    (h, chi), (e, xi) = emb(b)
+    for k, t in dict(h=h, chi=chi, e=e, xi=xi).items():
+        close(t.detach().cpu(), f.o[k], **FWD)
+
+
+def _load_layer(G, f, upd):
+    layer = G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0,
+                              updating_node_positions=upd).cuda()
+    layer.load_state_dict(f.p)
+    return layer.eval()
+
+
+def test_message_passing_golden(G):
+    f = Fixture("message_passing")
+    mp = G.GCPMessagePassing((64, 16), (64, 16), (32, 4), cfg=G.default_module_cfg(),
+                             mp_cfg=G.default_layer_cfg().mp_cfg).cuda()
+    mp.load_state_dict(f.p)
+    ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
+    msg = mp.message((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
+    close(msg.detach().cpu(), f.o["messages"], atol=2e-5, rtol=2e-5)
+    s, v = mp((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
+    close(s.detach().cpu(), f.o["s"], atol=2e-5, rtol=2e-5)
+    close(v.detach().cpu(), f.o["v"], atol=2e-5, rtol=2e-5)
+    sq_loss(s, v).backward()
+    for k, t in ins.items():
+        close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=5e-4)
+    for k, p in mp.named_parameters():
+        close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=5e-4)
+
+
+@pytest.mark.parametrize("name", ["interactions", "interactions_posupd"])
+def test_interactions_golden(G, name):
+    f = Fixture(name)
+    upd = name.endswith("posupd")
+    layer = _load_layer(G, f, upd)
+    ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
+    if upd:
+        (h, chi), x = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, node_pos=f.i["x"].cuda())
+        outs = dict(h=h, chi=chi, x=x)
+    else:
+        h, chi = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
+        outs = dict(h=h, chi=chi)
+    for k, t in outs.items():
+        close(t.detach().cpu(), f.o[k], atol=2e-5, rtol=2e-5)
+    sq_loss(*outs.values()).backward()
+    for k, t in ins.items():
+        close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=1e-3)
+    for k, p in layer.named_parameters():
+        if "w." + k in f.g:
+            close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=1e-3)
+
+
+def test_interactions_prenorm_silu_golden(G):
+    f = Fixture("interactions_prenorm_silu")
+    cfg = G.default_module_cfg(scalar_nonlinearity="silu", vector_nonlinearity="silu")
+    lc = G.default_layer_cfg(pre_norm=True, num_feedforward_layers=3, num_message_layers=3)
+    layer = G.GCPInteractions((16, 4), (8, 4), cfg=cfg, layer_cfg=lc, dropout=0.0).cuda().eval()
+    layer.load_state_dict(f.p)
+    i = {k: v.cuda() for k, v in f.i.items()}
+    h, chi = layer((i["h"], i["chi"]), (i["e"], i["xi"]), i["edge_index"], i["frames"])
+    close(h.cpu(), f.o["h"], atol=2e-5, rtol=2e-5)
+    close(chi.cpu(), f.o["chi"], atol=2e-5, rtol=2e-5)
+
+
+def test_model_nms_golden(G):
+    f = Fixture("model_nms_small")
+    model_cfg = dict(h_input_dim=1, chi_input_dim=3, e_input_dim=17, xi_input_dim=1, h_hidden_dim=32, chi_hidden_dim=8,
+                     e_hidden_dim=16, xi_hidden_dim=4, num_encoder_layers=2, dropout=0.0)
+    model = G.GCPNetNMS(model_cfg=model_cfg, module_cfg=G.default_module_cfg(),
+                        layer_cfg=G.default_layer_cfg(num_message_layers=4)).cuda().eval()
+    model.load_state_dict(f.p)
+    b = G.Batch(**{k: v.cuda() for k, v in f.i.items()})
+    with torch.no_grad():
+        b, x = model(b)
+    for k in ("h", "chi", "e", "xi", "x", "f_ij"):
+        close(getattr(b, k).cpu(), f.o[k], atol=1e-4, rtol=1e-4)  # model-level tolerance of the reference's tests
+
+
+def test_model_lba_golden(G):
+    f = Fixture("model_lba_small")
+    model_cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=20, chi_hidden_dim=4, e_hidden_dim=8,
+                     xi_hidden_dim=4, output_dim=1, output_scale_factor=2, num_encoder_layers=2, dropout=0.0,
+                     dense_dropout=0.1)
+    model = G.GCPNetLBA(model_cfg=model_cfg, module_cfg=G.default_module_cfg(),
+                        layer_cfg=G.default_layer_cfg(num_message_layers=4)).cuda().eval()
+    model.load_state_dict(f.p)
+    b = G.Batch(**{k: v.cuda() for k, v in f.i.items()})
+    with torch.no_grad():
+        b, pred = model(b)
+    close(b.h.cpu(), f.o["h"], atol=1e-4, rtol=1e-4)
+    close(b.chi.cpu(), f.o["chi"], atol=1e-4, rtol=1e-4)
+    close(pred.cpu(), f.o["pred"], atol=1e-4, rtol=1e-4)
+
+
+def test_interactions_large_vs_oracle(G):
+    """A bench-shaped (but smaller) layer: 2 000 nodes / 32 000 col-sorted edges, (128,16)/(32,4), fwd + bwd."""
+    torch.manual_seed(11)
+    n, e = 2000, 32000
+    layer = G.GCPInteractions((128, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
+                              dropout=0.0).cuda().eval()
+    ei, x = rand_graph(n, e, 12, sort_by_col=True)
+    fr = O.localize(x, ei)
+    g = torch.Generator().manual_seed(13)
+    ins = dict(h=torch.randn(n, 128, generator=g), chi=torch.randn(n, 16, 3, generator=g),
+               e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
+    P = {k: t.detach().cpu().clone().requires_grad_() for k, t in layer.state_dict().items()}
+    ci = {k: t.clone().requires_grad_() for k, t in ins.items()}
+    wh, wc = O.gcp_interactions(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], ei, fr, O.default_module_cfg(),
+                                O.default_layer_cfg())
+    gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
+    gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
+    close(gh.detach().cpu(), wh.detach(), atol=2e-5, rtol=2e-5)
+    close(gc.detach().cpu(), wc.detach(), atol=2e-5, rtol=2e-5)
+    sq_loss(wh, wc).backward()
+    sq_loss(gh, gc).backward()
+    for k in ins:
+        close(gi[k].grad.cpu(), ci[k].grad, atol=1e-6, rtol=2e-3)
+    for k, p in layer.named_parameters():
+        close(p.grad.cpu(), P[k].grad, atol=1e-6, rtol=2e-3)

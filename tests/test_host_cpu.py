@@ -1,0 +1,154 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the module tree
+mirrors the reference's parameter names, config handling, graph plans, and loud failure without a GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+import gcpnet_amd as G
+from gcpnet_amd import _lib, ops
+from tests.helpers import Fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gcpnet_hip.h")).read()
+    declared = set(re.findall(r"\b(gcpnet_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gcpnet_abi_version() == 1
+
+
+def test_host_only_entry_points():
+    lib = _lib.load()
+    # NMS message GCP0: (160,36)->(64,16), H=9: K=178 -> KP=184, NTG=2, NG=1, NUG=4, NGK=2
+    n = lib.gcpnet_gcp2_pack_floats(160, 36, 64, 16, 9, 1)
+    KK, NTG, NG, NUG, NGK, NS = 92, 2, 1, 4, 2, 32
+    assert n == NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * (NG * NTG * 8) * 64 + 8 * NG * 64 * NTG
+    assert lib.gcpnet_tn_splits(160000, 128, 142) == 157
+    assert lib.gcpnet_tn_splits(0, 1, 1) == 1
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    lib = _lib.load()
+    assert lib.gcpnet_segment_reduce(-1, None, None, None, 0, 4, 1, None, 0, 0, None) == -1
+    assert lib.gcpnet_tn_gemm(0, None, None) == -1
+    assert lib.gcpnet_localize(5, None, None, None, 1, None, None) == -1
+
+
+@pytest.mark.parametrize("name,upd", [("interactions", False), ("interactions_posupd", True)])
+def test_state_dict_names_match_reference(name, upd):
+    f = Fixture(name)
+    layer = G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
+                              dropout=0.0, updating_node_positions=upd)
+    sd = layer.state_dict()
+    assert list(sd) == list(f.p)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(f.p[k].shape), k
+    layer.load_state_dict(f.p)  # strict
+
+
+def test_model_state_dict_names_match_reference():
+    f = Fixture("model_lba_small")
+    model_cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=20, chi_hidden_dim=4, e_hidden_dim=8,
+                     xi_hidden_dim=4, output_dim=1, output_scale_factor=2, num_encoder_layers=2, dropout=0.0,
+                     dense_dropout=0.1)
+    model = G.GCPNetLBA(model_cfg=model_cfg, module_cfg=G.default_module_cfg(),
+                        layer_cfg=G.default_layer_cfg(num_message_layers=4))
+    assert set(model.state_dict()) == set(f.p)
+    model.load_state_dict(f.p)
+    f = Fixture("model_nms_small")
+    model_cfg = dict(h_input_dim=1, chi_input_dim=3, e_input_dim=17, xi_input_dim=1, h_hidden_dim=32, chi_hidden_dim=8,
+                     e_hidden_dim=16, xi_hidden_dim=4, num_encoder_layers=2, dropout=0.0)
+    model = G.GCPNetNMS(model_cfg=model_cfg, module_cfg=G.default_module_cfg(),
+                        layer_cfg=G.default_layer_cfg(num_message_layers=4))
+    assert set(model.state_dict()) == set(f.p)
+
+
+def test_reference_errors_are_reproduced():
+    with pytest.raises(AssertionError):  # gcpnet.py:294-296
+        G.GCP2((8, 6), (8, 6), bottleneck=4)
+    with pytest.raises(NotImplementedError):  # models/__init__.py:57
+        G.GCP2((8, 4), (8, 4), nonlinearities=("gelu", None))
+    with pytest.raises(NotImplementedError):
+        G.get_nonlinearity("tanh")
+
+
+def test_no_cpu_fallback():
+    block = G.GCP2((8, 4), (8, 4), nonlinearities=("relu", None), bottleneck=4)
+    s, v = torch.randn(5, 8), torch.randn(5, 4, 3)
+    ei = torch.stack((torch.arange(5), torch.arange(5)))
+    with pytest.raises(_lib.GcpnetHipError):
+        block((s, v), ei, torch.randn(5, 3, 3))
+    with pytest.raises(_lib.GcpnetHipError):
+        G.GCPLayerNorm((8, 4))(G.ScalarVector(s, v))
+
+
+def test_gather_plan():
+    idx = torch.tensor([2, 0, 2, 1, 0, 2])
+    p = ops.GatherPlan(idx, 4)
+    assert p.perm is not None and idx[p.perm.long()].tolist() == [0, 0, 1, 2, 2, 2]
+    assert p.seg_ptr.tolist() == [0, 2, 3, 6, 6]
+    assert torch.allclose(p.inv_count, torch.tensor([0.5, 1.0, 1 / 3, 1.0]))
+    p2 = ops.GatherPlan(torch.tensor([0, 0, 1, 3]), 4)
+    assert p2.perm is None and p2.seg_ptr.tolist() == [0, 2, 3, 3, 4]
+    ei = torch.tensor([[0, 1, 2, 0], [1, 2, 0, 2]])
+    g1 = ops.GraphPlan.get(ei, 3)
+    assert ops.GraphPlan.get(ei, 3) is g1 and g1.n_edges == 4
+
+
+def test_scalar_vector_surface():
+    s, v = torch.randn(4, 5), torch.randn(4, 2, 3)
+    sv = G.ScalarVector(s, v)
+    flat = sv.flatten()
+    assert flat.shape == (4, 11)
+    back = G.ScalarVector.recover(flat, 2)
+    assert torch.equal(back.scalar, s) and torch.equal(back.vector, v)
+    cs, cv = sv.concat((G.ScalarVector(s, v),))
+    assert cs.shape == (4, 10) and cv.shape == (4, 4, 3)  # vectors join on the channel axis
+    assert torch.equal((sv + sv).vector, 2 * v) and torch.equal((sv * 2).scalar, 2 * s)
+    assert torch.equal(sv.idx(torch.tensor([1, 3])).scalar, s[[1, 3]])
+
+
+def test_config_loader_accepts_reference_layout(tmp_path):
+    """A configs/model tree with the reference's key names, `defaults:` composition, `${..x}` interpolation and
+    `_target_` / `_partial_` entries (configs/model/gcpnet_nms.yaml, module_cfg/gcp_module_nms.yaml)."""
+    m = tmp_path / "model"
+    (m / "module_cfg").mkdir(parents=True)
+    (m / "layer_cfg" / "mp_cfg").mkdir(parents=True)
+    (m / "model_cfg").mkdir()
+    (m / "gcpnet_nms.yaml").write_text(
+        "_target_: src.models.gcpnet_nms_module.GCPNetNMSLitModule\n"
+        "layer_class:\n  _target_: src.models.components.gcpnet.GCPInteractions\n  _partial_: true\n"
+        "  updating_node_positions: true\n"
+        "optimizer:\n  _target_: torch.optim.Adam\n  _partial_: true\n  lr: 1e-4\n"
+        "defaults:\n  - model_cfg: gcp_model_nms.yaml\n  - module_cfg: gcp_module_nms.yaml\n"
+        "  - layer_cfg: gcp_interaction_layer_nms.yaml\n")
+    (m / "model_cfg" / "gcp_model_nms.yaml").write_text(
+        "h_input_dim: 1\nchi_input_dim: 3\ne_input_dim: 17\nxi_input_dim: 1\nh_hidden_dim: 16\nchi_hidden_dim: 4\n"
+        "e_hidden_dim: 8\nxi_hidden_dim: 4\nnum_encoder_layers: 2\ndropout: 0.1\n")
+    (m / "module_cfg" / "gcp_module_nms.yaml").write_text(
+        "selected_GCP:\n  _target_: src.models.components.gcpnet.GCP2\n  _partial_: true\n"
+        "norm_x_diff: true\nscalar_gate: 0\nvector_gate: true\nvector_residual: false\nvector_frame_residual: false\n"
+        "frame_gate: false\nsigma_frame_gate: false\nscalar_nonlinearity: relu\nvector_nonlinearity: \n"
+        "nonlinearities:\n  - ${..scalar_nonlinearity}\n  - ${..vector_nonlinearity}\nbottleneck: 4\n"
+        "vector_linear: true\nvector_identity: true\ndefault_vector_residual: false\ndefault_bottleneck: 4\n"
+        "node_positions_weight: 1.0\nablate_frame_updates: false\nablate_scalars: false\nablate_vectors: false\n"
+        "ablate_x_force_update: true\nenable_e3_equivariance: false\n")
+    (m / "layer_cfg" / "gcp_interaction_layer_nms.yaml").write_text(
+        "defaults:\n  - mp_cfg: gcp_mp_nms.yaml\npre_norm: false\nnum_feedforward_layers: 2\ndropout: 0.1\n"
+        "nonlinearity_slope: 1e-2\n")
+    (m / "layer_cfg" / "mp_cfg" / "gcp_mp_nms.yaml").write_text(
+        "edge_encoder: false\nedge_gate: false\nnum_message_layers: 3\nmessage_residual: 0\n"
+        "message_ff_multiplier: 1\nself_message: true\nuse_residual_message_gcp: true\n")
+    cfg = G.load_model_config(str(m / "gcpnet_nms.yaml"))
+    assert cfg.module_cfg.nonlinearities == ["relu", None]
+    assert cfg.layer_cfg.mp_cfg.num_message_layers == 3
+    model = G.instantiate(cfg)
+    assert isinstance(model, G.GCPNetNMS)
+    assert len(model.interaction_layers) == 2 and model.interaction_layers[0].updating_node_positions
+    assert "interaction_layers.1.interaction.message_fusion.2.scalar_out.weight" in model.state_dict()
