@@ -102,6 +102,8 @@ class GraphPlan:
 # ==============================================================================================================
 def _segment_reduce_raw(x: Tensor, col0: int, D: int, ld: int, plan: GatherPlan, mean: bool) -> Tensor:
     lib = _lib.load()
+    if plan.rows == 0:
+        return torch.zeros((plan.n_src, D), dtype=torch.float32, device=x.device)
     out = torch.empty((plan.n_src, D), dtype=torch.float32, device=x.device)
     check(lib.gcpnet_segment_reduce(plan.n_src, _p(plan.seg_ptr), _p(plan.perm), C.c_void_p(x.data_ptr() + 4 * col0), ld,
                                     D, int(mean), _p(out), D, 0, _stream()), "segment_reduce")
@@ -112,6 +114,8 @@ def _gather_rows_raw(x: Tensor, plan: GatherPlan, scale: Optional[Tensor]) -> Te
     lib = _lib.load()
     D = x.shape[1]
     out = torch.empty((plan.rows, D), dtype=torch.float32, device=x.device)
+    if plan.rows == 0:
+        return out
     check(lib.gcpnet_gather_rows(plan.rows, _p(plan.idx), _p(x), D, D, _p(scale), _p(out), D, _stream()), "gather_rows")
     return out
 
@@ -367,105 +371,22 @@ class _Gcp2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_s_out, d_v_out=None):
-        lib = _lib.load()
         spec, rows, n_s, n_v = ctx.spec, ctx.rows, ctx.n_s, ctx.n_v
         saved = ctx.saved_tensors
         s_src, v_src = list(saved[:n_s]), list(saved[n_s:n_s + n_v])
         w = tuple(saved[n_s + n_v:n_s + n_v + 7])
         pack, s_pre, gate = saved[n_s + n_v + 7:]
-        w_scalar, b_scalar, w_down, w_frames, w_up, w_gate, b_gate = w
-        dev = s_pre.device
-        f32 = dict(dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=s_pre.device)
         d_s_out = _req(d_s_out, "grad") if d_s_out is not None else torch.zeros((rows, spec.so), **f32)
         if spec.vo:
             d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
-        H, vi, vo, so, si = spec.hidden, spec.vi, spec.vo, spec.so, spec.si
-        nf = 9 if (spec.use_frames and vi > 0) else 0
-        has_vec, has_vout = vi > 0, vi > 0 and vo > 0
-        gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
-
-        d_s_in = torch.empty((rows, si), **f32)
-        d_v_in = torch.empty((rows, vi, 3), **f32) if has_vec else None
-        scr = BwdScratch()
-        ds_pre = torch.empty((rows, so), **f32)
-        scr.ds_pre = ds_pre.data_ptr()
-        ext = dvhf = vh = vt = dvu = dgate = None
-        if has_vec:
-            ext = torch.empty((rows, H + nf), **f32)
-            dvhf = torch.empty((rows * 3, H + 3), **f32)
-            vh = torch.empty((rows * 3, H), **f32)
-            vt = torch.empty((rows * 3, vi), **f32)
-            scr.ext, scr.dvhf, scr.vh, scr.vt = ext.data_ptr(), dvhf.data_ptr(), vh.data_ptr(), vt.data_ptr()
-            if has_vout:
-                dvu = torch.empty((rows * 3, vo), **f32)
-                scr.dvu = dvu.data_ptr()
-            if gated:
-                dgate = torch.empty((rows, vo), **f32)
-                scr.dgate = dgate.data_ptr()
-        ws = _weights_struct(spec, w, pack)
-        opts = _opts_struct(spec, fused_residual=spec.residual)
-        sc = _concat(s_src, spec.s_plans, False)
-        vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
-        check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(ctx.frames), C.byref(ws), C.byref(opts),
-                                       _p(s_pre), _p(gate), _p(d_s_out), _p(d_v_out) if spec.vo else None, _p(d_s_in),
-                                       _p(d_v_in), C.byref(scr), _stream()), "gcp2_backward")
-
-        # ---- weight gradients: TN GEMMs over the row axis ------------------------------------------------------
-        wgrads = [None] * 7
+        si, vi = spec.si, spec.vi
+        d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
+                                                 d_v_out)
         need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:]
+        wgrads = [None] * 7
         if any(need_w):
-            probs, keep = [], []
-
-            def operand(segs, act=None, ones=False):
-                op = Operand()
-                op.n = len(segs)
-                for k, (t, pl, dim, ld) in enumerate(segs):
-                    op.ptr[k], op.dim[k], op.ld[k] = t.data_ptr(), dim, ld
-                    op.idx[k] = pl.idx.data_ptr() if pl is not None else None
-                op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
-                return op
-
-            def problem(R, a, M, b, N, out, sm, sn):
-                pr = TnProblem()
-                pr.rows, pr.a, pr.b = R, a, b
-                pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
-                pr.splits = lib.gcpnet_tn_splits(R, M, N)
-                part = torch.empty((pr.splits, M, N), **f32)
-                keep.append(part)
-                pr.partial = part.data_ptr()
-                probs.append(pr)
-
-            K = spec.K
-            W1 = torch.empty((so, K + 1), **f32)
-            bsegs = [(t, pl, t.shape[1], t.shape[1]) for t, pl in zip(s_src, spec.s_plans)]
-            if has_vec:
-                bsegs.append((ext, None, H + nf, H + nf))
-            problem(rows, operand([(ds_pre, None, so, so)]), so, operand(bsegs, ones=True), K + 1, W1, K + 1, 1)
-            W2 = W3 = W4 = None
-            if gated:
-                W2 = torch.empty((so + 1, vo), **f32)
-                problem(rows, operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
-                        operand([(dgate, None, vo, vo)]), vo, W2, vo, 1)
-            if has_vout:
-                W3 = torch.empty((vo, H), **f32)
-                problem(rows * 3, operand([(dvu, None, vo, vo)]), vo, operand([(vh, None, H, H)]), H, W3, H, 1)
-            if has_vec:
-                W4 = torch.empty((vi, H + 3), **f32)
-                problem(rows * 3, operand([(vt, None, vi, vi)]), vi, operand([(dvhf, None, H + 3, H + 3)]), H + 3, W4,
-                        H + 3, 1)
-            arr = (TnProblem * len(probs))(*probs)
-            check(lib.gcpnet_tn_gemm(len(probs), arr, _stream()), "tn_gemm")
-            wgrads[0] = W1[:, :K].contiguous()
-            wgrads[1] = W1[:, K].contiguous()
-            if has_vec:
-                wgrads[2] = W4[:, :H].t().contiguous()
-                if nf:
-                    wgrads[3] = W4[:, H:].t().contiguous()
-            if has_vout:
-                wgrads[4] = W3
-            if gated:
-                wgrads[5] = W2[:so].t().contiguous()
-                wgrads[6] = W2[so].contiguous()
+            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr)
 
         # ---- input gradients: un-concatenate, scatter-add the gathered sources back to their rows -----------------
         grads_s: List[Optional[Tensor]] = []
@@ -490,6 +411,105 @@ class _Gcp2(torch.autograd.Function):
         g_res_v = d_v_out if ctx.has_res[1] else None
         wgrads = [g if need else None for g, need in zip(wgrads, need_w)]
         return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
+
+
+def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out):
+    """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs)."""
+    lib = _lib.load()
+    f32 = dict(dtype=torch.float32, device=s_pre.device)
+    H, vi, vo, so, si = spec.hidden, spec.vi, spec.vo, spec.so, spec.si
+    nf = 9 if (spec.use_frames and vi > 0) else 0
+    has_vec, has_vout = vi > 0, vi > 0 and vo > 0
+    gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
+    d_s_in = torch.empty((rows, si), **f32)
+    d_v_in = torch.empty((rows, vi, 3), **f32) if has_vec else None
+    scr = BwdScratch()
+    t = dict(ds_pre=torch.empty((rows, so), **f32))
+    scr.ds_pre = t["ds_pre"].data_ptr()
+    if has_vec:
+        t.update(ext=torch.empty((rows, H + nf), **f32), dvhf=torch.empty((rows * 3, H + 3), **f32),
+                 vh=torch.empty((rows * 3, H), **f32), vt=torch.empty((rows * 3, vi), **f32))
+        scr.ext, scr.dvhf, scr.vh, scr.vt = (t[k].data_ptr() for k in ("ext", "dvhf", "vh", "vt"))
+        if has_vout:
+            t["dvu"] = torch.empty((rows * 3, vo), **f32)
+            scr.dvu = t["dvu"].data_ptr()
+        if gated:
+            t["dgate"] = torch.empty((rows, vo), **f32)
+            scr.dgate = t["dgate"].data_ptr()
+    ws = _weights_struct(spec, w, pack)
+    opts = _opts_struct(spec, fused_residual=spec.residual)
+    sc = _concat(s_src, spec.s_plans, False)
+    vc = _concat(v_src, spec.v_plans, True) if len(v_src) else Concat()
+    check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts), _p(s_pre),
+                                   _p(gate), _p(d_s_out), _p(d_v_out) if vo else None, _p(d_s_in), _p(d_v_in),
+                                   C.byref(scr), _stream()), "gcp2_backward")
+    return d_s_in, d_v_in, t
+
+
+def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t) -> List[Optional[Tensor]]:
+    """Weight gradients of one GCP2 block as TN GEMMs over the row axis, fed by the backward kernel's scratch `t`.
+    Returns gradients in the order (scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up,
+    vector_out_scale.weight, vector_out_scale.bias)."""
+    lib = _lib.load()
+    f32 = dict(dtype=torch.float32, device=s_pre.device)
+    H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
+    nf = 9 if (spec.use_frames and vi > 0) else 0
+    has_vec, has_vout = vi > 0, vi > 0 and vo > 0
+    gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
+    probs, keep = [], []
+
+    def operand(segs, act=None, ones=False):
+        op = Operand()
+        op.n = len(segs)
+        for k, (x, pl, dim, ld) in enumerate(segs):
+            op.ptr[k], op.dim[k], op.ld[k] = x.data_ptr(), dim, ld
+            op.idx[k] = pl.idx.data_ptr() if pl is not None else None
+        op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
+        return op
+
+    def problem(R, a, M, b, N, out, sm, sn):
+        pr = TnProblem()
+        pr.rows, pr.a, pr.b = R, a, b
+        pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
+        pr.splits = lib.gcpnet_tn_splits(R, M, N)
+        part = torch.empty((pr.splits, M, N), **f32)
+        keep.append(part)
+        pr.partial = part.data_ptr()
+        probs.append(pr)
+
+    K = spec.K
+    W1 = torch.empty((so, K + 1), **f32)
+    bsegs = [(x, pl, x.shape[1], x.shape[1]) for x, pl in zip(s_src, spec.s_plans)]
+    if has_vec:
+        bsegs.append((t["ext"], None, H + nf, H + nf))
+    problem(rows, operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), K + 1, W1, K + 1, 1)
+    W2 = W3 = W4 = None
+    if gated:
+        W2 = torch.empty((so + 1, vo), **f32)
+        problem(rows, operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
+                operand([(t["dgate"], None, vo, vo)]), vo, W2, vo, 1)
+    if has_vout:
+        W3 = torch.empty((vo, H), **f32)
+        problem(rows * 3, operand([(t["dvu"], None, vo, vo)]), vo, operand([(t["vh"], None, H, H)]), H, W3, H, 1)
+    if has_vec:
+        W4 = torch.empty((vi, H + 3), **f32)
+        problem(rows * 3, operand([(t["vt"], None, vi, vi)]), vi, operand([(t["dvhf"], None, H + 3, H + 3)]), H + 3, W4,
+                H + 3, 1)
+    arr = (TnProblem * len(probs))(*probs)
+    check(lib.gcpnet_tn_gemm(len(probs), arr, _stream()), "tn_gemm")
+    g: List[Optional[Tensor]] = [None] * 7
+    g[0] = W1[:, :K].contiguous()
+    g[1] = W1[:, K].contiguous()
+    if has_vec:
+        g[2] = W4[:, :H].t().contiguous()
+        if nf:
+            g[3] = W4[:, H:].t().contiguous()
+    if has_vout:
+        g[4] = W3
+    if gated:
+        g[5] = W2[:so].t().contiguous()
+        g[6] = W2[so].contiguous()
+    return g
 
 
 def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor], frames: Optional[Tensor], weights,
