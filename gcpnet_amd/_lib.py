@@ -49,7 +49,8 @@ class Operand(C.Structure):
 
 class TnProblem(C.Structure):
     _fields_ = [("rows", C.c_int), ("a", Operand), ("b", Operand), ("out", C.c_void_p), ("out_sm", C.c_int64),
-                ("out_sn", C.c_int64), ("partial", C.c_void_p), ("splits", C.c_int)]
+                ("out_sn", C.c_int64), ("partial", C.c_void_p), ("splits", C.c_int), ("diag", C.c_int),
+                ("diag_m", C.c_int), ("diag_n", C.c_int)]
 
 
 class GcpnetHipError(RuntimeError):

@@ -10,6 +10,7 @@
 //     reduction indices are (j0, j0+4) needs no data movement at all; the packed A image is built for that pairing.
 // Weight gradients are reductions over rows and are left to gcpnet_tn_gemm, fed by the per-row scratch written here.
 #include "common.h"
+#include "tile_io.h"
 
 namespace {
 
@@ -53,29 +54,6 @@ __host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
     l.o_fr = l.o_dvhf + 32 * l.FS;
     l.total = l.o_fr + 32 * 9;
     return l;
-}
-
-__device__ __forceinline__ void load_concat_tile(const gcp_concat_t& c, int mult, int r0, int rows, float* tile,
-                                                 int stride, int lane) {
-    int coff = 0;
-    for (int sg = 0; sg < c.n; ++sg) {
-        const float* base = c.ptr[sg];
-        const int32_t* idx = c.idx[sg];
-        const int dim = c.dim[sg] * mult;
-#pragma unroll 4
-        for (int e = 0; e < GCP_TILE_ROWS; ++e) {
-            const int r = r0 + e;
-            float* dst = tile + e * stride + coff;
-            if (r < rows) {
-                const int64_t src = idx ? (int64_t)idx[r] : (int64_t)r;
-                const float* rowp = base + src * dim;
-                for (int j = lane; j < dim; j += GCP_WAVE) dst[j] = rowp[j];
-            } else {
-                for (int j = lane; j < dim; j += GCP_WAVE) dst[j] = 0.f;
-            }
-        }
-        coff += dim;
-    }
 }
 
 // 4 consecutive columns j0..j0+3 of row `row` of a [rows, ld] matrix (zeros outside).
@@ -126,7 +104,7 @@ struct WFragB<4> {
 };
 
 template <int NTG, int NUG>
-__global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
+__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
     const BwdLds L = bwd_lds(S);
@@ -145,6 +123,9 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
     float* dvhf = lds + L.o_dvhf;
     float* fr = lds + L.o_fr;
     const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H, HF = S.H + 3;
+    // row strides of the per-row scratch handed to the weight-gradient GEMMs: multiples of 4 floats (16-byte DMA pieces)
+    const int EP = gcp_round_up(S.H + S.nf, 4), HP = gcp_round_up(S.H, 4), VIP = gcp_round_up(S.vi, 4);
+    const int VOP = gcp_round_up(S.vo, 4), HFP = gcp_round_up(S.H + 3, 4);
     const float slope = p.o.slope;
     const bool scalar_gate = (p.o.vmode == GCP_VMODE_SCALAR_GATE) && vo > 0 && vi > 0;
     const bool has_vec = vi > 0;
@@ -152,7 +133,7 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
 
     // ---- 1. stage vectors / frames, recompute vh, its norms and the frame scalars ---------------------------
     if (has_vec) {
-        load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
+        gcp_load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
         if (S.nf)
             for (int i = lane; i < 32 * 9; i += GCP_WAVE) {
                 int rr = r0 + i / 9;
@@ -178,11 +159,23 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
             const float nr = sqrtf(a0 * a0 + a1 * a1 + a2 * a2 + 1e-8f);
             rn[e * L.NS_ + h] = 1.0f / nr;
             if (row_ok) {
-                p.sc.ext[(int64_t)row * (H + S.nf) + h] = nr + 1e-8f;
-                p.sc.vh[((int64_t)row * 3 + 0) * H + h] = a0;
-                p.sc.vh[((int64_t)row * 3 + 1) * H + h] = a1;
-                p.sc.vh[((int64_t)row * 3 + 2) * H + h] = a2;
+                p.sc.ext[(int64_t)row * EP + h] = nr + 1e-8f;
+                p.sc.vh[((int64_t)row * 3 + 0) * HP + h] = a0;
+                p.sc.vh[((int64_t)row * 3 + 1) * HP + h] = a1;
+                p.sc.vh[((int64_t)row * 3 + 2) * HP + h] = a2;
             }
+        }
+        if (row_ok && hi == 0) {  // zero the stride padding
+            for (int c = H + S.nf; c < EP; ++c) p.sc.ext[(int64_t)row * EP + c] = 0.f;
+            for (int d = 0; d < 3; ++d) {
+                for (int c = H; c < HP; ++c) p.sc.vh[((int64_t)row * 3 + d) * HP + c] = 0.f;
+                for (int c = vi; c < VIP; ++c) p.sc.vt[((int64_t)row * 3 + d) * VIP + c] = 0.f;
+                for (int c = HF; c < HFP; ++c) p.sc.dvhf[((int64_t)row * 3 + d) * HFP + c] = 0.f;
+                if (has_vout)
+                    for (int c = vo; c < VOP; ++c) p.sc.dvu[((int64_t)row * 3 + d) * VOP + c] = 0.f;
+            }
+            if (scalar_gate)
+                for (int c = vo; c < VOP; ++c) p.sc.dgate[(int64_t)row * VOP + c] = 0.f;
         }
         if (S.nf) {
             const float* f = fr + e * 9;
@@ -203,7 +196,7 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
                         dvhf[e * L.FS + 0 * HF + H + k] = pr < 0.f ? -1.f : 1.f;
                         pr = fabsf(pr);
                     }
-                    if (row_ok) p.sc.ext[(int64_t)row * (H + 9) + H + 3 * k + a] = pr;
+                    if (row_ok) p.sc.ext[(int64_t)row * EP + H + 3 * k + a] = pr;
                 }
             }
         }
@@ -211,7 +204,7 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
         if (row_ok)
             for (int c = hi; c < vi; c += 2)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) p.sc.vt[((int64_t)row * 3 + d) * vi + c] = vrow[3 * c + d];
+                for (int d = 0; d < 3; ++d) p.sc.vt[((int64_t)row * 3 + d) * VIP + c] = vrow[3 * c + d];
     }
     __syncthreads();
 
@@ -243,7 +236,7 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
                 du0 = g0 * sg; du1 = g1 * sg; du2 = g2 * sg;
                 const float dg = dot * sg * (1.f - sg);
                 dgt[e * L.GS2 + oc] = dg;
-                if (row_ok) p.sc.dgate[(int64_t)row * vo + oc] = dg;
+                if (row_ok) p.sc.dgate[(int64_t)row * VOP + oc] = dg;
             } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
                 const float rs = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
                 const float n = rs + 1e-8f;
@@ -255,9 +248,9 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
             dvut[e * L.US + 3 * oc + 1] = du1;
             dvut[e * L.US + 3 * oc + 2] = du2;
             if (row_ok) {
-                p.sc.dvu[((int64_t)row * 3 + 0) * vo + oc] = du0;
-                p.sc.dvu[((int64_t)row * 3 + 1) * vo + oc] = du1;
-                p.sc.dvu[((int64_t)row * 3 + 2) * vo + oc] = du2;
+                p.sc.dvu[((int64_t)row * 3 + 0) * VOP + oc] = du0;
+                p.sc.dvu[((int64_t)row * 3 + 1) * VOP + oc] = du1;
+                p.sc.dvu[((int64_t)row * 3 + 2) * VOP + oc] = du2;
             }
         }
     }
@@ -417,7 +410,7 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_bwd_kernel(BwdParams p) {
     }
     __syncthreads();
     if (row_ok) {
-        for (int i = hi; i < 3 * HF; i += 2) p.sc.dvhf[(int64_t)row * 3 * HF + i] = dvhf[e * L.FS + i];
+        for (int i = hi; i < 3 * HF; i += 2) p.sc.dvhf[((int64_t)row * 3 + i / HF) * HFP + (i % HF)] = dvhf[e * L.FS + i];
         for (int c = hi; c < vi; c += 2) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int h = 0; h < H; ++h) {

@@ -12,6 +12,7 @@
 //     per row; the vector gate Linear (vector_out_scale) runs on v_mfma_f32_16x16x4_f32 from the staged tile;
 //   * the concatenation [h_row | e | h_col] is never materialised: the tile loader gathers each source.
 #include "common.h"
+#include "tile_io.h"
 
 namespace {
 
@@ -27,6 +28,7 @@ struct FwdParams {
     float* v_out;
     float* s_pre;
     float* gate;
+    int fused_res;  // res_s / res_v are the (single, ungathered) input itself
     GcpShape sh;
 };
 
@@ -40,14 +42,15 @@ __host__ __device__ inline FwdLds fwd_lds(const GcpShape& s) {
     FwdLds l;
     l.KS = gcp_odd(s.KP);
     l.SS = 32 * s.NTG + 1;
-    l.VS = gcp_odd(3 * s.vi);
+    l.VS = gcp_odd(3 * (s.vi > s.vo ? s.vi : s.vo));
     l.HS = gcp_odd(3 * s.H);
     l.GS = gcp_odd(s.vo);
     int mrg = 32 * l.KS, stg = 32 * l.SS;
     l.o_mrg = 0;
-    if (s.NG == 1) {  // single output group: the staging tile may overwrite the merged tile after the MFMA loop
+    if (s.NG == 1) {  // single output group: the merged tile doubles as the staging tile (same row stride)
+        if (l.KS < l.SS) { l.KS = l.SS; mrg = 32 * l.KS; }
         l.o_stg = 0;
-        l.o_vt = mrg > stg ? mrg : stg;
+        l.o_vt = mrg;
     } else {
         l.o_stg = mrg;
         l.o_vt = mrg + stg;
@@ -57,30 +60,6 @@ __host__ __device__ inline FwdLds fwd_lds(const GcpShape& s) {
     l.o_fr = l.o_gt + 32 * l.GS;
     l.total = l.o_fr + 32 * 9;
     return l;
-}
-
-// Loads rows [r0, r0+32) of a concatenated source into a wave-private tile: tile[e * stride + col0 + j].
-__device__ __forceinline__ void load_concat_tile(const gcp_concat_t& c, int mult, int r0, int rows, float* tile,
-                                                 int stride, int lane) {
-    int coff = 0;
-    for (int sg = 0; sg < c.n; ++sg) {
-        const float* base = c.ptr[sg];
-        const int32_t* idx = c.idx[sg];
-        const int dim = c.dim[sg] * mult;
-#pragma unroll 4
-        for (int e = 0; e < GCP_TILE_ROWS; ++e) {
-            const int r = r0 + e;
-            float* dst = tile + e * stride + coff;
-            if (r < rows) {
-                const int64_t src = idx ? (int64_t)idx[r] : (int64_t)r;
-                const float* rowp = base + src * dim;
-                for (int j = lane; j < dim; j += GCP_WAVE) dst[j] = rowp[j];
-            } else {
-                for (int j = lane; j < dim; j += GCP_WAVE) dst[j] = 0.f;
-            }
-        }
-        coff += dim;
-    }
 }
 
 template <int NTG>
@@ -107,8 +86,8 @@ struct WFrag<4> {
     }
 };
 
-template <int NTG>
-__global__ __launch_bounds__(GCP_WAVE) void gcp2_fwd_kernel(FwdParams p) {
+template <int NTG, int MOT>
+__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
     const FwdLds L = fwd_lds(S);
@@ -128,9 +107,9 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_fwd_kernel(FwdParams p) {
     const float slope = p.o.slope;
 
     // ---- 1. stage the tile: scalars into the merged tile, vectors, frames --------------------------------
-    load_concat_tile(p.s_in, 1, r0, rows, mrg, L.KS, lane);
+    gcp_load_concat_tile(p.s_in, 1, r0, rows, mrg, L.KS, lane);
     if (vi > 0) {
-        load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
+        gcp_load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
         if (S.nf) {
             for (int i = lane; i < 32 * 9; i += GCP_WAVE) {
                 int rr = r0 + i / 9;
@@ -182,12 +161,13 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_fwd_kernel(FwdParams p) {
 
     // ---- 3. scalar_out on the matrix cores, one group of NTG 32-wide output tiles at a time ---------------
     const int NOT = S.NOT;
-    f32x4 gacc[4][2];
+    f32x4 gacc[MOT][2];  // MOT = compile-time bound on the 16-wide gate output tiles (vo <= 16 * MOT)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MOT; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) gacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool scalar_gate = (p.o.vmode == GCP_VMODE_SCALAR_GATE) && vo > 0;
+    const bool single = S.NG == 1;
 
     for (int g = 0; g < S.NG; ++g) {
         f32x16 acc[NTG];
@@ -201,66 +181,87 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_fwd_kernel(FwdParams p) {
         const float* wp = p.w.pack + S.offA + ((int64_t)g * S.KK * 64 + lane) * NTG;
         const float* bp = mrg + e * L.KS + hi;
         constexpr int U = 4;
-        WFrag<NTG> an[U];
-        float bn[U];
+        // software pipeline over k-pair steps: three rotating batches of U steps, so a batch's weight fragments (one
+        // 16-byte L2 load per step) are requested two batches (2 * U * NTG MFMAs ~ 2k cycles) before they are used
+        WFrag<NTG> A0[U], A1[U], A2[U];
+        float B0[U], B1[U], B2[U];
+        const int KK = S.KK;
+        auto ld = [&](WFrag<NTG>(&a)[U], float(&b)[U], int kk0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            an[u].load(wp + (int64_t)u * 64 * NTG);
-            bn[u] = bp[2 * u];
-        }
-        for (int kk0 = 0; kk0 < S.KK; kk0 += U) {
-            WFrag<NTG> a[U];
-            float b[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { a[u] = an[u]; b[u] = bn[u]; }
-            if (kk0 + U < S.KK) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    an[u].load(wp + (int64_t)(kk0 + U + u) * 64 * NTG);
-                    bn[u] = bp[2 * (kk0 + U + u)];
-                }
+            for (int u = 0; u < U; ++u) {
+                const int kk = min(kk0 + u, KK - 1);
+                a[u].load(wp + (int64_t)kk * 64 * NTG);
+                b[u] = bp[2 * kk];
             }
+        };
+        auto mm = [&](WFrag<NTG>(&a)[U], float(&b)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int t = 0; t < NTG; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], b[u], acc[t], 0, 0, 0);
+        };
+        ld(A0, B0, 0);
+        ld(A1, B1, U);
+        ld(A2, B2, 2 * U);
+        for (int kk0 = 0; kk0 < KK; kk0 += 3 * U) {  // KK is a multiple of U
+            mm(A0, B0);
+            ld(A0, B0, kk0 + 3 * U);
+            if (kk0 + U < KK) mm(A1, B1);
+            ld(A1, B1, kk0 + 4 * U);
+            if (kk0 + 2 * U < KK) mm(A2, B2);
+            ld(A2, B2, kk0 + 5 * U);
         }
-        __syncthreads();  // all B reads of the merged tile are done before a possible overwrite (NG == 1)
-
-        // ---- 4. epilogue of this group: stage s_pre, store s_pre / s_out coalesced, feed the gate GEMM ------
+        const int c0 = g * 32 * NTG;
+        const int gw = min(32 * NTG, so - c0);
+        // ---- 4. epilogue of this group ----------------------------------------------------------------------
+        // Staging tile: a separate region when there are several output groups; with a single group it is the merged
+        // tile itself, same addressing, so each lane overwrites exactly the elements it has just consumed (its own
+        // residual inputs) and the MFMA loop no longer needs them.
+        float* st = single ? mrg : stg;
+        const int sst = single ? L.KS : L.SS;
+        __syncthreads();  // every B read of the merged tile by the MFMA loop has completed
+        // (a) s_out = act(s_pre) (+ residual): with the fused residual x is read from the LDS tile, not from HBM
 #pragma unroll
         for (int t = 0; t < NTG; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stg[e * L.SS + 32 * t + gcp_crow(r, hi)] = acc[t][r];
-        __syncthreads();
-        const int c0 = g * 32 * NTG;
-        const int gw = min(32 * NTG, so - c0);
-        for (int ee = 0; ee < GCP_TILE_ROWS; ++ee) {
-            const int rr = r0 + ee;
-            if (rr >= rows) break;
-            for (int j = lane; j < gw; j += GCP_WAVE) {
-                const float x = stg[ee * L.SS + j];
-                const int64_t off = (int64_t)rr * so + c0 + j;
-                if (p.s_pre) p.s_pre[off] = x;
-                float y = gcp_act(p.o.act_s, x, slope);
-                if (p.res_s) y += p.res_s[off];
-                p.s_out[off] = y;
+            for (int r = 0; r < 16; ++r) {
+                const int jl = 32 * t + gcp_crow(r, hi);
+                float y = gcp_act(p.o.act_s, acc[t][r], slope);
+                if (p.fused_res && c0 + jl < so) y += mrg[e * L.KS + c0 + jl];
+                st[e * sst + jl] = y;
             }
+        __syncthreads();
+        if (p.res_s && !p.fused_res) {  // separate residual tensor: slow path, re-read from HBM
+            for (int ee = 0; ee < GCP_TILE_ROWS && r0 + ee < rows; ++ee)
+                for (int j = lane; j < gw; j += GCP_WAVE) st[ee * sst + j] += p.res_s[(int64_t)(r0 + ee) * so + c0 + j];
+            __syncthreads();
         }
-        if (scalar_gate) {  // vector_out_scale(act_v(s_pre)) accumulated over this group's columns (gcpnet.py:386)
-            const float* wg = p.w.pack + S.offC + ((int64_t)g * 8 * NTG) * 64 + lane;
-            const int e16 = lane & 15, q = lane >> 4;
-            for (int jj = 0; jj < 8 * NTG; ++jj) {
-                float b0 = gcp_act(p.o.act_v, stg[e16 * L.SS + 4 * jj + q], slope);
-                float b1 = gcp_act(p.o.act_v, stg[(16 + e16) * L.SS + 4 * jj + q], slope);
-                if (c0 + 4 * jj + q >= so) { b0 = 0.f; b1 = 0.f; }
+        gcp_store_tile(p.s_out, so, c0, gw, r0, rows, st, sst, lane);
+        // (b) the pre-activations: saved for the backward, and B operand of the gate GEMM
+        if (p.s_pre || scalar_gate) {
+            __syncthreads();
 #pragma unroll
-                for (int ot = 0; ot < 4; ++ot) {
-                    if (ot < NOT) {
-                        const float a = wg[((int64_t)ot * S.NJ4 + jj) * 64];
-                        gacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gacc[ot][0], 0, 0, 0);
-                        gacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, gacc[ot][1], 0, 0, 0);
+            for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[e * sst + 32 * t + gcp_crow(r, hi)] = acc[t][r];
+            __syncthreads();
+            if (p.s_pre) gcp_store_tile(p.s_pre, so, c0, gw, r0, rows, st, sst, lane);
+            if (scalar_gate) {  // vector_out_scale(act_v(s_pre)) accumulated over this group's columns (gcpnet.py:386)
+                const float* wg = p.w.pack + S.offC + ((int64_t)g * 8 * NTG) * 64 + lane;
+                const int e16 = lane & 15, q = lane >> 4;
+#pragma unroll 4
+                for (int jj = 0; jj < 8 * NTG; ++jj) {
+                    float b0 = gcp_act(p.o.act_v, st[e16 * sst + 4 * jj + q], slope);
+                    float b1 = gcp_act(p.o.act_v, st[(16 + e16) * sst + 4 * jj + q], slope);
+                    if (c0 + 4 * jj + q >= so) { b0 = 0.f; b1 = 0.f; }
+#pragma unroll
+                    for (int ot = 0; ot < MOT; ++ot) {
+                        if (ot < NOT) {
+                            const float a = wg[((int64_t)ot * S.NJ4 + jj) * 64];
+                            gacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gacc[ot][0], 0, 0, 0);
+                            gacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, gacc[ot][1], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_fwd_kernel(FwdParams p) {
     if (scalar_gate) {
         const int e16 = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
+        for (int ot = 0; ot < MOT; ++ot) {
             if (ot < NOT) {
 #pragma unroll
                 for (int eh = 0; eh < 2; ++eh)
@@ -304,25 +305,29 @@ __global__ __launch_bounds__(GCP_WAVE) void gcp2_fwd_kernel(FwdParams p) {
             u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
             u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
         }
-        if (p.o.vector_residual) {
-            u0 += vt[e * L.VS + 3 * oc + 0];
-            u1 += vt[e * L.VS + 3 * oc + 1];
-            u2 += vt[e * L.VS + 3 * oc + 2];
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;  // this channel of the input (vector residual / ResGCP residual)
+        if (p.o.vector_residual || p.fused_res) {
+            x0 = vt[e * L.VS + 3 * oc + 0]; x1 = vt[e * L.VS + 3 * oc + 1]; x2 = vt[e * L.VS + 3 * oc + 2];
         }
+        if (p.o.vector_residual) { u0 += x0; u1 += x1; u2 += x2; }
         float sc = 1.f;
         if (scalar_gate) {
             sc = gt[e * L.GS + oc];
-            if (p.gate && row_ok) p.gate[(int64_t)row * vo + oc] = sc;
         } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
             sc = gcp_act(p.o.act_v, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f, slope);
         }
-        if (row_ok) {
+        float y0 = u0 * sc, y1 = u1 * sc, y2 = u2 * sc;
+        if (p.fused_res) { y0 += x0; y1 += x1; y2 += x2; }
+        if (p.res_v && !p.fused_res && row_ok) {
             const int64_t off = ((int64_t)row * vo + oc) * 3;
-            float y0 = u0 * sc, y1 = u1 * sc, y2 = u2 * sc;
-            if (p.res_v) { y0 += p.res_v[off]; y1 += p.res_v[off + 1]; y2 += p.res_v[off + 2]; }
-            p.v_out[off] = y0; p.v_out[off + 1] = y1; p.v_out[off + 2] = y2;
+            y0 += p.res_v[off]; y1 += p.res_v[off + 1]; y2 += p.res_v[off + 2];
         }
+        // in place: this lane is the only reader of channel oc of its row (oc < vi whenever the input is read)
+        vt[e * L.VS + 3 * oc + 0] = y0; vt[e * L.VS + 3 * oc + 1] = y1; vt[e * L.VS + 3 * oc + 2] = y2;
     }
+    __syncthreads();
+    gcp_store_tile(p.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
+    if (scalar_gate && p.gate) gcp_store_tile(p.gate, vo, 0, vo, r0, rows, gt, L.GS, lane);
 }
 
 __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
@@ -365,18 +370,25 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
     out[i] = val;
 }
 
-template <int NTG>
-int launch_fwd(const FwdParams& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
+template <int NTG, int MOT>
+int launch_fwd2(const FwdParams& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
     static size_t cur_max = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per size
     if (lds_bytes > cur_max) {
-        hipError_t err = hipFuncSetAttribute((const void*)gcp2_fwd_kernel<NTG>,
+        hipError_t err = hipFuncSetAttribute((const void*)gcp2_fwd_kernel<NTG, MOT>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (err != hipSuccess) return (int)err;
         cur_max = lds_bytes;
     }
-    hipLaunchKernelGGL(gcp2_fwd_kernel<NTG>, grid, dim3(GCP_WAVE), lds_bytes, st, p);
+    hipLaunchKernelGGL((gcp2_fwd_kernel<NTG, MOT>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NTG>
+int launch_fwd(const FwdParams& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
+    if (p.sh.NOT <= 1) return launch_fwd2<NTG, 1>(p, grid, lds_bytes, st);
+    if (p.sh.NOT <= 2) return launch_fwd2<NTG, 2>(p, grid, lds_bytes, st);
+    return launch_fwd2<NTG, 4>(p, grid, lds_bytes, st);
 }
 
 int check_concat(const gcp_concat_t* c, int total) {
@@ -435,6 +447,9 @@ extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp
     if (w->vi == 0) p.o.vmode = GCP_VMODE_NONE;  // zero vectors: nothing to gate (gcpnet.py:447-449)
     p.res_s = res_s; p.res_v = res_v;
     p.s_out = s_out; p.v_out = v_out; p.s_pre = s_pre; p.gate = gate;
+    p.fused_res = (res_s && s_in->n == 1 && !s_in->idx[0] && res_s == s_in->ptr[0] && w->si == w->so &&
+                   (w->vo == 0 || (res_v && w->vi == w->vo && v_in->n == 1 && !v_in->idx[0] && res_v == v_in->ptr[0])))
+                      ? 1 : 0;
     p.sh = gcp_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames);
     const FwdLds L = fwd_lds(p.sh);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

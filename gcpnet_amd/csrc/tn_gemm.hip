@@ -2,19 +2,25 @@
 // edges or nodes, 1e4..1e6) is huge and whose output (a weight matrix, <= 1024 x 1100) is small.
 //
 // The reference gets these from autograd through nn.Linear (src/models/components/gcpnet.py:303-324); here they
-// are explicit.  Decomposition: the row axis is split across workgroups (1024 rows each); a workgroup of 4 waves
+// are explicit.  Decomposition: the row axis is split across workgroups (2048 rows each); a workgroup of 4 waves
 // owns a 128 x 160 block of the output, wave w holding m-tile w and up to five 32x32 fp32 accumulators
 // (v_mfma_f32_32x32x2_f32, reduction over row pairs).  Both operands are staged through LDS 32 rows at a time in
-// row-major order, which is bank-conflict free for both the A and the B fragment reads.  Operands are
-// concatenations of gathered sources (so [h_row | e | h_col | norms | frame scalars] is never materialised), can be
-// passed through an activation on load, and can carry a column of ones (bias gradients).  Per-split partial sums
-// go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
+// dense row-major order, which is bank-conflict free for both fragment reads (a fragment reads 32 consecutive
+// floats of one row per lane half).  Fast path: the rows go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round
+// trip), double buffered, one barrier per 32-row chunk, next chunk in flight under the current chunk's MFMAs; each
+// lane's source address is computed per lane, so operands that are concatenations of GATHERED sources
+// ([h_row | e | h_col | norms | frame scalars]) cost nothing extra and are never materialised.  A generic register-
+// staged kernel covers operands the DMA cannot (widths or strides that are not multiples of 4 floats).  Operands can
+// be passed through an activation (applied at fragment read) and carry a column of ones (bias gradients).
+// Per-split partial sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
 #include "common.h"
 
 namespace {
 
-constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32, TN_ROWS_PER_SPLIT = 1024;
-constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // +1: two row-halves of a fragment read never collide
+constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32, TN_ROWS_PER_SPLIT = 2048;
+constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
+constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread
+constexpr int TN_DMA_LDS_FLOATS = 2 * TN_RK * (TN_BM + TN_BN);
 
 struct TnArgs {
     int n;
@@ -30,7 +36,45 @@ __host__ __device__ inline int operand_width(const gcp_operand_t& o) {
     return w;
 }
 
-// Stage columns [c0, c0 + width) of rows [r0, r0 + 32) of an operand into S[32][LD].
+struct BlockWork {
+    int pi, split, m0, n0, mw, nw, ntiles, r_begin, r_end;
+};
+
+__device__ __forceinline__ BlockWork locate(const TnArgs& a) {
+    BlockWork w;
+    int pi = 0;
+    while (pi + 1 < a.n && (int)blockIdx.x >= a.block_start[pi + 1]) ++pi;
+    w.pi = pi;
+    const gcp_tn_problem_t& P = a.p[pi];
+    int b = blockIdx.x - a.block_start[pi];
+    w.split = b % P.splits; b /= P.splits;
+    const int nbi = b % a.nb[pi], mbi = b / a.nb[pi];
+    w.m0 = mbi * TN_BM; w.n0 = nbi * TN_BN;
+    w.mw = min(TN_BM, a.M[pi] - w.m0);
+    w.nw = min(TN_BN, a.N[pi] - w.n0);
+    w.ntiles = gcp_cdiv(w.nw, 32);
+    w.r_begin = w.split * TN_ROWS_PER_SPLIT;
+    w.r_end = min(P.rows, w.r_begin + TN_ROWS_PER_SPLIT);
+    return w;
+}
+
+__device__ __forceinline__ void store_partial(const gcp_tn_problem_t& P, const BlockWork& w, int M, int N, const f32x16* acc,
+                                              int wave, int col, int hi) {
+    float* part = P.partial + (int64_t)w.split * M * N;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        if (t < w.ntiles) {
+            const int n = w.n0 + 32 * t + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = w.m0 + wave * 32 + gcp_crow(r, hi);
+                if (m < M && n < N) part[(int64_t)m * N + n] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ---- generic path: register-staged, any widths / strides ---------------------------------------------------------
 __device__ __forceinline__ void stage_operand(const gcp_operand_t& op, int c0, int width, int r0, int rows, float* S,
                                               int LD, int wave, int lane) {
     for (int rr = wave; rr < TN_RK; rr += 4) {
@@ -65,30 +109,17 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
     __shared__ float Bs[TN_RK * TN_LDB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 31, hi = lane >> 5;
-    int pi = 0;
-    while (pi + 1 < a.n && (int)blockIdx.x >= a.block_start[pi + 1]) ++pi;
-    const gcp_tn_problem_t& P = a.p[pi];
-    const int M = a.M[pi], N = a.N[pi];
-    int b = blockIdx.x - a.block_start[pi];
-    const int split = b % P.splits; b /= P.splits;
-    const int nbi = b % a.nb[pi];
-    const int mbi = b / a.nb[pi];
-    const int m0 = mbi * TN_BM, n0 = nbi * TN_BN;
-    const int mw = min(TN_BM, M - m0), nw = min(TN_BN, N - n0);
-    const int ntiles = gcp_cdiv(nw, 32);
-    const bool wave_active = wave * 32 < mw;
-    const int r_begin = split * TN_ROWS_PER_SPLIT;
-    const int r_end = min(P.rows, r_begin + TN_ROWS_PER_SPLIT);
-
+    const BlockWork w = locate(a);
+    const gcp_tn_problem_t& P = a.p[w.pi];
+    const bool wave_active = wave * 32 < w.mw;
     f32x16 acc[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    for (int r0 = r_begin; r0 < r_end; r0 += TN_RK) {
-        stage_operand(P.a, m0, gcp_round_up(mw, 32), r0, r_end, As, TN_LDA, wave, lane);
-        stage_operand(P.b, n0, ntiles * 32, r0, r_end, Bs, TN_LDB, wave, lane);
+    for (int r0 = w.r_begin; r0 < w.r_end; r0 += TN_RK) {
+        stage_operand(P.a, w.m0, gcp_round_up(w.mw, 32), r0, w.r_end, As, TN_LDA, wave, lane);
+        stage_operand(P.b, w.n0, w.ntiles * 32, r0, w.r_end, Bs, TN_LDB, wave, lane);
         __syncthreads();
         if (wave_active) {
 #pragma unroll 4
@@ -97,37 +128,217 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
                 const float* brow = Bs + (2 * ss + hi) * TN_LDB + col;
 #pragma unroll
                 for (int t = 0; t < 5; ++t)
-                    if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[32 * t], acc[t], 0, 0, 0);
+                    if (t < w.ntiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[32 * t], acc[t], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    if (!wave_active) return;
-    float* part = P.partial + (int64_t)split * M * N;
+    if (wave_active) store_partial(P, w, a.M[w.pi], a.N[w.pi], acc, wave, col, hi);
+}
+
+// ---- fast path: HBM -> LDS DMA, double buffered -------------------------------------------------------------------
+struct Slot {
+    const float* base;   // segment pointer + column offset of this 16-byte piece
+    const int32_t* idx;  // optional row gather
+    int ld;
+    int row;             // row inside the 32-row chunk
+    bool on;             // piece belongs to a real column group of the operand
+};
+
+template <int NSLOT, int LD>
+__device__ __forceinline__ void make_slots(const gcp_operand_t& op, int c0, Slot* s, int tid) {
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        if (t < ntiles) {
-            const int n = n0 + 32 * t + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 + gcp_crow(r, hi);
-                if (m < M && n < N) part[(int64_t)m * N + n] = acc[t][r];
+    for (int k = 0; k < NSLOT; ++k) {
+        const int f = tid + 256 * k;
+        const int row = f / (LD / 4), c = c0 + 4 * (f % (LD / 4));
+        s[k].row = row; s[k].on = false; s[k].base = nullptr; s[k].idx = nullptr; s[k].ld = 0;
+        int cbase = 0;
+        for (int sg = 0; sg < op.n; ++sg) {
+            if (c >= cbase && c < cbase + op.dim[sg]) {
+                s[k].base = op.ptr[sg] + (c - cbase);
+                s[k].idx = op.idx[sg];
+                s[k].ld = op.ld[sg];
+                s[k].on = true;
             }
+            cbase += op.dim[sg];
         }
     }
 }
 
-__global__ void tn_reduce_kernel(TnArgs a) {
+// Source rows of the pieces of one chunk.  Gather indices are ordinary global loads: they are requested one chunk
+// ahead, so that no load result is consumed between DMA issues (hipcc drains vmcnt(0) at such a use, which would
+// serialise the DMAs).
+template <int NSLOT>
+__device__ __forceinline__ void fetch_issue(const Slot* s, int* v, int r0, int r_last, const int32_t* any_idx) {
+    if (any_idx) {  // wave-uniform: the operand has at least one gathered segment
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {  // unconditional loads (a per-piece branch would make hipcc wait per piece)
+            const int32_t* ip = s[k].idx ? s[k].idx : any_idx;
+            v[k] = ip[min(r0 + s[k].row, r_last)];
+        }
+    }
+}
+
+template <int NSLOT>
+__device__ __forceinline__ void fetch_finish(const Slot* s, const int* v, int64_t* src, int r0, int r_last,
+                                             const int32_t* any_idx) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int r = min(r0 + s[k].row, r_last);
+        src[k] = (any_idx && s[k].idx) ? (int64_t)v[k] : (int64_t)r;
+    }
+}
+
+template <int NSLOT>
+__device__ __forceinline__ void issue_dma(const Slot* s, const int64_t* src, float* buf, int tid) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        float* dst = buf + (256 * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
+        if (s[k].on)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s[k].base + src[k] * s[k].ld),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ const int32_t* any_gather(const gcp_operand_t& op) {
+    const int32_t* g = nullptr;
+    for (int k = 0; k < op.n; ++k)
+        if (op.idx[k]) g = op.idx[k];
+    return g;
+}
+
+// activation on the landed tile: real data columns of valid rows only (never the ones column or padding)
+__device__ __forceinline__ void act_in_lds(float* buf, int LD, int data_cols, int nvalid, int act, float slope, int tid) {
+    for (int i = tid; i < nvalid * data_cols; i += 256) {
+        const int r = i / data_cols, c = i - r * data_cols;
+        buf[r * LD + c] = gcp_act(act, buf[r * LD + c], slope);
+    }
+}
+
+__global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    const BlockWork w = locate(a);
+    const gcp_tn_problem_t& P = a.p[w.pi];
+    const bool wave_active = wave * 32 < w.mw;
+    auto Abuf = [&](int b) { return lds + b * (TN_RK * (TN_BM + TN_BN)); };
+    auto Bbuf = [&](int b) { return lds + b * (TN_RK * (TN_BM + TN_BN)) + TN_RK * TN_BM; };
+
+    Slot sa[TN_A_SLOTS], sb[TN_B_SLOTS];
+    make_slots<TN_A_SLOTS, TN_BM>(P.a, w.m0, sa, tid);
+    make_slots<TN_B_SLOTS, TN_BN>(P.b, w.n0, sb, tid);
+    const int32_t* ga = any_gather(P.a);
+    const int32_t* gb = any_gather(P.b);
+    // the ones column (bias gradients) is written by hand; its position inside the tile, or -1
+    const int a_data = operand_width(P.a) - (P.a.ones ? 1 : 0), b_data = operand_width(P.b) - (P.b.ones ? 1 : 0);
+    const int a_ones = P.a.ones ? (a_data - w.m0) : -1, b_ones = P.b.ones ? (b_data - w.n0) : -1;
+    const bool a_has_ones = a_ones >= 0 && a_ones < TN_BM, b_has_ones = b_ones >= 0 && b_ones < TN_BN;
+    const int a_cols = max(0, min(TN_BM, a_data - w.m0)), b_cols = max(0, min(TN_BN, b_data - w.n0));
+
+    for (int i = tid; i < TN_DMA_LDS_FLOATS; i += 256) lds[i] = 0.f;  // columns no DMA piece covers stay zero
+    __syncthreads();
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int r_last = w.r_end - 1;
+    const int nchunks = gcp_cdiv(w.r_end - w.r_begin, TN_RK);
+    int64_t ra[TN_A_SLOTS], rb[TN_B_SLOTS];
+    auto stage = [&](int chunk, int b) {  // rows of `chunk` are in ra / rb
+        const int r0 = w.r_begin + chunk * TN_RK;
+        issue_dma<TN_A_SLOTS>(sa, ra, Abuf(b), tid);
+        issue_dma<TN_B_SLOTS>(sb, rb, Bbuf(b), tid);
+        if (tid < TN_RK) {
+            const float one = (r0 + tid <= r_last) ? 1.f : 0.f;
+            if (a_has_ones) Abuf(b)[tid * TN_BM + a_ones] = one;
+            if (b_has_ones) Bbuf(b)[tid * TN_BN + b_ones] = one;
+        }
+    };
+    int va[TN_A_SLOTS], vb[TN_B_SLOTS];
+    fetch_issue<TN_A_SLOTS>(sa, va, w.r_begin, r_last, ga);
+    fetch_issue<TN_B_SLOTS>(sb, vb, w.r_begin, r_last, gb);
+    fetch_finish<TN_A_SLOTS>(sa, va, ra, w.r_begin, r_last, ga);
+    fetch_finish<TN_B_SLOTS>(sb, vb, rb, w.r_begin, r_last, gb);
+    stage(0, 0);
+    fetch_issue<TN_A_SLOTS>(sa, va, w.r_begin + TN_RK, r_last, ga);
+    fetch_issue<TN_B_SLOTS>(sb, vb, w.r_begin + TN_RK, r_last, gb);
+    fetch_finish<TN_A_SLOTS>(sa, va, ra, w.r_begin + TN_RK, r_last, ga);
+    fetch_finish<TN_B_SLOTS>(sb, vb, rb, w.r_begin + TN_RK, r_last, gb);
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        __syncthreads();  // vmcnt(0) + barrier: this chunk has landed, and every wave is done with the other buffer
+        const int nvalid = min(TN_RK, w.r_end - (w.r_begin + c * TN_RK));
+        if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
+            for (int i = tid; i < (TN_RK - nvalid) * TN_BM; i += 256) Abuf(cur)[nvalid * TN_BM + i] = 0.f;
+            for (int i = tid; i < (TN_RK - nvalid) * TN_BN; i += 256) Bbuf(cur)[nvalid * TN_BN + i] = 0.f;
+            __syncthreads();
+        }
+        if (P.a.act || P.b.act) {
+            if (P.a.act) act_in_lds(Abuf(cur), TN_BM, a_cols, nvalid, P.a.act, P.a.slope, tid);
+            if (P.b.act) act_in_lds(Bbuf(cur), TN_BN, b_cols, nvalid, P.b.act, P.b.slope, tid);
+            __syncthreads();
+        }
+        const int rn = w.r_begin + (c + 2) * TN_RK;  // gather indices of the chunk after next: requested now,
+        if (c + 1 < nchunks) {                        // consumed after this chunk's MFMAs
+            stage(c + 1, cur ^ 1);
+            fetch_issue<TN_A_SLOTS>(sa, va, rn, r_last, ga);
+            fetch_issue<TN_B_SLOTS>(sb, vb, rn, r_last, gb);
+        }
+        if (wave_active) {
+            const float* As = Abuf(cur) + wave * 32 + col;
+            const float* Bs = Bbuf(cur) + col;
+#pragma unroll 4
+            for (int ss = 0; ss < TN_RK / 2; ++ss) {
+                const float av = As[(2 * ss + hi) * TN_BM];
+                const float* brow = Bs + (2 * ss + hi) * TN_BN;
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (t < w.ntiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[32 * t], acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) {
+            fetch_finish<TN_A_SLOTS>(sa, va, ra, rn, r_last, ga);
+            fetch_finish<TN_B_SLOTS>(sb, vb, rb, rn, r_last, gb);
+        }
+    }
+    if (wave_active) store_partial(P, w, a.M[w.pi], a.N[w.pi], acc, wave, col, hi);
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a) {
     const int pi = blockIdx.y;
     const gcp_tn_problem_t& P = a.p[pi];
     const int M = a.M[pi], N = a.N[pi];
-    const int64_t total = (int64_t)M * N;
+    const int64_t full = (int64_t)M * N;
+    const int om = P.diag > 0 ? P.diag_m : M, on = P.diag > 0 ? P.diag_n : N, nd = P.diag > 0 ? P.diag : 1;
+    const int64_t total = (int64_t)om * on;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / on), n = (int)(i % on);
         float s = 0.f;
-        for (int k = 0; k < P.splits; ++k) s += P.partial[(int64_t)k * total + i];
-        const int m = (int)(i / N), n = (int)(i % N);
+        for (int d = 0; d < nd; ++d) {
+            const float* src = P.partial + (int64_t)(d * om + m) * N + (d * on + n);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int k = 0;
+            for (; k + 3 < P.splits; k += 4) {
+                s0 += src[(int64_t)k * full];
+                s1 += src[(int64_t)(k + 1) * full];
+                s2 += src[(int64_t)(k + 2) * full];
+                s3 += src[(int64_t)(k + 3) * full];
+            }
+            for (; k < P.splits; ++k) s0 += src[(int64_t)k * full];
+            s += (s0 + s1) + (s2 + s3);
+        }
         P.out[m * P.out_sm + n * P.out_sn] = s;
     }
+}
+
+inline bool dma_ok(const gcp_operand_t& o) {
+    for (int k = 0; k < o.n; ++k)
+        if ((o.dim[k] & 3) || (o.ld[k] & 3) || (reinterpret_cast<uintptr_t>(o.ptr[k]) & 15)) return false;
+    return true;
 }
 
 }  // namespace
@@ -142,6 +353,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     TnArgs a;
     a.n = n_problems;
     int blocks = 0, max_mn = 0;
+    bool dma = true;
     for (int i = 0; i < n_problems; ++i) {
         const gcp_tn_problem_t& P = problems[i];
         if (P.rows < 0 || P.a.n < 0 || P.a.n > GCP_TN_MAX_SEG || P.b.n < 0 || P.b.n > GCP_TN_MAX_SEG || !P.out || !P.partial)
@@ -151,6 +363,8 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         a.M[i] = operand_width(P.a);
         a.N[i] = operand_width(P.b);
         if (a.M[i] <= 0 || a.N[i] <= 0) return GCPNET_E_BADARG;
+        if (P.diag > 0 && (P.diag * P.diag_m > a.M[i] || P.diag * P.diag_n > a.N[i])) return GCPNET_E_BADARG;
+        dma = dma && dma_ok(P.a) && dma_ok(P.b) && P.rows > 0;
         a.mb[i] = gcp_cdiv(a.M[i], TN_BM);
         a.nb[i] = gcp_cdiv(a.N[i], TN_BN);
         a.block_start[i] = blocks;
@@ -159,9 +373,21 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     }
     a.block_start[n_problems] = blocks;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(tn_gemm_kernel, dim3(blocks), dim3(256), 0, st, a);
+    if (dma) {
+        static bool configured = false;
+        const size_t lds_bytes = (size_t)TN_DMA_LDS_FLOATS * sizeof(float);
+        if (!configured) {
+            hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds_bytes);
+            if (err != hipSuccess) return (int)err;
+            configured = true;
+        }
+        hipLaunchKernelGGL(tn_gemm_dma_kernel, dim3(blocks), dim3(256), lds_bytes, st, a);
+    } else {
+        hipLaunchKernelGGL(tn_gemm_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
     GCP_HIP_CHECK_LAUNCH();
-    const int rblocks = min(256, gcp_cdiv(max_mn, 256));
+    const int rblocks = min(64, gcp_cdiv(max_mn, 256));
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(rblocks, n_problems), dim3(256), 0, st, a);
     GCP_HIP_CHECK_LAUNCH();
     return 0;

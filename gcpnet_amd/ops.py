@@ -426,15 +426,16 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     scr = BwdScratch()
     t = dict(ds_pre=torch.empty((rows, so), **f32))
     scr.ds_pre = t["ds_pre"].data_ptr()
+    r4 = lambda x: (x + 3) // 4 * 4
     if has_vec:
-        t.update(ext=torch.empty((rows, H + nf), **f32), dvhf=torch.empty((rows * 3, H + 3), **f32),
-                 vh=torch.empty((rows * 3, H), **f32), vt=torch.empty((rows * 3, vi), **f32))
+        t.update(ext=torch.empty((rows, r4(H + nf)), **f32), dvhf=torch.empty((rows, 3 * r4(H + 3)), **f32),
+                 vh=torch.empty((rows, 3 * r4(H)), **f32), vt=torch.empty((rows, 3 * r4(vi)), **f32))
         scr.ext, scr.dvhf, scr.vh, scr.vt = (t[k].data_ptr() for k in ("ext", "dvhf", "vh", "vt"))
         if has_vout:
-            t["dvu"] = torch.empty((rows * 3, vo), **f32)
+            t["dvu"] = torch.empty((rows, 3 * r4(vo)), **f32)
             scr.dvu = t["dvu"].data_ptr()
         if gated:
-            t["dgate"] = torch.empty((rows, vo), **f32)
+            t["dgate"] = torch.empty((rows, r4(vo)), **f32)
             scr.dgate = t["dgate"].data_ptr()
     ws = _weights_struct(spec, w, pack)
     opts = _opts_struct(spec, fused_residual=spec.residual)
@@ -467,48 +468,58 @@ def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t) -> List[Option
         op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
         return op
 
-    def problem(R, a, M, b, N, out, sm, sn):
+    def problem(a, M, b, N, out, sm, sn, diag=0, dm=0, dn=0):
         pr = TnProblem()
-        pr.rows, pr.a, pr.b = R, a, b
+        pr.rows, pr.a, pr.b = rows, a, b
         pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
-        pr.splits = lib.gcpnet_tn_splits(R, M, N)
+        pr.splits = lib.gcpnet_tn_splits(rows, M, N)
+        pr.diag, pr.diag_m, pr.diag_n = diag, dm, dn
         part = torch.empty((pr.splits, M, N), **f32)
         keep.append(part)
         pr.partial = part.data_ptr()
         probs.append(pr)
 
-    K = spec.K
-    W1 = torch.empty((so, K + 1), **f32)
+    r4 = lambda x: (x + 3) // 4 * 4
+    si = spec.si
+    EP, HP, VIP, VOP, HFP = r4(H + nf), r4(H), r4(vi), r4(vo), r4(H + 3)
+    # d scalar_out.weight / bias: ds_pre^T [s sources | norms | frame scalars | 1]
     bsegs = [(x, pl, x.shape[1], x.shape[1]) for x, pl in zip(s_src, spec.s_plans)]
+    n1 = si + 1
     if has_vec:
-        bsegs.append((t["ext"], None, H + nf, H + nf))
-    problem(rows, operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), K + 1, W1, K + 1, 1)
+        bsegs.append((t["ext"], None, EP, EP))
+        n1 = si + EP + 1
+    W1 = torch.empty((so, n1), **f32)
+    problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, W1, n1, 1)
     W2 = W3 = W4 = None
-    if gated:
-        W2 = torch.empty((so + 1, vo), **f32)
-        problem(rows, operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
-                operand([(t["dgate"], None, vo, vo)]), vo, W2, vo, 1)
-    if has_vout:
-        W3 = torch.empty((vo, H), **f32)
-        problem(rows * 3, operand([(t["dvu"], None, vo, vo)]), vo, operand([(t["vh"], None, H, H)]), H, W3, H, 1)
-    if has_vec:
-        W4 = torch.empty((vi, H + 3), **f32)
-        problem(rows * 3, operand([(t["vt"], None, vi, vi)]), vi, operand([(t["dvhf"], None, H + 3, H + 3)]), H + 3, W4,
-                H + 3, 1)
+    if gated:  # d vector_out_scale.weight / bias: [act_v(s_pre) | 1]^T dgate
+        W2 = torch.empty((so + 1, VOP), **f32)
+        problem(operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
+                operand([(t["dgate"], None, VOP, VOP)]), VOP, W2, VOP, 1)
+    if has_vout:  # d vector_up.weight: trace over xyz of dvu[(d,o)]^T vh[(d,h)]
+        W3 = torch.empty((VOP, HP), **f32)
+        problem(operand([(t["dvu"], None, 3 * VOP, 3 * VOP)]), 3 * VOP, operand([(t["vh"], None, 3 * HP, 3 * HP)]), 3 * HP,
+                W3, HP, 1, diag=3, dm=VOP, dn=HP)
+    if has_vec:  # d vector_down(.frames).weight: trace over xyz of v[(d,c)]^T [dvh | dvf][(d,x)]
+        W4 = torch.empty((VIP, HFP), **f32)
+        problem(operand([(t["vt"], None, 3 * VIP, 3 * VIP)]), 3 * VIP, operand([(t["dvhf"], None, 3 * HFP, 3 * HFP)]),
+                3 * HFP, W4, HFP, 1, diag=3, dm=VIP, dn=HFP)
     arr = (TnProblem * len(probs))(*probs)
     check(lib.gcpnet_tn_gemm(len(probs), arr, _stream()), "tn_gemm")
     g: List[Optional[Tensor]] = [None] * 7
-    g[0] = W1[:, :K].contiguous()
-    g[1] = W1[:, K].contiguous()
     if has_vec:
-        g[2] = W4[:, :H].t().contiguous()
+        g[0] = torch.cat((W1[:, :si], W1[:, si:si + H + nf]), dim=1)
+        g[1] = W1[:, si + EP].contiguous()
+        g[2] = W4[:vi, :H].t().contiguous()
         if nf:
-            g[3] = W4[:, H:].t().contiguous()
+            g[3] = W4[:vi, H:H + 3].t().contiguous()
+    else:
+        g[0] = W1[:, :si].contiguous()
+        g[1] = W1[:, si].contiguous()
     if has_vout:
-        g[4] = W3
+        g[4] = W3[:vo, :H].contiguous()
     if gated:
-        g[5] = W2[:so].t().contiguous()
-        g[6] = W2[so].contiguous()
+        g[5] = W2[:so, :vo].t().contiguous()
+        g[6] = W2[so, :vo].contiguous()
     return g
 
 

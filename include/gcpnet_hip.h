@@ -93,8 +93,9 @@ int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* 
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
  * concatenated layout, plus the per-row quantities the weight-gradient GEMMs consume (all row-major):
- *   ds_pre [rows, so], dgate [rows, vo], ext [rows, H+9] (= [|vh| norms | frame scalars]),
- *   dvu [rows, 3, vo], dvhf [rows, 3, H+3] (= [d vh | d vf]), vh [rows, 3, H], vt [rows, 3, vi]. */
+ *   ds_pre [rows, so], dgate [rows, vo'], ext [rows, (H+9)'] (= [|vh| norms | frame scalars]),
+ *   dvu [rows, 3, vo'], dvhf [rows, 3, (H+3)'] (= [d vh | d vf]), vh [rows, 3, H'], vt [rows, 3, vi'],
+ * where x' = x rounded up to a multiple of 4 floats (16-byte DMA pieces; the padding is written as zeros). */
 typedef struct {
     float* ds_pre;
     float* dgate;
@@ -135,6 +136,9 @@ typedef struct {
     int64_t out_sm, out_sn;
     float* partial;    /* scratch [splits, M, N] */
     int splits;
+    /* block-diagonal trace: when diag > 0 the operands are [rows, diag * diag_m] and [rows, diag * diag_n] (e.g. the
+     * xyz axis folded into the columns) and out[i, j] = sum_d full[d * diag_m + i, d * diag_n + j], i < diag_m, j < diag_n */
+    int diag, diag_m, diag_n;
 } gcp_tn_problem_t;
 
 #define GCP_TN_MAX_PROBLEMS 8
