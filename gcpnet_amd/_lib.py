@@ -16,7 +16,7 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_backward", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_segment_reduce", "gcpnet_gather_rows",
-    "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_axpy_clamp",
+    "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_axpy_clamp", "gcpnet_debug_set_phase_timing",
 ]
 
 
@@ -88,6 +88,7 @@ def load():
     lib.gcpnet_layernorm_forward.argtypes = [i32, i32, i32] + [vp] * 12
     lib.gcpnet_layernorm_backward.argtypes = [i32, i32, i32] + [vp] * 11
     lib.gcpnet_axpy_clamp.argtypes = [i64, vp, vp, f32, i32, f32, f32, vp, vp]
+    lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats",):

@@ -45,6 +45,31 @@ __device__ __forceinline__ float gcp_act_grad(int act, float x, float slope) {
     }
 }
 
+// Activations inside the kernels.  identity / relu / leakyrelu (every shipped GCP2 config) are one branch-free
+// piecewise-linear formula with a wave-uniform negative-side slope (1, 0, slope); kernels are instantiated with
+// PWL = true for them.  selu / silu / sigmoid go through the generic switch in a separate instantiation (PWL = false), so
+// that the common path does not carry exp / divide code inside its unrolled loops.
+__host__ __device__ inline bool gcp_is_pwl(int act) { return act == GCP_ACT_NONE || act == GCP_ACT_RELU || act == GCP_ACT_LEAKYRELU; }
+__host__ __device__ inline float gcp_neg_slope(int act, float slope) {
+    return act == GCP_ACT_NONE ? 1.f : (act == GCP_ACT_RELU ? 0.f : slope);
+}
+template <bool PWL>
+__device__ __forceinline__ float gcp_actf(int act, float ns, float slope, float x) {
+    if constexpr (PWL) return x > 0.f ? x : (ns == 0.f ? 0.f : ns * x);
+    else return gcp_act(act, x, slope);
+}
+template <bool PWL>
+__device__ __forceinline__ float gcp_dactf(int act, float ns, float slope, float x) {
+    if constexpr (PWL) return x > 0.f ? 1.f : ns;
+    else return gcp_act_grad(act, x, slope);
+}
+
+// Workgroup = one wavefront in the GCP kernels, so cross-lane hand-offs through LDS need no s_barrier and, above all,
+// no vmcnt(0): __syncthreads() would also wait for every outstanding global STORE of the wave to retire (vmcnt counts
+// stores on CDNA), which costs ~10 us per staging step under load.  DS operations of one wave complete in order;
+// waiting for lgkmcnt(0) (and stopping the compiler from moving memory operations across) is sufficient.
+__device__ __forceinline__ void gcp_wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // Row index inside a 32x32 MFMA C/D tile held by (register r, lane half hi): the column is lane & 31.
 __device__ __forceinline__ int gcp_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -90,6 +115,15 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.offD = s.offC + (int64_t)s.NOT * s.NJ4 * 64;
     s.total = s.offD + (int64_t)s.NOO * s.NG * 64 * s.NTG;
     return s;
+}
+
+// ---- optional phase timing (profiling hook): when a buffer is registered with gcpnet_debug_set_phase_timing(), every
+// wave-tile writes up to GCP_MAX_STAMPS s_memtime stamps to buf[tile * GCP_MAX_STAMPS + k] ---------------------------
+#define GCP_MAX_STAMPS 8
+extern unsigned long long* g_gcp_phase_buf;  // host-side copy of the registered device pointer (graph_ops.hip)
+extern long long g_gcp_phase_cap;
+__device__ __forceinline__ void gcp_stamp(unsigned long long* buf, long long cap, int k, int lane) {
+    if (buf && lane == 0 && (long long)blockIdx.x < cap) buf[(long long)blockIdx.x * GCP_MAX_STAMPS + k] = __builtin_amdgcn_s_memtime();
 }
 
 #define GCP_HIP_CHECK_LAUNCH()                         \

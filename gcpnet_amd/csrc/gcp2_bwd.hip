@@ -27,12 +27,14 @@ struct BwdParams {
     float* d_s_in;
     float* d_v_in;
     gcp2_bwd_scratch_t sc;
+    unsigned long long* stamps;
+    long long stamp_cap;
     GcpShape sh;
 };
 
 struct BwdLds {
     int VS, HS, NS_, US, GS2, DS, FS;
-    int o_vt, o_vht, o_rn, o_dvut, o_dgt, o_dext, o_dvhf, o_fr, total;
+    int o_vt, o_vht, o_rn, o_dvut, o_dvot, o_dgt, o_dext, o_dvhf, o_fr, o_sw, total;
 };
 
 __host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
@@ -48,11 +50,13 @@ __host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
     l.o_vht = l.o_vt + 32 * l.VS;
     l.o_rn = l.o_vht + 32 * l.HS;
     l.o_dvut = l.o_rn + 32 * l.NS_;
-    l.o_dgt = l.o_dvut + 32 * l.US;
+    l.o_dvot = l.o_dvut + 32 * l.US;
+    l.o_dgt = l.o_dvot + 32 * l.US;
     l.o_dext = l.o_dgt + 32 * l.GS2;
     l.o_dvhf = l.o_dext + 32 * l.DS;
     l.o_fr = l.o_dvhf + 32 * l.FS;
-    l.total = l.o_fr + 32 * 9;
+    l.o_sw = l.o_fr + 32 * 9;
+    l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
     return l;
 }
 
@@ -103,7 +107,7 @@ struct WFragB<4> {
     }
 };
 
-template <int NTG, int NUG>
+template <int NTG, int NUG, bool PWL>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     float* vht = lds + L.o_vht;
     float* rn = lds + L.o_rn;
     float* dvut = lds + L.o_dvut;
-    float* dgt = lds + L.o_dgt;
+    float* dvot = lds + L.o_dvot;  // d(v_out) tile, staged once with coalesced loads
+    float* dgt = lds + L.o_dgt;    // sigmoid(gate) tile on entry, overwritten in place by d(gate)
     float* dext = lds + L.o_dext;
     float* dvhf = lds + L.o_dvhf;
     float* fr = lds + L.o_fr;
@@ -127,25 +132,35 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     const int EP = gcp_round_up(S.H + S.nf, 4), HP = gcp_round_up(S.H, 4), VIP = gcp_round_up(S.vi, 4);
     const int VOP = gcp_round_up(S.vo, 4), HFP = gcp_round_up(S.H + 3, 4);
     const float slope = p.o.slope;
+    const float ns_s = gcp_neg_slope(p.o.act_s, slope), ns_v = gcp_neg_slope(p.o.act_v, slope);
     const bool scalar_gate = (p.o.vmode == GCP_VMODE_SCALAR_GATE) && vo > 0 && vi > 0;
     const bool has_vec = vi > 0;
     const bool has_vout = has_vec && vo > 0;
 
+    gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
     // ---- 1. stage vectors / frames, recompute vh, its norms and the frame scalars ---------------------------
-    if (has_vec) {
-        gcp_load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
-        if (S.nf)
-            for (int i = lane; i < 32 * 9; i += GCP_WAVE) {
-                int rr = r0 + i / 9;
-                fr[i] = rr < rows ? p.frames[(int64_t)rr * 9 + (i % 9)] : 0.f;
-            }
+    if (has_vec) {  // inputs, upstream vector gradients, gates and frames: one memory round trip
+        GcpSegBuf<8> vb0, gb0, tb0;
+        gcp_seg_issue(vb0, p.v_in.ptr[0], p.v_in.idx[0], 3 * p.v_in.dim[0], r0, rows, vt, L.VS, 0, lane);
+        if (has_vout) gcp_seg_issue(gb0, p.d_v_out, nullptr, 3 * vo, r0, rows, dvot, L.US, 0, lane);
+        if (scalar_gate) gcp_seg_issue(tb0, p.gate, nullptr, vo, r0, rows, dgt, L.GS2, 0, lane);
+        if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
+        gcp_seg_commit(vb0, vt, L.VS, 0);
+        if (has_vout) gcp_seg_commit(gb0, dvot, L.US, 0);
+        if (scalar_gate) gcp_seg_commit(tb0, dgt, L.GS2, 0);
+        int coff = 3 * p.v_in.dim[0];
+        for (int sg = 1; sg < p.v_in.n; ++sg) {
+            gcp_load_segment(p.v_in.ptr[sg], p.v_in.idx[sg], 3 * p.v_in.dim[sg], r0, rows, vt, L.VS, coff, lane);
+            coff += 3 * p.v_in.dim[sg];
+        }
     }
-    for (int i = hi; i < 2 * S.NOO; i += 2) dgt[e * L.GS2 + i] = 0.f;
-    __syncthreads();
+    const GcpSmallW sw = gcp_stage_small_weights(p.w, H, S.nf, lds + L.o_sw, lane);
+    for (int i = vo + hi; i < 2 * S.NOO; i += 2) dgt[e * L.GS2 + i] = 0.f;  // zero the gate-adjoint k padding
+    gcp_wave_lds_sync();
     if (has_vec) {
         const float* vrow = vt + e * L.VS;
         for (int h = hi; h < H; h += 2) {
-            const float* wd = p.w.w_down + h * vi;
+            const float* wd = sw.wd + h * vi;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int c = 0; c < vi; ++c) {
                 const float w = wd[c];
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
         if (S.nf) {
             const float* f = fr + e * 9;
             for (int k = hi; k < 3; k += 2) {
-                const float* wf = p.w.w_frames + k * vi;
+                const float* wf = sw.wf + k * vi;
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                 for (int c = 0; c < vi; ++c) {
                     const float w = wf[c];
@@ -206,67 +221,89 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) p.sc.vt[((int64_t)row * 3 + d) * VIP + c] = vrow[3 * c + d];
     }
-    __syncthreads();
+    gcp_wave_lds_sync();
+    gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
     // ---- 2. adjoint of the vector epilogue (gcpnet.py:364-391) ------------------------------------------------
     if (has_vout) {
-        for (int oc = hi; oc < vo; oc += 2) {
-            const float* wu = p.w.w_up + oc * H;
-            float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-            for (int h = 0; h < H; ++h) {
-                const float w = wu[h];
-                u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
-                u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
-                u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
+        for (int oc0 = hi; oc0 < vo; oc0 += 16) {  // 8 channels per lane per pass: all LDS reads, then the writes
+            float du[8][3], dgv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int oc = oc0 + 2 * i;
+                du[i][0] = du[i][1] = du[i][2] = 0.f; dgv[i] = 0.f;
+                if (oc < vo) {
+                    const float* wu = sw.wu + oc * H;
+                    float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                    for (int h = 0; h < H; ++h) {
+                        const float w = wu[h];
+                        u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
+                        u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
+                        u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
+                    }
+                    if (p.o.vector_residual) {
+                        u0 += vt[e * L.VS + 3 * oc + 0];
+                        u1 += vt[e * L.VS + 3 * oc + 1];
+                        u2 += vt[e * L.VS + 3 * oc + 2];
+                    }
+                    const float g0 = dvot[e * L.US + 3 * oc + 0], g1 = dvot[e * L.US + 3 * oc + 1], g2 = dvot[e * L.US + 3 * oc + 2];
+                    float du0 = g0, du1 = g1, du2 = g2;
+                    const float dot = g0 * u0 + g1 * u1 + g2 * u2;
+                    if (scalar_gate) {
+                        const float sg = dgt[e * L.GS2 + oc];
+                        du0 = g0 * sg; du1 = g1 * sg; du2 = g2 * sg;
+                        dgv[i] = dot * sg * (1.f - sg);
+                    } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
+                        const float rs = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
+                        const float n = rs + 1e-8f;
+                        const float a = gcp_actf<PWL>(p.o.act_v, ns_v, slope, n), da = gcp_dactf<PWL>(p.o.act_v, ns_v, slope, n);
+                        const float coef = dot * da / rs;
+                        du0 = g0 * a + coef * u0; du1 = g1 * a + coef * u1; du2 = g2 * a + coef * u2;
+                    }
+                    du[i][0] = du0; du[i][1] = du1; du[i][2] = du2;
+                }
             }
-            if (p.o.vector_residual) {
-                u0 += vt[e * L.VS + 3 * oc + 0];
-                u1 += vt[e * L.VS + 3 * oc + 1];
-                u2 += vt[e * L.VS + 3 * oc + 2];
-            }
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-            if (row_ok) {
-                const float* gp = p.d_v_out + ((int64_t)row * vo + oc) * 3;
-                g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
-            }
-            float du0 = g0, du1 = g1, du2 = g2;
-            const float dot = g0 * u0 + g1 * u1 + g2 * u2;
-            if (scalar_gate) {
-                const float sg = row_ok ? p.gate[(int64_t)row * vo + oc] : 0.f;
-                du0 = g0 * sg; du1 = g1 * sg; du2 = g2 * sg;
-                const float dg = dot * sg * (1.f - sg);
-                dgt[e * L.GS2 + oc] = dg;
-                if (row_ok) p.sc.dgate[(int64_t)row * VOP + oc] = dg;
-            } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
-                const float rs = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
-                const float n = rs + 1e-8f;
-                const float a = gcp_act(p.o.act_v, n, slope), da = gcp_act_grad(p.o.act_v, n, slope);
-                const float coef = dot * da / rs;
-                du0 = g0 * a + coef * u0; du1 = g1 * a + coef * u1; du2 = g2 * a + coef * u2;
-            }
-            dvut[e * L.US + 3 * oc + 0] = du0;
-            dvut[e * L.US + 3 * oc + 1] = du1;
-            dvut[e * L.US + 3 * oc + 2] = du2;
-            if (row_ok) {
-                p.sc.dvu[((int64_t)row * 3 + 0) * VOP + oc] = du0;
-                p.sc.dvu[((int64_t)row * 3 + 1) * VOP + oc] = du1;
-                p.sc.dvu[((int64_t)row * 3 + 2) * VOP + oc] = du2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int oc = oc0 + 2 * i;
+                if (oc < vo) {
+                    dvut[e * L.US + 3 * oc + 0] = du[i][0];
+                    dvut[e * L.US + 3 * oc + 1] = du[i][1];
+                    dvut[e * L.US + 3 * oc + 2] = du[i][2];
+                    if (scalar_gate) dgt[e * L.GS2 + oc] = dgv[i];
+                    if (row_ok) {
+                        p.sc.dvu[((int64_t)row * 3 + 0) * VOP + oc] = du[i][0];
+                        p.sc.dvu[((int64_t)row * 3 + 1) * VOP + oc] = du[i][1];
+                        p.sc.dvu[((int64_t)row * 3 + 2) * VOP + oc] = du[i][2];
+                        if (scalar_gate) p.sc.dgate[(int64_t)row * VOP + oc] = dgv[i];
+                    }
+                }
             }
         }
     }
-    __syncthreads();
+    gcp_wave_lds_sync();
+    gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
 
     // ---- 3. ds_pre = d_s_out * act_s'(s_pre) + act_v'(s_pre) * (Wg^T dgate)  (per output group) ----------------
     // ---- 4. dmerged = W^T ds_pre, accumulated over the output groups, per merged-axis group ---------------------
     const bool vec_so = (so & 3) == 0, vec_si = (si & 3) == 0;
     const bool single = S.NG == 1;
+    const float* __restrict__ sp_ptr = p.s_pre;
+    const float* __restrict__ dso_ptr = p.d_s_out;
+    float* __restrict__ dsp_ptr = p.sc.ds_pre;
     f32x16 dsr[NTG];
     for (int ug = 0; ug < S.NGK; ++ug) {
         f32x16 acc2[NUG];
+        // ResGCP: d(x) = d(out) + GCP^T d(out); the pass-through term initialises the accumulator (columns < si)
 #pragma unroll
         for (int uu = 0; uu < NUG; ++uu)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.o.fused_residual && k0 < si) v = load4(dso_ptr, row, so, k0, row_ok, vec_so);
+                acc2[uu][4 * q + 0] = v.x; acc2[uu][4 * q + 1] = v.y; acc2[uu][4 * q + 2] = v.z; acc2[uu][4 * q + 3] = v.w;
+            }
         for (int g = 0; g < S.NG; ++g) {
             if (ug == 0) {  // first pass over this output group: build ds_pre and keep a copy in HBM
                 f32x16 gacc[NTG];
@@ -286,35 +323,44 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < NTG; ++t)
+                for (int t = 0; t < NTG; ++t) {
+                    float4 sp[4], dy[4];  // one tile's loads in flight together
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
-                        const float4 sp = load4(p.s_pre, row, so, j0, row_ok, vec_so);
-                        const float4 dy = load4(p.d_s_out, row, so, j0, row_ok, vec_so);
-                        float4 d;
-                        d.x = dy.x * gcp_act_grad(p.o.act_s, sp.x, slope);
-                        d.y = dy.y * gcp_act_grad(p.o.act_s, sp.y, slope);
-                        d.z = dy.z * gcp_act_grad(p.o.act_s, sp.z, slope);
-                        d.w = dy.w * gcp_act_grad(p.o.act_s, sp.w, slope);
-                        if (scalar_gate) {
-                            d.x += gcp_act_grad(p.o.act_v, sp.x, slope) * gacc[t][4 * q + 0];
-                            d.y += gcp_act_grad(p.o.act_v, sp.y, slope) * gacc[t][4 * q + 1];
-                            d.z += gcp_act_grad(p.o.act_v, sp.z, slope) * gacc[t][4 * q + 2];
-                            d.w += gcp_act_grad(p.o.act_v, sp.w, slope) * gacc[t][4 * q + 3];
-                        }
-                        if (!row_ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
-                        dsr[t][4 * q + 0] = d.x; dsr[t][4 * q + 1] = d.y;
-                        dsr[t][4 * q + 2] = d.z; dsr[t][4 * q + 3] = d.w;
-                        store4(p.sc.ds_pre, row, so, j0, d, row_ok, vec_so);
+                        sp[q] = load4(sp_ptr, row, so, j0, row_ok, vec_so);
+                        dy[q] = load4(dso_ptr, row, so, j0, row_ok, vec_so);
                     }
+                    float4 d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        d[q].x = dy[q].x * gcp_dactf<PWL>(p.o.act_s, ns_s, slope, sp[q].x);
+                        d[q].y = dy[q].y * gcp_dactf<PWL>(p.o.act_s, ns_s, slope, sp[q].y);
+                        d[q].z = dy[q].z * gcp_dactf<PWL>(p.o.act_s, ns_s, slope, sp[q].z);
+                        d[q].w = dy[q].w * gcp_dactf<PWL>(p.o.act_s, ns_s, slope, sp[q].w);
+                        if (scalar_gate) {
+                            d[q].x += gcp_dactf<PWL>(p.o.act_v, ns_v, slope, sp[q].x) * gacc[t][4 * q + 0];
+                            d[q].y += gcp_dactf<PWL>(p.o.act_v, ns_v, slope, sp[q].y) * gacc[t][4 * q + 1];
+                            d[q].z += gcp_dactf<PWL>(p.o.act_v, ns_v, slope, sp[q].z) * gacc[t][4 * q + 2];
+                            d[q].w += gcp_dactf<PWL>(p.o.act_v, ns_v, slope, sp[q].w) * gacc[t][4 * q + 3];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
+                        if (!row_ok) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        dsr[t][4 * q + 0] = d[q].x; dsr[t][4 * q + 1] = d[q].y;
+                        dsr[t][4 * q + 2] = d[q].z; dsr[t][4 * q + 3] = d[q].w;
+                        store4(dsp_ptr, row, so, j0, d[q], row_ok, vec_so);
+                    }
+                }
             } else if (!single) {  // later merged-axis groups: re-read this lane's own ds_pre stores
 #pragma unroll
                 for (int t = 0; t < NTG; ++t)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
-                        const float4 d = load4(p.sc.ds_pre, row, so, j0, row_ok, vec_so);
+                        const float4 d = load4(dsp_ptr, row, so, j0, row_ok, vec_so);
                         dsr[t][4 * q + 0] = d.x; dsr[t][4 * q + 1] = d.y;
                         dsr[t][4 * q + 2] = d.z; dsr[t][4 * q + 3] = d.w;
                     }
@@ -352,18 +398,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
                 if (k0 + 3 < si) {
                     float4 v = make_float4(acc2[uu][4 * q], acc2[uu][4 * q + 1], acc2[uu][4 * q + 2], acc2[uu][4 * q + 3]);
-                    if (p.o.fused_residual) {
-                        const float4 dy = load4(p.d_s_out, row, so, k0, row_ok, vec_so);
-                        v.x += dy.x; v.y += dy.y; v.z += dy.z; v.w += dy.w;
-                    }
                     store4(p.d_s_in, row, si, k0, v, row_ok, vec_si);
                 } else {
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         const int k = k0 + x;
-                        float val = acc2[uu][4 * q + x];
+                        const float val = acc2[uu][4 * q + x];
                         if (k < si) {
-                            if (p.o.fused_residual && row_ok) val += p.d_s_out[(int64_t)row * so + k];
                             if (row_ok) p.d_s_in[(int64_t)row * si + k] = val;
                         } else if (k < S.K) {
                             dext[e * L.DS + (k - si)] = val;
@@ -372,13 +413,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 }
             }
     }
+    gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
     if (!has_vec) return;
-    __syncthreads();
+    gcp_wave_lds_sync();
 
     // ---- 5. adjoint of the vector prologue: d vh, d vf, then d v_in --------------------------------------------
     for (int h = hi; h < H; h += 2) {
         const float dn = dext[e * L.DS + h] * rn[e * L.NS_ + h];
-        const float* wu = p.w.w_up;  // [vo, H]
+        const float* wu = sw.wu;  // [vo, H]
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         if (has_vout)
             for (int oc = 0; oc < vo; ++oc) {
@@ -408,13 +450,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
         dvhf[e * L.FS + 1 * HF + H + k] = a1;
         dvhf[e * L.FS + 2 * HF + H + k] = a2;
     }
-    __syncthreads();
+    gcp_wave_lds_sync();
     if (row_ok) {
         for (int i = hi; i < 3 * HF; i += 2) p.sc.dvhf[((int64_t)row * 3 + i / HF) * HFP + (i % HF)] = dvhf[e * L.FS + i];
         for (int c = hi; c < vi; c += 2) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int h = 0; h < H; ++h) {
-                const float w = p.w.w_down[h * vi + c];
+                const float w = sw.wd[h * vi + c];
                 a0 = fmaf(w, dvhf[e * L.FS + 0 * HF + h], a0);
                 a1 = fmaf(w, dvhf[e * L.FS + 1 * HF + h], a1);
                 a2 = fmaf(w, dvhf[e * L.FS + 2 * HF + h], a2);
@@ -422,7 +464,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             if (S.nf)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float w = p.w.w_frames[k * vi + c];
+                    const float w = sw.wf[k * vi + c];
                     a0 = fmaf(w, dvhf[e * L.FS + 0 * HF + H + k], a0);
                     a1 = fmaf(w, dvhf[e * L.FS + 1 * HF + H + k], a1);
                     a2 = fmaf(w, dvhf[e * L.FS + 2 * HF + H + k], a2);
@@ -433,28 +475,34 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 a2 += dvut[e * L.US + 3 * c + 2];
             }
             if (p.o.fused_residual) {
-                const float* gp = p.d_v_out + ((int64_t)row * vo + c) * 3;
-                a0 += gp[0]; a1 += gp[1]; a2 += gp[2];
+                a0 += dvot[e * L.US + 3 * c + 0]; a1 += dvot[e * L.US + 3 * c + 1]; a2 += dvot[e * L.US + 3 * c + 2];
             }
             float* dp = p.d_v_in + ((int64_t)row * vi + c) * 3;
             dp[0] = a0; dp[1] = a1; dp[2] = a2;
         }
     }
+    gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
 }
 
-template <int NTG, int NUG>
-int launch(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
+template <int NTG, int NUG, bool PWL>
+int launch3(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
     static size_t cur_max = 64 * 1024;
     if (lds_bytes > cur_max) {
-        hipError_t err = hipFuncSetAttribute((const void*)gcp2_bwd_kernel<NTG, NUG>,
+        hipError_t err = hipFuncSetAttribute((const void*)gcp2_bwd_kernel<NTG, NUG, PWL>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (err != hipSuccess) return (int)err;
         cur_max = lds_bytes;
     }
-    hipLaunchKernelGGL((gcp2_bwd_kernel<NTG, NUG>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
+    hipLaunchKernelGGL((gcp2_bwd_kernel<NTG, NUG, PWL>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
                        lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NTG, int NUG>
+int launch(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
+    if (gcp_is_pwl(p.o.act_s) && gcp_is_pwl(p.o.act_v)) return launch3<NTG, NUG, true>(p, lds_bytes, st);
+    return launch3<NTG, NUG, false>(p, lds_bytes, st);
 }
 
 template <int NTG>
@@ -494,6 +542,7 @@ extern "C" int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gc
     p.s_pre = s_pre; p.gate = gate; p.d_s_out = d_s_out; p.d_v_out = d_v_out;
     p.d_s_in = d_s_in; p.d_v_in = d_v_in;
     p.sc = *sc;
+    p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     p.sh = gcp_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames);
     const BwdLds L = bwd_lds(p.sh);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

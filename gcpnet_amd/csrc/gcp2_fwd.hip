@@ -29,13 +29,15 @@ struct FwdParams {
     float* s_pre;
     float* gate;
     int fused_res;  // res_s / res_v are the (single, ungathered) input itself
+    unsigned long long* stamps;
+    long long stamp_cap;
     GcpShape sh;
 };
 
 // Wave-private LDS layout (floats).  All row strides are odd so that 32 rows hit 32 distinct banks.
 struct FwdLds {
     int KS, SS, VS, HS, GS;
-    int o_mrg, o_stg, o_vt, o_vht, o_gt, o_fr, total;
+    int o_mrg, o_stg, o_vt, o_vht, o_gt, o_fr, o_sw, total;
 };
 
 __host__ __device__ inline FwdLds fwd_lds(const GcpShape& s) {
@@ -58,7 +60,8 @@ __host__ __device__ inline FwdLds fwd_lds(const GcpShape& s) {
     l.o_vht = l.o_vt + 32 * l.VS;
     l.o_gt = l.o_vht + 32 * l.HS;
     l.o_fr = l.o_gt + 32 * l.GS;
-    l.total = l.o_fr + 32 * 9;
+    l.o_sw = l.o_fr + 32 * 9;
+    l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
     return l;
 }
 
@@ -86,7 +89,7 @@ struct WFrag<4> {
     }
 };
 
-template <int NTG, int MOT>
+template <int NTG, int MOT, bool PWL>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
@@ -105,26 +108,40 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
     float* fr = lds + L.o_fr;
     const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H;
     const float slope = p.o.slope;
+    const float ns_s = gcp_neg_slope(p.o.act_s, slope), ns_v = gcp_neg_slope(p.o.act_v, slope);
 
+    gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
     // ---- 1. stage the tile: scalars into the merged tile, vectors, frames --------------------------------
-    gcp_load_concat_tile(p.s_in, 1, r0, rows, mrg, L.KS, lane);
-    if (vi > 0) {
-        gcp_load_concat_tile(p.v_in, 3, r0, rows, vt, L.VS, lane);
-        if (S.nf) {
-            for (int i = lane; i < 32 * 9; i += GCP_WAVE) {
-                int rr = r0 + i / 9;
-                fr[i] = rr < rows ? p.frames[(int64_t)rr * 9 + (i % 9)] : 0.f;
-            }
+    // the first scalar and vector segments, the frames and the small weights go out in ONE memory round trip
+    {
+        GcpSegBuf<16> sb0;
+        GcpSegBuf<8> vb0;
+        gcp_seg_issue(sb0, p.s_in.ptr[0], p.s_in.idx[0], p.s_in.dim[0], r0, rows, mrg, L.KS, 0, lane);
+        if (vi > 0) gcp_seg_issue(vb0, p.v_in.ptr[0], p.v_in.idx[0], 3 * p.v_in.dim[0], r0, rows, vt, L.VS, 0, lane);
+        if (vi > 0 && S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
+        gcp_seg_commit(sb0, mrg, L.KS, 0);
+        if (vi > 0) gcp_seg_commit(vb0, vt, L.VS, 0);
+        int coff = p.s_in.dim[0];
+        for (int sg = 1; sg < p.s_in.n; ++sg) {
+            gcp_load_segment(p.s_in.ptr[sg], p.s_in.idx[sg], p.s_in.dim[sg], r0, rows, mrg, L.KS, coff, lane);
+            coff += p.s_in.dim[sg];
+        }
+        coff = vi > 0 ? 3 * p.v_in.dim[0] : 0;
+        for (int sg = 1; sg < p.v_in.n; ++sg) {
+            gcp_load_segment(p.v_in.ptr[sg], p.v_in.idx[sg], 3 * p.v_in.dim[sg], r0, rows, vt, L.VS, coff, lane);
+            coff += 3 * p.v_in.dim[sg];
         }
     }
+    const GcpSmallW sw = gcp_stage_small_weights(p.w, H, S.nf, lds + L.o_sw, lane);
     for (int k = S.K + hi; k < S.KP; k += 2) mrg[e * L.KS + k] = 0.f;  // zero the k padding
-    __syncthreads();
+    gcp_wave_lds_sync();
+    gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
     // ---- 2. vector prologue on the VALU: two lanes per row ----------------------------------------------
     if (vi > 0) {
         const float* vrow = vt + e * L.VS;
         for (int h = hi; h < H; h += 2) {  // vector_down + safe_norm over xyz (gcpnet.py:420-421)
-            const float* wd = p.w.w_down + h * vi;
+            const float* wd = sw.wd + h * vi;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int c = 0; c < vi; ++c) {
                 const float w = wd[c];
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
         if (S.nf) {  // vector_down_frames + scalarize (gcpnet.py:426-435, components/__init__.py:302,312)
             const float* f = fr + e * 9;
             for (int k = hi; k < 3; k += 2) {
-                const float* wf = p.w.w_frames + k * vi;
+                const float* wf = sw.wf + k * vi;
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                 for (int c = 0; c < vi; ++c) {
                     const float w = wf[c];
@@ -157,7 +174,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
             }
         }
     }
-    __syncthreads();
+    gcp_wave_lds_sync();
+    gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
 
     // ---- 3. scalar_out on the matrix cores, one group of NTG 32-wide output tiles at a time ---------------
     const int NOT = S.NOT;
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
             if (kk0 + 2 * U < KK) mm(A2, B2);
             ld(A2, B2, kk0 + 5 * U);
         }
+        gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
         const int c0 = g * 32 * NTG;
         const int gw = min(32 * NTG, so - c0);
         // ---- 4. epilogue of this group ----------------------------------------------------------------------
@@ -220,55 +239,76 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
         // residual inputs) and the MFMA loop no longer needs them.
         float* st = single ? mrg : stg;
         const int sst = single ? L.KS : L.SS;
-        __syncthreads();  // every B read of the merged tile by the MFMA loop has completed
-        // (a) s_out = act(s_pre) (+ residual): with the fused residual x is read from the LDS tile, not from HBM
+        gcp_wave_lds_sync();  // every B read of the merged tile by the MFMA loop has completed
+        // gate fragments of this group: requested now, consumed after the staging below (one L2 latency, hidden)
+        float wgf[8 * NTG];
+        if constexpr (MOT == 1) {
+            if (scalar_gate) {
+                const float* wg0 = p.w.pack + S.offC + ((int64_t)g * 8 * NTG) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < NTG; ++t)
+                for (int jj = 0; jj < 8 * NTG; ++jj) wgf[jj] = wg0[(int64_t)jj * 64];
+            }
+        }
+        // (a) s_out = act(s_pre) (+ residual): with the fused residual x is read from the LDS tile, not from HBM.
+        // Reads are batched per 32-wide tile before the writes (they alias for the compiler, which would otherwise
+        // serialise every read behind the previous write).
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+            float x[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jl = 32 * t + gcp_crow(r, hi);
-                float y = gcp_act(p.o.act_s, acc[t][r], slope);
-                if (p.fused_res && c0 + jl < so) y += mrg[e * L.KS + c0 + jl];
-                st[e * sst + jl] = y;
+                x[r] = (p.fused_res && c0 + jl < so) ? mrg[e * L.KS + c0 + jl] : 0.f;
             }
-        __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st[e * sst + 32 * t + gcp_crow(r, hi)] = gcp_actf<PWL>(p.o.act_s, ns_s, slope, acc[t][r]) + x[r];
+        }
+        gcp_wave_lds_sync();
         if (p.res_s && !p.fused_res) {  // separate residual tensor: slow path, re-read from HBM
             for (int ee = 0; ee < GCP_TILE_ROWS && r0 + ee < rows; ++ee)
                 for (int j = lane; j < gw; j += GCP_WAVE) st[ee * sst + j] += p.res_s[(int64_t)(r0 + ee) * so + c0 + j];
-            __syncthreads();
+            gcp_wave_lds_sync();
         }
         gcp_store_tile(p.s_out, so, c0, gw, r0, rows, st, sst, lane);
+        gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         // (b) the pre-activations: saved for the backward, and B operand of the gate GEMM
         if (p.s_pre || scalar_gate) {
-            __syncthreads();
+            gcp_wave_lds_sync();
 #pragma unroll
             for (int t = 0; t < NTG; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[e * sst + 32 * t + gcp_crow(r, hi)] = acc[t][r];
-            __syncthreads();
+            gcp_wave_lds_sync();
             if (p.s_pre) gcp_store_tile(p.s_pre, so, c0, gw, r0, rows, st, sst, lane);
             if (scalar_gate) {  // vector_out_scale(act_v(s_pre)) accumulated over this group's columns (gcpnet.py:386)
                 const float* wg = p.w.pack + S.offC + ((int64_t)g * 8 * NTG) * 64 + lane;
                 const int e16 = lane & 15, q = lane >> 4;
-#pragma unroll 4
-                for (int jj = 0; jj < 8 * NTG; ++jj) {
-                    float b0 = gcp_act(p.o.act_v, st[e16 * sst + 4 * jj + q], slope);
-                    float b1 = gcp_act(p.o.act_v, st[(16 + e16) * sst + 4 * jj + q], slope);
-                    if (c0 + 4 * jj + q >= so) { b0 = 0.f; b1 = 0.f; }
 #pragma unroll
-                    for (int ot = 0; ot < MOT; ++ot) {
-                        if (ot < NOT) {
-                            const float a = wg[((int64_t)ot * S.NJ4 + jj) * 64];
-                            gacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gacc[ot][0], 0, 0, 0);
-                            gacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, gacc[ot][1], 0, 0, 0);
+                for (int jj = 0; jj < 8 * NTG; ++jj) {
+                    float b0 = gcp_actf<PWL>(p.o.act_v, ns_v, slope, st[e16 * sst + 4 * jj + q]);
+                    float b1 = gcp_actf<PWL>(p.o.act_v, ns_v, slope, st[(16 + e16) * sst + 4 * jj + q]);
+                    if (c0 + 4 * jj + q >= so) { b0 = 0.f; b1 = 0.f; }
+                    if constexpr (MOT == 1) {
+                        gacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgf[jj], b0, gacc[0][0], 0, 0, 0);
+                        gacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgf[jj], b1, gacc[0][1], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < MOT; ++ot) {
+                            if (ot < NOT) {
+                                const float a = wg[((int64_t)ot * S.NJ4 + jj) * 64];
+                                gacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gacc[ot][0], 0, 0, 0);
+                                gacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, gacc[ot][1], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
         }
-        __syncthreads();
+        gcp_wave_lds_sync();
     }
 
+    gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
     if (vo == 0) return;
 
     // ---- 5. vector epilogue: sigmoid gate, vector_up, gating, residual (gcpnet.py:364-391) -----------------
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
             }
         }
     }
-    __syncthreads();
+    gcp_wave_lds_sync();
     if (vi == 0) {  // create_zero_vector (gcpnet.py:447-449)
         if (row_ok)
             for (int i = hi; i < 3 * vo; i += 2) {
@@ -296,38 +336,52 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
             }
         return;
     }
-    for (int oc = hi; oc < vo; oc += 2) {
-        const float* wu = p.w.w_up + oc * H;
-        float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-        for (int h = 0; h < H; ++h) {
-            const float w = wu[h];
-            u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
-            u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
-            u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
+    for (int oc0 = hi; oc0 < vo; oc0 += 16) {  // 8 channels per lane per pass: all reads, then the in-place writes
+        float y[8][3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int oc = oc0 + 2 * i;
+            y[i][0] = y[i][1] = y[i][2] = 0.f;
+            if (oc < vo) {
+                const float* wu = sw.wu + oc * H;
+                float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                for (int h = 0; h < H; ++h) {
+                    const float w = wu[h];
+                    u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
+                    u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
+                    u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
+                }
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f;  // this channel of the input (vector residual / ResGCP residual)
+                if (p.o.vector_residual || p.fused_res) {
+                    x0 = vt[e * L.VS + 3 * oc + 0]; x1 = vt[e * L.VS + 3 * oc + 1]; x2 = vt[e * L.VS + 3 * oc + 2];
+                }
+                if (p.o.vector_residual) { u0 += x0; u1 += x1; u2 += x2; }
+                float sc = 1.f;
+                if (scalar_gate) {
+                    sc = gt[e * L.GS + oc];
+                } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
+                    sc = gcp_actf<PWL>(p.o.act_v, ns_v, slope, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f);
+                }
+                float y0 = u0 * sc, y1 = u1 * sc, y2 = u2 * sc;
+                if (p.fused_res) { y0 += x0; y1 += x1; y2 += x2; }
+                if (p.res_v && !p.fused_res && row_ok) {
+                    const int64_t off = ((int64_t)row * vo + oc) * 3;
+                    y0 += p.res_v[off]; y1 += p.res_v[off + 1]; y2 += p.res_v[off + 2];
+                }
+                y[i][0] = y0; y[i][1] = y1; y[i][2] = y2;
+            }
         }
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f;  // this channel of the input (vector residual / ResGCP residual)
-        if (p.o.vector_residual || p.fused_res) {
-            x0 = vt[e * L.VS + 3 * oc + 0]; x1 = vt[e * L.VS + 3 * oc + 1]; x2 = vt[e * L.VS + 3 * oc + 2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int oc = oc0 + 2 * i;
+            // in place: this lane is the only reader of channel oc of its row (oc < vi whenever the input is read)
+            if (oc < vo) { vt[e * L.VS + 3 * oc + 0] = y[i][0]; vt[e * L.VS + 3 * oc + 1] = y[i][1]; vt[e * L.VS + 3 * oc + 2] = y[i][2]; }
         }
-        if (p.o.vector_residual) { u0 += x0; u1 += x1; u2 += x2; }
-        float sc = 1.f;
-        if (scalar_gate) {
-            sc = gt[e * L.GS + oc];
-        } else if (p.o.vmode == GCP_VMODE_SELF_GATE) {
-            sc = gcp_act(p.o.act_v, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f, slope);
-        }
-        float y0 = u0 * sc, y1 = u1 * sc, y2 = u2 * sc;
-        if (p.fused_res) { y0 += x0; y1 += x1; y2 += x2; }
-        if (p.res_v && !p.fused_res && row_ok) {
-            const int64_t off = ((int64_t)row * vo + oc) * 3;
-            y0 += p.res_v[off]; y1 += p.res_v[off + 1]; y2 += p.res_v[off + 2];
-        }
-        // in place: this lane is the only reader of channel oc of its row (oc < vi whenever the input is read)
-        vt[e * L.VS + 3 * oc + 0] = y0; vt[e * L.VS + 3 * oc + 1] = y1; vt[e * L.VS + 3 * oc + 2] = y2;
     }
-    __syncthreads();
+    gcp_wave_lds_sync();
     gcp_store_tile(p.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
     if (scalar_gate && p.gate) gcp_store_tile(p.gate, vo, 0, vo, r0, rows, gt, L.GS, lane);
+    gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
 }
 
 __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
@@ -370,18 +424,24 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
     out[i] = val;
 }
 
-template <int NTG, int MOT>
-int launch_fwd2(const FwdParams& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
+template <int NTG, int MOT, bool PWL>
+int launch_fwd3(const FwdParams& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
     static size_t cur_max = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per size
     if (lds_bytes > cur_max) {
-        hipError_t err = hipFuncSetAttribute((const void*)gcp2_fwd_kernel<NTG, MOT>,
+        hipError_t err = hipFuncSetAttribute((const void*)gcp2_fwd_kernel<NTG, MOT, PWL>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (err != hipSuccess) return (int)err;
         cur_max = lds_bytes;
     }
-    hipLaunchKernelGGL((gcp2_fwd_kernel<NTG, MOT>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+    hipLaunchKernelGGL((gcp2_fwd_kernel<NTG, MOT, PWL>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NTG, int MOT>
+int launch_fwd2(const FwdParams& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
+    if (gcp_is_pwl(p.o.act_s) && gcp_is_pwl(p.o.act_v)) return launch_fwd3<NTG, MOT, true>(p, grid, lds_bytes, st);
+    return launch_fwd3<NTG, MOT, false>(p, grid, lds_bytes, st);
 }
 
 template <int NTG>
@@ -450,6 +510,7 @@ extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp
     p.fused_res = (res_s && s_in->n == 1 && !s_in->idx[0] && res_s == s_in->ptr[0] && w->si == w->so &&
                    (w->vo == 0 || (res_v && w->vi == w->vo && v_in->n == 1 && !v_in->idx[0] && res_v == v_in->ptr[0])))
                       ? 1 : 0;
+    p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     p.sh = gcp_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames);
     const FwdLds L = fwd_lds(p.sh);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

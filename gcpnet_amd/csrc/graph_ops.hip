@@ -4,6 +4,9 @@
 // atomics are needed for scatter-add over variable-degree nodes.
 #include "common.h"
 
+unsigned long long* g_gcp_phase_buf = nullptr;
+long long g_gcp_phase_cap = 0;
+
 namespace {
 
 // ---- segment reduce: replaces torch_scatter.scatter(sum|mean) on sorted segments --------------------------------
@@ -313,5 +316,11 @@ extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, floa
     const int blocks = (int)(nb < 2048 ? nb : 2048);
     hipLaunchKernelGGL(axpy_clamp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b, alpha, clamp, lo, hi, y);
     GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles) {
+    g_gcp_phase_buf = reinterpret_cast<unsigned long long*>(buf);
+    g_gcp_phase_cap = buf ? n_tiles : 0;
     return 0;
 }

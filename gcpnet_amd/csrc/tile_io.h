@@ -14,7 +14,7 @@ __device__ __forceinline__ void gcp_load_segment(const float* __restrict__ base,
         const int rpi = 64 / q;  // rows covered by one wave-wide load instruction
         const int sub = lane / q, c4 = lane - sub * q;
         const bool lane_on = sub < rpi;
-        constexpr int B = 8;
+        constexpr int B = 16;
         for (int e0 = 0; e0 < GCP_TILE_ROWS; e0 += rpi * B) {
             float4 buf[B];
 #pragma unroll
@@ -52,6 +52,54 @@ __device__ __forceinline__ void gcp_load_segment(const float* __restrict__ base,
     }
 }
 
+// Deferred variant: `issue` puts the whole segment (<= B load instructions) in flight and returns; `commit` writes
+// it to the tile.  Several segments (scalars, vectors, gradients ...) can thus share ONE memory round trip.
+template <int B>
+struct GcpSegBuf {
+    float4 v[B];
+    int rpi, sub, c4;
+    bool deferred, lane_on;
+};
+
+template <int B>
+__device__ __forceinline__ void gcp_seg_issue(GcpSegBuf<B>& sb, const float* __restrict__ base,
+                                              const int32_t* __restrict__ idx, int dim, int r0, int rows, float* tile,
+                                              int stride, int coff, int lane) {
+    const int q = dim >> 2;
+    sb.deferred = false;
+    if ((dim & 3) == 0 && q > 0 && q <= 64 && gcp_aligned16(base) && gcp_cdiv(GCP_TILE_ROWS, 64 / q) <= B) {
+        sb.deferred = true;
+        sb.rpi = 64 / q;
+        sb.sub = lane / q;
+        sb.c4 = lane - sb.sub * q;
+        sb.lane_on = sb.sub < sb.rpi;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int e = b * sb.rpi + sb.sub;
+            sb.v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sb.lane_on && e < GCP_TILE_ROWS && r0 + e < rows) {
+                const int64_t src = idx ? (int64_t)idx[r0 + e] : (int64_t)(r0 + e);
+                sb.v[b] = *reinterpret_cast<const float4*>(base + src * dim + 4 * sb.c4);
+            }
+        }
+    } else {
+        gcp_load_segment(base, idx, dim, r0, rows, tile, stride, coff, lane);
+    }
+}
+
+template <int B>
+__device__ __forceinline__ void gcp_seg_commit(const GcpSegBuf<B>& sb, float* tile, int stride, int coff) {
+    if (!sb.deferred) return;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int e = b * sb.rpi + sb.sub;
+        if (sb.lane_on && e < GCP_TILE_ROWS) {
+            float* d = tile + e * stride + coff + 4 * sb.c4;
+            d[0] = sb.v[b].x; d[1] = sb.v[b].y; d[2] = sb.v[b].z; d[3] = sb.v[b].w;
+        }
+    }
+}
+
 __device__ __forceinline__ void gcp_load_concat_tile(const gcp_concat_t& c, int mult, int r0, int rows, float* tile,
                                                      int stride, int lane) {
     int coff = 0;
@@ -69,14 +117,88 @@ __device__ __forceinline__ void gcp_store_tile(float* __restrict__ dst, int64_t 
     if ((width & 3) == 0 && (ld & 3) == 0 && (col0 & 3) == 0 && q <= 64 && q > 0 && gcp_aligned16(dst)) {
         const int rpi = 64 / q;
         const int sub = lane / q, c4 = lane - sub * q;
-        if (sub < rpi) {
-            for (int e = sub; e < GCP_TILE_ROWS && r0 + e < rows; e += rpi) {
+        float* out = dst + col0 + 4 * c4;
+        if (rpi >= 2) {  // fixed trip count: all LDS reads of the tile are issued before the stores need them
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = min(sub + i * rpi, GCP_TILE_ROWS - 1);
                 const float* s = tile + e * stride + 4 * c4;
-                *reinterpret_cast<float4*>(dst + (int64_t)(r0 + e) * ld + col0 + 4 * c4) = make_float4(s[0], s[1], s[2], s[3]);
+                v[i] = make_float4(s[0], s[1], s[2], s[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = sub + i * rpi;
+                if (sub < rpi && e < GCP_TILE_ROWS && r0 + e < rows) *reinterpret_cast<float4*>(out + (int64_t)(r0 + e) * ld) = v[i];
+            }
+        } else {
+#pragma unroll 8
+            for (int e = 0; e < GCP_TILE_ROWS; ++e) {
+                const float* s = tile + e * stride + 4 * c4;
+                if (r0 + e < rows) *reinterpret_cast<float4*>(out + (int64_t)(r0 + e) * ld) = make_float4(s[0], s[1], s[2], s[3]);
             }
         }
         return;
     }
     for (int e = 0; e < GCP_TILE_ROWS && r0 + e < rows; ++e)
         for (int j = lane; j < width; j += GCP_WAVE) dst[(int64_t)(r0 + e) * ld + col0 + j] = tile[e * stride + j];
+}
+
+// Frames of rows [r0, r0 + 32): one contiguous 1152-byte block, all five loads of a lane in flight together.
+__device__ __forceinline__ void gcp_load_frames(const float* __restrict__ frames, int r0, int rows, float* fr, int lane) {
+    const int n = min(GCP_TILE_ROWS, rows - r0) * 9;
+    const float* src = frames + (int64_t)r0 * 9;
+    float t[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = lane + 64 * k;
+        t[k] = i < n ? src[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = lane + 64 * k;
+        if (i < GCP_TILE_ROWS * 9) fr[i] = t[k];
+    }
+}
+
+// The small vector weights of a GCP2 block (vector_down [H, vi], vector_down_frames [3, vi], vector_up [vo, H]) are
+// copied once into a wave-private LDS area; the per-row loops then read them with wave-uniform (broadcast) ds_reads
+// instead of one global load per multiply.
+struct GcpSmallW {
+    const float* wd;
+    const float* wf;
+    const float* wu;
+};
+
+__host__ __device__ inline int gcp_small_w_floats(int vi, int H, int vo, int nf) {
+    return vi > 0 ? (H * vi + (nf ? 3 * vi : 0) + vo * H + 4) : 0;
+}
+
+__device__ __forceinline__ void gcp_copy_to_lds(const float* __restrict__ src, float* dst, int n, int lane) {
+    for (int i0 = 0; i0 < n; i0 += 64 * 4) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + lane + 64 * k;
+            t[k] = i < n ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + lane + 64 * k;
+            if (i < n) dst[i] = t[k];
+        }
+    }
+}
+
+__device__ __forceinline__ GcpSmallW gcp_stage_small_weights(const gcp2_weights_t& w, int H, int nf, float* area, int lane) {
+    GcpSmallW r;
+    r.wd = area;
+    r.wf = area + H * w.vi;
+    r.wu = r.wf + (nf ? 3 * w.vi : 0);
+    if (w.vi > 0) {
+        gcp_copy_to_lds(w.w_down, area, H * w.vi, lane);
+        if (nf) gcp_copy_to_lds(w.w_frames, area + H * w.vi, 3 * w.vi, lane);
+        if (w.vo > 0) gcp_copy_to_lds(w.w_up, area + H * w.vi + (nf ? 3 * w.vi : 0), w.vo * H, lane);
+    }
+    return r;
 }

@@ -2,7 +2,7 @@
 // edges or nodes, 1e4..1e6) is huge and whose output (a weight matrix, <= 1024 x 1100) is small.
 //
 // The reference gets these from autograd through nn.Linear (src/models/components/gcpnet.py:303-324); here they
-// are explicit.  Decomposition: the row axis is split across workgroups (2048 rows each); a workgroup of 4 waves
+// are explicit.  Decomposition: the row axis is split across workgroups (512 rows each); a workgroup of 4 waves
 // owns a 128 x 160 block of the output, wave w holding m-tile w and up to five 32x32 fp32 accumulators
 // (v_mfma_f32_32x32x2_f32, reduction over row pairs).  Both operands are staged through LDS 32 rows at a time in
 // dense row-major order, which is bank-conflict free for both fragment reads (a fragment reads 32 consecutive
@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32, TN_ROWS_PER_SPLIT = 2048;
+constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32, TN_ROWS_PER_SPLIT = 512;
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
 constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread
 constexpr int TN_DMA_LDS_FLOATS = 2 * TN_RK * (TN_BM + TN_BN);

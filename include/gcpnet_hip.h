@@ -173,6 +173,10 @@ int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const float* s_sum, 
 int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi, float* y,
                       void* stream);
 
+/* ---- profiling hook: when `buf` (device memory, n_tiles * 8 uint64) is non-NULL, each 32-row wave-tile of the GCP2
+ * forward / backward kernels writes s_memtime stamps at its phase boundaries; NULL switches it off. */
+int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);
+
 int gcpnet_abi_version(void);
 
 #ifdef __cplusplus
