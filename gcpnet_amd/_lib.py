@@ -15,6 +15,7 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
+    "gcpnet_gcp2_chain_forward",
     "gcpnet_gcp2_backward", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_axpy_clamp", "gcpnet_debug_set_phase_timing",
 ]
@@ -35,6 +36,11 @@ class Gcp2Weights(C.Structure):
 class Gcp2Opts(C.Structure):
     _fields_ = [("act_s", C.c_int), ("act_v", C.c_int), ("slope", C.c_float), ("vmode", C.c_int),
                 ("vector_residual", C.c_int), ("e3", C.c_int), ("fused_residual", C.c_int)]
+
+
+class ChainItem(C.Structure):
+    _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p),
+                ("gate", C.c_void_p)]
 
 
 class BwdScratch(C.Structure):
@@ -78,6 +84,7 @@ def load():
     lib.gcpnet_pack_gcp2_weights.argtypes = [P(Gcp2Weights), vp, vp]
     lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
                                         vp, vp]
+    lib.gcpnet_gcp2_chain_forward.argtypes = [i32, vp, vp, vp, i32, P(ChainItem), vp]
     lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
                                          vp, P(BwdScratch), vp]
     lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]

@@ -88,10 +88,10 @@ struct GcpShape {
     int NUG;  // 32-wide tiles of the merged axis per backward accumulator group
     int NGK;  // merged-axis groups
     int NS;   // backward-data reduction steps = NG * NTG * 16
-    int NOT;  // 16-wide tiles of the vector-gate outputs
-    int NJ4;  // gate forward steps (4 scalar columns each) = NG * NTG * 8
+    int GT;   // 32-wide tiles of the vector-gate outputs (forward gate GEMM, fed from the accumulator registers)
     int NOO;  // gate backward steps (2 gate outputs each), padded to a multiple of 2
-    int64_t offA, offB, offC, offD, total;  // section offsets (floats) inside the packed image
+    int NTS;  // 32-wide tiles of the scalar input (register-resident chain kernel: the state is the B operand)
+    int64_t offA, offB, offC, offD, offF, total;  // section offsets (floats) inside the packed image
 };
 
 __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, int H, int use_frames) {
@@ -106,14 +106,16 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.NUG = s.K <= 32 ? 1 : (s.K <= 64 ? 2 : 4);
     s.NGK = gcp_cdiv(gcp_cdiv(s.K, 32), s.NUG);
     s.NS = s.NG * s.NTG * 16;
-    s.NOT = gcp_cdiv(vo, 16);
-    s.NJ4 = s.NG * s.NTG * 8;
+    s.GT = gcp_cdiv(vo, 32);
     s.NOO = gcp_round_up(gcp_cdiv(vo, 2), 2);
     s.offA = 0;
     s.offB = s.offA + (int64_t)s.NG * s.KK * 64 * s.NTG;
     s.offC = s.offB + (int64_t)s.NGK * s.NS * 64 * s.NUG;
-    s.offD = s.offC + (int64_t)s.NOT * s.NJ4 * 64;
-    s.total = s.offD + (int64_t)s.NOO * s.NG * 64 * s.NTG;
+    s.offD = s.offC + (int64_t)s.GT * s.NS * 64;
+    s.NTS = gcp_cdiv(si, 32);
+    s.offF = s.offD + (int64_t)s.NOO * s.NG * 64 * s.NTG;
+    // F (only used when the block can run in the register-resident chain kernel: one output group)
+    s.total = s.offF + (s.NG == 1 ? (int64_t)s.NTS * 16 * 64 * s.NTG : 0);
     return s;
 }
 

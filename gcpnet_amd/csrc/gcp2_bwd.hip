@@ -60,28 +60,8 @@ __host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
     return l;
 }
 
-// 4 consecutive columns j0..j0+3 of row `row` of a [rows, ld] matrix (zeros outside).
-__device__ __forceinline__ float4 load4(const float* base, int64_t row, int ld, int j0, bool ok, bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!ok) return v;
-    const float* p = base + row * ld + j0;
-    if (vec && j0 + 3 < ld) return *reinterpret_cast<const float4*>(p);
-    if (j0 + 0 < ld) v.x = p[0];
-    if (j0 + 1 < ld) v.y = p[1];
-    if (j0 + 2 < ld) v.z = p[2];
-    if (j0 + 3 < ld) v.w = p[3];
-    return v;
-}
-
-__device__ __forceinline__ void store4(float* base, int64_t row, int ld, int j0, float4 v, bool ok, bool vec) {
-    if (!ok) return;
-    float* p = base + row * ld + j0;
-    if (vec && j0 + 3 < ld) { *reinterpret_cast<float4*>(p) = v; return; }
-    if (j0 + 0 < ld) p[0] = v.x;
-    if (j0 + 1 < ld) p[1] = v.y;
-    if (j0 + 2 < ld) p[2] = v.z;
-    if (j0 + 3 < ld) p[3] = v.w;
-}
+#define load4 gcp_load4
+#define store4 gcp_store4
 
 template <int N>
 struct WFragB;
@@ -107,17 +87,18 @@ struct WFragB<4> {
     }
 };
 
-template <int NTG, int NUG, bool PWL>
+// SINGLE: one output group (so <= 128) -> straight-line fast path with the tile's s_pre / d(s_out) held in registers.
+template <int NTG, int NUG, bool PWL, bool SINGLE>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
     const BwdLds L = bwd_lds(S);
-    const int lane = threadIdx.x;
-    const int e = lane & 31, hi = lane >> 5;
+    int lane = threadIdx.x;
+    int e = lane & 31, hi = lane >> 5;
     const int r0 = blockIdx.x * GCP_TILE_ROWS;
     const int rows = p.rows;
-    const int row = r0 + e;
-    const bool row_ok = row < rows;
+    int row = r0 + e;
+    bool row_ok = row < rows;
     float* vt = lds + L.o_vt;
     float* vht = lds + L.o_vht;
     float* rn = lds + L.o_rn;
@@ -138,6 +119,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     const bool has_vout = has_vec && vo > 0;
 
     gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
+    const bool vec_so = (so & 3) == 0, vec_si = (si & 3) == 0;
+    constexpr bool single = SINGLE;
+    const float* __restrict__ sp_ptr = p.s_pre;
+    const float* __restrict__ dso_ptr = p.d_s_out;
+    float* __restrict__ dsp_ptr = p.sc.ds_pre;
+    f32x16 spr[NTG], dyr[NTG];
     // ---- 1. stage vectors / frames, recompute vh, its norms and the frame scalars ---------------------------
     if (has_vec) {  // inputs, upstream vector gradients, gates and frames: one memory round trip
         GcpSegBuf<8> vb0, gb0, tb0;
@@ -156,6 +143,21 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     }
     const GcpSmallW sw = gcp_stage_small_weights(p.w, H, S.nf, lds + L.o_sw, lane);
     for (int i = vo + hi; i < 2 * S.NOO; i += 2) dgt[e * L.GS2 + i] = 0.f;  // zero the gate-adjoint k padding
+    // Single output group (so <= 128): s_pre and d(s_out) of the tile are requested here (after every load
+    // phase 1 has to wait for: vmcnt retires in order), in the accumulator layout, and stay in flight
+    // under phases 1-2; d(s_out) later doubles as the ResGCP pass-through term of the accumulator.
+    if constexpr (SINGLE) {
+#pragma unroll
+        for (int t = 0; t < NTG; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j0 = 32 * t + 8 * q + 4 * hi;
+                const float4 a = load4(sp_ptr, row, so, j0, row_ok, vec_so);
+                const float4 b = load4(dso_ptr, row, so, j0, row_ok, vec_so);
+                spr[t][4 * q] = a.x; spr[t][4 * q + 1] = a.y; spr[t][4 * q + 2] = a.z; spr[t][4 * q + 3] = a.w;
+                dyr[t][4 * q] = b.x; dyr[t][4 * q + 1] = b.y; dyr[t][4 * q + 2] = b.z; dyr[t][4 * q + 3] = b.w;
+            }
+    }
     gcp_wave_lds_sync();
     if (has_vec) {
         const float* vrow = vt + e * L.VS;
@@ -224,6 +226,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     gcp_wave_lds_sync();
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
+    asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
+    row = r0 + e;
+    row_ok = row < rows;
     // ---- 2. adjoint of the vector epilogue (gcpnet.py:364-391) ------------------------------------------------
     if (has_vout) {
         for (int oc0 = hi; oc0 < vo; oc0 += 16) {  // 8 channels per lane per pass: all LDS reads, then the writes
@@ -286,24 +291,145 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
 
     // ---- 3. ds_pre = d_s_out * act_s'(s_pre) + act_v'(s_pre) * (Wg^T dgate)  (per output group) ----------------
     // ---- 4. dmerged = W^T ds_pre, accumulated over the output groups, per merged-axis group ---------------------
-    const bool vec_so = (so & 3) == 0, vec_si = (si & 3) == 0;
-    const bool single = S.NG == 1;
-    const float* __restrict__ sp_ptr = p.s_pre;
-    const float* __restrict__ dso_ptr = p.d_s_out;
-    float* __restrict__ dsp_ptr = p.sc.ds_pre;
-    f32x16 dsr[NTG];
-    for (int ug = 0; ug < S.NGK; ++ug) {
-        f32x16 acc2[NUG];
-        // ResGCP: d(x) = d(out) + GCP^T d(out); the pass-through term initialises the accumulator (columns < si)
+    // keep the address arithmetic of the phases below from being hoisted above (and spilled across) phases 1-2
+    asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
+    row = r0 + e;
+    row_ok = row < rows;
+    // epilogue of one merged-axis group: d_s_in columns go to HBM, the vector extras (norm / frame-scalar adjoints) to LDS
+    auto merged_epilogue = [&](int ug, f32x16(&acc2)[NUG]) {
 #pragma unroll
         for (int uu = 0; uu < NUG; ++uu)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.o.fused_residual && k0 < si) v = load4(dso_ptr, row, so, k0, row_ok, vec_so);
-                acc2[uu][4 * q + 0] = v.x; acc2[uu][4 * q + 1] = v.y; acc2[uu][4 * q + 2] = v.z; acc2[uu][4 * q + 3] = v.w;
+                if (k0 + 3 < si) {
+                    store4(p.d_s_in, row, si, k0,
+                           make_float4(acc2[uu][4 * q], acc2[uu][4 * q + 1], acc2[uu][4 * q + 2], acc2[uu][4 * q + 3]), row_ok, vec_si);
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int k = k0 + x;
+                        const float val = acc2[uu][4 * q + x];
+                        if (k < si) {
+                            if (row_ok) p.d_s_in[(int64_t)row * si + k] = val;
+                        } else if (k < S.K) {
+                            dext[e * L.DS + (k - si)] = val;
+                        }
+                    }
+                }
             }
+    };
+    // scalar_out adjoint over ALL 16 * NTG k-pair steps of one output group, B operands = the ds_pre registers;
+    // weight fragments rotate through three batches of 4 steps, requested two batches ahead and pinned there
+    auto data_gemm = [&](const float* wq, f32x16(&acc2)[NUG], f32x16(&ds)[NTG]) {
+        WFragB<NUG> A0[4], A1[4], A2[4];
+        auto ld = [&](WFragB<NUG>(&a)[4], int st0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u].load(wq + (int64_t)min(st0 + u, NTG * 16 - 1) * 64 * NUG);
+        };
+        ld(A0, 0);
+        ld(A1, 4);
+        ld(A2, 8);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NTG * 4; ++b) {
+            WFragB<NUG>(&a)[4] = (b % 3 == 0) ? A0 : ((b % 3 == 1) ? A1 : A2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int st = b * 4 + u;
+#pragma unroll
+                for (int uu = 0; uu < NUG; ++uu)
+                    acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[uu], ds[st / 16][st % 16], acc2[uu], 0, 0, 0);
+            }
+            if ((b + 3) * 4 < NTG * 16) ld(a, (b + 3) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if constexpr (SINGLE) {
+        // ---- fast path (so <= 128): straight-line, so that register lifetimes are visible to the compiler:
+        //      gate adjoint -> ds_pre (overwrites the s_pre registers) -> accumulator := d(s_out) (ResGCP) -> W^T ds_pre
+        {
+            f32x16 gacc[NTG];
+#pragma unroll
+            for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
+            if (scalar_gate) {
+                const float* wg = p.w.pack + S.offD + (int64_t)lane * NTG;
+                for (int oo0 = 0; oo0 < S.NOO; oo0 += 8) {
+                    WFragB<NTG> a[8];
+                    float b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int oo = min(oo0 + u, S.NOO - 1);
+                        a[u].load(wg + (int64_t)oo * S.NG * 64 * NTG);
+                        b[u] = dgt[e * L.GS2 + 2 * oo + hi];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (oo0 + u < S.NOO)
+#pragma unroll
+                            for (int t = 0; t < NTG; ++t)
+                                gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], b[u], gacc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sp = spr[t][r];
+                    float d = dyr[t][r] * gcp_dactf<PWL>(p.o.act_s, ns_s, slope, sp);
+                    if (scalar_gate) d += gcp_dactf<PWL>(p.o.act_v, ns_v, slope, sp) * gacc[t][r];
+                    spr[t][r] = row_ok ? d : 0.f;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NTG; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                store4(dsp_ptr, row, so, 32 * t + 8 * q + 4 * hi,
+                       make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]), row_ok, vec_so);
+        {
+            f32x16 acc2[NUG];
+#pragma unroll
+            for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[uu][r] = (p.o.fused_residual && uu < NTG) ? dyr[uu < NTG ? uu : 0][r] : 0.f;
+            data_gemm(p.w.pack + S.offB + (int64_t)lane * NUG, acc2, spr);
+            merged_epilogue(0, acc2);
+        }
+        for (int ug = 1; ug < S.NGK; ++ug) {
+            f32x16 acc2[NUG];
+#pragma unroll
+            for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
+            data_gemm(p.w.pack + S.offB + ((int64_t)ug * S.NS * 64 + lane) * NUG, acc2, spr);
+            merged_epilogue(ug, acc2);
+        }
+    } else {
+    f32x16(&dsr)[NTG] = spr;  // ds_pre overwrites s_pre in place, tile by tile
+    for (int ug = 0; ug < S.NGK; ++ug) {
+        f32x16 acc2[NUG];
+        // ResGCP: d(x) = d(out) + GCP^T d(out); the pass-through term initialises the accumulator (columns < si)
+        if (single && ug == 0 && NUG == NTG) {
+#pragma unroll
+            for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[uu][r] = p.o.fused_residual ? dyr[uu < NTG ? uu : 0][r] : 0.f;
+        } else {
+#pragma unroll
+            for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.o.fused_residual && k0 < si) v = load4(dso_ptr, row, so, k0, row_ok, vec_so);
+                    acc2[uu][4 * q + 0] = v.x; acc2[uu][4 * q + 1] = v.y; acc2[uu][4 * q + 2] = v.z; acc2[uu][4 * q + 3] = v.w;
+                }
+        }
         for (int g = 0; g < S.NG; ++g) {
             if (ug == 0) {  // first pass over this output group: build ds_pre and keep a copy in HBM
                 f32x16 gacc[NTG];
@@ -313,13 +439,22 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                     for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
                 if (scalar_gate) {
                     const float* wg = p.w.pack + S.offD + ((int64_t)g * 64 + lane) * NTG;
-                    for (int oo = 0; oo < S.NOO; ++oo) {
-                        WFragB<NTG> a;
-                        a.load(wg + (int64_t)oo * S.NG * 64 * NTG);
-                        const float b = dgt[e * L.GS2 + 2 * oo + hi];
+                    for (int oo0 = 0; oo0 < S.NOO; oo0 += 8) {  // fragments of 8 k-pair steps requested together
+                        WFragB<NTG> a[8];
+                        float b[8];
 #pragma unroll
-                        for (int t = 0; t < NTG; ++t)
-                            gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b, gacc[t], 0, 0, 0);
+                        for (int u = 0; u < 8; ++u) {
+                            const int oo = min(oo0 + u, S.NOO - 1);
+                            a[u].load(wg + (int64_t)oo * S.NG * 64 * NTG);
+                            b[u] = dgt[e * L.GS2 + 2 * oo + hi];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (oo0 + u < S.NOO)
+#pragma unroll
+                                for (int t = 0; t < NTG; ++t)
+                                    gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], b[u], gacc[t], 0, 0, 0);
                     }
                 }
 #pragma unroll
@@ -328,8 +463,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
-                        sp[q] = load4(sp_ptr, row, so, j0, row_ok, vec_so);
-                        dy[q] = load4(dso_ptr, row, so, j0, row_ok, vec_so);
+                        if (single) {
+                            sp[q] = make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]);
+                            dy[q] = make_float4(dyr[t][4 * q], dyr[t][4 * q + 1], dyr[t][4 * q + 2], dyr[t][4 * q + 3]);
+                        } else {
+                            sp[q] = load4(sp_ptr, row, so, j0, row_ok, vec_so);
+                            dy[q] = load4(dso_ptr, row, so, j0, row_ok, vec_so);
+                        }
                     }
                     float4 d[4];
 #pragma unroll
@@ -368,26 +508,30 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             // scalar_out adjoint for this (merged group, output group): 16 * NTG k-pair steps
             const float* wq = p.w.pack + S.offB + (((int64_t)ug * S.NS + (int64_t)g * NTG * 16) * 64 + lane) * NUG;
             {
-                WFragB<NUG> an[4];
+                // 16 * NTG steps, fully unrolled (the B operands are registers); weight fragments rotate through three
+                // batches of 4 steps, requested two batches ahead and pinned there (hipcc would sink them to their use)
+                WFragB<NUG> A0[4], A1[4], A2[4];
+                auto ld = [&](WFragB<NUG>(&a)[4], int st0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) an[u].load(wq + (int64_t)u * 64 * NUG);
+                    for (int u = 0; u < 4; ++u) a[u].load(wq + (int64_t)min(st0 + u, NTG * 16 - 1) * 64 * NUG);
+                };
+                ld(A0, 0);
+                ld(A1, 4);
+                ld(A2, 8);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < NTG; ++t)
+                for (int b = 0; b < NTG * 4; ++b) {
+                    WFragB<NUG>(&a)[4] = (b % 3 == 0) ? A0 : ((b % 3 == 1) ? A1 : A2);
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) {
-                        WFragB<NUG> a[4];
+                    for (int u = 0; u < 4; ++u) {
+                        const int st = b * 4 + u;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) a[u] = an[u];
-                        if (!(t == NTG - 1 && rb == 3)) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) an[u].load(wq + (int64_t)((t * 4 + rb + 1) * 4 + u) * 64 * NUG);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int uu = 0; uu < NUG; ++uu)
-                                acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[uu], dsr[t][rb * 4 + u], acc2[uu], 0, 0, 0);
+                        for (int uu = 0; uu < NUG; ++uu)
+                            acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[uu], dsr[st / 16][st % 16], acc2[uu], 0, 0, 0);
                     }
+                    if ((b + 3) * 4 < NTG * 16) ld(a, (b + 3) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // epilogue of this merged-axis group: d_s_in columns go to HBM, the vector extras to LDS
@@ -413,9 +557,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 }
             }
     }
+    }
     gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
     if (!has_vec) return;
     gcp_wave_lds_sync();
+    asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
+    row = r0 + e;
+    row_ok = row < rows;
 
     // ---- 5. adjoint of the vector prologue: d vh, d vf, then d v_in --------------------------------------------
     for (int h = hi; h < H; h += 2) {
@@ -484,19 +632,25 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
 }
 
-template <int NTG, int NUG, bool PWL>
-int launch3(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
+template <int NTG, int NUG, bool PWL, bool SINGLE>
+int launch4(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
     static size_t cur_max = 64 * 1024;
     if (lds_bytes > cur_max) {
-        hipError_t err = hipFuncSetAttribute((const void*)gcp2_bwd_kernel<NTG, NUG, PWL>,
+        hipError_t err = hipFuncSetAttribute((const void*)gcp2_bwd_kernel<NTG, NUG, PWL, SINGLE>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (err != hipSuccess) return (int)err;
         cur_max = lds_bytes;
     }
-    hipLaunchKernelGGL((gcp2_bwd_kernel<NTG, NUG, PWL>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
+    hipLaunchKernelGGL((gcp2_bwd_kernel<NTG, NUG, PWL, SINGLE>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
                        lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NTG, int NUG, bool PWL>
+int launch3(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
+    if (p.sh.NG == 1) return launch4<NTG, NUG, PWL, true>(p, lds_bytes, st);
+    return launch4<NTG, NUG, PWL, false>(p, lds_bytes, st);
 }
 
 template <int NTG, int NUG>

@@ -1,0 +1,354 @@
+// Register-resident chain of residual GCP2 blocks, x_k = x_{k-1} + GCP_k(x_{k-1}) (ResGCP, reference
+// src/models/components/gcpnet.py:921-924), forward, one launch for the whole chain.
+//
+// The scalar state of a 32-row tile lives in the 32x32 MFMA ACCUMULATOR LAYOUT for the whole chain: register (t, r) of
+// lane half `hi` holds column 32t + (r&3) + 8(r>>2) + 4hi of row lane&31.  That layout is at the same time
+//   * the B fragment of a k-pair step over columns (j0, j0+4) -> scalar_out reads its input straight from registers
+//     (weights packed for that pairing, section F of the packed image),
+//   * the layout scalar_out produces -> x += act(s_pre) is a plain register add,
+//   * the B fragment of the vector-gate GEMM,
+// so the scalar path needs NO LDS at all.  What is left in LDS is the 32 x 3V vector tile and a few hundred floats of
+// per-row scratch (~12 KB per wave), which is what lets two waves share a SIMD: one wave's VALU / LDS / store phases run
+// under the other's MFMAs.  The only per-row inputs of scalar_out that are not state, the H vector norms and 9 frame
+// scalars, go through a 32 x 16 LDS tile as ordinary B fragments.
+#include "common.h"
+#include "tile_io.h"
+
+namespace {
+
+struct ChainItemF {
+    const float* pack;
+    const float* b_scalar;
+    const float* w_down;
+    const float* w_frames;
+    const float* w_up;
+    const float* b_gate;
+    float* s_out;
+    float* v_out;
+    float* s_pre;
+    float* gate;
+    int act_s, act_v;
+};
+
+struct ChainParams {
+    int rows;
+    const float* s0;
+    const float* v0;
+    const float* frames;
+    gcp2_opts_t o;
+    int n;
+    ChainItemF it[GCP_MAX_CHAIN];
+    unsigned long long* stamps;
+    long long stamp_cap;
+    GcpShape sh;
+};
+
+struct ChainLds {
+    int VS, HS, GS, XS;
+    int o_vt, o_vht, o_gt, o_fr, o_ext, o_sw, total;
+};
+
+__host__ __device__ inline ChainLds chain_lds(const GcpShape& s) {
+    ChainLds l;
+    l.VS = gcp_odd(3 * s.vi);
+    l.HS = gcp_odd(3 * s.H);
+    l.GS = gcp_odd(s.vo);
+    l.XS = gcp_odd(gcp_round_up(s.H + s.nf, 2));
+    l.o_vt = 0;
+    l.o_vht = l.o_vt + 32 * l.VS;
+    l.o_gt = l.o_vht + 32 * l.HS;
+    l.o_fr = l.o_gt + 32 * l.GS;
+    l.o_ext = l.o_fr + 32 * 9;
+    l.o_sw = l.o_ext + 32 * l.XS;
+    l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
+    return l;
+}
+
+template <int N>
+struct WF;
+template <>
+struct WF<2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float* p) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <>
+struct WF<4> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+// NT = 32-wide tiles of the scalar state (so <= 32 * NT); PWL as in gcp2_fwd.hip.
+template <int NT, bool PWL>
+__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GcpShape& S = p.sh;
+    const ChainLds L = chain_lds(S);
+    int lane = threadIdx.x;
+    int e = lane & 31, hi = lane >> 5;
+    const int r0 = blockIdx.x * GCP_TILE_ROWS;
+    const int rows = p.rows;
+    int row = r0 + e;
+    bool row_ok = row < rows;
+    float* vt = lds + L.o_vt;
+    float* vht = lds + L.o_vht;
+    float* gt = lds + L.o_gt;
+    float* fr = lds + L.o_fr;
+    float* ext = lds + L.o_ext;
+    const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H;
+    const int NX = gcp_round_up(H + S.nf, 2) / 2;  // k-pair steps over the norms / frame scalars
+    const float slope = p.o.slope;
+    const bool scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;
+    const bool vec_so = (so & 3) == 0;
+    // ---- the tile: vectors + frames into LDS, scalars straight into the accumulator layout ---------------------------
+    f32x16 xs[NT];
+    {
+        GcpSegBuf<8> vb0;
+        gcp_seg_issue(vb0, p.v0, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
+        if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = gcp_load4(p.s0, row, so, 32 * t + 8 * q + 4 * hi, row_ok, vec_so);
+                xs[t][4 * q] = v.x; xs[t][4 * q + 1] = v.y; xs[t][4 * q + 2] = v.z; xs[t][4 * q + 3] = v.w;
+            }
+        gcp_seg_commit(vb0, vt, L.VS, 0);
+    }
+    for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
+
+    for (int ci = 0; ci < p.n; ++ci) {
+        asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));  // keep per-lane addresses from being hoisted and spilled
+        row = r0 + e;
+        row_ok = row < rows;
+        const ChainItemF& it = p.it[ci];
+        const float ns_s = gcp_neg_slope(it.act_s, slope), ns_v = gcp_neg_slope(it.act_v, slope);
+        gcp2_weights_t wsm;
+        wsm.vi = vi; wsm.vo = vo; wsm.w_down = it.w_down; wsm.w_frames = it.w_frames; wsm.w_up = it.w_up;
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
+        gcp_wave_lds_sync();
+        const GcpSmallW sw = gcp_stage_small_weights(wsm, H, S.nf, lds + L.o_sw, lane);
+        gcp_wave_lds_sync();
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+
+        // ---- vector prologue (VALU, two lanes per row): vh, its norms, the frame scalars ------------------------------
+        {
+            const float* vrow = vt + e * L.VS;
+            for (int h = hi; h < H; h += 2) {
+                const float* wd = sw.wd + h * vi;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                for (int c = 0; c < vi; ++c) {
+                    const float w = wd[c];
+                    a0 = fmaf(w, vrow[3 * c + 0], a0);
+                    a1 = fmaf(w, vrow[3 * c + 1], a1);
+                    a2 = fmaf(w, vrow[3 * c + 2], a2);
+                }
+                vht[e * L.HS + 3 * h + 0] = a0;
+                vht[e * L.HS + 3 * h + 1] = a1;
+                vht[e * L.HS + 3 * h + 2] = a2;
+                ext[e * L.XS + h] = sqrtf(a0 * a0 + a1 * a1 + a2 * a2 + 1e-8f) + 1e-8f;
+            }
+            if (S.nf) {
+                const float* f = fr + e * 9;
+                for (int k = hi; k < 3; k += 2) {
+                    const float* wf = sw.wf + k * vi;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                    for (int c = 0; c < vi; ++c) {
+                        const float w = wf[c];
+                        a0 = fmaf(w, vrow[3 * c + 0], a0);
+                        a1 = fmaf(w, vrow[3 * c + 1], a1);
+                        a2 = fmaf(w, vrow[3 * c + 2], a2);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float pr = f[3 * a + 0] * a0 + f[3 * a + 1] * a1 + f[3 * a + 2] * a2;
+                        if (p.o.e3 && a == 1) pr = fabsf(pr);
+                        ext[e * L.XS + H + 3 * k + a] = pr;
+                    }
+                }
+            }
+        }
+        gcp_wave_lds_sync();
+
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
+        // ---- scalar_out: acc = b + W[:, state] x^T + W[:, extras] ext^T --------------------------------------------------
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * t + gcp_crow(r, hi);
+                acc[t][r] = j < so ? it.b_scalar[j] : 0.f;
+            }
+        {
+            const float* wf = it.pack + S.offF + (int64_t)lane * NT;  // [step][64][NT]
+            constexpr int U = 4;
+            WF<NT> A0[U], A1[U], A2[U];
+            auto ld = [&](WF<NT>(&a)[U], int st0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u].load(wf + (int64_t)min(st0 + u, NT * 16 - 1) * 64 * NT);
+            };
+            ld(A0, 0);
+            ld(A1, U);
+            ld(A2, 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            // NT * 16 steps, fully unrolled so that the state registers are addressed statically; the weight fragments
+            // rotate through three batches of U steps (requested two batches ahead)
+#pragma unroll
+            for (int b = 0; b < NT * 16 / U; ++b) {
+                WF<NT>(&a)[U] = (b % 3 == 0) ? A0 : ((b % 3 == 1) ? A1 : A2);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int st = b * U + u;
+                    const float bv = xs[st / 16][st % 16];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], bv, acc[t], 0, 0, 0);
+                }
+                if ((b + 3) * U < NT * 16) ld(a, (b + 3) * U);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE: hipcc otherwise sinks each load to its use
+            }
+            if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
+            // norms and frame scalars: ordinary B fragments from the 32 x 16 LDS tile, weights from section A
+            const float* wa = it.pack + S.offA + (int64_t)lane * NT;
+            const int kk0 = si / 2;
+            for (int x = 0; x < NX; ++x) {
+                WF<NT> a;
+                a.load(wa + (int64_t)(kk0 + x) * 64 * NT);
+                const float bv = ext[e * L.XS + 2 * x + hi];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], bv, acc[t], 0, 0, 0);
+            }
+        }
+
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
+        // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
+        f32x16 gacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+        if (scalar_gate) {
+            const float* wg = it.pack + S.offC + lane;
+            float wa[16], wb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wa[r] = wg[(int64_t)r * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float(&cur)[16] = (t & 1) ? wb : wa;
+                float(&nxt)[16] = (t & 1) ? wa : wb;
+                if (t + 1 < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) nxt[r] = wg[(int64_t)((t + 1) * 16 + r) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // next tile's fragments stay in flight under this tile's MFMAs
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[r], gcp_actf<PWL>(it.act_v, ns_v, slope, acc[t][r]), gacc, 0, 0, 0);
+            }
+        }
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
+        // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j0 = 32 * t + 8 * q + 4 * hi;
+                if (it.s_pre)
+                    gcp_store4(it.s_pre, row, so, j0,
+                               make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), row_ok, vec_so);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) xs[t][4 * q + x] += gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][4 * q + x]);
+                if (it.s_out)
+                    gcp_store4(it.s_out, row, so, j0,
+                               make_float4(xs[t][4 * q], xs[t][4 * q + 1], xs[t][4 * q + 2], xs[t][4 * q + 3]), row_ok, vec_so);
+            }
+
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
+        // ---- vector epilogue: sigmoid gate, vector_up, gating, residual; the vector tile is updated in place ---------------
+        if (scalar_gate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oo = gcp_crow(r, hi);
+                if (oo < vo) gt[e * L.GS + oo] = gcp_sigmoid(gacc[r] + it.b_gate[oo]);
+            }
+        }
+        gcp_wave_lds_sync();
+        for (int oc0 = hi; oc0 < vo; oc0 += 16) {
+            float y[8][3];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int oc = oc0 + 2 * i;
+                y[i][0] = y[i][1] = y[i][2] = 0.f;
+                if (oc < vo) {
+                    const float* wu = sw.wu + oc * H;
+                    float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                    for (int h = 0; h < H; ++h) {
+                        const float w = wu[h];
+                        u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
+                        u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
+                        u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
+                    }
+                    const float x0 = vt[e * L.VS + 3 * oc + 0], x1 = vt[e * L.VS + 3 * oc + 1], x2 = vt[e * L.VS + 3 * oc + 2];
+                    if (p.o.vector_residual) { u0 += x0; u1 += x1; u2 += x2; }
+                    float sc = 1.f;
+                    if (scalar_gate) sc = gt[e * L.GS + oc];
+                    else if (p.o.vmode == GCP_VMODE_SELF_GATE)
+                        sc = gcp_actf<PWL>(it.act_v, ns_v, slope, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f);
+                    y[i][0] = x0 + u0 * sc; y[i][1] = x1 + u1 * sc; y[i][2] = x2 + u2 * sc;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int oc = oc0 + 2 * i;
+                if (oc < vo) { vt[e * L.VS + 3 * oc + 0] = y[i][0]; vt[e * L.VS + 3 * oc + 1] = y[i][1]; vt[e * L.VS + 3 * oc + 2] = y[i][2]; }
+            }
+        }
+        gcp_wave_lds_sync();
+        if (it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
+        if (scalar_gate && it.gate) gcp_store_tile(it.gate, vo, 0, vo, r0, rows, gt, L.GS, lane);
+        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
+    }
+}
+
+template <int NT, bool PWL>
+int launch_chain(const ChainParams& p, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
+                       lds_bytes, st, p);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// Returns GCPNET_E_UNSUPPORTED when the shape does not fit the register-resident kernel; the caller then uses the
+// LDS-resident chain of gcp2_fwd.hip.
+int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const float* frames, int n,
+                             const gcp2_chain_item_t* items, hipStream_t st) {
+    const gcp2_weights_t& w0 = items[0].w;
+    const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
+    if (S.NG != 1 || S.NTG < 2 || (w0.si & 1) || w0.vi <= 0 || w0.vo <= 0 || w0.vo > 32 || S.GT != 1) return GCPNET_E_UNSUPPORTED;
+    if (S.NTS != S.NTG) return GCPNET_E_UNSUPPORTED;
+    ChainParams p;
+    p.rows = rows; p.s0 = s0; p.v0 = v0; p.frames = frames;
+    p.o = items[0].o;
+    p.n = n;
+    bool pwl = true;
+    for (int k = 0; k < n; ++k) {
+        const gcp2_chain_item_t& c = items[k];
+        ChainItemF& it = p.it[k];
+        it.pack = c.w.pack; it.b_scalar = c.w.b_scalar; it.w_down = c.w.w_down; it.w_frames = c.w.w_frames;
+        it.w_up = c.w.w_up; it.b_gate = c.w.b_gate; it.s_out = c.s_out; it.v_out = c.v_out; it.s_pre = c.s_pre;
+        it.gate = c.gate; it.act_s = c.o.act_s; it.act_v = c.o.act_v;
+        pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
+    }
+    p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
+    p.sh = S;
+    const size_t lds_bytes = (size_t)chain_lds(S).total * sizeof(float);
+    if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
+    if (S.NTG == 2) return pwl ? launch_chain<2, true>(p, lds_bytes, st) : launch_chain<2, false>(p, lds_bytes, st);
+    return pwl ? launch_chain<4, true>(p, lds_bytes, st) : launch_chain<4, false>(p, lds_bytes, st);
+}

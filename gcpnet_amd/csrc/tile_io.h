@@ -15,23 +15,28 @@ __device__ __forceinline__ void gcp_load_segment(const float* __restrict__ base,
         const int sub = lane / q, c4 = lane - sub * q;
         const bool lane_on = sub < rpi;
         constexpr int B = 16;
+        const int rmax = min(rows, r0 + GCP_TILE_ROWS) - 1;  // loads are UNCONDITIONAL (clamped address + select): a guarded
+        const int c4c = lane_on ? c4 : 0;                    // load makes hipcc branch around it and wait vmcnt(0) per element
         for (int e0 = 0; e0 < GCP_TILE_ROWS; e0 += rpi * B) {
             float4 buf[B];
+            if (idx) {
+                int src[B];
 #pragma unroll
-            for (int b = 0; b < B; ++b) {
-                const int e = e0 + b * rpi + sub;
-                buf[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane_on && e < GCP_TILE_ROWS && r0 + e < rows) {
-                    const int64_t src = idx ? (int64_t)idx[r0 + e] : (int64_t)(r0 + e);
-                    buf[b] = *reinterpret_cast<const float4*>(base + src * dim + 4 * c4);
-                }
+                for (int b = 0; b < B; ++b) src[b] = idx[min(r0 + e0 + b * rpi + sub, rmax)];
+#pragma unroll
+                for (int b = 0; b < B; ++b) buf[b] = *reinterpret_cast<const float4*>(base + (int64_t)src[b] * dim + 4 * c4c);
+            } else {
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+                    buf[b] = *reinterpret_cast<const float4*>(base + (int64_t)min(r0 + e0 + b * rpi + sub, rmax) * dim + 4 * c4c);
             }
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const int e = e0 + b * rpi + sub;
                 if (lane_on && e < GCP_TILE_ROWS) {
+                    const bool ok = r0 + e < rows;
                     float* d = tile + e * stride + coff + 4 * c4;
-                    d[0] = buf[b].x; d[1] = buf[b].y; d[2] = buf[b].z; d[3] = buf[b].w;
+                    d[0] = ok ? buf[b].x : 0.f; d[1] = ok ? buf[b].y : 0.f; d[2] = ok ? buf[b].z : 0.f; d[3] = ok ? buf[b].w : 0.f;
                 }
             }
         }
@@ -57,7 +62,7 @@ __device__ __forceinline__ void gcp_load_segment(const float* __restrict__ base,
 template <int B>
 struct GcpSegBuf {
     float4 v[B];
-    int rpi, sub, c4;
+    int rpi, sub, c4, nvalid;
     bool deferred, lane_on;
 };
 
@@ -73,14 +78,19 @@ __device__ __forceinline__ void gcp_seg_issue(GcpSegBuf<B>& sb, const float* __r
         sb.sub = lane / q;
         sb.c4 = lane - sb.sub * q;
         sb.lane_on = sb.sub < sb.rpi;
+        sb.nvalid = min(rows - r0, GCP_TILE_ROWS);
+        const int rmax = r0 + sb.nvalid - 1;
+        const int c4c = sb.lane_on ? sb.c4 : 0;  // unconditional loads from clamped addresses; `commit` zeroes the rest
+        if (idx) {
+            int src[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            const int e = b * sb.rpi + sb.sub;
-            sb.v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sb.lane_on && e < GCP_TILE_ROWS && r0 + e < rows) {
-                const int64_t src = idx ? (int64_t)idx[r0 + e] : (int64_t)(r0 + e);
-                sb.v[b] = *reinterpret_cast<const float4*>(base + src * dim + 4 * sb.c4);
-            }
+            for (int b = 0; b < B; ++b) src[b] = idx[min(r0 + b * sb.rpi + sb.sub, rmax)];
+#pragma unroll
+            for (int b = 0; b < B; ++b) sb.v[b] = *reinterpret_cast<const float4*>(base + (int64_t)src[b] * dim + 4 * c4c);
+        } else {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                sb.v[b] = *reinterpret_cast<const float4*>(base + (int64_t)min(r0 + b * sb.rpi + sb.sub, rmax) * dim + 4 * c4c);
         }
     } else {
         gcp_load_segment(base, idx, dim, r0, rows, tile, stride, coff, lane);
@@ -94,8 +104,9 @@ __device__ __forceinline__ void gcp_seg_commit(const GcpSegBuf<B>& sb, float* ti
     for (int b = 0; b < B; ++b) {
         const int e = b * sb.rpi + sb.sub;
         if (sb.lane_on && e < GCP_TILE_ROWS) {
+            const bool ok = e < sb.nvalid;
             float* d = tile + e * stride + coff + 4 * sb.c4;
-            d[0] = sb.v[b].x; d[1] = sb.v[b].y; d[2] = sb.v[b].z; d[3] = sb.v[b].w;
+            d[0] = ok ? sb.v[b].x : 0.f; d[1] = ok ? sb.v[b].y : 0.f; d[2] = ok ? sb.v[b].z : 0.f; d[3] = ok ? sb.v[b].w : 0.f;
         }
     }
 }
@@ -150,14 +161,11 @@ __device__ __forceinline__ void gcp_load_frames(const float* __restrict__ frames
     const float* src = frames + (int64_t)r0 * 9;
     float t[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int i = lane + 64 * k;
-        t[k] = i < n ? src[i] : 0.f;
-    }
+    for (int k = 0; k < 5; ++k) t[k] = src[min(lane + 64 * k, n - 1)];  // unconditional, clamped
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int i = lane + 64 * k;
-        if (i < GCP_TILE_ROWS * 9) fr[i] = t[k];
+        if (i < GCP_TILE_ROWS * 9) fr[i] = i < n ? t[k] : 0.f;
     }
 }
 
@@ -179,8 +187,7 @@ __device__ __forceinline__ void gcp_copy_to_lds(const float* __restrict__ src, f
         float t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int i = i0 + lane + 64 * k;
-            t[k] = i < n ? src[i] : 0.f;
+            t[k] = src[min(i0 + lane + 64 * k, n - 1)];  // unconditional, clamped
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -201,4 +208,33 @@ __device__ __forceinline__ GcpSmallW gcp_stage_small_weights(const gcp2_weights_
         if (w.vo > 0) gcp_copy_to_lds(w.w_up, area + H * w.vi + (nf ? 3 * w.vi : 0), w.vo * H, lane);
     }
     return r;
+}
+
+// 4 consecutive columns j0..j0+3 of row `row` of a [rows, ld] matrix (zeros outside): the accumulator-layout access.
+__device__ __forceinline__ float4 gcp_load4(const float* base, int64_t row, int ld, int j0, bool ok, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {  // wave-uniform.  The load itself is unconditional (clamped address) and the result is selected: a guarded
+                // load would make hipcc branch around it and wait vmcnt(0) for each one
+        const bool in = ok && j0 + 3 < ld;
+        const float4 t = *reinterpret_cast<const float4*>(base + (ok ? row : 0) * ld + min(j0, ld - 4));
+        v.x = in ? t.x : 0.f; v.y = in ? t.y : 0.f; v.z = in ? t.z : 0.f; v.w = in ? t.w : 0.f;
+        return v;
+    }
+    if (!ok) return v;
+    const float* p = base + row * ld + j0;
+    if (j0 + 0 < ld) v.x = p[0];
+    if (j0 + 1 < ld) v.y = p[1];
+    if (j0 + 2 < ld) v.z = p[2];
+    if (j0 + 3 < ld) v.w = p[3];
+    return v;
+}
+
+__device__ __forceinline__ void gcp_store4(float* base, int64_t row, int ld, int j0, float4 v, bool ok, bool vec) {
+    if (!ok) return;
+    float* p = base + row * ld + j0;
+    if (vec && j0 + 3 < ld) { *reinterpret_cast<float4*>(p) = v; return; }
+    if (j0 + 0 < ld) p[0] = v.x;
+    if (j0 + 1 < ld) p[1] = v.y;
+    if (j0 + 2 < ld) p[2] = v.z;
+    if (j0 + 3 < ld) p[3] = v.w;
 }

@@ -308,30 +308,41 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     if (wave_active) store_partial(P, w, a.M[w.pi], a.N[w.pi], acc, wave, col, hi);
 }
 
+// Deterministic reduction of the per-split partial sums.  A workgroup handles 64 consecutive output elements; its four
+// waves take the splits k = w, w+4, ... (coalesced 256-byte rows, eight loads in flight per lane) and are combined in a
+// fixed order through LDS.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a) {
+    __shared__ float red[4][64];
     const int pi = blockIdx.y;
     const gcp_tn_problem_t& P = a.p[pi];
     const int M = a.M[pi], N = a.N[pi];
     const int64_t full = (int64_t)M * N;
     const int om = P.diag > 0 ? P.diag_m : M, on = P.diag > 0 ? P.diag_n : N, nd = P.diag > 0 ? P.diag : 1;
     const int64_t total = (int64_t)om * on;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int m = (int)(i / on), n = (int)(i % on);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < total;
+        const int m = ok ? (int)(i / on) : 0, n = ok ? (int)(i % on) : 0;
         float s = 0.f;
         for (int d = 0; d < nd; ++d) {
             const float* src = P.partial + (int64_t)(d * om + m) * N + (d * on + n);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int k = 0;
-            for (; k + 3 < P.splits; k += 4) {
-                s0 += src[(int64_t)k * full];
-                s1 += src[(int64_t)(k + 1) * full];
-                s2 += src[(int64_t)(k + 2) * full];
-                s3 += src[(int64_t)(k + 3) * full];
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+            for (int k0 = w; k0 < P.splits; k0 += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 4 * u;
+                    acc[u] += src[(int64_t)min(k, P.splits - 1) * full] * (k < P.splits ? 1.f : 0.f);
+                }
             }
-            for (; k < P.splits; ++k) s0 += src[(int64_t)k * full];
-            s += (s0 + s1) + (s2 + s3);
+            s += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
-        P.out[m * P.out_sm + n * P.out_sn] = s;
+        red[w][lane] = s;
+        __syncthreads();
+        if (w == 0 && ok) P.out[m * P.out_sm + n * P.out_sn] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
     }
 }
 
@@ -387,7 +398,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         hipLaunchKernelGGL(tn_gemm_kernel, dim3(blocks), dim3(256), 0, st, a);
     }
     GCP_HIP_CHECK_LAUNCH();
-    const int rblocks = min(64, gcp_cdiv(max_mn, 256));
+    const int rblocks = min(1024, gcp_cdiv(max_mn, 64));
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(rblocks, n_problems), dim3(256), 0, st, a);
     GCP_HIP_CHECK_LAUNCH();
     return 0;

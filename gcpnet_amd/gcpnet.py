@@ -111,18 +111,22 @@ class GCP2(nn.Module):
         return (self.scalar_out.weight, self.scalar_out.bias, g("vector_down"), g("vector_down_frames"), g("vector_up"),
                 None if gate is None else gate.weight, None if gate is None else gate.bias)
 
-    def apply_rows(self, s_sources: Sequence[torch.Tensor], s_plans: Sequence[Optional[GatherPlan]],
-                   v_sources: Sequence[torch.Tensor], v_plans: Sequence[Optional[GatherPlan]],
-                   row_frames: Optional[torch.Tensor], residual: bool = False):
-        """Runs the block on rows whose inputs are concatenations of (optionally gathered) sources.  `row_frames`
-        holds one frame per row.  With `residual` the result is x + GCP(x) for the single source x (ResGCP)."""
+    def make_spec(self, s_plans, v_plans, residual: bool = False) -> Gcp2Spec:
         use_frames = bool(self.vector_input_dim) and not self.ablate_frame_updates
-        spec = Gcp2Spec(
+        return Gcp2Spec(
             si=self.scalar_input_dim, vi=self.vector_input_dim, so=self.scalar_output_dim, vo=self.vector_output_dim,
             hidden=self.hidden_dim, use_frames=use_frames, act_s=self.act_s, act_v=self.act_v, slope=self.slope,
             vmode=self._vmode(), vector_residual=bool(self.vector_residual) and bool(self.vector_input_dim),
             e3=bool(self.enable_e3_equivariance), s_plans=list(s_plans), v_plans=list(v_plans), residual=residual,
             pack_cache=self._pack_cache)
+
+    def apply_rows(self, s_sources: Sequence[torch.Tensor], s_plans: Sequence[Optional[GatherPlan]],
+                   v_sources: Sequence[torch.Tensor], v_plans: Sequence[Optional[GatherPlan]],
+                   row_frames: Optional[torch.Tensor], residual: bool = False):
+        """Runs the block on rows whose inputs are concatenations of (optionally gathered) sources.  `row_frames`
+        holds one frame per row.  With `residual` the result is x + GCP(x) for the single source x (ResGCP)."""
+        spec = self.make_spec(s_plans, v_plans, residual)
+        use_frames = spec.use_frames
         return ops.gcp2(spec, s_sources, v_sources, row_frames if use_frames else None, self._weights())
 
     def forward(self, s_maybe_v, edge_index, frames, node_inputs: bool = False, node_mask=None):
@@ -262,7 +266,12 @@ class GCPMessagePassing(nn.Module):
         # message = [h_row | e | h_col], [chi_row | xi | chi_col] (:907-917): gathered inside the kernel's tile loader
         m = first.apply_rows([h, e, h], [plan.row, None, plan.col], [chi, xi, chi], [plan.row, None, plan.col], frames)
         m = ScalarVector(*m)
-        for module in self.message_fusion[1:]:
+        rest = list(self.message_fusion[1:])
+        if rest and self._chainable(rest):
+            # ResGCP chain (:921-924) in one launch: the (s, V) state of each 32-edge tile never leaves the chip
+            specs = [mod.make_spec([None], [None], residual=True) for mod in rest]
+            return ScalarVector(*ops.gcp2_chain(specs, m[0], m[1], frames, [mod._weights() for mod in rest]))
+        for module in rest:
             same = (module.scalar_input_dim == module.scalar_output_dim
                     and module.vector_input_dim == module.vector_output_dim)
             if self.use_residual_message_gcp and same:  # ResGCP (:921-924), residual add fused into the kernel
@@ -272,6 +281,18 @@ class GCPMessagePassing(nn.Module):
             else:
                 m = ScalarVector(*module.apply_rows([m[0]], [None], [m[1]], [None], frames))
         return m
+
+    def _chainable(self, mods) -> bool:
+        if not self.use_residual_message_gcp or len(mods) > 8:
+            return False
+        a = mods[0]
+        if a.scalar_output_dim > 128 or not a.vector_input_dim or not a.vector_output_dim or a.vector_output_dim > 64:
+            return False
+        key = lambda m: (m.scalar_input_dim, m.vector_input_dim, m.scalar_output_dim, m.vector_output_dim, m.hidden_dim,
+                         m.ablate_frame_updates, m._vmode(), bool(m.vector_residual), bool(m.enable_e3_equivariance),
+                         m.ablate_scalars, m.ablate_vectors)
+        return (a.scalar_input_dim == a.scalar_output_dim and a.vector_input_dim == a.vector_output_dim
+                and not a.ablate_scalars and not a.ablate_vectors and all(key(m) == key(a) for m in mods))
 
     def message(self, node_rep, edge_rep, edge_index, frames, node_mask=None):
         if node_mask is not None:

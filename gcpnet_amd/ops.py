@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT, BwdScratch, Concat, Gcp2Opts, Gcp2Weights, Operand, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
+from ._lib import (ACT, BwdScratch, ChainItem, Concat, Gcp2Opts, Gcp2Weights, Operand, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
                    VMODE_SELF_GATE, check)
 
 Tensor = torch.Tensor
@@ -447,80 +447,173 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     return d_s_in, d_v_in, t
 
 
-def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t) -> List[Optional[Tensor]]:
-    """Weight gradients of one GCP2 block as TN GEMMs over the row axis, fed by the backward kernel's scratch `t`.
-    Returns gradients in the order (scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up,
-    vector_out_scale.weight, vector_out_scale.bias)."""
+class _WeightGradJob:
+    """TN-GEMM problems for the weight gradients of one GCP2 block, fed by the backward kernel's scratch `t`."""
+
+    def __init__(self, spec: Gcp2Spec, rows: int, s_src, s_pre, t):
+        lib = _lib.load()
+        f32 = dict(dtype=torch.float32, device=s_pre.device)
+        H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
+        nf = 9 if (spec.use_frames and vi > 0) else 0
+        self.spec, self.nf = spec, nf
+        self.has_vec, self.has_vout = vi > 0, vi > 0 and vo > 0
+        self.gated = spec.vmode == VMODE_SCALAR_GATE and self.has_vout
+        self.probs, self.keep = [], [t, s_pre, list(s_src)]
+
+        def operand(segs, act=None, ones=False):
+            op = Operand()
+            op.n = len(segs)
+            for k, (x, pl, dim, ld) in enumerate(segs):
+                op.ptr[k], op.dim[k], op.ld[k] = x.data_ptr(), dim, ld
+                op.idx[k] = pl.idx.data_ptr() if pl is not None else None
+            op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
+            return op
+
+        def problem(a, M, b, N, out, sm, sn, diag=0, dm=0, dn=0):
+            pr = TnProblem()
+            pr.rows, pr.a, pr.b = rows, a, b
+            pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
+            pr.splits = lib.gcpnet_tn_splits(rows, M, N)
+            pr.diag, pr.diag_m, pr.diag_n = diag, dm, dn
+            part = torch.empty((pr.splits, M, N), **f32)
+            self.keep.append(part)
+            pr.partial = part.data_ptr()
+            self.probs.append(pr)
+
+        r4 = lambda x: (x + 3) // 4 * 4
+        si = spec.si
+        EP, HP, VIP, VOP, HFP = r4(H + nf), r4(H), r4(vi), r4(vo), r4(H + 3)
+        self.EP = EP
+        # d scalar_out.weight / bias: ds_pre^T [s sources | norms | frame scalars | 1]
+        bsegs = [(x, pl, x.shape[1], x.shape[1]) for x, pl in zip(s_src, spec.s_plans)]
+        n1 = si + 1
+        if self.has_vec:
+            bsegs.append((t["ext"], None, EP, EP))
+            n1 = si + EP + 1
+        self.W1 = torch.empty((so, n1), **f32)
+        problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, self.W1, n1, 1)
+        self.W2 = self.W3 = self.W4 = None
+        if self.gated:  # d vector_out_scale.weight / bias: [act_v(s_pre) | 1]^T dgate
+            self.W2 = torch.empty((so + 1, VOP), **f32)
+            problem(operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
+                    operand([(t["dgate"], None, VOP, VOP)]), VOP, self.W2, VOP, 1)
+        if self.has_vout:  # d vector_up.weight: trace over xyz of dvu[(d,o)]^T vh[(d,h)]
+            self.W3 = torch.empty((VOP, HP), **f32)
+            problem(operand([(t["dvu"], None, 3 * VOP, 3 * VOP)]), 3 * VOP, operand([(t["vh"], None, 3 * HP, 3 * HP)]),
+                    3 * HP, self.W3, HP, 1, diag=3, dm=VOP, dn=HP)
+        if self.has_vec:  # d vector_down(.frames).weight: trace over xyz of v[(d,c)]^T [dvh | dvf][(d,x)]
+            self.W4 = torch.empty((VIP, HFP), **f32)
+            problem(operand([(t["vt"], None, 3 * VIP, 3 * VIP)]), 3 * VIP, operand([(t["dvhf"], None, 3 * HFP, 3 * HFP)]),
+                    3 * HFP, self.W4, HFP, 1, diag=3, dm=VIP, dn=HFP)
+
+    def grads(self) -> List[Optional[Tensor]]:
+        """(scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up, gate.weight, gate.bias)"""
+        spec, nf = self.spec, self.nf
+        H, vi, vo, so, si = spec.hidden, spec.vi, spec.vo, spec.so, spec.si
+        W1, W2, W3, W4 = self.W1, self.W2, self.W3, self.W4
+        g: List[Optional[Tensor]] = [None] * 7
+        if self.has_vec:
+            g[0] = torch.cat((W1[:, :si], W1[:, si:si + H + nf]), dim=1)
+            g[1] = W1[:, si + self.EP].contiguous()
+            g[2] = W4[:vi, :H].t().contiguous()
+            if nf:
+                g[3] = W4[:vi, H:H + 3].t().contiguous()
+        else:
+            g[0] = W1[:, :si].contiguous()
+            g[1] = W1[:, si].contiguous()
+        if self.has_vout:
+            g[4] = W3[:vo, :H].contiguous()
+        if self.gated:
+            g[5] = W2[:so, :vo].t().contiguous()
+            g[6] = W2[so, :vo].contiguous()
+        return g
+
+
+def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob]) -> None:
+    """Launches the TN GEMMs of several blocks, up to 8 problems per launch."""
     lib = _lib.load()
-    f32 = dict(dtype=torch.float32, device=s_pre.device)
-    H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
-    nf = 9 if (spec.use_frames and vi > 0) else 0
-    has_vec, has_vout = vi > 0, vi > 0 and vo > 0
-    gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
-    probs, keep = [], []
+    probs = [pr for j in jobs for pr in j.probs]
+    for i in range(0, len(probs), _lib.TN_MAX_PROBLEMS):
+        chunk = probs[i:i + _lib.TN_MAX_PROBLEMS]
+        arr = (TnProblem * len(chunk))(*chunk)
+        check(lib.gcpnet_tn_gemm(len(chunk), arr, _stream()), "tn_gemm")
 
-    def operand(segs, act=None, ones=False):
-        op = Operand()
-        op.n = len(segs)
-        for k, (x, pl, dim, ld) in enumerate(segs):
-            op.ptr[k], op.dim[k], op.ld[k] = x.data_ptr(), dim, ld
-            op.idx[k] = pl.idx.data_ptr() if pl is not None else None
-        op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
-        return op
 
-    def problem(a, M, b, N, out, sm, sn, diag=0, dm=0, dn=0):
-        pr = TnProblem()
-        pr.rows, pr.a, pr.b = rows, a, b
-        pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
-        pr.splits = lib.gcpnet_tn_splits(rows, M, N)
-        pr.diag, pr.diag_m, pr.diag_n = diag, dm, dn
-        part = torch.empty((pr.splits, M, N), **f32)
-        keep.append(part)
-        pr.partial = part.data_ptr()
-        probs.append(pr)
+def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t) -> List[Optional[Tensor]]:
+    job = _WeightGradJob(spec, rows, s_src, s_pre, t)
+    run_weight_grad_jobs([job])
+    return job.grads()
 
-    r4 = lambda x: (x + 3) // 4 * 4
-    si = spec.si
-    EP, HP, VIP, VOP, HFP = r4(H + nf), r4(H), r4(vi), r4(vo), r4(H + 3)
-    # d scalar_out.weight / bias: ds_pre^T [s sources | norms | frame scalars | 1]
-    bsegs = [(x, pl, x.shape[1], x.shape[1]) for x, pl in zip(s_src, spec.s_plans)]
-    n1 = si + 1
-    if has_vec:
-        bsegs.append((t["ext"], None, EP, EP))
-        n1 = si + EP + 1
-    W1 = torch.empty((so, n1), **f32)
-    problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, W1, n1, 1)
-    W2 = W3 = W4 = None
-    if gated:  # d vector_out_scale.weight / bias: [act_v(s_pre) | 1]^T dgate
-        W2 = torch.empty((so + 1, VOP), **f32)
-        problem(operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
-                operand([(t["dgate"], None, VOP, VOP)]), VOP, W2, VOP, 1)
-    if has_vout:  # d vector_up.weight: trace over xyz of dvu[(d,o)]^T vh[(d,h)]
-        W3 = torch.empty((VOP, HP), **f32)
-        problem(operand([(t["dvu"], None, 3 * VOP, 3 * VOP)]), 3 * VOP, operand([(t["vh"], None, 3 * HP, 3 * HP)]), 3 * HP,
-                W3, HP, 1, diag=3, dm=VOP, dn=HP)
-    if has_vec:  # d vector_down(.frames).weight: trace over xyz of v[(d,c)]^T [dvh | dvf][(d,x)]
-        W4 = torch.empty((VIP, HFP), **f32)
-        problem(operand([(t["vt"], None, 3 * VIP, 3 * VIP)]), 3 * VIP, operand([(t["dvhf"], None, 3 * HFP, 3 * HFP)]),
-                3 * HFP, W4, HFP, 1, diag=3, dm=VIP, dn=HFP)
-    arr = (TnProblem * len(probs))(*probs)
-    check(lib.gcpnet_tn_gemm(len(probs), arr, _stream()), "tn_gemm")
-    g: List[Optional[Tensor]] = [None] * 7
-    if has_vec:
-        g[0] = torch.cat((W1[:, :si], W1[:, si:si + H + nf]), dim=1)
-        g[1] = W1[:, si + EP].contiguous()
-        g[2] = W4[:vi, :H].t().contiguous()
-        if nf:
-            g[3] = W4[:vi, H:H + 3].t().contiguous()
-    else:
-        g[0] = W1[:, :si].contiguous()
-        g[1] = W1[:, si].contiguous()
-    if has_vout:
-        g[4] = W3[:vo, :H].contiguous()
-    if gated:
-        g[5] = W2[:so, :vo].t().contiguous()
-        g[6] = W2[so, :vo].contiguous()
-    return g
+
+class _Gcp2Chain(torch.autograd.Function):
+    """x_k = x_{k-1} + GCP_k(x_{k-1}), k = 1..n, in ONE forward launch with the tile state kept on chip.
+    inputs: specs (one per block), frames, s0, v0, then 7 weights per block."""
+
+    @staticmethod
+    def forward(ctx, specs, frames, s0, v0, *weights):
+        lib = _lib.load()
+        n = len(specs)
+        rows, dev = s0.shape[0], s0.device
+        need_grad = any(ctx.needs_input_grad)
+        f32 = dict(dtype=torch.float32, device=dev)
+        items = (ChainItem * n)()
+        ws, packs, outs = [], [], []
+        for k, spec in enumerate(specs):
+            w = tuple(weights[7 * k:7 * k + 7])
+            pack = _pack(spec, w)
+            last = k == n - 1  # intermediate states are only materialised when the backward will need them
+            s_out = torch.empty((rows, spec.so), **f32) if (need_grad or last) else None
+            v_out = torch.empty((rows, spec.vo, 3), **f32) if (need_grad or last) else None
+            s_pre = torch.empty((rows, spec.so), **f32) if need_grad else None
+            gated = spec.vmode == VMODE_SCALAR_GATE
+            gate = torch.empty((rows, spec.vo), **f32) if (need_grad and gated) else None
+            items[k].w = _weights_struct(spec, w, pack)
+            items[k].o = _opts_struct(spec)
+            items[k].s_out = s_out.data_ptr() if s_out is not None else None
+            items[k].v_out = v_out.data_ptr() if v_out is not None else None
+            items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
+            items[k].gate = gate.data_ptr() if gate is not None else None
+            ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
+        check(lib.gcpnet_gcp2_chain_forward(rows, _p(s0), _p(v0), _p(frames), n, items, _stream()), "gcp2_chain_forward")
+        if need_grad:
+            ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
+            ctx.state = (s0, v0, ws, packs, outs)
+        return outs[-1][0], outs[-1][1]
+
+    @staticmethod
+    def backward(ctx, d_s, d_v):
+        specs, frames, rows = ctx.specs, ctx.frames, ctx.rows
+        s0, v0, ws, packs, outs = ctx.state
+        n = len(specs)
+        f32 = dict(dtype=torch.float32, device=s0.device)
+        d_s = _req(d_s, "grad") if d_s is not None else torch.zeros((rows, specs[0].so), **f32)
+        d_v = _req(d_v, "grad") if d_v is not None else torch.zeros((rows, specs[0].vo, 3), **f32)
+        need_w = ctx.needs_input_grad[4:]
+        jobs: List[Optional[_WeightGradJob]] = [None] * n
+        for k in range(n - 1, -1, -1):
+            s_in, v_in = (s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1])
+            _, _, s_pre, gate = outs[k]
+            d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s, d_v)
+            if any(need_w[7 * k:7 * k + 7]):
+                jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
+        live = [j for j in jobs if j is not None]
+        if live:
+            run_weight_grad_jobs(live)
+        wgrads: List[Optional[Tensor]] = []
+        for k in range(n):
+            g = jobs[k].grads() if jobs[k] is not None else [None] * 7
+            wgrads += [gi if need else None for gi, need in zip(g, need_w[7 * k:7 * k + 7])]
+        ctx.state = None
+        return (None, None, d_s, d_v, *wgrads)
+
+
+def gcp2_chain(specs: Sequence[Gcp2Spec], s0: Tensor, v0: Tensor, frames: Optional[Tensor], weights: Sequence[tuple]):
+    """Chain of residual GCP2 blocks with identical dims (ResGCP).  `weights[k]` as for gcp2()."""
+    s0, v0 = _req(s0, "scalar input"), _req(v0, "vector input")
+    if frames is not None:
+        frames = _req(frames.detach(), "frames")
+    flat = [None if t is None else _req(t, "weight") for w in weights for t in w]
+    return _Gcp2Chain.apply(list(specs), frames, s0, v0, *flat)
 
 
 def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor], frames: Optional[Tensor], weights,

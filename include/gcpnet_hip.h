@@ -90,6 +90,22 @@ int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* 
                         const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* res_s, const float* res_v,
                         float* s_out, float* v_out, float* s_pre, float* gate, void* stream);
 
+/* ---- chain of residual GCP2 blocks: x_k = x_{k-1} + GCP_k(x_{k-1}), k = 1..n (ResGCP, components/gcpnet.py:921-924).
+ * One launch; the (s, V) state of a 32-row tile stays on chip between the blocks.  All blocks share the dims
+ * (si == so <= 128, vi == vo), frames and gating mode; each item carries its own weights, activations and outputs
+ * (s_out/v_out = x_k, s_pre/gate saved for the backward when non-NULL). */
+typedef struct {
+    gcp2_weights_t w;
+    gcp2_opts_t o;
+    float* s_out;
+    float* v_out;
+    float* s_pre;
+    float* gate;
+} gcp2_chain_item_t;
+#define GCP_MAX_CHAIN 8
+int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const float* frames, int n,
+                              const gcp2_chain_item_t* items, void* stream);
+
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
  * concatenated layout, plus the per-row quantities the weight-gradient GEMMs consume (all row-major):

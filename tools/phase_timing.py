@@ -67,3 +67,28 @@ with torch.no_grad():
     ops.gcp2_backward_data(spec, E, [s.detach()], [v], fr, w, pack, s_pre, gate, ds, dv)
     report("bwd", 5, ["load + recompute vh", "vector epilogue adjoint", "ds_pre + W^T ds (mfma)", "vector prologue adjoint"])
 lib.gcpnet_debug_set_phase_timing(None, 0)
+
+# ---- register-resident chain of 7 residual blocks (stamps taken on the LAST block: steady state) ------------------------
+mods = [G.GCP2((S, V), (S, V), nonlinearities=("relu", None), bottleneck=4).cuda() for _ in range(7)]
+specs = [m.make_spec([None], [None], residual=True) for m in mods]
+ws = [tuple(None if t is None else t.detach() for t in m._weights()) for m in mods]
+for need_grad in (False, True):
+    sx = s.detach().clone().requires_grad_(need_grad)
+    buf.zero_()
+    with torch.set_grad_enabled(need_grad):
+        ops.gcp2_chain(specs, sx, v, fr, ws)
+        lib.gcpnet_debug_set_phase_timing(C.c_void_p(buf.data_ptr()), ntiles)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.gcp2_chain(specs, sx, v, fr, ws)
+        b.record()
+        torch.cuda.synchronize()
+        lib.gcpnet_debug_set_phase_timing(None, 0)
+    print(f"chain x7 launch {a.elapsed_time(b) * 1e3:.0f} us (need_grad={need_grad})")
+    t = buf.view(ntiles, 8).cpu().double()
+    tot = t[:, 7] - t[:, 0]
+    print(f"   last block total median {tot.median().item():.0f} ticks")
+    for i, lab in enumerate(["stage small weights", "vector prologue", "bias + mfma (state)", "mfma (norms/frames)", "gate gemm",
+                             "s_pre/s_out stores + x update", "vector epilogue + stores"]):
+        d = t[:, i + 1] - t[:, i]
+        print(f"   {lab:30s} median {d.median().item():9.0f}  mean {d.mean().item():9.0f}")
