@@ -28,7 +28,8 @@ def test_host_only_entry_points():
     # NMS message GCP0: (160,36)->(64,16), H=9: K=178 -> KP=184, NTG=2, NG=1, NUG=4, NGK=2
     n = lib.gcpnet_gcp2_pack_floats(160, 36, 64, 16, 9, 1)
     KK, NTG, NG, NUG, NGK, NS = 92, 2, 1, 4, 2, 32
-    assert n == NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * NS * 64 + 8 * NG * 64 * NTG
+    NTS = 5  # 32-wide tiles of the 160 scalar inputs (section F, register-resident chain kernel)
+    assert n == NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * NS * 64 + 8 * NG * 64 * NTG + NTS * 16 * 64 * NTG
     assert lib.gcpnet_tn_splits(160000, 128, 142) == 313
     assert lib.gcpnet_tn_splits(0, 1, 1) == 1
 
