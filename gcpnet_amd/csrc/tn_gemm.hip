@@ -58,17 +58,22 @@ __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
     return w;
 }
 
+// Output tiles (32x32) of a block are dealt round-robin to the four waves: tile id = wave + 4 i, i < 5, with
+// (m-tile, n-tile) = (id / ntiles, id % ntiles).  This keeps all waves busy for skinny problems (M = 16 or N = 16).
 __device__ __forceinline__ void store_partial(const gcp_tn_problem_t& P, const BlockWork& w, int M, int N, const f32x16* acc,
                                               int wave, int col, int hi) {
     float* part = P.partial + (int64_t)w.split * M * N;
+    const int mtiles = gcp_cdiv(w.mw, 32), total = mtiles * w.ntiles;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        if (t < w.ntiles) {
-            const int n = w.n0 + 32 * t + col;
+    for (int i = 0; i < 5; ++i) {
+        const int id = wave + 4 * i;
+        if (id < total) {
+            const int mi = id / w.ntiles, ni = id - mi * w.ntiles;
+            const int n = w.n0 + 32 * ni + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = w.m0 + wave * 32 + gcp_crow(r, hi);
-                if (m < M && n < N) part[(int64_t)m * N + n] = acc[t][r];
+                const int m = w.m0 + 32 * mi + gcp_crow(r, hi);
+                if (m < M && n < N) part[(int64_t)m * N + n] = acc[i][r];
             }
         }
     }
@@ -111,7 +116,15 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
     const int col = lane & 31, hi = lane >> 5;
     const BlockWork w = locate(a);
     const gcp_tn_problem_t& P = a.p[w.pi];
-    const bool wave_active = wave * 32 < w.mw;
+    const int total_tiles = gcp_cdiv(w.mw, 32) * w.ntiles;
+    const int my_tiles = wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0;
+    const bool wave_active = my_tiles > 0;
+    int aoff[5], boff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int id = min(wave + 4 * i, total_tiles - 1), mi = id / w.ntiles;
+        aoff[i] = 32 * mi; boff[i] = 32 * (id - mi * w.ntiles);
+    }
     f32x16 acc[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
@@ -124,11 +137,11 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
         if (wave_active) {
 #pragma unroll 4
             for (int ss = 0; ss < TN_RK / 2; ++ss) {
-                const float av = As[(2 * ss + hi) * TN_LDA + wave * 32 + col];
+                const float* arow = As + (2 * ss + hi) * TN_LDA + col;
                 const float* brow = Bs + (2 * ss + hi) * TN_LDB + col;
 #pragma unroll
-                for (int t = 0; t < 5; ++t)
-                    if (t < w.ntiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[32 * t], acc[t], 0, 0, 0);
+                for (int i = 0; i < 5; ++i)
+                    if (i < my_tiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[aoff[i]], brow[boff[i]], acc[i], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -221,7 +234,15 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     const int col = lane & 31, hi = lane >> 5;
     const BlockWork w = locate(a);
     const gcp_tn_problem_t& P = a.p[w.pi];
-    const bool wave_active = wave * 32 < w.mw;
+    const int total_tiles = gcp_cdiv(w.mw, 32) * w.ntiles;
+    const int my_tiles = wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0;
+    const bool wave_active = my_tiles > 0;
+    int aoff[5], boff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int id = min(wave + 4 * i, total_tiles - 1), mi = id / w.ntiles;
+        aoff[i] = 32 * mi; boff[i] = 32 * (id - mi * w.ntiles);
+    }
     auto Abuf = [&](int b) { return lds + b * (TN_RK * (TN_BM + TN_BN)); };
     auto Bbuf = [&](int b) { return lds + b * (TN_RK * (TN_BM + TN_BN)) + TN_RK * TN_BM; };
 
@@ -289,15 +310,15 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
             fetch_issue<TN_B_SLOTS>(sb, vb, rn, r_last, gb);
         }
         if (wave_active) {
-            const float* As = Abuf(cur) + wave * 32 + col;
+            const float* As = Abuf(cur) + col;
             const float* Bs = Bbuf(cur) + col;
 #pragma unroll 4
             for (int ss = 0; ss < TN_RK / 2; ++ss) {
-                const float av = As[(2 * ss + hi) * TN_BM];
+                const float* arow = As + (2 * ss + hi) * TN_BM;
                 const float* brow = Bs + (2 * ss + hi) * TN_BN;
 #pragma unroll
-                for (int t = 0; t < 5; ++t)
-                    if (t < w.ntiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[32 * t], acc[t], 0, 0, 0);
+                for (int i = 0; i < 5; ++i)
+                    if (i < my_tiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[aoff[i]], brow[boff[i]], acc[i], 0, 0, 0);
             }
         }
         if (c + 1 < nchunks) {

@@ -493,10 +493,10 @@ class _WeightGradJob:
         self.W1 = torch.empty((so, n1), **f32)
         problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, self.W1, n1, 1)
         self.W2 = self.W3 = self.W4 = None
-        if self.gated:  # d vector_out_scale.weight / bias: [act_v(s_pre) | 1]^T dgate
-            self.W2 = torch.empty((so + 1, VOP), **f32)
-            problem(operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1,
-                    operand([(t["dgate"], None, VOP, VOP)]), VOP, self.W2, VOP, 1)
+        if self.gated:  # d vector_out_scale.weight / bias: dgate^T [act_v(s_pre) | 1]  (the wide side carries the ones)
+            self.W2 = torch.empty((VOP, so + 1), **f32)
+            problem(operand([(t["dgate"], None, VOP, VOP)]), VOP,
+                    operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1, self.W2, so + 1, 1)
         if self.has_vout:  # d vector_up.weight: trace over xyz of dvu[(d,o)]^T vh[(d,h)]
             self.W3 = torch.empty((VOP, HP), **f32)
             problem(operand([(t["dvu"], None, 3 * VOP, 3 * VOP)]), 3 * VOP, operand([(t["vh"], None, 3 * HP, 3 * HP)]),
@@ -524,8 +524,8 @@ class _WeightGradJob:
         if self.has_vout:
             g[4] = W3[:vo, :H].contiguous()
         if self.gated:
-            g[5] = W2[:so, :vo].t().contiguous()
-            g[6] = W2[so, :vo].contiguous()
+            g[5] = W2[:vo, :so].contiguous()
+            g[6] = W2[:vo, so].contiguous()
         return g
 
 
