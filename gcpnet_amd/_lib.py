@@ -16,7 +16,8 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_chain_forward",
-    "gcpnet_gcp2_backward", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_segment_reduce", "gcpnet_gather_rows",
+    "gcpnet_gcp2_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
+    "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_axpy_clamp", "gcpnet_debug_set_phase_timing",
 ]
 
@@ -44,7 +45,7 @@ class ChainItem(C.Structure):
 
 
 class BwdScratch(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ds_pre", "dgate", "ext", "dvu", "dvhf", "vh", "vt")]
+    _fields_ = [(n, C.c_void_p) for n in ("ds_pre", "dgate", "ext", "w_part")]
 
 
 class Operand(C.Structure):
@@ -89,6 +90,9 @@ def load():
                                          vp, P(BwdScratch), vp]
     lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]
     lib.gcpnet_tn_splits.argtypes = [i32, i32, i32]
+    lib.gcpnet_gcp2_bwd_tiles.argtypes = [i32]
+    lib.gcpnet_reduce_partials.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.gcpnet_reduce_partials_groups.argtypes = [i32]
     lib.gcpnet_segment_reduce.argtypes = [i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp]
     lib.gcpnet_gather_rows.argtypes = [i32, vp, vp, i64, i32, vp, vp, i64, vp]
     lib.gcpnet_localize.argtypes = [i32, vp, vp, vp, i32, vp, vp]

@@ -12,6 +12,8 @@
 #include "common.h"
 #include "tile_io.h"
 
+#include <type_traits>
+
 namespace {
 
 struct BwdParams {
@@ -60,6 +62,14 @@ __host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
     return l;
 }
 
+// -DGCP_BWD_FINE: the 8 stamp slots subdivide phases 1-2 instead of marking the 5 phase boundaries (tools/phase_timing.py)
+#ifdef GCP_BWD_FINE
+#define STAMP(k) ((void)0)
+#define FSTAMP(k) gcp_stamp(p.stamps, p.stamp_cap, k, lane)
+#else
+#define STAMP(k) gcp_stamp(p.stamps, p.stamp_cap, k, lane)
+#define FSTAMP(k) ((void)0)
+#endif
 #define load4 gcp_load4
 #define store4 gcp_store4
 
@@ -110,15 +120,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     float* fr = lds + L.o_fr;
     const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H, HF = S.H + 3;
     // row strides of the per-row scratch handed to the weight-gradient GEMMs: multiples of 4 floats (16-byte DMA pieces)
-    const int EP = gcp_round_up(S.H + S.nf, 4), HP = gcp_round_up(S.H, 4), VIP = gcp_round_up(S.vi, 4);
-    const int VOP = gcp_round_up(S.vo, 4), HFP = gcp_round_up(S.H + 3, 4);
+    const int EP = gcp_round_up(S.H + S.nf, 4), VOP = gcp_round_up(S.vo, 4);
     const float slope = p.o.slope;
     const float ns_s = gcp_neg_slope(p.o.act_s, slope), ns_v = gcp_neg_slope(p.o.act_v, slope);
     const bool scalar_gate = (p.o.vmode == GCP_VMODE_SCALAR_GATE) && vo > 0 && vi > 0;
     const bool has_vec = vi > 0;
     const bool has_vout = has_vec && vo > 0;
 
-    gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
+    STAMP(0);
+    FSTAMP(0);
     const bool vec_so = (so & 3) == 0, vec_si = (si & 3) == 0;
     constexpr bool single = SINGLE;
     const float* __restrict__ sp_ptr = p.s_pre;
@@ -141,7 +151,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             coff += 3 * p.v_in.dim[sg];
         }
     }
+    FSTAMP(1);
     const GcpSmallW sw = gcp_stage_small_weights(p.w, H, S.nf, lds + L.o_sw, lane);
+    FSTAMP(2);
     for (int i = vo + hi; i < 2 * S.NOO; i += 2) dgt[e * L.GS2 + i] = 0.f;  // zero the gate-adjoint k padding
     // Single output group (so <= 128): s_pre and d(s_out) of the tile are requested here (after every load
     // phase 1 has to wait for: vmcnt retires in order), in the accumulator layout, and stay in flight
@@ -159,6 +171,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             }
     }
     gcp_wave_lds_sync();
+    FSTAMP(3);
     if (has_vec) {
         const float* vrow = vt + e * L.VS;
         for (int h = hi; h < H; h += 2) {
@@ -175,25 +188,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             vht[e * L.HS + 3 * h + 2] = a2;
             const float nr = sqrtf(a0 * a0 + a1 * a1 + a2 * a2 + 1e-8f);
             rn[e * L.NS_ + h] = 1.0f / nr;
-            if (row_ok) {
-                p.sc.ext[(int64_t)row * EP + h] = nr + 1e-8f;
-                p.sc.vh[((int64_t)row * 3 + 0) * HP + h] = a0;
-                p.sc.vh[((int64_t)row * 3 + 1) * HP + h] = a1;
-                p.sc.vh[((int64_t)row * 3 + 2) * HP + h] = a2;
-            }
+            if (row_ok) p.sc.ext[(int64_t)row * EP + h] = nr + 1e-8f;
         }
         if (row_ok && hi == 0) {  // zero the stride padding
             for (int c = H + S.nf; c < EP; ++c) p.sc.ext[(int64_t)row * EP + c] = 0.f;
-            for (int d = 0; d < 3; ++d) {
-                for (int c = H; c < HP; ++c) p.sc.vh[((int64_t)row * 3 + d) * HP + c] = 0.f;
-                for (int c = vi; c < VIP; ++c) p.sc.vt[((int64_t)row * 3 + d) * VIP + c] = 0.f;
-                for (int c = HF; c < HFP; ++c) p.sc.dvhf[((int64_t)row * 3 + d) * HFP + c] = 0.f;
-                if (has_vout)
-                    for (int c = vo; c < VOP; ++c) p.sc.dvu[((int64_t)row * 3 + d) * VOP + c] = 0.f;
-            }
             if (scalar_gate)
                 for (int c = vo; c < VOP; ++c) p.sc.dgate[(int64_t)row * VOP + c] = 0.f;
         }
+        FSTAMP(4);
         if (S.nf) {
             const float* f = fr + e * 9;
             for (int k = hi; k < 3; k += 2) {
@@ -217,14 +219,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 }
             }
         }
-        // transposed copy of the inputs for the vector_down weight gradients: vt_out[(row, d), c]
-        if (row_ok)
-            for (int c = hi; c < vi; c += 2)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) p.sc.vt[((int64_t)row * 3 + d) * VIP + c] = vrow[3 * c + d];
+        FSTAMP(5);
     }
     gcp_wave_lds_sync();
-    gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+    STAMP(1);
+    FSTAMP(6);
 
     asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
     row = r0 + e;
@@ -276,18 +275,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                     dvut[e * L.US + 3 * oc + 1] = du[i][1];
                     dvut[e * L.US + 3 * oc + 2] = du[i][2];
                     if (scalar_gate) dgt[e * L.GS2 + oc] = dgv[i];
-                    if (row_ok) {
-                        p.sc.dvu[((int64_t)row * 3 + 0) * VOP + oc] = du[i][0];
-                        p.sc.dvu[((int64_t)row * 3 + 1) * VOP + oc] = du[i][1];
-                        p.sc.dvu[((int64_t)row * 3 + 2) * VOP + oc] = du[i][2];
-                        if (scalar_gate) p.sc.dgate[(int64_t)row * VOP + oc] = dgv[i];
-                    }
+                    if (row_ok && scalar_gate) p.sc.dgate[(int64_t)row * VOP + oc] = dgv[i];
                 }
             }
         }
     }
     gcp_wave_lds_sync();
-    gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
+    STAMP(2);
+    FSTAMP(7);
 
     // ---- 3. ds_pre = d_s_out * act_s'(s_pre) + act_v'(s_pre) * (Wg^T dgate)  (per output group) ----------------
     // ---- 4. dmerged = W^T ds_pre, accumulated over the output groups, per merged-axis group ---------------------
@@ -296,9 +291,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     row = r0 + e;
     row_ok = row < rows;
     // epilogue of one merged-axis group: d_s_in columns go to HBM, the vector extras (norm / frame-scalar adjoints) to LDS
-    auto merged_epilogue = [&](int ug, f32x16(&acc2)[NUG]) {
+    auto merged_epilogue = [&](auto nu_tag, int ug, f32x16(&acc2)[NUG]) {
+        constexpr int NU = decltype(nu_tag)::value;
 #pragma unroll
-        for (int uu = 0; uu < NUG; ++uu)
+        for (int uu = 0; uu < NU; ++uu)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
@@ -321,9 +317,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     };
     // scalar_out adjoint over ALL 16 * NTG k-pair steps of one output group, B operands = the ds_pre registers;
     // weight fragments rotate through three batches of 4 steps, requested two batches ahead and pinned there
-    auto data_gemm = [&](const float* wq, f32x16(&acc2)[NUG], f32x16(&ds)[NTG]) {
-        WFragB<NUG> A0[4], A1[4], A2[4];
-        auto ld = [&](WFragB<NUG>(&a)[4], int st0) {
+    // (NU = live tiles of the group: the last merged-axis group is usually mostly padding, e.g. 1 of 4 for K = 153)
+    auto data_gemm = [&](auto nu_tag, const float* wq, f32x16(&acc2)[NUG], f32x16(&ds)[NTG]) {
+        constexpr int NU = decltype(nu_tag)::value;
+        WFragB<NU> A0[4], A1[4], A2[4];
+        auto ld = [&](WFragB<NU>(&a)[4], int st0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u].load(wq + (int64_t)min(st0 + u, NTG * 16 - 1) * 64 * NUG);
         };
@@ -333,17 +331,26 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NTG * 4; ++b) {
-            WFragB<NUG>(&a)[4] = (b % 3 == 0) ? A0 : ((b % 3 == 1) ? A1 : A2);
+            WFragB<NU>(&a)[4] = (b % 3 == 0) ? A0 : ((b % 3 == 1) ? A1 : A2);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int st = b * 4 + u;
 #pragma unroll
-                for (int uu = 0; uu < NUG; ++uu)
+                for (int uu = 0; uu < NU; ++uu)
                     acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[uu], ds[st / 16][st % 16], acc2[uu], 0, 0, 0);
             }
             if ((b + 3) * 4 < NTG * 16) ld(a, (b + 3) * 4);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto tail_group = [&](auto nu_tag, int ug) {
+        f32x16 acc2[NUG];
+#pragma unroll
+        for (int uu = 0; uu < NUG; ++uu)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
+        data_gemm(nu_tag, p.w.pack + S.offB + ((int64_t)ug * S.NS * 64 + lane) * NUG, acc2, spr);
+        merged_epilogue(nu_tag, ug, acc2);
     };
 
     if constexpr (SINGLE) {
@@ -397,17 +404,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             for (int uu = 0; uu < NUG; ++uu)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[uu][r] = (p.o.fused_residual && uu < NTG) ? dyr[uu < NTG ? uu : 0][r] : 0.f;
-            data_gemm(p.w.pack + S.offB + (int64_t)lane * NUG, acc2, spr);
-            merged_epilogue(0, acc2);
+            data_gemm(std::integral_constant<int, NUG>{}, p.w.pack + S.offB + (int64_t)lane * NUG, acc2, spr);
+            merged_epilogue(std::integral_constant<int, NUG>{}, 0, acc2);
         }
         for (int ug = 1; ug < S.NGK; ++ug) {
-            f32x16 acc2[NUG];
-#pragma unroll
-            for (int uu = 0; uu < NUG; ++uu)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
-            data_gemm(p.w.pack + S.offB + ((int64_t)ug * S.NS * 64 + lane) * NUG, acc2, spr);
-            merged_epilogue(ug, acc2);
+            const int live = min(NUG, gcp_cdiv(S.K, 32) - ug * NUG);  // wave-uniform
+            if (NUG >= 4 && live == 1) tail_group(std::integral_constant<int, 1>{}, ug);
+            else if (NUG >= 4 && live == 2) tail_group(std::integral_constant<int, (NUG >= 2 ? 2 : 1)>{}, ug);
+            else tail_group(std::integral_constant<int, NUG>{}, ug);
         }
     } else {
     f32x16(&dsr)[NTG] = spr;  // ds_pre overwrites s_pre in place, tile by tile
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             }
     }
     }
-    gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
+    STAMP(3);
     if (!has_vec) return;
     gcp_wave_lds_sync();
     asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
@@ -600,7 +604,6 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     }
     gcp_wave_lds_sync();
     if (row_ok) {
-        for (int i = hi; i < 3 * HF; i += 2) p.sc.dvhf[((int64_t)row * 3 + i / HF) * HFP + (i % HF)] = dvhf[e * L.FS + i];
         for (int c = hi; c < vi; c += 2) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int h = 0; h < H; ++h) {
@@ -629,7 +632,43 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             dp[0] = a0; dp[1] = a1; dp[2] = a2;
         }
     }
-    gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
+    // ---- 6. this tile's share of the small vector weight gradients, on v_mfma_f32_16x16x4_f32 with the reduction
+    //         running over the tile's 96 (row, xyz) pairs; all four operand tiles are still in LDS:
+    //           d vector_up[o, h]                    = sum dvu[row, o, d] * vh[row, h, d]
+    //           d [vector_down | vector_down_frames][c, x] = sum v[row, c, d] * [dvh | dvf][row, d, x]
+    //         The per-tile sums go to sc.w_part[tile, :] and are reduced over tiles by gcpnet_reduce_partials.
+    if (p.sc.w_part) {
+        asm volatile("" : "+v"(lane));
+        const int l16 = lane & 15, kq = lane >> 4;
+        float* part = p.sc.w_part + (int64_t)blockIdx.x * (vo * H + vi * HF);
+        auto small_tn = [&](const float* A, int ars, int ams, int ads, int M, const float* B, int brs, int bms, int bds, int N,
+                            float* out) {
+            for (int mt = 0; mt < M; mt += 16)
+                for (int nt = 0; nt < N; nt += 16) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const int m = mt + l16, n = nt + l16;
+                    const bool mok = m < M, nok = n < N;
+                    const float* ap = A + (mok ? m : 0) * ams;
+                    const float* bp = B + (nok ? n : 0) * bms;
+#pragma unroll 8
+                    for (int st = 0; st < 24; ++st) {
+                        const int kidx = 4 * st + kq, rr = kidx / 3, d = kidx - 3 * rr;
+                        float a = ap[rr * ars + d * ads], b = bp[rr * brs + d * bds];
+                        a = (mok && r0 + rr < rows) ? a : 0.f;
+                        b = nok ? b : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = mt + 4 * kq + r;
+                        if (i < M && nok) out[i * N + n] = acc[r];
+                    }
+                }
+        };
+        if (has_vout) small_tn(dvut, L.US, 3, 1, vo, vht, L.HS, 3, 1, H, part);
+        small_tn(vt, L.VS, 3, 1, vi, dvhf, L.FS, 1, HF, HF, part + vo * H);
+    }
+    STAMP(4);
 }
 
 template <int NTG, int NUG, bool PWL, bool SINGLE>
@@ -670,6 +709,8 @@ int launch_ntg(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int gcpnet_gcp2_bwd_tiles(int rows) { return rows <= 0 ? 0 : gcp_cdiv(rows, GCP_TILE_ROWS); }
+
 extern "C" int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
                                     const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* s_pre,
                                     const float* gate, const float* d_s_out, const float* d_v_out, float* d_s_in,
@@ -679,9 +720,9 @@ extern "C" int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gc
     if (rows == 0) return 0;
     const bool has_vec = w->vi > 0;
     if (has_vec) {
-        if (!v_in || v_in->n < 1 || !w->w_down || !d_v_in || !sc->ext || !sc->vh || !sc->vt || !sc->dvhf) return GCPNET_E_BADARG;
+        if (!v_in || v_in->n < 1 || !w->w_down || !d_v_in || !sc->ext) return GCPNET_E_BADARG;
         if (w->use_frames && (!frames || !w->w_frames)) return GCPNET_E_BADARG;
-        if (w->vo > 0 && (!d_v_out || !w->w_up || !sc->dvu)) return GCPNET_E_BADARG;
+        if (w->vo > 0 && (!d_v_out || !w->w_up)) return GCPNET_E_BADARG;
     }
     if (w->vo > 64) return GCPNET_E_UNSUPPORTED;
     if (opts->fused_residual && (w->si != w->so || w->vi != w->vo)) return GCPNET_E_BADARG;

@@ -12,12 +12,20 @@
 // ([h_row | e | h_col | norms | frame scalars]) cost nothing extra and are never materialised.  A generic register-
 // staged kernel covers operands the DMA cannot (widths or strides that are not multiples of 4 floats).  Operands can
 // be passed through an activation (applied at fragment read) and carry a column of ones (bias gradients).
+// the row axis is split across workgroups (see tn_rows_per_split).
 // Per-split partial sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
 #include "common.h"
 
 namespace {
 
-constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32, TN_ROWS_PER_SPLIT = 512;
+constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32;
+// Rows per split: about one split per CU for the big (edge-row) problems -- with one or two output blocks that is one
+// balanced wave of workgroups over the 256 CUs, two resident per CU -- and never fewer than 64 rows (node-row problems).
+constexpr int TN_TARGET_SPLITS = 256, TN_MIN_ROWS_PER_SPLIT = 64;
+__host__ __device__ inline int tn_rows_per_split(int rows) {
+    const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, TN_TARGET_SPLITS), TN_RK);
+    return r < TN_MIN_ROWS_PER_SPLIT ? TN_MIN_ROWS_PER_SPLIT : r;
+}
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
 constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread
 constexpr int TN_DMA_LDS_FLOATS = 2 * TN_RK * (TN_BM + TN_BN);
@@ -53,8 +61,9 @@ __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
     w.mw = min(TN_BM, a.M[pi] - w.m0);
     w.nw = min(TN_BN, a.N[pi] - w.n0);
     w.ntiles = gcp_cdiv(w.nw, 32);
-    w.r_begin = w.split * TN_ROWS_PER_SPLIT;
-    w.r_end = min(P.rows, w.r_begin + TN_ROWS_PER_SPLIT);
+    const int rps = tn_rows_per_split(P.rows);
+    w.r_begin = w.split * rps;
+    w.r_end = min(P.rows, w.r_begin + rps);
     return w;
 }
 
@@ -367,6 +376,25 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a) {
     }
 }
 
+// Column sums of parts[n_parts, width] in two deterministic levels: groups of RP_GROUP parts, then the group sums.
+constexpr int RP_GROUP = 64;
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, int n_parts, int width, int group,
+                                                             float* __restrict__ out) {
+    const int p0 = blockIdx.x * group, p1 = min(n_parts, p0 + group);
+    for (int c = threadIdx.x; c < width; c += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int q = p0;
+        for (; q + 3 < p1; q += 4) {
+            a0 += in[(int64_t)q * width + c];
+            a1 += in[(int64_t)(q + 1) * width + c];
+            a2 += in[(int64_t)(q + 2) * width + c];
+            a3 += in[(int64_t)(q + 3) * width + c];
+        }
+        for (; q < p1; ++q) a0 += in[(int64_t)q * width + c];
+        out[(int64_t)blockIdx.x * width + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 inline bool dma_ok(const gcp_operand_t& o) {
     for (int k = 0; k < o.n; ++k)
         if ((o.dim[k] & 3) || (o.ld[k] & 3) || (reinterpret_cast<uintptr_t>(o.ptr[k]) & 15)) return false;
@@ -377,7 +405,7 @@ inline bool dma_ok(const gcp_operand_t& o) {
 
 extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
     (void)M; (void)N;
-    return rows <= 0 ? 1 : gcp_cdiv(rows, TN_ROWS_PER_SPLIT);
+    return rows <= 0 ? 1 : gcp_cdiv(rows, tn_rows_per_split(rows));
 }
 
 extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream) {
@@ -421,6 +449,23 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     GCP_HIP_CHECK_LAUNCH();
     const int rblocks = min(1024, gcp_cdiv(max_mn, 64));
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(rblocks, n_problems), dim3(256), 0, st, a);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_reduce_partials_groups(int n_parts) { return n_parts <= 0 ? 1 : gcp_cdiv(n_parts, RP_GROUP); }
+
+extern "C" int gcpnet_reduce_partials(const float* parts, int n_parts, int width, float* tmp, float* out, void* stream) {
+    if (n_parts < 0 || width <= 0 || !out || (n_parts > 0 && (!parts || !tmp))) return GCPNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_parts == 0) {
+        hipError_t err = hipMemsetAsync(out, 0, sizeof(float) * width, st);
+        return err == hipSuccess ? 0 : (int)err;
+    }
+    const int groups = gcp_cdiv(n_parts, RP_GROUP);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(groups), dim3(256), 0, st, parts, n_parts, width, RP_GROUP, tmp);
+    GCP_HIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp, groups, width, groups, out);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

@@ -381,9 +381,9 @@ class _Gcp2(torch.autograd.Function):
         if spec.vo:
             d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
         si, vi = spec.si, spec.vi
-        d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
-                                                 d_v_out)
         need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:]
+        d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
+                                                 d_v_out, need_w=any(need_w))
         wgrads = [None] * 7
         if any(need_w):
             wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr)
@@ -413,7 +413,8 @@ class _Gcp2(torch.autograd.Function):
         return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
 
 
-def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out):
+def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out,
+                       need_w: bool = True):
     """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs)."""
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=s_pre.device)
@@ -428,12 +429,11 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     scr.ds_pre = t["ds_pre"].data_ptr()
     r4 = lambda x: (x + 3) // 4 * 4
     if has_vec:
-        t.update(ext=torch.empty((rows, r4(H + nf)), **f32), dvhf=torch.empty((rows, 3 * r4(H + 3)), **f32),
-                 vh=torch.empty((rows, 3 * r4(H)), **f32), vt=torch.empty((rows, 3 * r4(vi)), **f32))
-        scr.ext, scr.dvhf, scr.vh, scr.vt = (t[k].data_ptr() for k in ("ext", "dvhf", "vh", "vt"))
-        if has_vout:
-            t["dvu"] = torch.empty((rows, 3 * r4(vo)), **f32)
-            scr.dvu = t["dvu"].data_ptr()
+        t["ext"] = torch.empty((rows, r4(H + nf)), **f32)
+        scr.ext = t["ext"].data_ptr()
+        if need_w:  # per-tile shares of the small vector weight gradients (summed over tiles in _WeightGradJob)
+            t["w_part"] = torch.empty((lib.gcpnet_gcp2_bwd_tiles(rows), vo * H + vi * (H + 3)), **f32)
+            scr.w_part = t["w_part"].data_ptr()
         if gated:
             t["dgate"] = torch.empty((rows, r4(vo)), **f32)
             scr.dgate = t["dgate"].data_ptr()
@@ -482,7 +482,7 @@ class _WeightGradJob:
 
         r4 = lambda x: (x + 3) // 4 * 4
         si = spec.si
-        EP, HP, VIP, VOP, HFP = r4(H + nf), r4(H), r4(vi), r4(vo), r4(H + 3)
+        EP, VOP = r4(H + nf), r4(vo)
         self.EP = EP
         # d scalar_out.weight / bias: ds_pre^T [s sources | norms | frame scalars | 1]
         bsegs = [(x, pl, x.shape[1], x.shape[1]) for x, pl in zip(s_src, spec.s_plans)]
@@ -497,14 +497,14 @@ class _WeightGradJob:
             self.W2 = torch.empty((VOP, so + 1), **f32)
             problem(operand([(t["dgate"], None, VOP, VOP)]), VOP,
                     operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1, self.W2, so + 1, 1)
-        if self.has_vout:  # d vector_up.weight: trace over xyz of dvu[(d,o)]^T vh[(d,h)]
-            self.W3 = torch.empty((VOP, HP), **f32)
-            problem(operand([(t["dvu"], None, 3 * VOP, 3 * VOP)]), 3 * VOP, operand([(t["vh"], None, 3 * HP, 3 * HP)]),
-                    3 * HP, self.W3, HP, 1, diag=3, dm=VOP, dn=HP)
-        if self.has_vec:  # d vector_down(.frames).weight: trace over xyz of v[(d,c)]^T [dvh | dvf][(d,x)]
-            self.W4 = torch.empty((VIP, HFP), **f32)
-            problem(operand([(t["vt"], None, 3 * VIP, 3 * VIP)]), 3 * VIP, operand([(t["dvhf"], None, 3 * HFP, 3 * HFP)]),
-                    3 * HFP, self.W4, HFP, 1, diag=3, dm=VIP, dn=HFP)
+        if self.has_vec:  # d vector_up / vector_down(.frames): the backward kernel left one partial sum per tile
+            part = t["w_part"]
+            self.Wv = torch.empty((part.shape[1],), **f32)
+            tmp = torch.empty((lib.gcpnet_reduce_partials_groups(part.shape[0]), part.shape[1]), **f32)
+            check(lib.gcpnet_reduce_partials(_p(part), part.shape[0], part.shape[1], _p(tmp), _p(self.Wv), _stream()),
+                  "reduce_partials")
+            self.W3 = self.Wv[:vo * H].view(vo, H) if self.has_vout else None
+            self.W4 = self.Wv[vo * H:].view(vi, H + 3)
 
     def grads(self) -> List[Optional[Tensor]]:
         """(scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up, gate.weight, gate.bias)"""
@@ -515,14 +515,14 @@ class _WeightGradJob:
         if self.has_vec:
             g[0] = torch.cat((W1[:, :si], W1[:, si:si + H + nf]), dim=1)
             g[1] = W1[:, si + self.EP].contiguous()
-            g[2] = W4[:vi, :H].t().contiguous()
+            g[2] = W4[:, :H].t().contiguous()
             if nf:
-                g[3] = W4[:vi, H:H + 3].t().contiguous()
+                g[3] = W4[:, H:H + 3].t().contiguous()
         else:
             g[0] = W1[:, :si].contiguous()
             g[1] = W1[:, si].contiguous()
         if self.has_vout:
-            g[4] = W3[:vo, :H].contiguous()
+            g[4] = W3.contiguous()
         if self.gated:
             g[5] = W2[:vo, :so].contiguous()
             g[6] = W2[:vo, so].contiguous()
@@ -593,8 +593,10 @@ class _Gcp2Chain(torch.autograd.Function):
         for k in range(n - 1, -1, -1):
             s_in, v_in = (s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1])
             _, _, s_pre, gate = outs[k]
-            d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s, d_v)
-            if any(need_w[7 * k:7 * k + 7]):
+            nw = any(need_w[7 * k:7 * k + 7])
+            d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s, d_v,
+                                               need_w=nw)
+            if nw:
                 jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
         if live:

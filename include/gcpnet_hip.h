@@ -108,19 +108,20 @@ int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const 
 
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
- * concatenated layout, plus the per-row quantities the weight-gradient GEMMs consume (all row-major):
- *   ds_pre [rows, so], dgate [rows, vo'], ext [rows, (H+9)'] (= [|vh| norms | frame scalars]),
- *   dvu [rows, 3, vo'], dvhf [rows, 3, (H+3)'] (= [d vh | d vf]), vh [rows, 3, H'], vt [rows, 3, vi'],
- * where x' = x rounded up to a multiple of 4 floats (16-byte DMA pieces; the padding is written as zeros). */
+ * concatenated layout, plus what the weight gradients need:
+ *   - per-row operands of the big weight-gradient GEMMs (gcpnet_tn_gemm), row-major:
+ *       ds_pre [rows, so], dgate [rows, vo'], ext [rows, (H+9)'] (= [|vh| norms | frame scalars]),
+ *     where x' = x rounded up to a multiple of 4 floats (16-byte DMA pieces; the padding is written as zeros);
+ *   - w_part [gcpnet_gcp2_bwd_tiles(rows), vo*H + vi*(H+3)] (optional, may be NULL): per 32-row tile, that tile's
+ *     share of d vector_up.weight [vo, H] followed by d [vector_down | vector_down_frames].weight^T [vi, H+3]; sum
+ *     over tiles with gcpnet_reduce_partials. */
 typedef struct {
     float* ds_pre;
     float* dgate;
     float* ext;
-    float* dvu;
-    float* dvhf;
-    float* vh;
-    float* vt;
+    float* w_part;
 } gcp2_bwd_scratch_t;
+int gcpnet_gcp2_bwd_tiles(int rows);
 
 int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
                          const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* s_pre, const float* gate,
@@ -161,6 +162,11 @@ typedef struct {
 int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream);
 /* scratch floats a problem of this shape needs (splits * M * N) and the split count the library will use */
 int gcpnet_tn_splits(int rows, int M, int N);
+
+/* Column sums out[width] = sum_p parts[p, width] in a fixed order (deterministic); tmp holds
+ * gcpnet_reduce_partials_groups(n_parts) * width floats.  Used for gcp2_bwd_scratch_t.w_part. */
+int gcpnet_reduce_partials(const float* parts, int n_parts, int width, float* tmp, float* out, void* stream);
+int gcpnet_reduce_partials_groups(int n_parts);
 
 /* ---- segment reductions: torch_scatter.scatter(reduce=sum|mean) over sorted segments ------------------------
  * out[s, 0:D] = reduce_{p in [seg_ptr[s], seg_ptr[s+1])} x[(perm ? perm[p] : p) * ldx + 0:D]

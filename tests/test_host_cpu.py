@@ -30,7 +30,7 @@ def test_host_only_entry_points():
     KK, NTG, NG, NUG, NGK, NS = 92, 2, 1, 4, 2, 32
     NTS = 5  # 32-wide tiles of the 160 scalar inputs (section F, register-resident chain kernel)
     assert n == NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * NS * 64 + 8 * NG * 64 * NTG + NTS * 16 * 64 * NTG
-    assert lib.gcpnet_tn_splits(160000, 128, 142) == 313
+    assert lib.gcpnet_tn_splits(160000, 128, 142) == 250
     assert lib.gcpnet_tn_splits(0, 1, 1) == 1
 
 

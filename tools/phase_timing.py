@@ -65,7 +65,11 @@ report("fwd(training)", 7, ["load tile", "vector prologue", "mfma loop", "s_out 
 buf.zero_()
 with torch.no_grad():
     ops.gcp2_backward_data(spec, E, [s.detach()], [v], fr, w, pack, s_pre, gate, ds, dv)
-    report("bwd", 5, ["load + recompute vh", "vector epilogue adjoint", "ds_pre + W^T ds (mfma)", "vector prologue adjoint"])
+    if os.environ.get("GCP_BWD_FINE"):  # library built with GCPNET_HIPCC_EXTRA=-DGCP_BWD_FINE
+        report("bwd(fine)", 8, ["tile loads committed", "small weights staged", "s_pre/d_s_out requested", "vh recompute + scratch",
+                                "frame scalars", "transposed v copy", "vector epilogue adjoint"])
+    else:
+        report("bwd", 5, ["load + recompute vh", "vector epilogue adjoint", "ds_pre + W^T ds (mfma)", "vector prologue adjoint"])
 lib.gcpnet_debug_set_phase_timing(None, 0)
 
 # ---- register-resident chain of 7 residual blocks (stamps taken on the LAST block: steady state) ------------------------
