@@ -16,7 +16,7 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_chain_forward",
-    "gcpnet_gcp2_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
+    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_axpy_clamp", "gcpnet_debug_set_phase_timing",
 ]
@@ -48,6 +48,11 @@ class BwdScratch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ds_pre", "dgate", "ext", "w_part")]
 
 
+class ChainBwdItem(C.Structure):
+    _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("v_in", C.c_void_p), ("s_pre", C.c_void_p), ("gate", C.c_void_p),
+                ("sc", BwdScratch)]
+
+
 class Operand(C.Structure):
     _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * TN_MAX_SEG), ("idx", C.c_void_p * TN_MAX_SEG),
                 ("dim", C.c_int * TN_MAX_SEG), ("ld", C.c_int * TN_MAX_SEG), ("act", C.c_int), ("slope", C.c_float),
@@ -56,8 +61,15 @@ class Operand(C.Structure):
 
 class TnProblem(C.Structure):
     _fields_ = [("rows", C.c_int), ("a", Operand), ("b", Operand), ("out", C.c_void_p), ("out_sm", C.c_int64),
-                ("out_sn", C.c_int64), ("partial", C.c_void_p), ("splits", C.c_int), ("diag", C.c_int),
-                ("diag_m", C.c_int), ("diag_n", C.c_int)]
+                ("out_sn", C.c_int64), ("out_m", C.c_int), ("out_n", C.c_int), ("out2", C.c_void_p), ("out2_n", C.c_int),
+                ("partial", C.c_void_p), ("splits", C.c_int)]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("parts", C.c_void_p), ("n_parts", C.c_int), ("width", C.c_int), ("tmp", C.c_void_p), ("out", C.c_void_p)]
+
+
+REDUCE_MAX_JOBS = 8
 
 
 class GcpnetHipError(RuntimeError):
@@ -88,10 +100,11 @@ def load():
     lib.gcpnet_gcp2_chain_forward.argtypes = [i32, vp, vp, vp, i32, P(ChainItem), vp]
     lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
                                          vp, P(BwdScratch), vp]
+    lib.gcpnet_gcp2_chain_backward.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp]
     lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]
     lib.gcpnet_tn_splits.argtypes = [i32, i32, i32]
     lib.gcpnet_gcp2_bwd_tiles.argtypes = [i32]
-    lib.gcpnet_reduce_partials.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.gcpnet_reduce_partials.argtypes = [i32, P(ReduceJob), vp]
     lib.gcpnet_reduce_partials_groups.argtypes = [i32]
     lib.gcpnet_segment_reduce.argtypes = [i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp]
     lib.gcpnet_gather_rows.argtypes = [i32, vp, vp, i64, i32, vp, vp, i64, vp]
@@ -108,6 +121,9 @@ def load():
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+E_BADARG, E_UNSUPPORTED = -1, -2  # GCPNET_E_* of include/gcpnet_hip.h
 
 
 def check(rc, what):

@@ -635,14 +635,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     // ---- 6. this tile's share of the small vector weight gradients, on v_mfma_f32_16x16x4_f32 with the reduction
     //         running over the tile's 96 (row, xyz) pairs; all four operand tiles are still in LDS:
     //           d vector_up[o, h]                    = sum dvu[row, o, d] * vh[row, h, d]
-    //           d [vector_down | vector_down_frames][c, x] = sum v[row, c, d] * [dvh | dvf][row, d, x]
+    //           d [vector_down ; vector_down_frames][x, c] = sum v[row, c, d] * [dvh | dvf][row, d, x]
     //         The per-tile sums go to sc.w_part[tile, :] and are reduced over tiles by gcpnet_reduce_partials.
     if (p.sc.w_part) {
         asm volatile("" : "+v"(lane));
         const int l16 = lane & 15, kq = lane >> 4;
         float* part = p.sc.w_part + (int64_t)blockIdx.x * (vo * H + vi * HF);
         auto small_tn = [&](const float* A, int ars, int ams, int ads, int M, const float* B, int brs, int bms, int bds, int N,
-                            float* out) {
+                            float* out, bool transposed) {
             for (int mt = 0; mt < M; mt += 16)
                 for (int nt = 0; nt < N; nt += 16) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -661,12 +661,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = mt + 4 * kq + r;
-                        if (i < M && nok) out[i * N + n] = acc[r];
+                        if (i < M && nok) out[transposed ? n * M + i : i * N + n] = acc[r];
                     }
                 }
         };
-        if (has_vout) small_tn(dvut, L.US, 3, 1, vo, vht, L.HS, 3, 1, H, part);
-        small_tn(vt, L.VS, 3, 1, vi, dvhf, L.FS, 1, HF, HF, part + vo * H);
+        if (has_vout) small_tn(dvut, L.US, 3, 1, vo, vht, L.HS, 3, 1, H, part, false);
+        small_tn(vt, L.VS, 3, 1, vi, dvhf, L.FS, 1, HF, HF, part + vo * H, true);  // stored as [H + 3, vi]
     }
     STAMP(4);
 }

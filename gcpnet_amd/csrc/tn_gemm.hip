@@ -347,39 +347,48 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a) {
     const gcp_tn_problem_t& P = a.p[pi];
     const int M = a.M[pi], N = a.N[pi];
     const int64_t full = (int64_t)M * N;
-    const int om = P.diag > 0 ? P.diag_m : M, on = P.diag > 0 ? P.diag_n : N, nd = P.diag > 0 ? P.diag : 1;
-    const int64_t total = (int64_t)om * on;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < full; base += (int64_t)gridDim.x * 64) {
         const int64_t i = base + lane;
-        const bool ok = i < total;
-        const int m = ok ? (int)(i / on) : 0, n = ok ? (int)(i % on) : 0;
-        float s = 0.f;
-        for (int d = 0; d < nd; ++d) {
-            const float* src = P.partial + (int64_t)(d * om + m) * N + (d * on + n);
-            float acc[8];
+        const bool ok = i < full;
+        const int m = ok ? (int)(i / N) : 0, n = ok ? (int)(i % N) : 0;
+        const float* src = P.partial + (int64_t)m * N + n;
+        float acc[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-            for (int k0 = w; k0 < P.splits; k0 += 32) {
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        for (int k0 = w; k0 < P.splits; k0 += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + 4 * u;
-                    acc[u] += src[(int64_t)min(k, P.splits - 1) * full] * (k < P.splits ? 1.f : 0.f);
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 4 * u;
+                acc[u] += src[(int64_t)min(k, P.splits - 1) * full] * (k < P.splits ? 1.f : 0.f);
             }
-            s += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
-        red[w][lane] = s;
+        red[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         __syncthreads();
-        if (w == 0 && ok) P.out[m * P.out_sm + n * P.out_sn] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (w == 0 && ok && m < P.out_m) {  // gradients leave in their final layouts: weight block, bias column; padding dropped
+            const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            if (n < P.out_n) P.out[m * P.out_sm + n * P.out_sn] = v;
+            else if (P.out2 && n == P.out2_n) P.out2[m] = v;
+        }
         __syncthreads();
     }
 }
 
 // Column sums of parts[n_parts, width] in two deterministic levels: groups of RP_GROUP parts, then the group sums.
 constexpr int RP_GROUP = 64;
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, int n_parts, int width, int group,
-                                                             float* __restrict__ out) {
+struct ReduceArgs {
+    gcp_reduce_job_t j[GCP_REDUCE_MAX_JOBS];
+};
+template <bool SECOND>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
+    const gcp_reduce_job_t& J = a.j[blockIdx.y];
+    const int width = J.width;
+    const int groups = gcp_cdiv(J.n_parts, RP_GROUP);
+    const float* __restrict__ in = SECOND ? J.tmp : J.parts;
+    float* __restrict__ out = SECOND ? J.out : J.tmp;
+    const int n_parts = SECOND ? groups : J.n_parts;
+    const int group = SECOND ? groups : RP_GROUP;
+    if (SECOND ? blockIdx.x > 0 : (int)blockIdx.x >= groups) return;
     const int p0 = blockIdx.x * group, p1 = min(n_parts, p0 + group);
     for (int c = threadIdx.x; c < width; c += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -423,7 +432,8 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         a.M[i] = operand_width(P.a);
         a.N[i] = operand_width(P.b);
         if (a.M[i] <= 0 || a.N[i] <= 0) return GCPNET_E_BADARG;
-        if (P.diag > 0 && (P.diag * P.diag_m > a.M[i] || P.diag * P.diag_n > a.N[i])) return GCPNET_E_BADARG;
+        if (P.out_m < 0 || P.out_m > a.M[i] || P.out_n < 0 || P.out_n > a.N[i] || (P.out2 && (P.out2_n < 0 || P.out2_n >= a.N[i])))
+            return GCPNET_E_BADARG;
         dma = dma && dma_ok(P.a) && dma_ok(P.b) && P.rows > 0;
         a.mb[i] = gcp_cdiv(a.M[i], TN_BM);
         a.nb[i] = gcp_cdiv(a.N[i], TN_BN);
@@ -455,17 +465,20 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
 
 extern "C" int gcpnet_reduce_partials_groups(int n_parts) { return n_parts <= 0 ? 1 : gcp_cdiv(n_parts, RP_GROUP); }
 
-extern "C" int gcpnet_reduce_partials(const float* parts, int n_parts, int width, float* tmp, float* out, void* stream) {
-    if (n_parts < 0 || width <= 0 || !out || (n_parts > 0 && (!parts || !tmp))) return GCPNET_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (n_parts == 0) {
-        hipError_t err = hipMemsetAsync(out, 0, sizeof(float) * width, st);
-        return err == hipSuccess ? 0 : (int)err;
+extern "C" int gcpnet_reduce_partials(int n_jobs, const gcp_reduce_job_t* jobs, void* stream) {
+    if (n_jobs <= 0 || n_jobs > GCP_REDUCE_MAX_JOBS || !jobs) return GCPNET_E_BADARG;
+    ReduceArgs a;
+    int max_groups = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        const gcp_reduce_job_t& J = jobs[i];
+        if (J.n_parts <= 0 || J.width <= 0 || !J.parts || !J.tmp || !J.out) return GCPNET_E_BADARG;
+        a.j[i] = J;
+        max_groups = max(max_groups, gcp_cdiv(J.n_parts, RP_GROUP));
     }
-    const int groups = gcp_cdiv(n_parts, RP_GROUP);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(groups), dim3(256), 0, st, parts, n_parts, width, RP_GROUP, tmp);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3(max_groups, n_jobs), dim3(256), 0, st, a);
     GCP_HIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp, groups, width, groups, out);
+    hipLaunchKernelGGL(reduce_partials_kernel<true>, dim3(1, n_jobs), dim3(256), 0, st, a);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

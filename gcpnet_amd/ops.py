@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT, BwdScratch, ChainItem, Concat, Gcp2Opts, Gcp2Weights, Operand, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
+from ._lib import (ACT, BwdScratch, ChainBwdItem, ChainItem, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
                    VMODE_SELF_GATE, check)
 
 Tensor = torch.Tensor
@@ -418,12 +418,28 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs)."""
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=s_pre.device)
-    H, vi, vo, so, si = spec.hidden, spec.vi, spec.vo, spec.so, spec.si
+    si, vi, vo = spec.si, spec.vi, spec.vo
+    d_s_in = torch.empty((rows, si), **f32)
+    d_v_in = torch.empty((rows, vi, 3), **f32) if vi > 0 else None
+    scr, t = _alloc_bwd_scratch(spec, rows, need_w, s_pre.device)
+    ws = _weights_struct(spec, w, pack)
+    opts = _opts_struct(spec, fused_residual=spec.residual)
+    sc = _concat(s_src, spec.s_plans, False)
+    vc = _concat(v_src, spec.v_plans, True) if len(v_src) else Concat()
+    check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts), _p(s_pre),
+                                   _p(gate), _p(d_s_out), _p(d_v_out) if vo else None, _p(d_s_in), _p(d_v_in),
+                                   C.byref(scr), _stream()), "gcp2_backward")
+    return d_s_in, d_v_in, t
+
+
+def _alloc_bwd_scratch(spec: Gcp2Spec, rows: int, need_w: bool, device):
+    """The backward kernels' per-row / per-tile outputs for the weight gradients (include/gcpnet_hip.h, gcp2_bwd_scratch_t)."""
+    lib = _lib.load()
+    f32 = dict(dtype=torch.float32, device=device)
+    H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
     nf = 9 if (spec.use_frames and vi > 0) else 0
     has_vec, has_vout = vi > 0, vi > 0 and vo > 0
     gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
-    d_s_in = torch.empty((rows, si), **f32)
-    d_v_in = torch.empty((rows, vi, 3), **f32) if has_vec else None
     scr = BwdScratch()
     t = dict(ds_pre=torch.empty((rows, so), **f32))
     scr.ds_pre = t["ds_pre"].data_ptr()
@@ -437,14 +453,7 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
         if gated:
             t["dgate"] = torch.empty((rows, r4(vo)), **f32)
             scr.dgate = t["dgate"].data_ptr()
-    ws = _weights_struct(spec, w, pack)
-    opts = _opts_struct(spec, fused_residual=spec.residual)
-    sc = _concat(s_src, spec.s_plans, False)
-    vc = _concat(v_src, spec.v_plans, True) if len(v_src) else Concat()
-    check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts), _p(s_pre),
-                                   _p(gate), _p(d_s_out), _p(d_v_out) if vo else None, _p(d_s_in), _p(d_v_in),
-                                   C.byref(scr), _stream()), "gcp2_backward")
-    return d_s_in, d_v_in, t
+    return scr, t
 
 
 class _WeightGradJob:
@@ -469,12 +478,14 @@ class _WeightGradJob:
             op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
             return op
 
-        def problem(a, M, b, N, out, sm, sn, diag=0, dm=0, dn=0):
+        def problem(a, M, b, N, out, out2, out2_n):
+            # the reduction writes the gradients in their final layouts: out = [weight block], out2 = bias column
             pr = TnProblem()
             pr.rows, pr.a, pr.b = rows, a, b
-            pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), sm, sn
+            pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), out.shape[1], 1
+            pr.out_m, pr.out_n = out.shape
+            pr.out2, pr.out2_n = out2.data_ptr(), out2_n
             pr.splits = lib.gcpnet_tn_splits(rows, M, N)
-            pr.diag, pr.diag_m, pr.diag_n = diag, dm, dn
             part = torch.empty((pr.splits, M, N), **f32)
             self.keep.append(part)
             pr.partial = part.data_ptr()
@@ -490,43 +501,34 @@ class _WeightGradJob:
         if self.has_vec:
             bsegs.append((t["ext"], None, EP, EP))
             n1 = si + EP + 1
-        self.W1 = torch.empty((so, n1), **f32)
-        problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, self.W1, n1, 1)
-        self.W2 = self.W3 = self.W4 = None
+        g: List[Optional[Tensor]] = [None] * 7
+        self.g = g
+        g[0], g[1] = torch.empty((so, spec.K), **f32), torch.empty((so,), **f32)
+        # (columns of the product: [s sources | norms, frame scalars, stride padding | 1]; K = si + H + nf of them are weights)
+        problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, g[0], g[1], n1 - 1)
         if self.gated:  # d vector_out_scale.weight / bias: dgate^T [act_v(s_pre) | 1]  (the wide side carries the ones)
-            self.W2 = torch.empty((VOP, so + 1), **f32)
+            g[5], g[6] = torch.empty((vo, so), **f32), torch.empty((vo,), **f32)
             problem(operand([(t["dgate"], None, VOP, VOP)]), VOP,
-                    operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1, self.W2, so + 1, 1)
+                    operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1, g[5], g[6], so)
+        self.reduce = None
         if self.has_vec:  # d vector_up / vector_down(.frames): the backward kernel left one partial sum per tile
             part = t["w_part"]
-            self.Wv = torch.empty((part.shape[1],), **f32)
+            wv = torch.empty((part.shape[1],), **f32)
             tmp = torch.empty((lib.gcpnet_reduce_partials_groups(part.shape[0]), part.shape[1]), **f32)
-            check(lib.gcpnet_reduce_partials(_p(part), part.shape[0], part.shape[1], _p(tmp), _p(self.Wv), _stream()),
-                  "reduce_partials")
-            self.W3 = self.Wv[:vo * H].view(vo, H) if self.has_vout else None
-            self.W4 = self.Wv[vo * H:].view(vi, H + 3)
+            self.keep.append(tmp)
+            job = ReduceJob()
+            job.parts, job.n_parts, job.width, job.tmp, job.out = part.data_ptr(), part.shape[0], part.shape[1], tmp.data_ptr(), wv.data_ptr()
+            self.reduce = job
+            o1, o2 = vo * H, vo * H + H * vi
+            if self.has_vout:
+                g[4] = wv[:o1].view(vo, H)
+            g[2] = wv[o1:o2].view(H, vi)
+            if nf:
+                g[3] = wv[o2:].view(3, vi)
 
     def grads(self) -> List[Optional[Tensor]]:
         """(scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up, gate.weight, gate.bias)"""
-        spec, nf = self.spec, self.nf
-        H, vi, vo, so, si = spec.hidden, spec.vi, spec.vo, spec.so, spec.si
-        W1, W2, W3, W4 = self.W1, self.W2, self.W3, self.W4
-        g: List[Optional[Tensor]] = [None] * 7
-        if self.has_vec:
-            g[0] = torch.cat((W1[:, :si], W1[:, si:si + H + nf]), dim=1)
-            g[1] = W1[:, si + self.EP].contiguous()
-            g[2] = W4[:, :H].t().contiguous()
-            if nf:
-                g[3] = W4[:, H:H + 3].t().contiguous()
-        else:
-            g[0] = W1[:, :si].contiguous()
-            g[1] = W1[:, si].contiguous()
-        if self.has_vout:
-            g[4] = W3.contiguous()
-        if self.gated:
-            g[5] = W2[:vo, :so].contiguous()
-            g[6] = W2[:vo, so].contiguous()
-        return g
+        return self.g
 
 
 def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob]) -> None:
@@ -537,6 +539,11 @@ def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob]) -> None:
         chunk = probs[i:i + _lib.TN_MAX_PROBLEMS]
         arr = (TnProblem * len(chunk))(*chunk)
         check(lib.gcpnet_tn_gemm(len(chunk), arr, _stream()), "tn_gemm")
+    reds = [j.reduce for j in jobs if j.reduce is not None]
+    for i in range(0, len(reds), _lib.REDUCE_MAX_JOBS):
+        chunk = reds[i:i + _lib.REDUCE_MAX_JOBS]
+        arr = (ReduceJob * len(chunk))(*chunk)
+        check(lib.gcpnet_reduce_partials(len(chunk), arr, _stream()), "reduce_partials")
 
 
 def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t) -> List[Optional[Tensor]]:
@@ -590,14 +597,39 @@ class _Gcp2Chain(torch.autograd.Function):
         d_v = _req(d_v, "grad") if d_v is not None else torch.zeros((rows, specs[0].vo, 3), **f32)
         need_w = ctx.needs_input_grad[4:]
         jobs: List[Optional[_WeightGradJob]] = [None] * n
-        for k in range(n - 1, -1, -1):
-            s_in, v_in = (s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1])
-            _, _, s_pre, gate = outs[k]
-            nw = any(need_w[7 * k:7 * k + 7])
-            d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s, d_v,
-                                               need_w=nw)
-            if nw:
-                jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
+        ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
+        nws = [any(need_w[7 * k:7 * k + 7]) for k in range(n)]
+        # one launch for the whole chain (gradient state on chip); shapes outside that kernel go block by block
+        lib = _lib.load()
+        items = (ChainBwdItem * n)()
+        scrs = []
+        for k in range(n):
+            scr, t = _alloc_bwd_scratch(specs[k], rows, nws[k], s0.device)
+            scrs.append(t)
+            items[k].w = _weights_struct(specs[k], ws[k], packs[k])
+            items[k].o = _opts_struct(specs[k], fused_residual=True)
+            items[k].v_in = ins[k][1].data_ptr()
+            items[k].s_pre = outs[k][2].data_ptr()
+            items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
+            items[k].sc = scr
+        d_s_in, d_v_in = torch.empty_like(d_s), torch.empty_like(d_v)
+        rc = lib.gcpnet_gcp2_chain_backward(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(d_s_in), _p(d_v_in), _stream())
+        if rc == 0:
+            d_s, d_v = d_s_in, d_v_in
+            for k in range(n):
+                if nws[k]:
+                    jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k])
+        elif rc == _lib.E_UNSUPPORTED:
+            del scrs, items
+            for k in range(n - 1, -1, -1):
+                s_in, v_in = ins[k]
+                _, _, s_pre, gate = outs[k]
+                d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s,
+                                                   d_v, need_w=nws[k])
+                if nws[k]:
+                    jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
+        else:
+            check(rc, "gcp2_chain_backward")
         live = [j for j in jobs if j is not None]
         if live:
             run_weight_grad_jobs(live)

@@ -112,9 +112,9 @@ int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const 
  *   - per-row operands of the big weight-gradient GEMMs (gcpnet_tn_gemm), row-major:
  *       ds_pre [rows, so], dgate [rows, vo'], ext [rows, (H+9)'] (= [|vh| norms | frame scalars]),
  *     where x' = x rounded up to a multiple of 4 floats (16-byte DMA pieces; the padding is written as zeros);
- *   - w_part [gcpnet_gcp2_bwd_tiles(rows), vo*H + vi*(H+3)] (optional, may be NULL): per 32-row tile, that tile's
- *     share of d vector_up.weight [vo, H] followed by d [vector_down | vector_down_frames].weight^T [vi, H+3]; sum
- *     over tiles with gcpnet_reduce_partials. */
+ *   - w_part [gcpnet_gcp2_bwd_tiles(rows), vo*H + (H+3)*vi] (optional, may be NULL): per 32-row tile, that tile's
+ *     share of d vector_up.weight [vo, H], d vector_down.weight [H, vi] and d vector_down_frames.weight [3, vi], in
+ *     this order; sum over tiles with gcpnet_reduce_partials. */
 typedef struct {
     float* ds_pre;
     float* dgate;
@@ -128,11 +128,28 @@ int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t*
                          const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in,
                          const gcp2_bwd_scratch_t* scratch, void* stream);
 
+/* ---- backward of a chain of residual GCP2 blocks (the adjoint of gcpnet_gcp2_chain_forward), one launch:
+ * d(s), d(V) of a 32-row tile stay on chip between the blocks; per block k (items[k], forward order) the kernel reads
+ * the block's input vectors v_in = V_{k-1} [rows, vi, 3] and the saved s_pre / gate, and fills items[k].sc exactly as
+ * gcpnet_gcp2_backward does.  d_s_out / d_v_out are the gradients of the chain's output, d_s_in / d_v_in those of its
+ * input.  Returns GCPNET_E_UNSUPPORTED for shapes outside the kernel (si == so in {32, 64, 128}, vi == vo <= 20 and a
+ * multiple of 4, 16-byte aligned tensors); the caller then chains gcpnet_gcp2_backward with fused_residual. */
+typedef struct {
+    gcp2_weights_t w;
+    gcp2_opts_t o;
+    const float* v_in;
+    const float* s_pre;
+    const float* gate;
+    gcp2_bwd_scratch_t sc;
+} gcp2_chain_bwd_item_t;
+int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
+                               const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in, void* stream);
+
 /* ---- weight-gradient GEMM: out[m, n] (+)= sum_r A[r, m] * B[r, n] -------------------------------------------
  * A and B are row-wise concatenations (gcp_concat_t with per-segment leading dimension), optionally passed
  * through an activation, optionally extended by a column of ones (bias gradients).  Used for
- * d scalar_out.weight = ds_pre^T [s | norms | frame scalars], d vector_out_scale.weight, d vector_up.weight,
- * d vector_down(.frames).weight. */
+ * d scalar_out.weight = ds_pre^T [s | norms | frame scalars] and d vector_out_scale.weight (the small vector weights
+ * get their gradients from the backward kernels' per-tile partial sums). */
 #define GCP_TN_MAX_SEG 4
 typedef struct {
     int n;
@@ -149,13 +166,13 @@ typedef struct {
     int rows;          /* reduction length */
     gcp_operand_t a;   /* [rows, M]  (M = sum dims + ones) */
     gcp_operand_t b;   /* [rows, N] */
-    float* out;        /* out[m * out_sm + n * out_sn] += ... */
+    float* out;        /* out[m * out_sm + n * out_sn] = result[m, n] for m < out_m, n < out_n (the rest is padding) */
     int64_t out_sm, out_sn;
+    int out_m, out_n;
+    float* out2;       /* optional: out2[m] = result[m, out2_n] for m < out_m (the bias gradient: the ones column) */
+    int out2_n;
     float* partial;    /* scratch [splits, M, N] */
     int splits;
-    /* block-diagonal trace: when diag > 0 the operands are [rows, diag * diag_m] and [rows, diag * diag_n] (e.g. the
-     * xyz axis folded into the columns) and out[i, j] = sum_d full[d * diag_m + i, d * diag_n + j], i < diag_m, j < diag_n */
-    int diag, diag_m, diag_n;
 } gcp_tn_problem_t;
 
 #define GCP_TN_MAX_PROBLEMS 8
@@ -164,8 +181,16 @@ int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* strea
 int gcpnet_tn_splits(int rows, int M, int N);
 
 /* Column sums out[width] = sum_p parts[p, width] in a fixed order (deterministic); tmp holds
- * gcpnet_reduce_partials_groups(n_parts) * width floats.  Used for gcp2_bwd_scratch_t.w_part. */
-int gcpnet_reduce_partials(const float* parts, int n_parts, int width, float* tmp, float* out, void* stream);
+ * gcpnet_reduce_partials_groups(n_parts) * width floats.  Used for gcp2_bwd_scratch_t.w_part.  Up to
+ * GCP_REDUCE_MAX_JOBS independent sums per call (two launches in total). */
+typedef struct {
+    const float* parts;
+    int n_parts, width;
+    float* tmp;
+    float* out;
+} gcp_reduce_job_t;
+#define GCP_REDUCE_MAX_JOBS 8
+int gcpnet_reduce_partials(int n_jobs, const gcp_reduce_job_t* jobs, void* stream);
 int gcpnet_reduce_partials_groups(int n_parts);
 
 /* ---- segment reductions: torch_scatter.scatter(reduce=sum|mean) over sorted segments ------------------------

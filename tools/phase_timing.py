@@ -96,3 +96,29 @@ for need_grad in (False, True):
                              "s_pre/s_out stores + x update", "vector epilogue + stores"]):
         d = t[:, i + 1] - t[:, i]
         print(f"   {lab:30s} median {d.median().item():9.0f}  mean {d.mean().item():9.0f}")
+
+# ---- backward of the same chain (stamps 2..6 taken on the FIRST block = last loop iteration: steady state) ---------------
+sx = s.detach().clone().requires_grad_(True)
+vx = v.detach().clone().requires_grad_(True)
+for m in mods:
+    for q in m.parameters():
+        q.requires_grad_(True)
+ws_g = [m._weights() for m in mods]
+o_s, o_v = ops.gcp2_chain(specs, sx, vx, fr, ws_g)
+buf.zero_()
+torch.cuda.synchronize()
+lib.gcpnet_debug_set_phase_timing(C.c_void_p(buf.data_ptr()), ntiles)
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+torch.autograd.backward([o_s, o_v], [ds, dv])
+b.record()
+torch.cuda.synchronize()
+lib.gcpnet_debug_set_phase_timing(None, 0)
+print(f"chain x7 backward (data kernel + weight-gradient GEMMs) {a.elapsed_time(b) * 1e3:.0f} us")
+t = buf.view(ntiles, 8).cpu().double()
+print(f"   chain bwd kernel: tile total median {(t[:, 7] - t[:, 0]).median().item():.0f} ticks")
+for i, lab in enumerate(["prologue (loads of the last block)", "blocks n-1 .. 1", "recompute vh (block 0)", "vector epilogue adjoint",
+                         "gate adjoint + ds_pre + W^T ds (mfma)", "requests for next + vector prologue adjoint",
+                         "small weight-gradient partials"]):
+    d = t[:, i + 1] - t[:, i]
+    print(f"   {lab:45s} median {d.median().item():9.0f}  mean {d.mean().item():9.0f}")
