@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--sdim", type=int, default=128)
     ap.add_argument("--vdim", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-only", action="store_true", help="profiling runs: only the timed steps (no per-kernel timing, no CPU baseline)")
     ap.add_argument("--cpu-layers", type=int, default=1, help="layers of the stack the CPU baseline runs (bounded sample)")
     return ap.parse_args()
 
@@ -155,7 +156,9 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(loss).item(), "non-finite loss"
 
-    if rank == 0:
+    if rank == 0 and args.step_only:
+        print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup}))
+    elif rank == 0:
         value = world * n_edges * args.layers * args.steps / elapsed
         fl = layer_flops(args.nodes, n_edges, node_dims, edge_dims)
         kr = kernel_roofline(G, ops, layers[0], ins, frames, dev["edge_index"], n_edges, args.sdim, args.vdim)

@@ -95,8 +95,8 @@ def load():
     lib.gcpnet_gcp2_pack_floats.restype = i64
     lib.gcpnet_gcp2_pack_floats.argtypes = [i32] * 6
     lib.gcpnet_pack_gcp2_weights.argtypes = [P(Gcp2Weights), vp, vp]
-    lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
-                                        vp, vp]
+    lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), vp, vp, vp,
+                                        vp, vp, vp, vp]
     lib.gcpnet_gcp2_chain_forward.argtypes = [i32, vp, vp, vp, i32, P(ChainItem), vp]
     lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
                                          vp, P(BwdScratch), vp]

@@ -46,6 +46,7 @@ struct FwdParams {
     gcp2_opts_t o;  // shared: slope, vmode, vector_residual, e3 (activations are per item)
     int n;
     ChainItem it[GCP_MAX_CHAIN];
+    gcp_concat_t s_add;  // pre-projected scalar inputs: rows of [n_src, so] tables gathered and added to s_pre (n == 1, NG == 1)
     const float* res_s;  // separate residual tensors (n == 1 only)
     const float* res_v;
     int fused_res;  // out = x + GCP(x) with x the tile itself
@@ -229,6 +230,28 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
                     const int j = 32 * (g * NTG + t) + gcp_crow(r, hi);
                     acc[t][r] = j < so ? it.b_scalar[j] : 0.f;
                 }
+            // Pre-projected inputs (node-level GEMMs done by the caller): their gathered rows are requested here, in the
+            // accumulator layout, and added after the k loop -- the gather latency is spent under the MFMAs.
+            f32x16 pre[NTG];
+            const bool has_add = p.s_add.n > 0;  // wave-uniform; only with a single output group and n == 1
+            if (has_add) {
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pre[t][r] = 0.f;
+                for (int k = 0; k < p.s_add.n; ++k) {
+                    const int32_t* ix = p.s_add.idx[k];
+                    const int rc = min(row, rows - 1);
+                    const int64_t src = ix ? (int64_t)ix[rc] : (int64_t)rc;
+#pragma unroll
+                    for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = gcp_load4(p.s_add.ptr[k], src, so, 32 * t + 8 * q + 4 * hi, true, vec_so);
+                            pre[t][4 * q] += v.x; pre[t][4 * q + 1] += v.y; pre[t][4 * q + 2] += v.z; pre[t][4 * q + 3] += v.w;
+                        }
+                }
+            }
             const float* wp = it.pack + S.offA + ((int64_t)g * S.KK * 64 + lane) * NTG;
             const float* bp = mrg + e * L.KS + hi;
             constexpr int U = 4;
@@ -267,6 +290,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
                 if (kk0 + 2 * U < KK) mm(A2, B2);
                 ld(A2, B2, kk0 + 5 * U);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (has_add) {
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += pre[t][r];
             }
             if (ci == 0) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
             const int c0 = g * 32 * NTG;
@@ -537,11 +566,17 @@ extern "C" int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out
 }
 
 extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
-                                   const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* res_s,
-                                   const float* res_v, float* s_out, float* v_out, float* s_pre, float* gate,
-                                   void* stream) {
+                                   const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* s_add,
+                                   const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre,
+                                   float* gate, void* stream) {
     if (rows < 0 || !s_out) return GCPNET_E_BADARG;
     if (int rc = check_weights(w, opts, w && w->vo > 0)) return rc;
+    if (s_add && s_add->n > 0) {
+        if (s_add->n > GCP_MAX_SEG) return GCPNET_E_BADARG;
+        for (int k = 0; k < s_add->n; ++k)
+            if (!s_add->ptr[k] || s_add->dim[k] != w->so) return GCPNET_E_BADARG;
+        if (w->so > 128) return GCPNET_E_UNSUPPORTED;  // single output group only
+    }
     if (rows == 0) return 0;
     if (check_concat(s_in, w->si)) return GCPNET_E_BADARG;
     if (w->vi > 0) {
@@ -559,6 +594,7 @@ extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp
     if (w->vi == 0) p.o.vmode = GCP_VMODE_NONE;  // zero vectors: nothing to gate (gcpnet.py:447-449)
     p.n = 1;
     fill_item(p.it[0], *w, *opts, s_out, v_out, s_pre, gate);
+    if (s_add && s_add->n > 0) p.s_add = *s_add; else p.s_add.n = 0;
     p.res_s = res_s; p.res_v = res_v;
     p.fused_res = (res_s && s_in->n == 1 && !s_in->idx[0] && res_s == s_in->ptr[0] && w->si == w->so &&
                    (w->vo == 0 || (res_v && w->vi == w->vo && v_in->n == 1 && !v_in->idx[0] && res_v == v_in->ptr[0])))
@@ -598,6 +634,7 @@ extern "C" int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float*
     if (w0.vi == 0) p.o.vmode = GCP_VMODE_NONE;
     p.n = n;
     for (int k = 0; k < n; ++k) fill_item(p.it[k], items[k].w, items[k].o, items[k].s_out, items[k].v_out, items[k].s_pre, items[k].gate);
+    p.s_add.n = 0;
     p.res_s = nullptr; p.res_v = nullptr;
     p.fused_res = 1;
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;

@@ -6,7 +6,7 @@ PyTorch provides device allocations, the current stream and the autograd graph -
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -280,6 +280,8 @@ class Gcp2Spec:
     v_plans: List[Optional[GatherPlan]] = field(default_factory=list)
     residual: bool = False  # out = x + GCP(x) with x the single ungathered source (ResGCP)
     pack_cache: Optional[dict] = None
+    # pre-projected scalar inputs ("project, then gather"): one gather plan (or None) per [n_src, so] table passed to _Gcp2
+    add_plans: List[Optional[GatherPlan]] = field(default_factory=list)
 
     @property
     def K(self):
@@ -333,7 +335,7 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
 
 
 class _Gcp2(torch.autograd.Function):
-    """inputs: spec, frames, then n_s scalar sources, n_v vector sources, res_s, res_v, 7 weights."""
+    """inputs: spec, frames, then n_s scalar sources, n_v vector sources, res_s, res_v, 7 weights, n_add addend tables."""
 
     @staticmethod
     def forward(ctx, spec: Gcp2Spec, frames, *tensors):
@@ -342,7 +344,9 @@ class _Gcp2(torch.autograd.Function):
         s_src = list(tensors[:n_s])
         v_src = list(tensors[n_s:n_s + n_v])
         res_s, res_v = tensors[n_s + n_v], tensors[n_s + n_v + 1]
-        w = tuple(tensors[n_s + n_v + 2:])
+        w = tuple(tensors[n_s + n_v + 2:n_s + n_v + 9])
+        adds = list(tensors[n_s + n_v + 9:])
+        assert len(adds) == len(spec.add_plans)
         rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_src[0].shape[0]
         dev = s_src[0].device
         pack = _pack(spec, w)
@@ -350,6 +354,7 @@ class _Gcp2(torch.autograd.Function):
         opts = _opts_struct(spec)
         sc = _concat(s_src, spec.s_plans, False)
         vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
+        ac = _concat(adds, spec.add_plans, False) if adds else None
         if spec.residual:
             res_s, res_v = s_src[0], (v_src[0] if n_v else None)
         need_grad = any(ctx.needs_input_grad)
@@ -358,8 +363,9 @@ class _Gcp2(torch.autograd.Function):
         s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
         gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
         gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
-        check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts), _p(res_s),
-                                      _p(res_v), _p(s_out), _p(v_out), _p(s_pre), _p(gate), _stream()), "gcp2_forward")
+        check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts),
+                                      C.byref(ac) if ac is not None else None, _p(res_s), _p(res_v), _p(s_out), _p(v_out),
+                                      _p(s_pre), _p(gate), _stream()), "gcp2_forward")
         if need_grad:
             ctx.spec, ctx.rows, ctx.n_s, ctx.n_v = spec, rows, n_s, n_v
             ctx.frames = frames
@@ -375,13 +381,13 @@ class _Gcp2(torch.autograd.Function):
         saved = ctx.saved_tensors
         s_src, v_src = list(saved[:n_s]), list(saved[n_s:n_s + n_v])
         w = tuple(saved[n_s + n_v:n_s + n_v + 7])
-        pack, s_pre, gate = saved[n_s + n_v + 7:]
+        pack, s_pre, gate = saved[n_s + n_v + 7:n_s + n_v + 10]
         f32 = dict(dtype=torch.float32, device=s_pre.device)
         d_s_out = _req(d_s_out, "grad") if d_s_out is not None else torch.zeros((rows, spec.so), **f32)
         if spec.vo:
             d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
         si, vi = spec.si, spec.vi
-        need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:]
+        need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:2 + n_s + n_v + 9]
         d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
                                                  d_v_out, need_w=any(need_w))
         wgrads = [None] * 7
@@ -410,7 +416,11 @@ class _Gcp2(torch.autograd.Function):
         g_res_s = d_s_out if ctx.has_res[0] else None
         g_res_v = d_v_out if ctx.has_res[1] else None
         wgrads = [g if need else None for g, need in zip(wgrads, need_w)]
-        return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
+        # pre-projected inputs enter s_pre additively: their gradient is ds_pre, summed over the rows that gathered them
+        ds_pre = scr["ds_pre"]
+        grads_add = [ds_pre if pl is None else _segment_reduce_raw(ds_pre, 0, spec.so, spec.so, pl, False)
+                     for pl in spec.add_plans]
+        return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads, *grads_add)
 
 
 def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out,
@@ -665,4 +675,36 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
         res_s = _req(res_s, "residual")
     if res_v is not None:
         res_v = _req(res_v, "residual")
+    proj = _projectable(spec, s_sources) if PROJECT_GATHERED_SCALARS else None
+    if proj is not None:
+        # "Project, then gather": scalar_out is linear in its concatenated input, so the share of a GATHERED source
+        # (h[row], h[col] in a message GCP, reference gcpnet.py:907-917) is computed once per source row -- a plain
+        # [n_src, dim] x [dim, so] library GEMM on 16x fewer rows than edges -- and the kernel adds the gathered result
+        # rows to s_pre.  The per-edge reduction shrinks from K = si + H + 9 to the un-gathered columns.
+        gath, rest = proj
+        w_scalar = weights[0]
+        dims = [t.shape[1] for t in s_sources]
+        offs = [sum(dims[:k]) for k in range(len(dims))]
+        adds = [torch.matmul(s_sources[k], w_scalar[:, offs[k]:offs[k] + dims[k]].t()) for k in gath]
+        w_rest = torch.cat([w_scalar[:, offs[k]:offs[k] + dims[k]] for k in rest] + [w_scalar[:, spec.si:]], dim=1)
+        spec = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=None,
+                       add_plans=[spec.s_plans[k] for k in gath])
+        weights = (w_rest,) + tuple(weights[1:])
+        s_sources = [s_sources[k] for k in rest]
+        return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, *adds)
     return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights)
+
+
+PROJECT_GATHERED_SCALARS = True  # module switch (tests compare both paths)
+
+
+def _projectable(spec: Gcp2Spec, s_sources):
+    """Which scalar sources are worth projecting at their source rows: gathered ones read by >= 2x more rows than they
+    have; needs a single output group (so <= 128) and at least one source left for the kernel's own reduction."""
+    if spec.so > 128 or spec.residual or spec.add_plans:
+        return None
+    gath = [k for k, pl in enumerate(spec.s_plans) if pl is not None and pl.rows >= 2 * s_sources[k].shape[0]]
+    rest = [k for k in range(len(s_sources)) if k not in gath]
+    if not gath or not rest:
+        return None
+    return gath, rest

@@ -85,10 +85,15 @@ int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out, void* str
  * out-edge frame mean for node rows, which is what scalarize(node_inputs=True) reduces to:
  * components/__init__.py:286,314-323).  res_s/res_v (optional) are added to the outputs (ResGCP,
  * components/gcpnet.py:921-924).  s_pre [rows,so] and gate [rows,vo] (sigmoid of the vector gate) are saved
- * for the backward when non-NULL. */
+ * for the backward when non-NULL.
+ * s_add (optional): scalar inputs whose share of scalar_out was computed beforehand at their source rows
+ * ("project, then gather": for a message GCP over [h_row | e | h_col] the two node terms are node-level GEMMs, 16x
+ * fewer rows than edges): s_add->ptr[k] is a [n_src, so] table, s_add->idx[k] the gather (NULL = row r), dim[k] = so;
+ * s_pre = scalar_out([s_in | norms | frame scalars]) + sum_k table_k[idx_k[r]].  Needs so <= 128. */
 int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
-                        const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* res_s, const float* res_v,
-                        float* s_out, float* v_out, float* s_pre, float* gate, void* stream);
+                        const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* s_add,
+                        const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre, float* gate,
+                        void* stream);
 
 /* ---- chain of residual GCP2 blocks: x_k = x_{k-1} + GCP_k(x_{k-1}), k = 1..n (ResGCP, components/gcpnet.py:921-924).
  * One launch; the (s, V) state of a 32-row tile stays on chip between the blocks.  All blocks share the dims
