@@ -89,9 +89,13 @@ struct GcpShape {
     int NGK;  // merged-axis groups
     int NS;   // backward-data reduction steps = NG * NTG * 16
     int GT;   // 32-wide tiles of the vector-gate outputs (forward gate GEMM, fed from the accumulator registers)
-    int NOO;  // gate backward steps (2 gate outputs each), padded to a multiple of 2
+    int NOO;  // gate backward steps: k-pair step r pairs the gate outputs (crow(r, 0), crow(r, 1)) = (j0, j0 + 4)
     int NTS;  // 32-wide tiles of the scalar input (register-resident chain kernel: the state is the B operand)
-    int64_t offA, offB, offC, offD, offF, total;  // section offsets (floats) inside the packed image
+    // small vector Linears on the matrix cores (vec_mfma.h); vmm = the shape fits (H + 3 <= 32, vo <= 32)
+    int vmm, HF;             // HF = H + (nf ? 3 : 0): rows of [vector_down ; vector_down_frames]
+    int SVA, SVB, SVC, SVD;  // k-pair steps of the four products, CT = 32-wide tiles of vi
+    int CT;
+    int64_t offA, offB, offC, offD, offF, offVA, offVB, offVC, offVD, total;  // section offsets (floats) inside the packed image
 };
 
 __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, int H, int use_frames) {
@@ -107,7 +111,7 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.NGK = gcp_cdiv(gcp_cdiv(s.K, 32), s.NUG);
     s.NS = s.NG * s.NTG * 16;
     s.GT = gcp_cdiv(vo, 32);
-    s.NOO = gcp_round_up(gcp_cdiv(vo, 2), 2);
+    s.NOO = 4 * gcp_cdiv(vo, 8);
     s.offA = 0;
     s.offB = s.offA + (int64_t)s.NG * s.KK * 64 * s.NTG;
     s.offC = s.offB + (int64_t)s.NGK * s.NS * 64 * s.NUG;
@@ -115,7 +119,19 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.NTS = gcp_cdiv(si, 32);
     s.offF = s.offD + (int64_t)s.NOO * s.NG * 64 * s.NTG;
     // F (only used when the block can run in the register-resident chain kernel: one output group)
-    s.total = s.offF + (s.NG == 1 ? (int64_t)s.NTS * 16 * 64 * s.NTG : 0);
+    s.offVA = s.offF + (s.NG == 1 ? (int64_t)s.NTS * 16 * 64 * s.NTG : 0);
+    // V: [vector_down ; vector_down_frames] forward, vector_up forward, vector_up^T and [down ; frames]^T (backward)
+    s.HF = s.H + (s.nf ? 3 : 0);
+    s.vmm = (vi > 0 && vo > 0 && s.HF <= 32 && vo <= 32) ? 1 : 0;
+    s.SVA = gcp_cdiv(vi, 2);
+    s.SVB = 4 * gcp_cdiv(s.H, 8);
+    s.SVC = s.NOO;
+    s.SVD = 4 * gcp_cdiv(s.HF, 8);
+    s.CT = gcp_cdiv(vi, 32);
+    s.offVB = s.offVA + (s.vmm ? (int64_t)s.SVA * 64 : 0);
+    s.offVC = s.offVB + (s.vmm ? (int64_t)s.SVB * 64 : 0);
+    s.offVD = s.offVC + (s.vmm ? (int64_t)s.SVC * 64 : 0);
+    s.total = s.offVD + (s.vmm ? (int64_t)s.CT * s.SVD * 64 : 0);
     return s;
 }
 

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_chain_bwd_kernel(ChainBwdPar
                     for (int u = 0; u < 8; ++u) {
                         const int oo = min(oo0 + u, S.NOO - 1);
                         a[u].load(wg + (int64_t)oo * 64 * NTG);
-                        b[u] = dgt[e * L.GS2 + 2 * oo + hi];
+                        b[u] = dgt[e * L.GS2 + gcp_crow(oo, hi)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -13,15 +13,13 @@
 // scalars, go through a 32 x 16 LDS tile as ordinary B fragments.
 #include "common.h"
 #include "tile_io.h"
+#include "vec_mfma.h"
 
 namespace {
 
 struct ChainItemF {
     const float* pack;
     const float* b_scalar;
-    const float* w_down;
-    const float* w_frames;
-    const float* w_up;
     const float* b_gate;
     float* s_out;
     float* v_out;
@@ -44,23 +42,19 @@ struct ChainParams {
 };
 
 struct ChainLds {
-    int VS, HS, GS, XS;
-    int o_vt, o_vht, o_gt, o_fr, o_ext, o_sw, total;
+    int VS, XS;
+    int o_vt, o_fr, o_ext, o_ust, total;
 };
 
 __host__ __device__ inline ChainLds chain_lds(const GcpShape& s) {
     ChainLds l;
     l.VS = gcp_odd(3 * s.vi);
-    l.HS = gcp_odd(3 * s.H);
-    l.GS = gcp_odd(s.vo);
     l.XS = gcp_odd(gcp_round_up(s.H + s.nf, 2));
     l.o_vt = 0;
-    l.o_vht = l.o_vt + 32 * l.VS;
-    l.o_gt = l.o_vht + 32 * l.HS;
-    l.o_fr = l.o_gt + 32 * l.GS;
+    l.o_fr = l.o_vt + 32 * l.VS;
     l.o_ext = l.o_fr + 32 * 9;
-    l.o_sw = l.o_ext + 32 * l.XS;
-    l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
+    l.o_ust = l.o_ext + 32 * l.XS;
+    l.total = l.o_ust + s.SVB * 3 * 64;  // vector_down outputs parked between the vector prologue and epilogue
     return l;
 }
 
@@ -96,10 +90,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
     int row = r0 + e;
     bool row_ok = row < rows;
     float* vt = lds + L.o_vt;
-    float* vht = lds + L.o_vht;
-    float* gt = lds + L.o_gt;
     float* fr = lds + L.o_fr;
     float* ext = lds + L.o_ext;
+    float* ust = lds + L.o_ust;
     const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H;
     const int NX = gcp_round_up(H + S.nf, 2) / 2;  // k-pair steps over the norms / frame scalars
     const float slope = p.o.slope;
@@ -128,45 +121,32 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
         row_ok = row < rows;
         const ChainItemF& it = p.it[ci];
         const float ns_s = gcp_neg_slope(it.act_s, slope), ns_v = gcp_neg_slope(it.act_v, slope);
-        gcp2_weights_t wsm;
-        wsm.vi = vi; wsm.vo = vo; wsm.w_down = it.w_down; wsm.w_frames = it.w_frames; wsm.w_up = it.w_up;
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
-        gcp_wave_lds_sync();
-        const GcpSmallW sw = gcp_stage_small_weights(wsm, H, S.nf, lds + L.o_sw, lane);
-        gcp_wave_lds_sync();
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+        gcp_wave_lds_sync();  // the previous block's vector tile update
 
-        // ---- vector prologue (VALU, two lanes per row): vh, its norms, the frame scalars ------------------------------
+        // ---- vector prologue on the matrix cores: [vh | vf] = [vector_down ; vector_down_frames] v, then (element-wise,
+        //      in registers) the norms of vh and the projections of vf onto the row's frame -> the 32 x XS extras tile ------
         {
-            const float* vrow = vt + e * L.VS;
-            for (int h = hi; h < H; h += 2) {
-                const float* wd = sw.wd + h * vi;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                for (int c = 0; c < vi; ++c) {
-                    const float w = wd[c];
-                    a0 = fmaf(w, vrow[3 * c + 0], a0);
-                    a1 = fmaf(w, vrow[3 * c + 1], a1);
-                    a2 = fmaf(w, vrow[3 * c + 2], a2);
+            gcp_xyz_acc u;
+            gcp_vmm_down<16>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
+            if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+            float f[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = gcp_crow(r, hi);
+                const float u0 = u[0][r], u1 = u[1][r], u2 = u[2][r];
+                if (r < S.SVB) {  // parked for vector_up in the epilogue (wave-uniform guard)
+                    ust[(r * 3 + 0) * 64 + lane] = u0; ust[(r * 3 + 1) * 64 + lane] = u1; ust[(r * 3 + 2) * 64 + lane] = u2;
                 }
-                vht[e * L.HS + 3 * h + 0] = a0;
-                vht[e * L.HS + 3 * h + 1] = a1;
-                vht[e * L.HS + 3 * h + 2] = a2;
-                ext[e * L.XS + h] = sqrtf(a0 * a0 + a1 * a1 + a2 * a2 + 1e-8f) + 1e-8f;
-            }
-            if (S.nf) {
-                const float* f = fr + e * 9;
-                for (int k = hi; k < 3; k += 2) {
-                    const float* wf = sw.wf + k * vi;
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                    for (int c = 0; c < vi; ++c) {
-                        const float w = wf[c];
-                        a0 = fmaf(w, vrow[3 * c + 0], a0);
-                        a1 = fmaf(w, vrow[3 * c + 1], a1);
-                        a2 = fmaf(w, vrow[3 * c + 2], a2);
-                    }
+                if (x < H) {
+                    ext[e * L.XS + x] = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f;
+                } else if (x < S.HF) {
+                    const int k = x - H;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        float pr = f[3 * a + 0] * a0 + f[3 * a + 1] * a1 + f[3 * a + 2] * a2;
+                        float pr = f[3 * a + 0] * u0 + f[3 * a + 1] * u1 + f[3 * a + 2] * u2;
                         if (p.o.e3 && a == 1) pr = fabsf(pr);
                         ext[e * L.XS + H + 3 * k + a] = pr;
                     }
@@ -229,7 +209,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
         // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
         f32x16 gacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) gacc[r] = (scalar_gate && gcp_crow(r, hi) < vo) ? it.b_gate[min(gcp_crow(r, hi), vo - 1)] : 0.f;
         if (scalar_gate) {
             const float* wg = it.pack + S.offC + lane;
             float wa[16], wb[16];
@@ -268,48 +248,48 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
             }
 
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
-        // ---- vector epilogue: sigmoid gate, vector_up, gating, residual; the vector tile is updated in place ---------------
-        if (scalar_gate) {
+        // ---- vector epilogue: vector_up on the matrix cores (B fragments = the parked vector_down outputs), then sigmoid
+        //      gate, gating and residual element-wise in registers; the vector tile is updated in place ------------------
+        {
+            gcp_xyz_acc uin, vu;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) uin[d][r] = r < S.SVB ? ust[(r * 3 + d) * 64 + lane] : 0.f;
+            gcp_xyz_zero(vu);
+            gcp_vmm_regs<16>(it.pack + S.offVB + lane, S.SVB, uin, vu);
+            float sg[16], x[16][3];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int oo = gcp_crow(r, hi);
-                if (oo < vo) gt[e * L.GS + oo] = gcp_sigmoid(gacc[r] + it.b_gate[oo]);
-            }
-        }
-        gcp_wave_lds_sync();
-        for (int oc0 = hi; oc0 < vo; oc0 += 16) {
-            float y[8][3];
+                const int o = min(gcp_crow(r, hi), vo - 1);
+                sg[r] = scalar_gate ? gcp_sigmoid(gacc[r]) : 1.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int oc = oc0 + 2 * i;
-                y[i][0] = y[i][1] = y[i][2] = 0.f;
-                if (oc < vo) {
-                    const float* wu = sw.wu + oc * H;
-                    float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-                    for (int h = 0; h < H; ++h) {
-                        const float w = wu[h];
-                        u0 = fmaf(w, vht[e * L.HS + 3 * h + 0], u0);
-                        u1 = fmaf(w, vht[e * L.HS + 3 * h + 1], u1);
-                        u2 = fmaf(w, vht[e * L.HS + 3 * h + 2], u2);
-                    }
-                    const float x0 = vt[e * L.VS + 3 * oc + 0], x1 = vt[e * L.VS + 3 * oc + 1], x2 = vt[e * L.VS + 3 * oc + 2];
-                    if (p.o.vector_residual) { u0 += x0; u1 += x1; u2 += x2; }
-                    float sc = 1.f;
-                    if (scalar_gate) sc = gt[e * L.GS + oc];
-                    else if (p.o.vmode == GCP_VMODE_SELF_GATE)
+                for (int d = 0; d < 3; ++d) x[r][d] = vt[e * L.VS + 3 * o + d];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = gcp_crow(r, hi);
+                if (o < vo) {
+                    float u0 = vu[0][r], u1 = vu[1][r], u2 = vu[2][r];
+                    if (p.o.vector_residual) { u0 += x[r][0]; u1 += x[r][1]; u2 += x[r][2]; }
+                    float sc = sg[r];
+                    if (p.o.vmode == GCP_VMODE_SELF_GATE)
                         sc = gcp_actf<PWL>(it.act_v, ns_v, slope, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f);
-                    y[i][0] = x0 + u0 * sc; y[i][1] = x1 + u1 * sc; y[i][2] = x2 + u2 * sc;
+                    vt[e * L.VS + 3 * o + 0] = x[r][0] + u0 * sc;
+                    vt[e * L.VS + 3 * o + 1] = x[r][1] + u1 * sc;
+                    vt[e * L.VS + 3 * o + 2] = x[r][2] + u2 * sc;
                 }
             }
+            if (scalar_gate && it.gate) {  // saved for the backward, straight from the registers (accumulator-layout rows)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int oc = oc0 + 2 * i;
-                if (oc < vo) { vt[e * L.VS + 3 * oc + 0] = y[i][0]; vt[e * L.VS + 3 * oc + 1] = y[i][1]; vt[e * L.VS + 3 * oc + 2] = y[i][2]; }
+                for (int q = 0; q < 4; ++q)
+                    if (8 * q < vo)
+                        gcp_store4(it.gate, row, vo, 8 * q + 4 * hi, make_float4(sg[4 * q], sg[4 * q + 1], sg[4 * q + 2], sg[4 * q + 3]),
+                                   row_ok, (vo & 3) == 0);
             }
         }
         gcp_wave_lds_sync();
         if (it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
-        if (scalar_gate && it.gate) gcp_store_tile(it.gate, vo, 0, vo, r0, rows, gt, L.GS, lane);
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
     }
 }
@@ -331,7 +311,7 @@ int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const f
     const gcp2_weights_t& w0 = items[0].w;
     const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
     if (S.NG != 1 || S.NTG < 2 || (w0.si & 1) || w0.vi <= 0 || w0.vo <= 0 || w0.vo > 32 || S.GT != 1) return GCPNET_E_UNSUPPORTED;
-    if (S.NTS != S.NTG) return GCPNET_E_UNSUPPORTED;
+    if (S.NTS != S.NTG || !S.vmm || w0.vi > 32) return GCPNET_E_UNSUPPORTED;
     ChainParams p;
     p.rows = rows; p.s0 = s0; p.v0 = v0; p.frames = frames;
     p.o = items[0].o;
@@ -340,8 +320,8 @@ int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const f
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_item_t& c = items[k];
         ChainItemF& it = p.it[k];
-        it.pack = c.w.pack; it.b_scalar = c.w.b_scalar; it.w_down = c.w.w_down; it.w_frames = c.w.w_frames;
-        it.w_up = c.w.w_up; it.b_gate = c.w.b_gate; it.s_out = c.s_out; it.v_out = c.v_out; it.s_pre = c.s_pre;
+        it.pack = c.w.pack; it.b_scalar = c.w.b_scalar;
+        it.b_gate = c.w.b_gate; it.s_out = c.s_out; it.v_out = c.v_out; it.s_pre = c.s_pre;
         it.gate = c.gate; it.act_s = c.o.act_s; it.act_v = c.o.act_v;
         pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
     }

@@ -464,6 +464,34 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
         const int a = x / S.NS;
         const int o = 32 * a + (lane & 31), j = 32 * (st / 16) + gcp_crow(st % 16, lane >> 5);
         if (w.w_gate && o < S.vo && j < S.so) val = w.w_gate[(int64_t)o * S.so + j];
+    } else if (i >= S.offVA) {  // V: the small vector Linears as MFMA A fragments (vec_mfma.h), all [step][64]
+        // Wdf = [vector_down ; vector_down_frames] is [HF, vi]; Wu = vector_up is [vo, H]
+        auto wdf = [&](int x, int c) -> float {
+            if (x < S.H) return w.w_down[(int64_t)x * S.vi + c];
+            return w.w_frames[(int64_t)(x - S.H) * S.vi + c];
+        };
+        if (i < S.offVB) {  // VA[s][lane] = Wdf[x = lane & 31, c = 2 s + half]
+            const int64_t x0 = i - S.offVA;
+            const int lane = x0 % 64, s = (int)(x0 / 64);
+            const int x = lane & 31, c = 2 * s + (lane >> 5);
+            if (x < S.HF && c < S.vi) val = wdf(x, c);
+        } else if (i < S.offVC) {  // VB[r][lane] = Wu[o = lane & 31, h = crow(r, half)]
+            const int64_t x0 = i - S.offVB;
+            const int lane = x0 % 64, r = (int)(x0 / 64);
+            const int o = lane & 31, h = gcp_crow(r, lane >> 5);
+            if (o < S.vo && h < S.H) val = w.w_up[(int64_t)o * S.H + h];
+        } else if (i < S.offVD) {  // VC[r][lane] = Wu[o = crow(r, half), h = lane & 31]
+            const int64_t x0 = i - S.offVC;
+            const int lane = x0 % 64, r = (int)(x0 / 64);
+            const int h = lane & 31, o = gcp_crow(r, lane >> 5);
+            if (o < S.vo && h < S.H) val = w.w_up[(int64_t)o * S.H + h];
+        } else {  // VD[ct][r][lane] = Wdf[x = crow(r, half), c = 32 ct + (lane & 31)]
+            int64_t x0 = i - S.offVD;
+            const int lane = x0 % 64; x0 /= 64;
+            const int r = x0 % S.SVD, ct = (int)(x0 / S.SVD);
+            const int c = 32 * ct + (lane & 31), x = gcp_crow(r, lane >> 5);
+            if (x < S.HF && c < S.vi) val = wdf(x, c);
+        }
     } else if (i >= S.offF) {  // F: forward fragments for a register-resident state [NTS*16][64][NTG] = W[j, k(step, half)]
         int64_t x = i - S.offF;
         const int t = x % S.NTG; x /= S.NTG;
@@ -477,7 +505,7 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
         const int lane = x % 64; x /= 64;
         const int g = x % S.NG;
         const int oo = x / S.NG;
-        const int o = 2 * oo + (lane >> 5), j = 32 * (g * S.NTG + t) + (lane & 31);
+        const int o = gcp_crow(oo, lane >> 5), j = 32 * (g * S.NTG + t) + (lane & 31);
         if (w.w_gate && o < S.vo && j < S.so) val = w.w_gate[(int64_t)o * S.so + j];
     }
     out[i] = val;

@@ -1,0 +1,57 @@
+// The small vector Linears of a GCP2 block (vector_down [H, vi], vector_down_frames [3, vi], vector_up [vo, H]; reference
+// src/models/components/gcpnet.py:303-324,420-435,364-391) on the matrix cores, in the same transposed, rows-on-lanes form as
+// scalar_out: out^T[channels, 32 rows] = W[channels, k] x in^T[k, 32 rows], one product per xyz component.
+//
+// Every intermediate lives in the 32x32 C/D layout of v_mfma_f32_32x32x2_f32: register r of lane (row = lane & 31, half =
+// lane >> 5) holds channel gcp_crow(r, half) of that row.  Two consequences the kernels rely on:
+//   * the per-row nonlinear steps between the Linears (norms, frame projections, gating, their adjoints) are plain
+//     element-wise register arithmetic -- a row's xyz components of one channel sit in the SAME register index of three
+//     accumulators;
+//   * a C/D register is directly the B fragment of a k-pair step over channels (j0, j0 + 4) (j0 = crow(r, 0)), so chained
+//     Linears (vector_down -> vector_up, and all the adjoints) need no LDS round trip; the weights are packed for that
+//     pairing (sections VB / VC / VD of the packed image, pack_gcp2_kernel).
+// Only the first product reads LDS (the row's input vectors, one conflict-free ds_read_b32 per xyz component and step).
+#pragma once
+#include "common.h"
+
+typedef f32x16 gcp_xyz_acc[3];
+
+__device__ __forceinline__ void gcp_xyz_zero(gcp_xyz_acc& u) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[d][r] = 0.f;
+}
+
+// u[d][x] = sum_c Wdf[x, c] v[row, c, d]: A fragments from section VA (`wa` already offset by the lane), B fragments from the
+// row's vector tile `vrow` ([c][xyz] floats).  MAXS = compile-time bound on the k-pair steps (ceil(vi / 2)).
+template <int MAXS>
+__device__ __forceinline__ void gcp_vmm_down(const float* __restrict__ wa, int steps, int vi, const float* vrow, int hi,
+                                             gcp_xyz_acc& u) {
+    float a[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) a[s] = wa[(int64_t)min(s, steps - 1) * 64];
+    gcp_xyz_zero(u);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+        if (s < steps) {  // wave-uniform
+            const float* b = vrow + 3 * min(2 * s + hi, vi - 1);  // (an odd vi pads with a zero weight)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) u[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[d], u[d], 0, 0, 0);
+        }
+}
+
+// out[d] += W x in[d], the reduction running over the channels held by registers r < steps of `in` (k-pair (crow(r, 0),
+// crow(r, 1)) per step); `w` = section VB / VC / VD already offset by the lane.
+template <int MAXR>
+__device__ __forceinline__ void gcp_vmm_regs(const float* __restrict__ w, int steps, const gcp_xyz_acc& in, gcp_xyz_acc& out) {
+    float a[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) a[r] = w[(int64_t)min(r, steps - 1) * 64];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+        if (r < steps) {  // wave-uniform
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
+        }
+}

@@ -321,7 +321,7 @@ def _opts_struct(spec: Gcp2Spec, fused_residual: bool = False) -> Gcp2Opts:
 def _pack(spec: Gcp2Spec, w) -> Tensor:
     lib = _lib.load()
     w_scalar, w_gate = w[0], w[5]
-    key = (w_scalar.data_ptr(), w_scalar._version, None if w_gate is None else (w_gate.data_ptr(), w_gate._version))
+    key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate, w[2], w[3], w[4]))
     cache = spec.pack_cache
     if cache is not None and cache.get("key") == key:
         return cache["pack"]

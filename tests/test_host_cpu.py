@@ -29,7 +29,10 @@ def test_host_only_entry_points():
     n = lib.gcpnet_gcp2_pack_floats(160, 36, 64, 16, 9, 1)
     KK, NTG, NG, NUG, NGK, NS = 92, 2, 1, 4, 2, 32
     NTS = 5  # 32-wide tiles of the 160 scalar inputs (section F, register-resident chain kernel)
-    assert n == NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * NS * 64 + 8 * NG * 64 * NTG + NTS * 16 * 64 * NTG
+    # vector Linears as MFMA fragments: H + 3 = 12 rows: ceil(36/2) + 4*ceil(9/8) + 4*ceil(16/8) + ceil(36/32) * 4*ceil(12/8) steps
+    SV = 18 + 8 + 8 + 2 * 8
+    assert n == (NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * NS * 64 + 8 * NG * 64 * NTG + NTS * 16 * 64 * NTG
+                 + SV * 64)
     assert lib.gcpnet_tn_splits(160000, 128, 142) == 250
     assert lib.gcpnet_tn_splits(0, 1, 1) == 1
 
