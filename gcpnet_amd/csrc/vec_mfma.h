@@ -33,11 +33,15 @@ __device__ __forceinline__ void gcp_vmm_down(const float* __restrict__ wa, int s
     for (int s = 0; s < MAXS; ++s) a[s] = wa[(int64_t)min(s, steps - 1) * 64];
     gcp_xyz_zero(u);
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-        if (s < steps) {  // wave-uniform
-            const float* b = vrow + 3 * min(2 * s + hi, vi - 1);  // (an odd vi pads with a zero weight)
+    for (int s0 = 0; s0 < MAXS; s0 += 2)
+        if (s0 < steps) {  // wave-uniform, one test per two steps (a step past the end multiplies by a zero weight)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) u[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[d], u[d], 0, 0, 0);
+            for (int s = s0; s < s0 + 2 && s < MAXS; ++s) {
+                const float* b = vrow + 3 * min(2 * s + hi, vi - 1);  // (an odd vi pads with a zero weight)
+                const float as = s < steps ? a[s] : 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) u[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b[d], u[d], 0, 0, 0);
+            }
         }
 }
 
@@ -48,10 +52,30 @@ __device__ __forceinline__ void gcp_vmm_regs(const float* __restrict__ w, int st
     float a[MAXR];
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) a[r] = w[(int64_t)min(r, steps - 1) * 64];
+    static_assert(MAXR % 4 == 0, "steps come in groups of four registers");
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r)
-        if (r < steps) {  // wave-uniform
+    for (int r0 = 0; r0 < MAXR; r0 += 4)
+        if (r0 < steps) {  // wave-uniform; the step counts are multiples of 4
 #pragma unroll
-            for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
+            for (int r = r0; r < r0 + 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
+        }
+}
+
+// Same with the input held in plain register arrays in[d][r] (r < NR).
+template <int NR>
+__device__ __forceinline__ void gcp_vmm_arr(const float* __restrict__ w, int steps, const float (&in)[3][NR], gcp_xyz_acc& out) {
+    float a[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) a[r] = w[(int64_t)min(r, steps - 1) * 64];
+    static_assert(NR % 4 == 0, "steps come in groups of four registers");
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += 4)
+        if (r0 < steps) {  // wave-uniform; the step counts are multiples of 4
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
         }
 }
