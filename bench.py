@@ -11,8 +11,10 @@ step      = one forward + scalar loss + backward (to inputs and weights) of a st
             dropout 0); N > 1: every rank holds its own graph of that size (graphs shard by whole graphs, weak
             scaling) and the weight gradients are all-reduced over RCCL each step.
 value     = edges processed per second by the whole job = n_gpus * E * layers * steps / max-over-ranks time.
-roofline  = the dominant kernel (the GCP2 backward data kernel on edge rows), timed live with HIP events on the
-            stream it is launched on: algorithmic FLOPs per launch / average launch time vs the fp32 MFMA peak.
+roofline  = the dominant kernel (forward / backward / weight-gradient GEMM of the 7-block ResGCP message chain on edge
+            rows, whichever is slowest), timed live with HIP events on the stream it is launched on: algorithmic FLOPs per
+            launch / average launch time vs the fp32 MFMA peak; its algorithmic HBM bytes / time is reported next to it.
+aggregate_kernel = the scatter-mean (segmented reduction) kernel against the HBM roofline.
 cpu_baseline = the oracle (pure PyTorch on the host cores) on one step of the same stack and inputs.
 """
 import argparse
@@ -46,26 +48,21 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_roofline(G, ops, layer, inputs, frames, edge_index, n_edges, sdim, vdim, iters=20):
-    """Times the dominant kernels alone on the current stream (HIP events via torch.cuda.Event, which records on
-    torch's current stream -- the stream every gcpnet kernel is launched on)."""
+def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
+    """Times the three kernels that carry the step -- forward, backward and weight-gradient GEMM of the 7-block ResGCP message
+    chain of one layer, on E edge rows -- each alone, with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  All three do the same algorithmic work per launch: 7 * 2 * E * gcp_macs FLOP."""
     from gcpnet_amd.synthetic import gcp_macs
 
-    block = layer.interaction.message_fusion[1]  # a residual message GCP: (s,V)->(s,V) on E rows
+    blocks = list(layer.interaction.message_fusion[1:])  # the residual message GCPs: (s,V)->(s,V) on E rows
+    n = len(blocks)
     g = torch.Generator(device="cuda").manual_seed(0)
-    s = torch.randn(n_edges, sdim, device="cuda", generator=g)
-    v = torch.randn(n_edges, vdim, 3, device="cuda", generator=g)
+    s = torch.randn(n_edges, sdim, device="cuda", generator=g).requires_grad_()
+    v = torch.randn(n_edges, vdim, 3, device="cuda", generator=g).requires_grad_()
     ds = torch.randn(n_edges, sdim, device="cuda", generator=g)
     dv = torch.randn(n_edges, vdim, 3, device="cuda", generator=g)
-    spec = ops.Gcp2Spec(si=sdim, vi=vdim, so=sdim, vo=vdim, hidden=block.hidden_dim, use_frames=True, act_s=block.act_s,
-                        act_v=block.act_v, slope=1e-2, vmode=block._vmode(), vector_residual=False, e3=False,
-                        s_plans=[None], v_plans=[None], residual=True, pack_cache={})
-    w = tuple(None if t is None else t.detach() for t in block._weights())
-    s.requires_grad_()
-    out_s, out_v = ops.gcp2(spec, [s], [v], frames, w)  # forward with saved tensors
-    fn = out_s.grad_fn
-    saved = fn.saved_tensors
-    pack, s_pre, gate = saved[-3], saved[-2], saved[-1]
+    specs = [b.make_spec([None], [None], residual=True) for b in blocks]
+    ws = [tuple(None if t is None else t.detach().requires_grad_() for t in b._weights()) for b in blocks]
 
     def timeit(f):
         for _ in range(3):
@@ -79,18 +76,70 @@ def kernel_roofline(G, ops, layer, inputs, frames, edge_index, n_edges, sdim, vd
         torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e-3
 
-    with torch.no_grad():
-        t_fwd = timeit(lambda: ops.gcp2(spec, [s.detach()], [v], frames, w))
-        res = {}
+    keep = {}
 
+    def fwd():
+        keep["out"] = ops.gcp2_chain(specs, s, v, frames, ws)  # training mode: s_pre / gates / states are saved
+
+    t_fwd = timeit(fwd)
+    s0, v0, ws_, packs, outs = keep["out"][0].grad_fn.state
+    ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
+    with torch.no_grad():
         def bwd():
-            res["r"] = ops.gcp2_backward_data(spec, n_edges, [s.detach()], [v], frames, w, pack, s_pre, gate, ds, dv)
+            keep["bwd"] = ops.gcp2_chain_backward_data(specs, n_edges, ins, outs, frames, ws_, packs, ds, dv, [True] * n)
 
         t_bwd = timeit(bwd)
-        scr = res["r"][2]
-        t_tn = timeit(lambda: ops.gcp2_weight_grads(spec, n_edges, [s.detach()], s_pre, scr))
-    flops = 2.0 * n_edges * gcp_macs(sdim, vdim, sdim, vdim)
-    return dict(t_fwd=t_fwd, t_bwd=t_bwd, t_tn=t_tn, flops=flops)
+        assert keep["bwd"] is not None, "the chain backward kernel does not cover this shape"
+        scrs = keep["bwd"][2]
+
+        def tn():
+            ops.run_weight_grad_jobs([ops._WeightGradJob(specs[k], n_edges, [ins[k][0]], outs[k][2], scrs[k]) for k in range(n)])
+
+        t_tn = timeit(tn)
+    flops = n * 2.0 * n_edges * gcp_macs(sdim, vdim, sdim, vdim)
+    H = blocks[0].hidden_dim
+    row_s, row_v = 4 * sdim, 12 * vdim
+    ext, gate = 4 * ((H + 9 + 3) // 4 * 4), 4 * vdim
+    # algorithmic HBM bytes per launch (every tensor a kernel must read or write once, per edge row)
+    bytes_fwd = n_edges * ((row_s + row_v + 36) + n * (row_s + row_v + row_s + gate))
+    bytes_bwd = n_edges * (2 * (row_s + row_v) + 36 + n * ((row_s + row_v + gate) + (row_s + gate + ext)))
+    bytes_tn = n_edges * n * ((row_s + row_s + ext) + (gate + row_s))
+    return dict(t_fwd=t_fwd, t_bwd=t_bwd, t_tn=t_tn, flops=flops, n_blocks=n,
+                bytes=dict(fwd=bytes_fwd, bwd=bytes_bwd, tn=bytes_tn))
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/README.md); None when not collected."""
+    path = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except OSError:
+        return None
+
+
+def aggregate_roofline(G, ops, dev, n_nodes, n_edges, sdim, iters=50):
+    """The gather / aggregate kernel (scatter-mean of the edge messages onto their target nodes, gcpnet.py:946) against the
+    HBM roofline: algorithmic bytes = E * s_dim * 4 read + N * s_dim * 4 written."""
+    plan = ops.GraphPlan.get(dev["edge_index"], n_nodes)
+    msg = torch.randn(n_edges, sdim, device="cuda")
+    col_plan = plan.col if hasattr(plan, "col") else None
+    if col_plan is None:
+        return None
+    for _ in range(3):
+        ops.segment_reduce(msg, col_plan, True)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        ops.segment_reduce(msg, col_plan, True)
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) / iters * 1e-3
+    nbytes = 4.0 * sdim * (n_edges + n_nodes)
+    return {"kernel": "segment_reduce_kernel<mean> (edge messages -> nodes)", "bound": "hbm", "achieved": nbytes / t / 1e9,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "avg_launch_ms": t * 1e3,
+            "bytes_per_launch": nbytes}
 
 
 def main():
@@ -161,9 +210,12 @@ def main():
     elif rank == 0:
         value = world * n_edges * args.layers * args.steps / elapsed
         fl = layer_flops(args.nodes, n_edges, node_dims, edge_dims)
-        kr = kernel_roofline(G, ops, layers[0], ins, frames, dev["edge_index"], n_edges, args.sdim, args.vdim)
-        times = {"gcp2_fwd_kernel<4>": kr["t_fwd"], "gcp2_bwd_kernel<4,4>": kr["t_bwd"], "tn_gemm_kernel(+reduce)": kr["t_tn"]}
-        dom = max(times, key=times.get)  # each of the three does ~the same algorithmic work: 2 * E * gcp_macs FLOP
+        kr = kernel_roofline(G, ops, layers[0], frames, n_edges, args.sdim, args.vdim)
+        times = {"gcp2_chain_fwd_kernel": kr["t_fwd"], "gcp2_chain_bwd_kernel": kr["t_bwd"],
+                 "tn_gemm_dma_kernel(+reduce)": kr["t_tn"]}
+        kbytes = {"gcp2_chain_fwd_kernel": kr["bytes"]["fwd"], "gcp2_chain_bwd_kernel": kr["bytes"]["bwd"],
+                  "tn_gemm_dma_kernel(+reduce)": kr["bytes"]["tn"]}
+        dom = max(times, key=times.get)  # each of the three does the same algorithmic work: n_blocks * 2 * E * gcp_macs FLOP
         achieved = kr["flops"] / times[dom] / 1e12
         out = {
             "metric": "processed edges/sec (GCP fwd+bwd)", "value": value, "unit": "edges/s", "n_gpus": world,
@@ -181,13 +233,17 @@ def main():
                 "frac_of_fp32_mfma_peak": fl["fwd_bwd"] * args.layers * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             },
             "roofline": {
-                "kernel": dom + " on one residual message GCP (s,V)->(s,V), E rows", "bound": "mfma",
-                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "kernel": f"{dom} on the {kr['n_blocks']}-block residual message chain (s,V)->(s,V) of one layer, E rows",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                 "avg_launch_ms": times[dom] * 1e3, "flop_per_launch": kr["flops"],
+                "algorithmic_hbm_gbs": kbytes[dom] / times[dom] / 1e9,
+                "algorithmic_hbm_frac": kbytes[dom] / times[dom] / 1e9 / PEAK_HBM_GBS,
                 "all_kernels_ms": {k: v * 1e3 for k, v in times.items()},
                 "all_kernels_tflops": {k: kr["flops"] / v / 1e12 for k, v in times.items()},
+                "all_kernels_algorithmic_hbm_gbs": {k: kbytes[k] / v / 1e9 for k, v in times.items()},
             },
+            "aggregate_kernel": aggregate_roofline(G, ops, dev, args.nodes, n_edges, args.sdim),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(layers, host, args)

@@ -610,27 +610,13 @@ class _Gcp2Chain(torch.autograd.Function):
         ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
         nws = [any(need_w[7 * k:7 * k + 7]) for k in range(n)]
         # one launch for the whole chain (gradient state on chip); shapes outside that kernel go block by block
-        lib = _lib.load()
-        items = (ChainBwdItem * n)()
-        scrs = []
-        for k in range(n):
-            scr, t = _alloc_bwd_scratch(specs[k], rows, nws[k], s0.device)
-            scrs.append(t)
-            items[k].w = _weights_struct(specs[k], ws[k], packs[k])
-            items[k].o = _opts_struct(specs[k], fused_residual=True)
-            items[k].v_in = ins[k][1].data_ptr()
-            items[k].s_pre = outs[k][2].data_ptr()
-            items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
-            items[k].sc = scr
-        d_s_in, d_v_in = torch.empty_like(d_s), torch.empty_like(d_v)
-        rc = lib.gcpnet_gcp2_chain_backward(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(d_s_in), _p(d_v_in), _stream())
-        if rc == 0:
-            d_s, d_v = d_s_in, d_v_in
+        res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
+        if res is not None:
+            d_s, d_v, scrs = res
             for k in range(n):
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k])
-        elif rc == _lib.E_UNSUPPORTED:
-            del scrs, items
+        else:
             for k in range(n - 1, -1, -1):
                 s_in, v_in = ins[k]
                 _, _, s_pre, gate = outs[k]
@@ -638,8 +624,6 @@ class _Gcp2Chain(torch.autograd.Function):
                                                    d_v, need_w=nws[k])
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
-        else:
-            check(rc, "gcp2_chain_backward")
         live = [j for j in jobs if j is not None]
         if live:
             run_weight_grad_jobs(live)
@@ -649,6 +633,31 @@ class _Gcp2Chain(torch.autograd.Function):
             wgrads += [gi if need else None for gi, need in zip(g, need_w[7 * k:7 * k + 7])]
         ctx.state = None
         return (None, None, d_s, d_v, *wgrads)
+
+
+def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s: Tensor, d_v: Tensor, need_w: Sequence[bool]):
+    """Backward data path of a whole ResGCP chain in one launch (gcpnet_gcp2_chain_backward).  ins[k] = (s, V) input of block
+    k, outs[k] = (s_out, v_out, s_pre, gate) saved by the forward.  Returns (d_s_in, d_v_in, per-block scratch dicts), or None
+    when the shape is outside that kernel (the caller then goes block by block)."""
+    lib = _lib.load()
+    n = len(specs)
+    items = (ChainBwdItem * n)()
+    scrs = []
+    for k in range(n):
+        scr, t = _alloc_bwd_scratch(specs[k], rows, need_w[k], d_s.device)
+        scrs.append(t)
+        items[k].w = _weights_struct(specs[k], ws[k], packs[k])
+        items[k].o = _opts_struct(specs[k], fused_residual=True)
+        items[k].v_in = ins[k][1].data_ptr()
+        items[k].s_pre = outs[k][2].data_ptr()
+        items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
+        items[k].sc = scr
+    d_s_in, d_v_in = torch.empty_like(d_s), torch.empty_like(d_v)
+    rc = lib.gcpnet_gcp2_chain_backward(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(d_s_in), _p(d_v_in), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "gcp2_chain_backward")
+    return d_s_in, d_v_in, scrs
 
 
 def gcp2_chain(specs: Sequence[Gcp2Spec], s0: Tensor, v0: Tensor, frames: Optional[Tensor], weights: Sequence[tuple]):
