@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int rows, int sdim, 
 }
 
 #define LN_MAX_PER_LANE 16  // sdim <= 1024
+static inline int ln_bwd_blocks(int rows) { return min(gcp_cdiv(rows, 8), 512); }
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, int vdim,
                                                             const float* __restrict__ s_sum,
                                                             const float* __restrict__ v_sum,
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, 
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ d_s_out,
                                                             const float* __restrict__ d_v_out, float* __restrict__ d_s,
-                                                            float* __restrict__ d_v, float* __restrict__ d_gamma,
-                                                            float* __restrict__ d_beta) {
+                                                            float* __restrict__ d_v, float* __restrict__ part) {
+    __shared__ float red[4][2 * 64 * LN_MAX_PER_LANE / 4];  // per-wave column sums, sdim <= 256 per pass
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     float dg[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE];
@@ -220,10 +221,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, 
             }
         }
     }
+    // d gamma / d beta: the block's share goes to part[block, 0:sdim | sdim:2 sdim] (combined over its four waves through
+    // LDS, 256 columns per pass); gcpnet_reduce_partials sums the blocks in a fixed order -- deterministic, no atomics
+    const int w = threadIdx.x >> 6;
+    float* mine = part + (int64_t)blockIdx.x * 2 * sdim;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int j = lane + 64 * i;
-        if (j < sdim) { atomicAdd(d_gamma + j, dg[i]); atomicAdd(d_beta + j, db[i]); }
+    for (int i0 = 0; i0 < LN_MAX_PER_LANE; i0 += 4) {
+        if (64 * i0 >= sdim) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[w][64 * i + lane] = dg[i0 + i];
+            red[w][256 + 64 * i + lane] = db[i0 + i];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 512; c += 256) {
+            const int j = 64 * i0 + (c & 255);
+            if (j < sdim) mine[(c >> 8) * sdim + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        }
+        __syncthreads();
     }
 }
 
@@ -292,19 +307,32 @@ extern "C" int gcpnet_layernorm_forward(int rows, int sdim, int vdim, const floa
     return 0;
 }
 
+extern "C" int64_t gcpnet_layernorm_bwd_scratch_floats(int rows, int sdim) {
+    if (rows <= 0 || sdim <= 0) return 1;
+    const int blocks = ln_bwd_blocks(rows);
+    return (int64_t)(blocks + gcpnet_reduce_partials_groups(blocks)) * 2 * sdim;
+}
+
 extern "C" int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const float* s_sum, const float* v_sum,
                                          const float* stats, const float* gamma, const float* d_s_out,
-                                         const float* d_v_out, float* d_s, float* d_v, float* d_gamma, float* d_beta,
-                                         void* stream) {
-    if (rows < 0 || sdim <= 0 || vdim < 0 || !s_sum || !stats || !gamma || !d_s_out || !d_s || !d_gamma || !d_beta)
+                                         const float* d_v_out, float* d_s, float* d_v, float* d_gamma_beta,
+                                         float* scratch, void* stream) {
+    if (rows < 0 || sdim <= 0 || vdim < 0 || !s_sum || !stats || !gamma || !d_s_out || !d_s || !d_gamma_beta || !scratch)
         return GCPNET_E_BADARG;
     if (sdim > 64 * LN_MAX_PER_LANE) return GCPNET_E_UNSUPPORTED;
     if (vdim > 0 && (!v_sum || !d_v_out || !d_v)) return GCPNET_E_BADARG;
-    if (rows == 0) return 0;
-    const int blocks = min(gcp_cdiv(rows, 4), 512);  // d_gamma / d_beta must be zeroed by the caller
+    if (rows == 0) {
+        hipError_t err = hipMemsetAsync(d_gamma_beta, 0, sizeof(float) * 2 * sdim, (hipStream_t)stream);
+        return err == hipSuccess ? 0 : (int)err;
+    }
+    const int blocks = ln_bwd_blocks(rows);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, sdim, vdim, s_sum,
-                       v_sum, stats, gamma, d_s_out, d_v_out, d_s, d_v, d_gamma, d_beta);
+                       v_sum, stats, gamma, d_s_out, d_v_out, d_s, d_v, scratch);
     GCP_HIP_CHECK_LAUNCH();
+    gcp_reduce_job_t job;
+    job.parts = scratch; job.n_parts = blocks; job.width = 2 * sdim;
+    job.tmp = scratch + (int64_t)blocks * 2 * sdim; job.out = d_gamma_beta;
+    if (int rc = gcpnet_reduce_partials(1, &job, stream)) return rc;
     return 0;
 }
 

@@ -203,12 +203,12 @@ class _LayerNorm(torch.autograd.Function):
             d_v = _req(d_v, "grad") if d_v is not None else torch.zeros_like(v_sum)
         gs = torch.empty_like(s_sum)
         gv = torch.empty_like(v_sum) if vdim else None
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(gamma)
+        gb = torch.empty((2, sdim), dtype=torch.float32, device=gamma.device)  # d gamma, d beta
+        scratch = torch.empty((int(lib.gcpnet_layernorm_bwd_scratch_floats(rows, sdim)),), dtype=torch.float32, device=gamma.device)
         check(lib.gcpnet_layernorm_backward(rows, sdim, vdim, _p(s_sum), _p(v_sum), _p(stats), _p(gamma), _p(d_s),
-                                            _p(d_v) if vdim else None, _p(gs), _p(gv), _p(dgamma), _p(dbeta), _stream()),
+                                            _p(d_v) if vdim else None, _p(gs), _p(gv), _p(gb), _p(scratch), _stream()),
               "layernorm_backward")
-        return gs, (gs if ctx.has_b[0] else None), gv, (gv if ctx.has_b[1] else None), dgamma, dbeta
+        return gs, (gs if ctx.has_b[0] else None), gv, (gv if ctx.has_b[1] else None), gb[0], gb[1]
 
 
 def layernorm(s_a: Tensor, v_a: Optional[Tensor], gamma: Tensor, beta: Tensor, s_b: Optional[Tensor] = None,

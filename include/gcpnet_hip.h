@@ -216,9 +216,12 @@ int gcpnet_localize(int n_edges, const int32_t* row, const int32_t* col, const f
 int gcpnet_layernorm_forward(int rows, int sdim, int vdim, const float* s_a, const float* s_b, const float* v_a,
                              const float* v_b, const float* gamma, const float* beta, float* s_out, float* v_out,
                              float* stats /* [rows,3]: mean, rstd, vnorm */, float* s_sum, float* v_sum, void* stream);
+/* d_gamma_beta [2 * sdim] receives d gamma followed by d beta (summed over rows in a fixed order: per-block partial sums in
+ * `scratch`, gcpnet_layernorm_bwd_scratch_floats(rows, sdim) floats, reduced by gcpnet_reduce_partials). */
 int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const float* s_sum, const float* v_sum,
                               const float* stats, const float* gamma, const float* d_s_out, const float* d_v_out,
-                              float* d_s, float* d_v, float* d_gamma, float* d_beta, void* stream);
+                              float* d_s, float* d_v, float* d_gamma_beta, float* scratch, void* stream);
+int64_t gcpnet_layernorm_bwd_scratch_floats(int rows, int sdim);
 
 /* ---- small elementwise pieces ---------------------------------------------------------------------------------
  * y = a + alpha * b, clamped to [lo, hi] when clamp != 0 (position update, components/gcpnet.py:1156-1158,1258) */
