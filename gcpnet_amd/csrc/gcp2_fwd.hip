@@ -19,6 +19,7 @@
 //     the MFMAs of block k+1.
 #include "common.h"
 #include "tile_io.h"
+#include "vec_mfma.h"
 
 int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const float* frames, int n,
                              const gcp2_chain_item_t* items, hipStream_t st);
@@ -80,7 +81,9 @@ __host__ __device__ inline FwdLds fwd_lds(const GcpShape& s) {
         l.o_vt = mrg + stg;
     }
     l.o_vht = l.o_vt + 32 * l.VS;
-    l.o_gt = l.o_vht + 32 * l.HS;
+    // vector_down outputs between the vector prologue and epilogue: row-major (VALU path) or parked registers (MFMA path)
+    const int vht = 32 * l.HS, ust = s.vmm ? s.SVB * 3 * 64 : 0;
+    l.o_gt = l.o_vht + (vht > ust ? vht : ust);
     l.o_fr = l.o_gt + 32 * l.GS;
     l.o_sw = l.o_fr + 32 * 9;
     l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
@@ -114,7 +117,7 @@ struct WFrag<4> {
 // NTG: 32-wide output tiles per accumulator group; GT: 32-wide tiles of the gate outputs (vo <= 32 * GT);
 // PWL: both activations are identity / relu / leakyrelu.
 template <int NTG, int GT, bool PWL>
-__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
     const FwdLds L = fwd_lds(S);
@@ -171,11 +174,41 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
         gcp2_weights_t wsm;
         wsm.vi = vi; wsm.vo = vo; wsm.w_down = it.w_down; wsm.w_frames = it.w_frames; wsm.w_up = it.w_up;
         gcp_wave_lds_sync();  // the previous block is done with the small-weight area
-        const GcpSmallW sw = gcp_stage_small_weights(wsm, H, S.nf, lds + L.o_sw, lane);
+        const bool vmm = S.vmm != 0;  // the small vector Linears run on the matrix cores (vec_mfma.h); else on the VALU
+        GcpSmallW sw;
+        sw.wd = sw.wf = sw.wu = nullptr;
+        if (!vmm) sw = gcp_stage_small_weights(wsm, H, S.nf, lds + L.o_sw, lane);
         gcp_wave_lds_sync();
 
-        // ---- 2. vector prologue on the VALU: two lanes per row --------------------------------------------------
-        if (vi > 0) {
+        // ---- 2. vector prologue: vh = vector_down(v) and its norms over xyz (gcpnet.py:420-421), vector_down_frames +
+        //         scalarize (gcpnet.py:426-435, components/__init__.py:302,312) -> columns si.. of the merged tile -----------
+        if (vmm) {
+            gcp_xyz_acc u;
+            gcp_vmm_down_loop(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
+            float f[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
+            float* ust = vht;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = gcp_crow(r, hi);
+                const float u0 = u[0][r], u1 = u[1][r], u2 = u[2][r];
+                if (r < S.SVB) {  // parked for vector_up in the epilogue (wave-uniform guard)
+                    ust[(r * 3 + 0) * 64 + lane] = u0; ust[(r * 3 + 1) * 64 + lane] = u1; ust[(r * 3 + 2) * 64 + lane] = u2;
+                }
+                if (x < H) {
+                    mrg[e * L.KS + si + x] = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f;
+                } else if (x < S.HF) {
+                    const int k = x - H;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float pr = f[3 * a + 0] * u0 + f[3 * a + 1] * u1 + f[3 * a + 2] * u2;
+                        if (p.o.e3 && a == 1) pr = fabsf(pr);
+                        mrg[e * L.KS + si + H + 3 * k + a] = pr;
+                    }
+                }
+            }
+        } else if (vi > 0) {
             const float* vrow = vt + e * L.VS;
             for (int h = hi; h < H; h += 2) {  // vector_down + safe_norm over xyz (gcpnet.py:420-421)
                 const float* wd = sw.wd + h * vi;
@@ -368,7 +401,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
         if (vo == 0) continue;
 
         // ---- 5. vector epilogue: sigmoid gate, vector_up, gating, residual (gcpnet.py:364-391) -------------------
-        if (scalar_gate) {
+        if (scalar_gate && !vmm) {
 #pragma unroll
             for (int a = 0; a < GT; ++a)
 #pragma unroll
@@ -387,6 +420,52 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
                 }
             continue;
         }
+        if (vmm) {
+            // vector_up on the matrix cores (B fragments = the parked vector_down outputs); sigmoid gate, gating and the
+            // residuals element-wise in registers; the vector tile is updated in place (channel crow(r, hi) of row e)
+            gcp_xyz_acc uin, vu;
+            const float* ust = vht;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) uin[d][r] = r < S.SVB ? ust[(r * 3 + d) * 64 + lane] : 0.f;
+            gcp_xyz_zero(vu);
+            gcp_vmm_regs<16>(it.pack + S.offVB + lane, S.SVB, uin, vu);
+            float sg[16], x[16][3];
+            const bool need_x = p.o.vector_residual || p.fused_res;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = min(gcp_crow(r, hi), vo - 1);
+                sg[r] = scalar_gate ? gcp_sigmoid(gacc[0][r] + it.b_gate[o]) : 1.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) x[r][d] = need_x ? vt[e * L.VS + 3 * o + d] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = gcp_crow(r, hi);
+                if (o < vo) {
+                    float u0 = vu[0][r], u1 = vu[1][r], u2 = vu[2][r];
+                    if (p.o.vector_residual) { u0 += x[r][0]; u1 += x[r][1]; u2 += x[r][2]; }
+                    float sc = sg[r];
+                    if (p.o.vmode == GCP_VMODE_SELF_GATE)
+                        sc = gcp_actf<PWL>(it.act_v, ns_v, slope, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f);
+                    float y0 = u0 * sc, y1 = u1 * sc, y2 = u2 * sc;
+                    if (p.fused_res) { y0 += x[r][0]; y1 += x[r][1]; y2 += x[r][2]; }
+                    if (p.res_v && !p.fused_res && row_ok) {
+                        const int64_t off = ((int64_t)row * vo + o) * 3;
+                        y0 += p.res_v[off]; y1 += p.res_v[off + 1]; y2 += p.res_v[off + 2];
+                    }
+                    vt[e * L.VS + 3 * o + 0] = y0; vt[e * L.VS + 3 * o + 1] = y1; vt[e * L.VS + 3 * o + 2] = y2;
+                }
+            }
+            if (scalar_gate && it.gate) {  // saved for the backward, straight from the registers
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (8 * q < vo)
+                        gcp_store4(it.gate, row, vo, 8 * q + 4 * hi, make_float4(sg[4 * q], sg[4 * q + 1], sg[4 * q + 2], sg[4 * q + 3]),
+                                   row_ok, (vo & 3) == 0);
+            }
+        } else
         for (int oc0 = hi; oc0 < vo; oc0 += 16) {  // 8 channels per lane per pass: all reads, then the in-place writes
             float y[8][3];
 #pragma unroll
@@ -431,7 +510,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_fwd_kernel(FwdParams p) {
         }
         gcp_wave_lds_sync();
         if (it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
-        if (scalar_gate && it.gate) gcp_store_tile(it.gate, vo, 0, vo, r0, rows, gt, L.GS, lane);
+        if (!vmm && scalar_gate && it.gate) gcp_store_tile(it.gate, vo, 0, vo, r0, rows, gt, L.GS, lane);
         if (ci == 0) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
     }
 }

@@ -45,6 +45,29 @@ __device__ __forceinline__ void gcp_vmm_down(const float* __restrict__ wa, int s
         }
 }
 
+// Same for any vi: the k-pair steps go in chunks of eight (runtime loop), each chunk's weight fragments requested together.
+__device__ __forceinline__ void gcp_vmm_down_loop(const float* __restrict__ wa, int steps, int vi, const float* vrow, int hi,
+                                                  gcp_xyz_acc& u) {
+    gcp_xyz_zero(u);
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = wa[(int64_t)min(s0 + i, steps - 1) * 64];
+#pragma unroll
+        for (int i0 = 0; i0 < 8; i0 += 2)
+            if (s0 + i0 < steps) {  // wave-uniform
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) {
+                    const int s = s0 + i;
+                    const float* b = vrow + 3 * min(2 * s + hi, vi - 1);
+                    const float as = s < steps ? a[i] : 0.f;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) u[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b[d], u[d], 0, 0, 0);
+                }
+            }
+    }
+}
+
 // out[d] += W x in[d], the reduction running over the channels held by registers r < steps of `in` (k-pair (crow(r, 0),
 // crow(r, 1)) per step); `w` = section VB / VC / VD already offset by the lane.
 template <int MAXR>

@@ -294,16 +294,17 @@ def test_model_lba_golden(G):
     close(pred.cpu(), f.o["pred"], atol=1e-4, rtol=1e-4)
 
 
-def test_interactions_large_vs_oracle(G):
-    """A bench-shaped (but smaller) layer: 2 000 nodes / 32 000 col-sorted edges, (128,16)/(32,4), fwd + bwd."""
+@pytest.mark.parametrize("n,e,dims", [(2000, 32000, (128, 16)), (600, 6000, (256, 32))], ids=["C2-dims", "C5-dims"])
+def test_interactions_large_vs_oracle(G, n, e, dims):
+    """Bench-shaped (but smaller) layers, col-sorted edges, edge dims (32,4), fwd + bwd: BASELINE configs[1] dims (128,16)
+    (register-resident chain kernels) and configs[4] dims (256,32) (two output groups: block-by-block kernels)."""
     torch.manual_seed(11)
-    n, e = 2000, 32000
-    layer = G.GCPInteractions((128, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
+    layer = G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
                               dropout=0.0).cuda().eval()
     ei, x = rand_graph(n, e, 12, sort_by_col=True)
     fr = O.localize(x, ei)
     g = torch.Generator().manual_seed(13)
-    ins = dict(h=torch.randn(n, 128, generator=g), chi=torch.randn(n, 16, 3, generator=g),
+    ins = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g),
                e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
     P = {k: t.detach().cpu().clone().requires_grad_() for k, t in layer.state_dict().items()}
     ci = {k: t.clone().requires_grad_() for k, t in ins.items()}
