@@ -15,6 +15,7 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
+    "gcpnet_gcp2_forward_lds_bytes",
     "gcpnet_gcp2_chain_forward",
     "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
@@ -94,6 +95,8 @@ def load():
     lib.gcpnet_abi_version.restype = i32
     lib.gcpnet_gcp2_pack_floats.restype = i64
     lib.gcpnet_gcp2_pack_floats.argtypes = [i32] * 6
+    lib.gcpnet_gcp2_forward_lds_bytes.restype = i64
+    lib.gcpnet_gcp2_forward_lds_bytes.argtypes = [i32] * 6
     lib.gcpnet_pack_gcp2_weights.argtypes = [P(Gcp2Weights), vp, vp]
     lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), vp, vp, vp,
                                         vp, vp, vp, vp]
@@ -117,7 +120,7 @@ def load():
     lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats"):
+        if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes"):
             fn.restype = i32
     if lib.gcpnet_abi_version() != 1:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
             // Pre-projected inputs (node-level GEMMs done by the caller): their gathered rows are requested here, in the
             // accumulator layout, and added after the k loop -- the gather latency is spent under the MFMAs.
             f32x16 pre[NTG];
-            const bool has_add = p.s_add.n > 0;  // wave-uniform; only with a single output group and n == 1
+            const bool has_add = p.s_add.n > 0;  // wave-uniform; n == 1 only
             if (has_add) {
 #pragma unroll
                 for (int t = 0; t < NTG; ++t)
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
                     for (int t = 0; t < NTG; ++t)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float4 v = gcp_load4(p.s_add.ptr[k], src, so, 32 * t + 8 * q + 4 * hi, true, vec_so);
+                            const float4 v = gcp_load4(p.s_add.ptr[k], src, so, 32 * (g * NTG + t) + 8 * q + 4 * hi, true, vec_so);
                             pre[t][4 * q] += v.x; pre[t][4 * q + 1] += v.y; pre[t][4 * q + 2] += v.z; pre[t][4 * q + 3] += v.w;
                         }
                 }
@@ -672,6 +672,10 @@ extern "C" int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out
     return 0;
 }
 
+extern "C" int64_t gcpnet_gcp2_forward_lds_bytes(int si, int vi, int so, int vo, int hidden, int use_frames) {
+    return (int64_t)fwd_lds(gcp_shape(si, vi, so, vo, hidden, use_frames)).total * (int64_t)sizeof(float);
+}
+
 extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
                                    const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* s_add,
                                    const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre,
@@ -682,7 +686,6 @@ extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp
         if (s_add->n > GCP_MAX_SEG) return GCPNET_E_BADARG;
         for (int k = 0; k < s_add->n; ++k)
             if (!s_add->ptr[k] || s_add->dim[k] != w->so) return GCPNET_E_BADARG;
-        if (w->so > 128) return GCPNET_E_UNSUPPORTED;  // single output group only
     }
     if (rows == 0) return 0;
     if (check_concat(s_in, w->si)) return GCPNET_E_BADARG;

@@ -685,6 +685,23 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
     if res_v is not None:
         res_v = _req(res_v, "residual")
     proj = _projectable(spec, s_sources) if PROJECT_GATHERED_SCALARS else None
+    if proj is None:
+        wide = _too_wide(spec, s_sources)
+        if wide is not None:
+            # The 32 x (si + H + 9) merged tile of a wave does not fit in LDS (e.g. the second feed-forward GCP at (256,32):
+            # 1024 scalar inputs).  scalar_out is linear: the leading columns of the widest source go through a plain library
+            # GEMM and enter as an addend; the kernel reduces over the remaining columns.
+            k, cut = wide
+            w_scalar = weights[0]
+            dims = [t.shape[1] for t in s_sources]
+            off = sum(dims[:k])
+            src = s_sources[k]
+            add = torch.matmul(src[:, :cut], w_scalar[:, off:off + cut].t())
+            w_rest = torch.cat([w_scalar[:, :off], w_scalar[:, off + cut:]], dim=1)
+            s_sources = list(s_sources[:k]) + [src[:, cut:].contiguous()] + list(s_sources[k + 1:])
+            spec = replace(spec, si=spec.si - cut, pack_cache=None, add_plans=[spec.s_plans[k]])
+            weights = (w_rest,) + tuple(weights[1:])
+            return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, add)
     if proj is not None:
         # "Project, then gather": scalar_out is linear in its concatenated input, so the share of a GATHERED source
         # (h[row], h[col] in a message GCP, reference gcpnet.py:907-917) is computed once per source row -- a plain
@@ -707,10 +724,27 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
 PROJECT_GATHERED_SCALARS = True  # module switch (tests compare both paths)
 
 
+LDS_LIMIT = 160 * 1024
+
+
+def _too_wide(spec: Gcp2Spec, s_sources):
+    """(source index, leading columns to project) when the forward kernel's merged tile does not fit in LDS, else None."""
+    lib = _lib.load()
+    need = lambda si: lib.gcpnet_gcp2_forward_lds_bytes(si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames))
+    if spec.residual or spec.add_plans or need(spec.si) <= LDS_LIMIT:
+        return None
+    dims = [t.shape[1] for t in s_sources]
+    k = max(range(len(dims)), key=lambda i: dims[i])
+    cut = 0
+    while cut + 32 < dims[k] and need(spec.si - cut) > LDS_LIMIT // 2:  # leave room for two waves per CU
+        cut += 32
+    return (k, cut) if cut > 0 and need(spec.si - cut) <= LDS_LIMIT else None
+
+
 def _projectable(spec: Gcp2Spec, s_sources):
     """Which scalar sources are worth projecting at their source rows: gathered ones read by >= 2x more rows than they
     have; needs a single output group (so <= 128) and at least one source left for the kernel's own reduction."""
-    if spec.so > 128 or spec.residual or spec.add_plans:
+    if spec.residual or spec.add_plans:
         return None
     gath = [k for k, pl in enumerate(spec.s_plans) if pl is not None and pl.rows >= 2 * s_sources[k].shape[0]]
     rest = [k for k in range(len(s_sources)) if k not in gath]

@@ -89,7 +89,10 @@ int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out, void* str
  * s_add (optional): scalar inputs whose share of scalar_out was computed beforehand at their source rows
  * ("project, then gather": for a message GCP over [h_row | e | h_col] the two node terms are node-level GEMMs, 16x
  * fewer rows than edges): s_add->ptr[k] is a [n_src, so] table, s_add->idx[k] the gather (NULL = row r), dim[k] = so;
- * s_pre = scalar_out([s_in | norms | frame scalars]) + sum_k table_k[idx_k[r]].  Needs so <= 128. */
+ * s_pre = scalar_out([s_in | norms | frame scalars]) + sum_k table_k[idx_k[r]].
+ * gcpnet_gcp2_forward_lds_bytes: LDS a wave-tile of these dims needs (the kernel returns GCPNET_E_UNSUPPORTED above 160 KB:
+ * the 32 x (si + H + 9) merged tile is the large term; a caller can shrink si by pre-projecting columns into s_add). */
+int64_t gcpnet_gcp2_forward_lds_bytes(int si, int vi, int so, int vo, int hidden, int use_frames);
 int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
                         const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* s_add,
                         const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre, float* gate,
