@@ -55,7 +55,7 @@ struct ChainBwdParams {
 
 struct CbLds {
     int VS, HS, FS, DS;
-    int o_vt, o_x, o_dvt, o_vht, o_fr, o_dext, o_e3, total;
+    int o_vt, o_x, o_dvt, o_vht, o_fr, o_dext, o_e3, o_stage, total;
 };
 
 __host__ __device__ inline CbLds cb_lds(const GcpShape& s) {
@@ -71,7 +71,8 @@ __host__ __device__ inline CbLds cb_lds(const GcpShape& s) {
     l.o_fr = l.o_vht + 32 * l.HS;
     l.o_dext = l.o_fr + 32 * 9;
     l.o_e3 = l.o_dext + 32 * l.DS;
-    l.total = l.o_e3 + 32 * 3;
+    l.o_stage = l.o_e3 + 32 * 3;
+    l.total = l.o_stage + GCP_ACC_STAGE_HALF_FLOATS;
     return l;
 }
 
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     float* dvt = lds + L.o_dvt;    // d(V) chain state, [row][channel][xyz]
     float* dext = lds + L.o_dext;  // d(norms | frame scalars): from the lanes of the scalar_out adjoint to the vh / vf channels' lanes
     float* e3t = lds + L.o_e3;     // signs of the x_cross projections (e3 variant only)
+    float* stage = lds + L.o_stage;  // transposition tile of the row-wise stores (tile_io.h, gcp_store_acc_rows)
     const int so = S.so, vi = S.vi, H = S.H, HF = S.HF;  // si == so, vo == vi
     const int EP = gcp_round_up(S.H + S.nf, 4), VOP = gcp_round_up(vi, 4);
     const float slope = p.o.slope;
@@ -323,12 +325,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < NTG; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                gcp_store4(it.ds_pre, row, so, 32 * t + 8 * q + 4 * hi,
-                           make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]), row_ok, true);
+        gcp_store_acc_rows_half<NTG>(it.ds_pre, so, 0, so, r0, rows, spr, stage, lane);
 
         // ---- E. d(s) += W^T ds_pre: 16 * NTG k-pair steps whose B operands are the ds_pre registers; the weight
         //         fragments rotate through three batches of 4 steps, requested two batches ahead and pinned there ------
@@ -371,14 +368,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
 
-        if (k == 0) {  // first block of the chain: d(s) leaves the chip
-#pragma unroll
-            for (int t = 0; t < NTG; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    gcp_store4(p.d_s_in, row, so, 32 * t + 8 * q + 4 * hi,
-                               make_float4(dyr[t][4 * q], dyr[t][4 * q + 1], dyr[t][4 * q + 2], dyr[t][4 * q + 3]), row_ok, true);
-        }
+        if (k == 0) gcp_store_acc_rows_half<NTG>(p.d_s_in, so, 0, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
 
         // ---- F. adjoint of the vector prologue: d[vh | vf] = Wu^T dvu + (norm and frame-scalar terms), d(V) += Wdf^T d[vh | vf] ---

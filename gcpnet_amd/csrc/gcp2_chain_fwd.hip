@@ -43,7 +43,7 @@ struct ChainParams {
 
 struct ChainLds {
     int VS, XS;
-    int o_vt, o_fr, o_ext, o_ust, total;
+    int o_vt, o_fr, o_ext, o_ust, o_stage, total;
 };
 
 __host__ __device__ inline ChainLds chain_lds(const GcpShape& s) {
@@ -54,7 +54,8 @@ __host__ __device__ inline ChainLds chain_lds(const GcpShape& s) {
     l.o_fr = l.o_vt + 32 * l.VS;
     l.o_ext = l.o_fr + 32 * 9;
     l.o_ust = l.o_ext + 32 * l.XS;
-    l.total = l.o_ust + s.SVB * 3 * 64;  // vector_down outputs parked between the vector prologue and epilogue
+    l.o_stage = l.o_ust + s.SVB * 3 * 64;  // (ust: vector_down outputs parked between the vector prologue and epilogue)
+    l.total = l.o_stage + GCP_ACC_STAGE_FLOATS;
     return l;
 }
 
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
     float* fr = lds + L.o_fr;
     float* ext = lds + L.o_ext;
     float* ust = lds + L.o_ust;
+    float* stage = lds + L.o_stage;
     const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H;
     const int NX = gcp_round_up(H + S.nf, 2) / 2;  // k-pair steps over the norms / frame scalars
     const float slope = p.o.slope;
@@ -232,20 +234,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
         }
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
+        if (it.s_pre) gcp_store_acc_rows<NT>(it.s_pre, so, 0, so, r0, rows, acc, stage, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j0 = 32 * t + 8 * q + 4 * hi;
-                if (it.s_pre)
-                    gcp_store4(it.s_pre, row, so, j0,
-                               make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), row_ok, vec_so);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) xs[t][4 * q + x] += gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][4 * q + x]);
-                if (it.s_out)
-                    gcp_store4(it.s_out, row, so, j0,
-                               make_float4(xs[t][4 * q], xs[t][4 * q + 1], xs[t][4 * q + 2], xs[t][4 * q + 3]), row_ok, vec_so);
-            }
+            for (int r = 0; r < 16; ++r) xs[t][r] += gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][r]);
+        if (it.s_out) gcp_store_acc_rows<NT>(it.s_out, so, 0, so, r0, rows, xs, stage, lane);
 
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
         // ---- vector epilogue: vector_up on the matrix cores (B fragments = the parked vector_down outputs), then sigmoid

@@ -238,3 +238,84 @@ __device__ __forceinline__ void gcp_store4(float* base, int64_t row, int ld, int
     if (j0 + 2 < ld) p[2] = v.z;
     if (j0 + 3 < ld) p[3] = v.w;
 }
+
+// Stores NT 32x32 accumulator tiles (C/D layout: register r of lane (row = lane & 31, half) holds column crow(r, half)) to
+// dst[(r0 + row) * ld + col0 + 32 t + column], through a wave-private 32 x 36 LDS staging tile, one 32-column tile at a time.
+// Why not store the registers directly (16 bytes per lane at column 8 q + 4 half): each such instruction writes 32-byte
+// pieces of 32 different rows, i.e. a quarter of a 128-byte line per request, and HBM write throughput drops to ~2.4 TB/s
+// (tools/ubench/tile_access.hip); after the LDS transposition every instruction writes eight full 128-byte lines (4.5 TB/s).
+#define GCP_ACC_STAGE_FLOATS (32 * 36)
+template <int NT>
+__device__ __forceinline__ void gcp_store_acc_rows(float* __restrict__ dst, int ld, int col0, int width, int r0, int rows,
+                                                   const f32x16 (&acc)[NT], float* stage, int lane) {
+    const int e = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 3, c4 = 4 * (lane & 7);
+    const bool vec = (ld & 3) == 0 && (col0 & 3) == 0 && gcp_aligned16(dst);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(stage + e * 36 + 8 * q + 4 * hi) =
+                make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const float4*>(stage + (8 * j + sub) * 36 + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 8 * j + sub, c = 32 * t + c4;
+            if (row < rows) {
+                float* p = dst + (int64_t)row * ld + col0 + c;
+                if (vec && c + 3 < width) {
+                    *reinterpret_cast<float4*>(p) = w[j];
+                } else {
+                    if (c + 0 < width) p[0] = w[j].x;
+                    if (c + 1 < width) p[1] = w[j].y;
+                    if (c + 2 < width) p[2] = w[j].z;
+                    if (c + 3 < width) p[3] = w[j].w;
+                }
+            }
+        }
+    }
+}
+
+// Same through a 32 x 20 staging tile (2.5 KB): half tiles at a time, 64-byte pieces per row, 16 rows per store instruction
+// (4.1 TB/s in tools/ubench/tile_access.hip) -- for kernels whose occupancy is bound by LDS.
+#define GCP_ACC_STAGE_HALF_FLOATS (32 * 20)
+template <int NT>
+__device__ __forceinline__ void gcp_store_acc_rows_half(float* __restrict__ dst, int ld, int col0, int width, int r0, int rows,
+                                                        const f32x16 (&acc)[NT], float* stage, int lane) {
+    const int e = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 2, c4 = 4 * (lane & 3);
+    const bool vec = (ld & 3) == 0 && (col0 & 3) == 0 && gcp_aligned16(dst);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous piece's reads are done
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                *reinterpret_cast<float4*>(stage + e * 20 + 8 * q + 4 * hi) =
+                    make_float4(acc[t][8 * h + 4 * q], acc[t][8 * h + 4 * q + 1], acc[t][8 * h + 4 * q + 2], acc[t][8 * h + 4 * q + 3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float4 w[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const float4*>(stage + (16 * j + sub) * 20 + c4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = r0 + 16 * j + sub, c = 32 * t + 16 * h + c4;
+                if (row < rows) {
+                    float* p = dst + (int64_t)row * ld + col0 + c;
+                    if (vec && c + 3 < width) {
+                        *reinterpret_cast<float4*>(p) = w[j];
+                    } else {
+                        if (c + 0 < width) p[0] = w[j].x;
+                        if (c + 1 < width) p[1] = w[j].y;
+                        if (c + 2 < width) p[2] = w[j].z;
+                        if (c + 3 < width) p[3] = w[j].w;
+                    }
+                }
+            }
+        }
+}
