@@ -370,6 +370,7 @@ class _Gcp2(torch.autograd.Function):
             ctx.spec, ctx.rows, ctx.n_s, ctx.n_v = spec, rows, n_s, n_v
             ctx.frames = frames
             ctx.has_res = (tensors[n_s + n_v] is not None, tensors[n_s + n_v + 1] is not None)
+            ctx.w_leaf = all(t is None or t.is_leaf for t in w)  # nothing downstream of the weight gradients in this backward
             ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate)
         if spec.vo:
             return s_out, v_out
@@ -392,7 +393,7 @@ class _Gcp2(torch.autograd.Function):
                                                  d_v_out, need_w=any(need_w))
         wgrads = [None] * 7
         if any(need_w):
-            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr)
+            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr, in_backward_of_leaves=ctx.w_leaf)
 
         # ---- input gradients: un-concatenate, scatter-add the gathered sources back to their rows -----------------
         grads_s: List[Optional[Tensor]] = []
@@ -537,12 +538,45 @@ class _WeightGradJob:
                 g[3] = wv[o2:].view(3, vi)
 
     def grads(self) -> List[Optional[Tensor]]:
-        """(scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up, gate.weight, gate.bias)"""
-        return self.g
+        """(scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up, gate.weight, gate.bias).
+        Hands the tensors over: the job keeps no reference, so that autograd can take them as .grad without a copy (and
+        without reading them on its own stream before the weight-gradient stream has written them)."""
+        g, self.g = self.g, None
+        return g
 
 
-def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob]) -> None:
-    """Launches the TN GEMMs of several blocks, up to 8 problems per launch."""
+WEIGHT_GRADS_ON_SIDE_STREAM = True  # module switch
+_side_streams: dict = {}
+_side_pending: list = []
+
+
+def _join_side_stream():
+    """End-of-backward callback: the caller's stream waits for the weight-gradient stream; scratch is released."""
+    for main, side in {(m, s) for m, s, _ in _side_pending}:
+        main.wait_stream(side)
+    _side_pending.clear()
+
+
+def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: bool = False) -> None:
+    """Launches the TN GEMMs of several blocks, up to 8 problems per launch.
+
+    Weight gradients are off the critical path of the backward pass (nothing downstream reads them when the weights are leaf
+    parameters), so from inside autograd they are enqueued on a second HIP stream: they then run concurrently with the data-path
+    kernels of the following blocks, which on their own leave most CUs idle for node-row launches.  The caller's stream
+    joins that stream in a callback at the end of the backward pass (before any optimizer / all-reduce can touch .grad)."""
+    if in_backward_of_leaves and WEIGHT_GRADS_ON_SIDE_STREAM and jobs:
+        dev = torch.cuda.current_device()
+        main = torch.cuda.current_stream()
+        side = _side_streams.get(dev)
+        if side is None:
+            side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)  # the operands (backward-kernel outputs) are ready
+        if not _side_pending:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+        _side_pending.append((main, side, [j.keep for j in jobs]))  # operands / partial buffers stay alive until the join
+        with torch.cuda.stream(side):
+            run_weight_grad_jobs(jobs)
+        return
     lib = _lib.load()
     probs = [pr for j in jobs for pr in j.probs]
     for i in range(0, len(probs), _lib.TN_MAX_PROBLEMS):
@@ -556,9 +590,9 @@ def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob]) -> None:
         check(lib.gcpnet_reduce_partials(len(chunk), arr, _stream()), "reduce_partials")
 
 
-def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t) -> List[Optional[Tensor]]:
+def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t, in_backward_of_leaves: bool = False) -> List[Optional[Tensor]]:
     job = _WeightGradJob(spec, rows, s_src, s_pre, t)
-    run_weight_grad_jobs([job])
+    run_weight_grad_jobs([job], in_backward_of_leaves)
     return job.grads()
 
 
@@ -595,6 +629,7 @@ class _Gcp2Chain(torch.autograd.Function):
         if need_grad:
             ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
             ctx.state = (s0, v0, ws, packs, outs)
+            ctx.w_leaf = all(t is None or t.is_leaf for t in weights)
         return outs[-1][0], outs[-1][1]
 
     @staticmethod
@@ -626,7 +661,7 @@ class _Gcp2Chain(torch.autograd.Function):
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
         if live:
-            run_weight_grad_jobs(live)
+            run_weight_grad_jobs(live, in_backward_of_leaves=ctx.w_leaf)
         wgrads: List[Optional[Tensor]] = []
         for k in range(n):
             g = jobs[k].grads() if jobs[k] is not None else [None] * 7
