@@ -721,17 +721,20 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
         res_v = _req(res_v, "residual")
     proj = _projectable(spec, s_sources) if PROJECT_GATHERED_SCALARS else None
     if proj is None:
-        wide = _too_wide(spec, s_sources)
+        rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_sources[0].shape[0]
+        wide = _too_wide(spec, s_sources, rows)
         if wide is not None:
-            # The 32 x (si + H + 9) merged tile of a wave does not fit in LDS (e.g. the second feed-forward GCP at (256,32):
-            # 1024 scalar inputs).  scalar_out is linear: the leading columns of the widest source go through a plain library
-            # GEMM and enter as an addend; the kernel reduces over the remaining columns.
+            # scalar_out is linear, so leading columns of the widest source can go through a plain library GEMM and enter as
+            # an addend; the kernel reduces over the remaining columns.  Done (a) when the 32 x (si + H + 9) merged tile of a
+            # wave does not fit in LDS (the second feed-forward GCP at (256,32): 1024 scalar inputs) and (b) for launches of
+            # few rows (node rows: 313 wave-tiles for 1024 SIMDs), where the wave-per-tile kernel is latency-bound on its
+            # serial k loop while the library GEMM spreads the same FLOPs over the whole chip.
             k, cut = wide
             w_scalar = weights[0]
             dims = [t.shape[1] for t in s_sources]
             off = sum(dims[:k])
             src = s_sources[k]
-            add = torch.matmul(src[:, :cut], w_scalar[:, off:off + cut].t())
+            add = _Project.apply(src[:, :cut], w_scalar[:, off:off + cut])
             w_rest = torch.cat([w_scalar[:, :off], w_scalar[:, off + cut:]], dim=1)
             s_sources = list(s_sources[:k]) + [src[:, cut:].contiguous()] + list(s_sources[k + 1:])
             spec = replace(spec, si=spec.si - cut, pack_cache=None, add_plans=[spec.s_plans[k]])
@@ -746,7 +749,7 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
         w_scalar = weights[0]
         dims = [t.shape[1] for t in s_sources]
         offs = [sum(dims[:k]) for k in range(len(dims))]
-        adds = [torch.matmul(s_sources[k], w_scalar[:, offs[k]:offs[k] + dims[k]].t()) for k in gath]
+        adds = [_Project.apply(s_sources[k], w_scalar[:, offs[k]:offs[k] + dims[k]]) for k in gath]
         w_rest = torch.cat([w_scalar[:, offs[k]:offs[k] + dims[k]] for k in rest] + [w_scalar[:, spec.si:]], dim=1)
         spec = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=None,
                        add_plans=[spec.s_plans[k] for k in gath])
@@ -756,20 +759,69 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
     return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights)
 
 
-PROJECT_GATHERED_SCALARS = True  # module switch (tests compare both paths)
+PROJECT_GATHERED_SCALARS = True  # module switches (tests compare both paths)
+PROJECT_SMALL_LAUNCHES = False  # measured: no gain at 10 000 node rows (extra small launches cost what the shorter k loop saves)
+
+
+class _Project(torch.autograd.Function):
+    """P = x @ w^T for x [n, dim] (a column slice of a source is fine) and w [so, dim] (a column slice of scalar_out.weight):
+    the forward and the input gradient are plain library GEMMs; the weight gradient dP^T x reduces over the n rows and goes
+    through gcpnet_tn_gemm (row-split, deterministic), which a BLAS call without split-K handles poorly at n ~ 1e4."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.matmul(x, w.t())
+
+    @staticmethod
+    def backward(ctx, dP):
+        x, w = ctx.saved_tensors
+        dx = torch.matmul(dP, w) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dP = _req(dP, "grad")
+            n, so = dP.shape
+            dim = x.shape[1]
+            ok = (x.stride(1) == 1 and x.stride(0) % 4 == 0 and dim % 4 == 0 and so % 4 == 0 and x.data_ptr() % 16 == 0 and n > 0)
+            if not ok:
+                dw = torch.matmul(dP.t(), x)
+            else:
+                lib = _lib.load()
+                a, b = Operand(), Operand()
+                a.n, b.n = 1, 1
+                a.ptr[0], a.dim[0], a.ld[0] = dP.data_ptr(), so, so
+                b.ptr[0], b.dim[0], b.ld[0] = x.data_ptr(), dim, x.stride(0)
+                dw = torch.empty((so, dim), dtype=torch.float32, device=dP.device)
+                pr = TnProblem()
+                pr.rows, pr.a, pr.b = n, a, b
+                pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = dw.data_ptr(), dim, 1, so, dim
+                pr.out2, pr.out2_n = None, 0
+                pr.splits = lib.gcpnet_tn_splits(n, so, dim)
+                part = torch.empty((pr.splits, so, dim), dtype=torch.float32, device=dP.device)
+                pr.partial = part.data_ptr()
+                check(lib.gcpnet_tn_gemm(1, C.byref(pr), _stream()), "tn_gemm")
+        return dx, dw
 
 
 LDS_LIMIT = 160 * 1024
 
 
-def _too_wide(spec: Gcp2Spec, s_sources):
-    """(source index, leading columns to project) when the forward kernel's merged tile does not fit in LDS, else None."""
+SMALL_LAUNCH_ROWS = 32768  # below this a launch has fewer wave-tiles (rows / 32) than the chip has SIMDs
+SPLIT_KEEP_COLUMNS = 32
+
+
+def _too_wide(spec: Gcp2Spec, s_sources, rows: int):
+    """(source index, leading columns to project), see gcp2(); None to leave the block as it is."""
     lib = _lib.load()
     need = lambda si: lib.gcpnet_gcp2_forward_lds_bytes(si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames))
-    if spec.residual or spec.add_plans or need(spec.si) <= LDS_LIMIT:
+    if spec.residual or spec.add_plans:
         return None
     dims = [t.shape[1] for t in s_sources]
     k = max(range(len(dims)), key=lambda i: dims[i])
+    if need(spec.si) <= LDS_LIMIT:
+        if PROJECT_SMALL_LAUNCHES and rows <= SMALL_LAUNCH_ROWS and dims[k] >= 3 * SPLIT_KEEP_COLUMNS and dims[k] % 4 == 0:
+            return k, (dims[k] - SPLIT_KEEP_COLUMNS) // 32 * 32
+        return None
     cut = 0
     while cut + 32 < dims[k] and need(spec.si - cut) > LDS_LIMIT // 2:  # leave room for two waves per CU
         cut += 32
