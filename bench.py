@@ -118,26 +118,26 @@ def pmc_traffic(kernel):
         return None
 
 
-def aggregate_roofline(G, ops, dev, n_nodes, n_edges, sdim, iters=50):
-    """The gather / aggregate kernel (scatter-mean of the edge messages onto their target nodes, gcpnet.py:946) against the
-    HBM roofline: algorithmic bytes = E * s_dim * 4 read + N * s_dim * 4 written."""
-    plan = ops.GraphPlan.get(dev["edge_index"], n_nodes)
-    msg = torch.randn(n_edges, sdim, device="cuda")
-    col_plan = plan.col if hasattr(plan, "col") else None
-    if col_plan is None:
-        return None
+def aggregate_roofline(G, ops, n_nodes, n_edges, width, label, iters=30):
+    """The gather / aggregate kernel (scatter-mean of the edge messages [E, s + 3V] onto their target nodes, gcpnet.py:946)
+    against the HBM roofline: algorithmic bytes = (E + N) * width * 4 (+ the CSR pointers)."""
+    from gcpnet_amd.synthetic import make_inputs
+    g = torch.Generator(device="cuda").manual_seed(1)
+    col = torch.sort(torch.randint(0, n_nodes, (n_edges,), device="cuda", generator=g)).values
+    plan = ops.GatherPlan(col, n_nodes)
+    msg = torch.randn(n_edges, width, device="cuda", generator=g)
     for _ in range(3):
-        ops.segment_reduce(msg, col_plan, True)
+        ops.segment_reduce(msg, plan, True)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     a.record()
     for _ in range(iters):
-        ops.segment_reduce(msg, col_plan, True)
+        ops.segment_reduce(msg, plan, True)
     b.record()
     torch.cuda.synchronize()
     t = a.elapsed_time(b) / iters * 1e-3
-    nbytes = 4.0 * sdim * (n_edges + n_nodes)
-    return {"kernel": "segment_reduce_kernel<mean> (edge messages -> nodes)", "bound": "hbm", "achieved": nbytes / t / 1e9,
+    nbytes = 4.0 * width * (n_edges + n_nodes) + 4.0 * (n_nodes + 1)
+    return {"kernel": "segment_reduce_kernel<mean>", "workload": label, "bound": "hbm", "achieved": nbytes / t / 1e9,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "avg_launch_ms": t * 1e3,
             "bytes_per_launch": nbytes}
 
@@ -243,7 +243,12 @@ def main():
                 "all_kernels_tflops": {k: kr["flops"] / v / 1e12 for k, v in times.items()},
                 "all_kernels_algorithmic_hbm_gbs": {k: kbytes[k] / v / 1e9 for k, v in times.items()},
             },
-            "aggregate_kernel": aggregate_roofline(G, ops, dev, args.nodes, n_edges, args.sdim),
+            # the gather / aggregate kernel against the HBM roofline, at this run's size and at BASELINE configs[4]'s
+            # (100k nodes / 1M edges, (256,32): 1.5 GB per launch, far beyond the 256 MB Infinity Cache)
+            "aggregate_kernel": aggregate_roofline(G, ops, args.nodes, n_edges, args.sdim + 3 * args.vdim,
+                                                   f"{args.nodes} nodes / {n_edges} edges, width s+3V = {args.sdim + 3 * args.vdim}"),
+            "aggregate_kernel_c5": aggregate_roofline(G, ops, 100000, 1000000, 256 + 96,
+                                                      "100000 nodes / 1000000 edges, width s+3V = 352", iters=10),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(layers, host, args)

@@ -30,19 +30,25 @@ class GradAllReducer:
 
     @torch.no_grad()
     def all_reduce_mean(self):
+        """Gradients -> flat bucket (one multi-tensor copy), ONE all-reduce (averaging inside RCCL), and the parameters'
+        .grad become views of the bucket (no copy back): three launches per step instead of two per parameter tensor."""
         world = dist.get_world_size(self.group)
+        dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-            else:
-                v.copy_(p.grad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(world)
+            elif p.grad.data_ptr() != v.data_ptr():  # (already the bucket view when the caller accumulates in place)
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:  # gloo has no AVG
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(world)
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            p.grad = v
 
 
 def shard_graph_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
