@@ -569,7 +569,7 @@ def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: 
         main = torch.cuda.current_stream()
         side = _side_streams.get(dev)
         if side is None:
-            side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+            side = _side_streams[dev] = torch.cuda.Stream(device=dev)  # (this device only offers priorities {0, -1}: nothing below the default)
         side.wait_stream(main)  # the operands (backward-kernel outputs) are ready
         if not _side_pending:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
