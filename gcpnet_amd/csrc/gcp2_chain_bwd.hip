@@ -55,7 +55,7 @@ struct ChainBwdParams {
 
 struct CbLds {
     int VS, HS, FS, DS;
-    int o_vt, o_x, o_dvt, o_vht, o_fr, o_dext, o_e3, o_stage, total;
+    int o_vt, o_x, o_vht, o_fr, o_dext, o_e3, o_stage, total;
 };
 
 __host__ __device__ inline CbLds cb_lds(const GcpShape& s) {
@@ -66,8 +66,7 @@ __host__ __device__ inline CbLds cb_lds(const GcpShape& s) {
     l.DS = gcp_odd(s.H + s.nf);
     l.o_vt = 0;
     l.o_x = l.o_vt + 32 * l.VS;
-    l.o_dvt = l.o_x + 32 * (l.VS > l.FS ? l.VS : l.FS);
-    l.o_vht = l.o_dvt + 32 * l.VS;
+    l.o_vht = l.o_x + 32 * (l.VS > l.FS ? l.VS : l.FS);
     l.o_fr = l.o_vht + 32 * l.HS;
     l.o_dext = l.o_fr + 32 * 9;
     l.o_e3 = l.o_dext + 32 * l.DS;
@@ -119,7 +118,6 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     float* xt = lds + L.o_x;       // row-major copy of d(vector_up output), later of [d vh | d vf] (weight-gradient partials)
     float* vht = lds + L.o_vht;    // row-major copy of vector_down(v)
     float* fr = lds + L.o_fr;
-    float* dvt = lds + L.o_dvt;    // d(V) chain state, [row][channel][xyz]
     float* dext = lds + L.o_dext;  // d(norms | frame scalars): from the lanes of the scalar_out adjoint to the vh / vf channels' lanes
     float* e3t = lds + L.o_e3;     // signs of the x_cross projections (e3 variant only)
     float* stage = lds + L.o_stage;  // transposition tile of the row-wise stores (tile_io.h, gcp_store_acc_rows)
@@ -137,9 +135,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     // ---- prologue: everything the LAST block needs, plus the incoming gradients, in one memory round trip ----------
     {
         const ChainItemB& it = p.it[p.n - 1];
-        GcpSegBuf<8> vb, gb;
+        GcpSegBuf<8> vb;
         gcp_seg_issue(vb, it.v_in, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
-        gcp_seg_issue(gb, p.d_v_out, nullptr, 3 * vi, r0, rows, dvt, L.VS, 0, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
 #pragma unroll
         for (int q = 0; q < VQ; ++q) {
@@ -156,7 +153,6 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 dyr[t][4 * q] = b.x; dyr[t][4 * q + 1] = b.y; dyr[t][4 * q + 2] = b.z; dyr[t][4 * q + 3] = b.w;
             }
         gcp_seg_commit(vb, vt, L.VS, 0);
-        gcp_seg_commit(gb, dvt, L.VS, 0);
     }
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
@@ -168,6 +164,29 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         const ChainItemB& it = p.it[k];
         const float ns_s = gcp_neg_slope(it.act_s, slope), ns_v = gcp_neg_slope(it.act_v, slope);
         const bool stamp_here = k == 0;
+        // d(V) chain state: channel crow(r, hi) of row e, 12 consecutive floats per register quad.  It travels through the
+        // output buffer d_v_in between blocks (each lane re-reads exactly the 48 bytes it wrote itself a whole block earlier,
+        // so ordinary single-thread memory ordering applies; the lines come back from L2) -- 6 KB of LDS per wave less, which
+        // is what lets eight waves share a CU.
+        const float* state_src = (k == p.n - 1) ? p.d_v_out : p.d_v_in;
+        auto load_state = [&](float(&out)[3][NV]) {
+#pragma unroll
+            for (int q = 0; q < VQ; ++q) {
+                const int o0 = 8 * q + 4 * hi;
+                const bool on = row_ok && o0 < vi;
+                const float4* sp = reinterpret_cast<const float4*>(state_src + (on ? (int64_t)row * 3 * vi + 3 * o0 : 0));
+                float t[12];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float4 x = sp[j];
+                    t[4 * j] = on ? x.x : 0.f; t[4 * j + 1] = on ? x.y : 0.f; t[4 * j + 2] = on ? x.z : 0.f; t[4 * j + 3] = on ? x.w : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) out[d][4 * q + i] = t[3 * i + d];
+            }
+        };
         gcp_wave_lds_sync();
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
 
@@ -175,6 +194,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         //         (element-wise) go to the weight-gradient GEMM's operand `ext`; 1/|vh| and the e3 signs stay in registers --
         float dgr[NV];
         {
+            float dvs[3][NV];
+            load_state(dvs);
             gcp_xyz_acc u;
             gcp_vmm_down<10>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
             float f[9];
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 if (p.o.vector_residual) {
                     u0 += vt[e * L.VS + 3 * oc + 0]; u1 += vt[e * L.VS + 3 * oc + 1]; u2 += vt[e * L.VS + 3 * oc + 2];
                 }
-                const float g0 = dvt[e * L.VS + 3 * oc + 0], g1 = dvt[e * L.VS + 3 * oc + 1], g2 = dvt[e * L.VS + 3 * oc + 2];
+                const float g0 = dvs[0][r], g1 = dvs[1][r], g2 = dvs[2][r];
                 float d0 = g0, d1 = g1, d2 = g2, dg = 0.f;
                 const float dot = g0 * u0 + g1 * u1 + g2 * u2;
                 if (scalar_gate) {
@@ -417,21 +438,21 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_xyz_acc dv;
             gcp_xyz_zero(dv);
             gcp_vmm_regs<NX>(it.pack + S.offVD + lane, S.SVD, dacc, dv);
-            float st[3][NV];  // ResGCP pass-through + this block's contribution, in place in the state tile
+            float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
+            load_state(st);
 #pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const int oc = min(gcp_crow(r, hi), vi - 1);
+            for (int q = 0; q < VQ; ++q) {
+                const int o0 = 8 * q + 4 * hi;
+                float t[12];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) st[d][r] = dvt[e * L.VS + 3 * oc + d];
-            }
-#pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const int o = gcp_crow(r, hi);
-                if (o < vi) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        dvt[e * L.VS + 3 * o + d] = st[d][r] + dv[d][r] + (p.o.vector_residual ? dvu[d][r] : 0.f);
-                }
+                        t[3 * i + d] = st[d][4 * q + i] + dv[d][4 * q + i] + (p.o.vector_residual ? dvu[d][4 * q + i] : 0.f);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    gcp_store4(p.d_v_in, row, 3 * vi, 3 * o0 + 4 * j, make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]),
+                               row_ok && o0 < vi, vec_vo);
             }
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
@@ -457,8 +478,6 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         gcp_wave_lds_sync();
         if (k > 0) {
             gcp_seg_commit(vb, vt, L.VS, 0);
-        } else {  // d(V) leaves the chip
-            gcp_store_tile(p.d_v_in, 3 * vi, 0, 3 * vi, r0, rows, dvt, L.VS, lane);
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
     }
