@@ -46,7 +46,7 @@ class ChainItem(C.Structure):
 
 
 class BwdScratch(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ds_pre", "dgate", "ext", "w_part")]
+    _fields_ = [(n, C.c_void_p) for n in ("ds_pre", "dgate", "ext", "w_part", "dvhf")]
 
 
 class ChainBwdItem(C.Structure):
@@ -98,11 +98,11 @@ def load():
     lib.gcpnet_gcp2_forward_lds_bytes.restype = i64
     lib.gcpnet_gcp2_forward_lds_bytes.argtypes = [i32] * 6
     lib.gcpnet_pack_gcp2_weights.argtypes = [P(Gcp2Weights), vp, vp]
-    lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), vp, vp, vp,
-                                        vp, vp, vp, vp]
+    lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), P(Concat), vp,
+                                        vp, vp, vp, vp, vp, vp]
     lib.gcpnet_gcp2_chain_forward.argtypes = [i32, vp, vp, vp, i32, P(ChainItem), vp]
-    lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), vp, vp, vp, vp, vp,
-                                         vp, P(BwdScratch), vp]
+    lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), vp, vp, vp,
+                                         vp, vp, vp, P(BwdScratch), vp]
     lib.gcpnet_gcp2_chain_backward.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp]
     lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]
     lib.gcpnet_tn_splits.argtypes = [i32, i32, i32]

@@ -19,6 +19,7 @@ namespace {
 struct BwdParams {
     int rows;
     gcp_concat_t v_in;
+    gcp_concat_t v_add;  // pre-projected vector inputs, as in the forward (gcp2_fwd.hip)
     const float* frames;
     gcp2_weights_t w;
     gcp2_opts_t o;
@@ -172,6 +173,17 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     }
     gcp_wave_lds_sync();
     FSTAMP(3);
+    // rows of the pre-projected vector tables this lane's row gathers ([n_src, 3, HF'] each)
+    const int HFPQ = gcp_round_up(HF, 4);
+    const float* vq[GCP_MAX_SEG];
+#pragma unroll
+    for (int k = 0; k < GCP_MAX_SEG; ++k) {
+        vq[k] = nullptr;
+        if (k < p.v_add.n) {
+            const int rc = min(row, rows - 1);
+            vq[k] = p.v_add.ptr[k] + (p.v_add.idx[k] ? (int64_t)p.v_add.idx[k][rc] : (int64_t)rc) * 3 * HFPQ;
+        }
+    }
     if (has_vec) {
         const float* vrow = vt + e * L.VS;
         for (int h = hi; h < H; h += 2) {
@@ -182,6 +194,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 a0 = fmaf(w, vrow[3 * c + 0], a0);
                 a1 = fmaf(w, vrow[3 * c + 1], a1);
                 a2 = fmaf(w, vrow[3 * c + 2], a2);
+            }
+            for (int k = 0; k < p.v_add.n; ++k) {  // shares of the pre-projected (gathered) sources
+                a0 += vq[k][0 * HFPQ + h]; a1 += vq[k][1 * HFPQ + h]; a2 += vq[k][2 * HFPQ + h];
             }
             vht[e * L.HS + 3 * h + 0] = a0;
             vht[e * L.HS + 3 * h + 1] = a1;
@@ -206,6 +221,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                     a0 = fmaf(w, vrow[3 * c + 0], a0);
                     a1 = fmaf(w, vrow[3 * c + 1], a1);
                     a2 = fmaf(w, vrow[3 * c + 2], a2);
+                }
+                for (int q = 0; q < p.v_add.n; ++q) {
+                    a0 += vq[q][0 * HFPQ + H + k]; a1 += vq[q][1 * HFPQ + H + k]; a2 += vq[q][2 * HFPQ + H + k];
                 }
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -603,6 +621,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
         dvhf[e * L.FS + 2 * HF + H + k] = a2;
     }
     gcp_wave_lds_sync();
+    if (p.sc.dvhf && row_ok)  // d[vh | vf] per row, [3, HF'] xyz-major: the gradient of the pre-projected vector tables
+        for (int i = hi; i < 3 * HFPQ; i += 2) {
+            const int d = i / HFPQ, x = i - d * HFPQ;
+            p.sc.dvhf[(int64_t)row * 3 * HFPQ + i] = x < HF ? dvhf[e * L.FS + d * HF + x] : 0.f;
+        }
     if (row_ok) {
         for (int c = hi; c < vi; c += 2) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -712,7 +735,7 @@ int launch_ntg(const BwdParams& p, size_t lds_bytes, hipStream_t st) {
 extern "C" int gcpnet_gcp2_bwd_tiles(int rows) { return rows <= 0 ? 0 : gcp_cdiv(rows, GCP_TILE_ROWS); }
 
 extern "C" int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
-                                    const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* s_pre,
+                                    const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* v_add, const float* s_pre,
                                     const float* gate, const float* d_s_out, const float* d_v_out, float* d_s_in,
                                     float* d_v_in, const gcp2_bwd_scratch_t* sc, void* stream) {
     (void)s_in;
@@ -729,6 +752,13 @@ extern "C" int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gc
     BwdParams p;
     p.rows = rows;
     if (has_vec) p.v_in = *v_in; else p.v_in.n = 0;
+    p.v_add.n = 0;
+    if (v_add && v_add->n > 0) {
+        if (!has_vec || v_add->n > GCP_MAX_SEG || !sc->dvhf) return GCPNET_E_BADARG;
+        for (int k = 0; k < v_add->n; ++k)
+            if (!v_add->ptr[k] || v_add->dim[k] != gcp_round_up(w->hidden + (w->use_frames ? 3 : 0), 4)) return GCPNET_E_BADARG;
+        p.v_add = *v_add;
+    }
     p.frames = frames;
     p.w = *w;
     p.o = *opts;

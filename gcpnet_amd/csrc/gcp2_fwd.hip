@@ -47,6 +47,7 @@ struct FwdParams {
     gcp2_opts_t o;  // shared: slope, vmode, vector_residual, e3 (activations are per item)
     int n;
     ChainItem it[GCP_MAX_CHAIN];
+    gcp_concat_t v_add;  // pre-projected vector inputs: rows of [n_src, 3, HFP] tables gathered and added to [vh | vf] (n == 1)
     gcp_concat_t s_add;  // pre-projected scalar inputs: rows of [n_src, so] tables gathered and added to s_pre (n == 1, NG == 1)
     const float* res_s;  // separate residual tensors (n == 1 only)
     const float* res_v;
@@ -183,8 +184,43 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
         // ---- 2. vector prologue: vh = vector_down(v) and its norms over xyz (gcpnet.py:420-421), vector_down_frames +
         //         scalarize (gcpnet.py:426-435, components/__init__.py:302,312) -> columns si.. of the merged tile -----------
         if (vmm) {
+            // pre-projected vector inputs (node-level products done by the caller): gathered rows of [n_src, 3, HFP] tables,
+            // requested before the product below and added to its result -- channels crow(r, hi) of this lane, four at a time
+            float qa[4][12];
+            const bool has_vadd = p.v_add.n > 0;  // wave-uniform
+            if (has_vadd) {
+                const int HFP = gcp_round_up(S.HF, 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) qa[q][j] = 0.f;
+                for (int k = 0; k < p.v_add.n; ++k) {
+                    const int32_t* ix = p.v_add.idx[k];
+                    const int rc = min(row, rows - 1);
+                    const float* trow = p.v_add.ptr[k] + (ix ? (int64_t)ix[rc] : (int64_t)rc) * 3 * HFP;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int x0 = 8 * q + 4 * hi;
+                        const bool on = x0 < S.HF;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const float4 t = *reinterpret_cast<const float4*>(trow + d * HFP + (on ? x0 : 0));
+                            qa[q][4 * d + 0] += on ? t.x : 0.f; qa[q][4 * d + 1] += on ? t.y : 0.f;
+                            qa[q][4 * d + 2] += on ? t.z : 0.f; qa[q][4 * d + 3] += on ? t.w : 0.f;
+                        }
+                    }
+                }
+            }
             gcp_xyz_acc u;
             gcp_vmm_down_loop(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
+            if (has_vadd) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) u[d][4 * q + i] += qa[q][4 * d + i];
+            }
             float f[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
@@ -678,7 +714,7 @@ extern "C" int64_t gcpnet_gcp2_forward_lds_bytes(int si, int vi, int so, int vo,
 
 extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
                                    const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* s_add,
-                                   const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre,
+                                   const gcp_concat_t* v_add, const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre,
                                    float* gate, void* stream) {
     if (rows < 0 || !s_out) return GCPNET_E_BADARG;
     if (int rc = check_weights(w, opts, w && w->vo > 0)) return rc;
@@ -705,6 +741,16 @@ extern "C" int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp
     p.n = 1;
     fill_item(p.it[0], *w, *opts, s_out, v_out, s_pre, gate);
     if (s_add && s_add->n > 0) p.s_add = *s_add; else p.s_add.n = 0;
+    p.v_add.n = 0;
+    if (v_add && v_add->n > 0) {
+        const GcpShape sv = gcp_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames);
+        if (v_add->n > GCP_MAX_SEG) return GCPNET_E_BADARG;
+        if (!sv.vmm) return GCPNET_E_UNSUPPORTED;  // the addends enter the MFMA form of the vector prologue
+        for (int k = 0; k < v_add->n; ++k)
+            if (!v_add->ptr[k] || v_add->dim[k] != gcp_round_up(sv.HF, 4) || (reinterpret_cast<uintptr_t>(v_add->ptr[k]) & 15))
+                return GCPNET_E_BADARG;
+        p.v_add = *v_add;
+    }
     p.res_s = res_s; p.res_v = res_v;
     p.fused_res = (res_s && s_in->n == 1 && !s_in->idx[0] && res_s == s_in->ptr[0] && w->si == w->so &&
                    (w->vo == 0 || (res_v && w->vi == w->vo && v_in->n == 1 && !v_in->idx[0] && res_v == v_in->ptr[0])))
@@ -745,6 +791,7 @@ extern "C" int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float*
     p.n = n;
     for (int k = 0; k < n; ++k) fill_item(p.it[k], items[k].w, items[k].o, items[k].s_out, items[k].v_out, items[k].s_pre, items[k].gate);
     p.s_add.n = 0;
+    p.v_add.n = 0;
     p.res_s = nullptr; p.res_v = nullptr;
     p.fused_res = 1;
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;

@@ -282,6 +282,8 @@ class Gcp2Spec:
     pack_cache: Optional[dict] = None
     # pre-projected scalar inputs ("project, then gather"): one gather plan (or None) per [n_src, so] table passed to _Gcp2
     add_plans: List[Optional[GatherPlan]] = field(default_factory=list)
+    # same for vector inputs: one plan per [n_src, 3, HF'] table ([vector_down ; vector_down_frames] applied at the source rows)
+    vadd_plans: List[Optional[GatherPlan]] = field(default_factory=list)
 
     @property
     def K(self):
@@ -335,7 +337,8 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
 
 
 class _Gcp2(torch.autograd.Function):
-    """inputs: spec, frames, then n_s scalar sources, n_v vector sources, res_s, res_v, 7 weights, n_add addend tables."""
+    """inputs: spec, frames, then n_s scalar sources, n_v vector sources, res_s, res_v, 7 weights, the scalar addend tables
+    (len(spec.add_plans)) and the vector addend tables (len(spec.vadd_plans))."""
 
     @staticmethod
     def forward(ctx, spec: Gcp2Spec, frames, *tensors):
@@ -345,8 +348,10 @@ class _Gcp2(torch.autograd.Function):
         v_src = list(tensors[n_s:n_s + n_v])
         res_s, res_v = tensors[n_s + n_v], tensors[n_s + n_v + 1]
         w = tuple(tensors[n_s + n_v + 2:n_s + n_v + 9])
-        adds = list(tensors[n_s + n_v + 9:])
-        assert len(adds) == len(spec.add_plans)
+        n_a = len(spec.add_plans)
+        adds = list(tensors[n_s + n_v + 9:n_s + n_v + 9 + n_a])
+        vadds = list(tensors[n_s + n_v + 9 + n_a:])
+        assert len(vadds) == len(spec.vadd_plans)
         rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_src[0].shape[0]
         dev = s_src[0].device
         pack = _pack(spec, w)
@@ -355,6 +360,7 @@ class _Gcp2(torch.autograd.Function):
         sc = _concat(s_src, spec.s_plans, False)
         vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
         ac = _concat(adds, spec.add_plans, False) if adds else None
+        vac = _vadd_concat(vadds, spec.vadd_plans) if vadds else None
         if spec.residual:
             res_s, res_v = s_src[0], (v_src[0] if n_v else None)
         need_grad = any(ctx.needs_input_grad)
@@ -364,14 +370,15 @@ class _Gcp2(torch.autograd.Function):
         gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
         gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
         check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts),
-                                      C.byref(ac) if ac is not None else None, _p(res_s), _p(res_v), _p(s_out), _p(v_out),
-                                      _p(s_pre), _p(gate), _stream()), "gcp2_forward")
+                                      C.byref(ac) if ac is not None else None, C.byref(vac) if vac is not None else None,
+                                      _p(res_s), _p(res_v), _p(s_out), _p(v_out), _p(s_pre), _p(gate), _stream()),
+              "gcp2_forward")
         if need_grad:
             ctx.spec, ctx.rows, ctx.n_s, ctx.n_v = spec, rows, n_s, n_v
             ctx.frames = frames
             ctx.has_res = (tensors[n_s + n_v] is not None, tensors[n_s + n_v + 1] is not None)
             ctx.w_leaf = all(t is None or t.is_leaf for t in w)  # nothing downstream of the weight gradients in this backward
-            ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate)
+            ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate, *vadds)
         if spec.vo:
             return s_out, v_out
         return s_out
@@ -383,6 +390,7 @@ class _Gcp2(torch.autograd.Function):
         s_src, v_src = list(saved[:n_s]), list(saved[n_s:n_s + n_v])
         w = tuple(saved[n_s + n_v:n_s + n_v + 7])
         pack, s_pre, gate = saved[n_s + n_v + 7:n_s + n_v + 10]
+        vadds = list(saved[n_s + n_v + 10:])
         f32 = dict(dtype=torch.float32, device=s_pre.device)
         d_s_out = _req(d_s_out, "grad") if d_s_out is not None else torch.zeros((rows, spec.so), **f32)
         if spec.vo:
@@ -390,7 +398,7 @@ class _Gcp2(torch.autograd.Function):
         si, vi = spec.si, spec.vi
         need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:2 + n_s + n_v + 9]
         d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
-                                                 d_v_out, need_w=any(need_w))
+                                                 d_v_out, need_w=any(need_w), vadds=vadds)
         wgrads = [None] * 7
         if any(need_w):
             wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr, in_backward_of_leaves=ctx.w_leaf)
@@ -421,11 +429,28 @@ class _Gcp2(torch.autograd.Function):
         ds_pre = scr["ds_pre"]
         grads_add = [ds_pre if pl is None else _segment_reduce_raw(ds_pre, 0, spec.so, spec.so, pl, False)
                      for pl in spec.add_plans]
-        return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads, *grads_add)
+        # pre-projected vector inputs enter [vh | vf] additively: their gradient is d[vh | vf], summed the same way
+        grads_vadd = []
+        for tb, pl in zip(vadds, spec.vadd_plans):
+            dq = scr["dvhf"]
+            width = dq.shape[1]
+            g = dq if pl is None else _segment_reduce_raw(dq, 0, width, width, pl, False)
+            grads_vadd.append(g.view(tb.shape))
+        return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads, *grads_add, *grads_vadd)
+
+
+def _vadd_concat(tables: Sequence[Tensor], plans: Sequence[Optional[GatherPlan]]) -> Concat:
+    c = Concat()
+    c.n = len(tables)
+    for k, (t, pl) in enumerate(zip(tables, plans)):
+        c.ptr[k] = t.data_ptr()
+        c.idx[k] = pl.idx.data_ptr() if pl is not None else None
+        c.dim[k] = t.shape[2]  # HF' (tables are [n_src, 3, HF'])
+    return c
 
 
 def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out,
-                       need_w: bool = True):
+                       need_w: bool = True, vadds: Sequence[Tensor] = ()):
     """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs)."""
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=s_pre.device)
@@ -437,9 +462,15 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     opts = _opts_struct(spec, fused_residual=spec.residual)
     sc = _concat(s_src, spec.s_plans, False)
     vc = _concat(v_src, spec.v_plans, True) if len(v_src) else Concat()
-    check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts), _p(s_pre),
-                                   _p(gate), _p(d_s_out), _p(d_v_out) if vo else None, _p(d_s_in), _p(d_v_in),
-                                   C.byref(scr), _stream()), "gcp2_backward")
+    vac = None
+    if len(vadds):
+        vac = _vadd_concat(vadds, spec.vadd_plans)
+        t["dvhf"] = torch.empty((rows, 3 * vadds[0].shape[2]), **f32)
+        scr.dvhf = t["dvhf"].data_ptr()
+    check(lib.gcpnet_gcp2_backward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts),
+                                   C.byref(vac) if vac is not None else None, _p(s_pre), _p(gate), _p(d_s_out),
+                                   _p(d_v_out) if vo else None, _p(d_s_in), _p(d_v_in), C.byref(scr), _stream()),
+          "gcp2_backward")
     return d_s_in, d_v_in, t
 
 
@@ -755,12 +786,82 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
                        add_plans=[spec.s_plans[k] for k in gath])
         weights = (w_rest,) + tuple(weights[1:])
         s_sources = [s_sources[k] for k in rest]
-        return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, *adds)
+        # The same for the vector inputs: vector_down and vector_down_frames are linear as well, so [vh | vf] of a gathered
+        # source (chi[row], chi[col]) is computed per source row -- [n_src, 3, V] x [V, H + 3] -- and the kernels add the
+        # gathered rows; the per-edge vector stage shrinks from V_in = 2 V + 4 to the un-gathered channels.
+        vproj = _v_projectable(spec, v_sources)
+        vadds: List[Tensor] = []
+        if vproj is not None:
+            vg, vr = vproj
+            w_down, w_frames = weights[2], weights[3]
+            chans = [t.shape[1] for t in v_sources]
+            voffs = [sum(chans[:k]) for k in range(len(chans))]
+            H = spec.hidden
+            hfp = (H + 3 + 3) // 4 * 4
+            for k in vg:
+                wseg = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]], w_frames[:, voffs[k]:voffs[k] + chans[k]]], dim=0)
+                wseg = torch.nn.functional.pad(wseg, (0, 0, 0, hfp - (H + 3)))  # [HF', V], zero rows past H + 3
+                vadds.append(_ProjectV.apply(v_sources[k], wseg))  # [n_src, 3, HF']
+            pick = lambda m: torch.cat([m[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1) if len(vr) > 1 else \
+                m[:, voffs[vr[0]]:voffs[vr[0]] + chans[vr[0]]].contiguous()
+            weights = (weights[0], weights[1], pick(w_down), pick(w_frames)) + tuple(weights[4:])
+            spec = replace(spec, vi=sum(chans[k] for k in vr), v_plans=[spec.v_plans[k] for k in vr],
+                           vadd_plans=[spec.v_plans[k] for k in vg])
+            v_sources = [v_sources[k] for k in vr]
+        return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, *adds, *vadds)
     return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights)
 
 
 PROJECT_GATHERED_SCALARS = True  # module switches (tests compare both paths)
 PROJECT_SMALL_LAUNCHES = False  # measured: no gain at 10 000 node rows (extra small launches cost what the shorter k loop saves)
+
+
+def _tn_weight_grad(a2d: Tensor, b2d: Tensor) -> Tensor:
+    """a2d^T b2d for row-major a2d [rows, M], b2d [rows, N] (M, N multiples of 4, 16-byte aligned) through gcpnet_tn_gemm."""
+    lib = _lib.load()
+    rows, M = a2d.shape
+    N = b2d.shape[1]
+    a, b = Operand(), Operand()
+    a.n, b.n = 1, 1
+    a.ptr[0], a.dim[0], a.ld[0] = a2d.data_ptr(), M, a2d.stride(0)
+    b.ptr[0], b.dim[0], b.ld[0] = b2d.data_ptr(), N, b2d.stride(0)
+    out = torch.empty((M, N), dtype=torch.float32, device=a2d.device)
+    pr = TnProblem()
+    pr.rows, pr.a, pr.b = rows, a, b
+    pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = out.data_ptr(), N, 1, M, N
+    pr.out2, pr.out2_n = None, 0
+    pr.splits = lib.gcpnet_tn_splits(rows, M, N)
+    part = torch.empty((pr.splits, M, N), dtype=torch.float32, device=a2d.device)
+    pr.partial = part.data_ptr()
+    check(lib.gcpnet_tn_gemm(1, C.byref(pr), _stream()), "tn_gemm")
+    return out
+
+
+class _ProjectV(torch.autograd.Function):
+    """Q[n, d, x] = sum_c W[x, c] v[n, c, d] for v [n, V, 3], W [HF', V]: [vector_down ; vector_down_frames] applied at the
+    source rows.  Forward and input gradient are plain library GEMMs on the xyz-major copy of v; the weight gradient reduces
+    over the 3 n rows and goes through gcpnet_tn_gemm (a BLAS call without split-K takes ~110 us for it at n = 1e4)."""
+
+    @staticmethod
+    def forward(ctx, v, w):
+        vt = v.transpose(1, 2).contiguous()  # [n, 3, V]
+        ctx.save_for_backward(vt, w)
+        return torch.matmul(vt, w.t())
+
+    @staticmethod
+    def backward(ctx, dq):
+        vt, w = ctx.saved_tensors
+        dq = _req(dq, "grad")
+        dv = torch.matmul(dq, w).transpose(1, 2) if ctx.needs_input_grad[0] else None  # [n, V, 3] (strided view)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            n, _, hfp = dq.shape
+            V = vt.shape[2]
+            if hfp % 4 == 0 and V % 4 == 0 and n > 0:
+                dw = _tn_weight_grad(dq.view(3 * n, hfp), vt.view(3 * n, V))
+            else:
+                dw = torch.matmul(dq.reshape(3 * n, hfp).t(), vt.reshape(3 * n, V))
+        return dv, dw
 
 
 class _Project(torch.autograd.Function):
@@ -826,6 +927,23 @@ def _too_wide(spec: Gcp2Spec, s_sources, rows: int):
     while cut + 32 < dims[k] and need(spec.si - cut) > LDS_LIMIT // 2:  # leave room for two waves per CU
         cut += 32
     return (k, cut) if cut > 0 and need(spec.si - cut) <= LDS_LIMIT else None
+
+
+PROJECT_GATHERED_VECTORS = True
+
+
+def _v_projectable(spec: Gcp2Spec, v_sources):
+    """Gathered vector sources worth projecting at their source rows (see gcp2()); the kernels' MFMA form of the vector
+    stage must apply (H + 3 <= 32, vo <= 32), frames in use, and at least one un-gathered source must remain."""
+    if not PROJECT_GATHERED_VECTORS or not spec.use_frames or spec.vi == 0 or spec.vo == 0 or spec.vo > 32:
+        return None
+    if spec.hidden + 3 > 32 or spec.vector_residual or spec.residual:
+        return None
+    gath = [k for k, pl in enumerate(spec.v_plans) if pl is not None and pl.rows >= 2 * v_sources[k].shape[0]]
+    rest = [k for k in range(len(v_sources)) if k not in gath]
+    if not gath or not rest:
+        return None
+    return gath, rest
 
 
 def _projectable(spec: Gcp2Spec, s_sources):

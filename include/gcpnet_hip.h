@@ -93,10 +93,14 @@ int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out, void* str
  * gcpnet_gcp2_forward_lds_bytes: LDS a wave-tile of these dims needs (the kernel returns GCPNET_E_UNSUPPORTED above 160 KB:
  * the 32 x (si + H + 9) merged tile is the large term; a caller can shrink si by pre-projecting columns into s_add). */
 int64_t gcpnet_gcp2_forward_lds_bytes(int si, int vi, int so, int vo, int hidden, int use_frames);
+/* v_add (optional): the same for the vector inputs: vector_down and vector_down_frames are linear too, so the shares of
+ * gathered sources (chi[row], chi[col]) are computed per source row; v_add->ptr[k] is a [n_src, 3, HF'] table
+ * ([vector_down ; vector_down_frames] W_k chi, xyz-major, HF' = H + 3 rounded up to 4, zero padded, dim[k] = HF'),
+ * added to [vh | vf] of the gathering row.  Needs H + 3 <= 32 and vo <= 32. */
 int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
                         const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* s_add,
-                        const float* res_s, const float* res_v, float* s_out, float* v_out, float* s_pre, float* gate,
-                        void* stream);
+                        const gcp_concat_t* v_add, const float* res_s, const float* res_v, float* s_out, float* v_out,
+                        float* s_pre, float* gate, void* stream);
 
 /* ---- chain of residual GCP2 blocks: x_k = x_{k-1} + GCP_k(x_{k-1}), k = 1..n (ResGCP, components/gcpnet.py:921-924).
  * One launch; the (s, V) state of a 32-row tile stays on chip between the blocks.  All blocks share the dims
@@ -128,11 +132,13 @@ typedef struct {
     float* dgate;
     float* ext;
     float* w_part;
+    float* dvhf;   /* optional [rows, 3, HF']: d[vh | vf] per row = the gradient of the v_add tables' gathered rows */
 } gcp2_bwd_scratch_t;
 int gcpnet_gcp2_bwd_tiles(int rows);
 
 int gcpnet_gcp2_backward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* v_in, const float* frames,
-                         const gcp2_weights_t* w, const gcp2_opts_t* opts, const float* s_pre, const float* gate,
+                         const gcp2_weights_t* w, const gcp2_opts_t* opts, const gcp_concat_t* v_add /* as in the forward */,
+                         const float* s_pre, const float* gate,
                          const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in,
                          const gcp2_bwd_scratch_t* scratch, void* stream);
 
