@@ -336,6 +336,36 @@ extern "C" int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const flo
     return 0;
 }
 
+// out[r, j] = sum_k in[r, k] W[k, j] for a tiny W (K * J <= 4096): the per-source-row side of the vector projections
+// ([3 n, H + 3] x [H + 3, V] and back), where a BLAS call picks tiles for shapes 100x larger and takes ~100 us.
+__global__ __launch_bounds__(256) void rows_matmul_small_kernel(int64_t rows, int K, int J, const float* __restrict__ in,
+                                                                int64_t ld_in, const float* __restrict__ W,
+                                                                float* __restrict__ out, int64_t ld_out) {
+    __shared__ float w[4096];
+    for (int i = threadIdx.x; i < K * J; i += 256) w[i] = W[i];
+    __syncthreads();
+    const int64_t total = rows * J;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / J;
+        const int j = (int)(i - r * J);
+        const float* x = in + r * ld_in;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[k * J + j], acc);
+        out[r * ld_out + j] = acc;
+    }
+}
+
+extern "C" int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,
+                                        int64_t ld_out, void* stream) {
+    if (rows < 0 || K <= 0 || J <= 0 || K * J > 4096 || !in || !W || !out) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    const int64_t nb = (rows * J + 255) / 256;
+    hipLaunchKernelGGL(rows_matmul_small_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, rows,
+                       K, J, in, ld_in, W, out, ld_out);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi,
                                  float* y, void* stream) {
     if (n < 0 || !b || !y) return GCPNET_E_BADARG;

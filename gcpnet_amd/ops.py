@@ -837,6 +837,19 @@ def _tn_weight_grad(a2d: Tensor, b2d: Tensor) -> Tensor:
     return out
 
 
+def _rows_matmul_small(x2d: Tensor, w: Tensor) -> Tensor:
+    """x2d [rows, K] @ w [K, J] for a tiny w (gcpnet_rows_matmul_small); a library GEMM when w is not tiny."""
+    K, J = w.shape
+    if K * J > 4096:
+        return torch.matmul(x2d, w)
+    lib = _lib.load()
+    x2d = _req(x2d, "rows")
+    out = torch.empty((x2d.shape[0], J), dtype=torch.float32, device=x2d.device)
+    check(lib.gcpnet_rows_matmul_small(x2d.shape[0], K, J, _p(x2d), x2d.stride(0), _p(w), _p(out), J, _stream()),
+          "rows_matmul_small")
+    return out
+
+
 class _ProjectV(torch.autograd.Function):
     """Q[n, d, x] = sum_c W[x, c] v[n, c, d] for v [n, V, 3], W [HF', V]: [vector_down ; vector_down_frames] applied at the
     source rows.  Forward and input gradient are plain library GEMMs on the xyz-major copy of v; the weight gradient reduces
@@ -846,13 +859,15 @@ class _ProjectV(torch.autograd.Function):
     def forward(ctx, v, w):
         vt = v.transpose(1, 2).contiguous()  # [n, 3, V]
         ctx.save_for_backward(vt, w)
-        return torch.matmul(vt, w.t())
+        return _rows_matmul_small(vt.view(-1, vt.shape[2]), w.t().contiguous()).view(vt.shape[0], 3, w.shape[0])
 
     @staticmethod
     def backward(ctx, dq):
         vt, w = ctx.saved_tensors
         dq = _req(dq, "grad")
-        dv = torch.matmul(dq, w).transpose(1, 2) if ctx.needs_input_grad[0] else None  # [n, V, 3] (strided view)
+        dv = None
+        if ctx.needs_input_grad[0]:  # [n, V, 3] as a strided view of the xyz-major product
+            dv = _rows_matmul_small(dq.view(-1, dq.shape[2]), w.contiguous()).view(dq.shape[0], 3, w.shape[1]).transpose(1, 2)
         dw = None
         if ctx.needs_input_grad[1]:
             n, _, hfp = dq.shape
@@ -871,6 +886,7 @@ class _Project(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
+        w = w.contiguous()  # (a column slice of scalar_out.weight: the BLAS heuristics do badly on its leading dimension)
         ctx.save_for_backward(x, w)
         return torch.matmul(x, w.t())
 

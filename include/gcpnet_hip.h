@@ -237,6 +237,11 @@ int64_t gcpnet_layernorm_bwd_scratch_floats(int rows, int sdim);
 int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi, float* y,
                       void* stream);
 
+/* out[r, j] = sum_k in[r, k] W[k, j], rows x K times a tiny row-major W [K, J] (K * J <= 4096): the per-source-row side of
+ * the vector projections of gcpnet_gcp2_forward's v_add tables ([vector_down ; vector_down_frames] applied at the source rows). */
+int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,
+                             int64_t ld_out, void* stream);
+
 /* ---- profiling hook: when `buf` (device memory, n_tiles * 8 uint64) is non-NULL, each 32-row wave-tile of the GCP2
  * forward / backward kernels writes s_memtime stamps at its phase boundaries; NULL switches it off. */
 int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);
