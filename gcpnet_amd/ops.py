@@ -352,27 +352,9 @@ class _Gcp2(torch.autograd.Function):
         adds = list(tensors[n_s + n_v + 9:n_s + n_v + 9 + n_a])
         vadds = list(tensors[n_s + n_v + 9 + n_a:])
         assert len(vadds) == len(spec.vadd_plans)
-        rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_src[0].shape[0]
-        dev = s_src[0].device
-        pack = _pack(spec, w)
-        ws = _weights_struct(spec, w, pack)
-        opts = _opts_struct(spec)
-        sc = _concat(s_src, spec.s_plans, False)
-        vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
-        ac = _concat(adds, spec.add_plans, False) if adds else None
-        vac = _vadd_concat(vadds, spec.vadd_plans) if vadds else None
-        if spec.residual:
-            res_s, res_v = s_src[0], (v_src[0] if n_v else None)
         need_grad = any(ctx.needs_input_grad)
-        s_out = torch.empty((rows, spec.so), dtype=torch.float32, device=dev)
-        v_out = torch.empty((rows, spec.vo, 3), dtype=torch.float32, device=dev) if spec.vo else None
-        s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
-        gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
-        gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
-        check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts),
-                                      C.byref(ac) if ac is not None else None, C.byref(vac) if vac is not None else None,
-                                      _p(res_s), _p(res_v), _p(s_out), _p(v_out), _p(s_pre), _p(gate), _stream()),
-              "gcp2_forward")
+        rows, s_out, v_out, pack, s_pre, gate = _gcp2_forward_launch(spec, frames, s_src, v_src, res_s, res_v, w, adds, vadds,
+                                                                     need_grad)
         if need_grad:
             ctx.spec, ctx.rows, ctx.n_s, ctx.n_v = spec, rows, n_s, n_v
             ctx.frames = frames
@@ -437,6 +419,33 @@ class _Gcp2(torch.autograd.Function):
             g = dq if pl is None else _segment_reduce_raw(dq, 0, width, width, pl, False)
             grads_vadd.append(g.view(tb.shape))
         return (None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads, *grads_add, *grads_vadd)
+
+
+def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, adds, vadds, need_grad: bool):
+    """One gcpnet_gcp2_forward launch.  Returns (rows, s_out, v_out, pack, s_pre, gate)."""
+    lib = _lib.load()
+    n_v = len(v_src)
+    rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_src[0].shape[0]
+    dev = s_src[0].device
+    pack = _pack(spec, w)
+    ws = _weights_struct(spec, w, pack)
+    opts = _opts_struct(spec)
+    sc = _concat(s_src, spec.s_plans, False)
+    vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
+    ac = _concat(adds, spec.add_plans, False) if adds else None
+    vac = _vadd_concat(vadds, spec.vadd_plans) if vadds else None
+    if spec.residual:
+        res_s, res_v = s_src[0], (v_src[0] if n_v else None)
+    s_out = torch.empty((rows, spec.so), dtype=torch.float32, device=dev)
+    v_out = torch.empty((rows, spec.vo, 3), dtype=torch.float32, device=dev) if spec.vo else None
+    s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
+    gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
+    gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
+    check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts),
+                                  C.byref(ac) if ac is not None else None, C.byref(vac) if vac is not None else None,
+                                  _p(res_s), _p(res_v), _p(s_out), _p(v_out), _p(s_pre), _p(gate), _stream()),
+          "gcp2_forward")
+    return rows, s_out, v_out, pack, s_pre, gate
 
 
 def _vadd_concat(tables: Sequence[Tensor], plans: Sequence[Optional[GatherPlan]]) -> Concat:
@@ -588,6 +597,22 @@ def _join_side_stream():
     _side_pending.clear()
 
 
+def _side_submit(fn, keep) -> None:
+    """Runs fn() with the weight-gradient stream current (ordered after everything enqueued on the caller's stream so far);
+    `keep` stays referenced until the caller's stream has joined at the end of the backward pass."""
+    dev = torch.cuda.current_device()
+    main = torch.cuda.current_stream()
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    if not _side_pending:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+    _side_pending.append((main, side, keep))
+    with torch.cuda.stream(side):
+        fn()
+
+
 def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: bool = False) -> None:
     """Launches the TN GEMMs of several blocks, up to 8 problems per launch.
 
@@ -596,17 +621,7 @@ def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: 
     kernels of the following blocks, which on their own leave most CUs idle for node-row launches.  The caller's stream
     joins that stream in a callback at the end of the backward pass (before any optimizer / all-reduce can touch .grad)."""
     if in_backward_of_leaves and WEIGHT_GRADS_ON_SIDE_STREAM and jobs:
-        dev = torch.cuda.current_device()
-        main = torch.cuda.current_stream()
-        side = _side_streams.get(dev)
-        if side is None:
-            side = _side_streams[dev] = torch.cuda.Stream(device=dev)  # (this device only offers priorities {0, -1}: nothing below the default)
-        side.wait_stream(main)  # the operands (backward-kernel outputs) are ready
-        if not _side_pending:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
-        _side_pending.append((main, side, [j.keep for j in jobs]))  # operands / partial buffers stay alive until the join
-        with torch.cuda.stream(side):
-            run_weight_grad_jobs(jobs)
+        _side_submit(lambda: run_weight_grad_jobs(jobs), [j.keep for j in jobs])  # operands / partials alive until the join
         return
     lib = _lib.load()
     probs = [pr for j in jobs for pr in j.probs]
@@ -772,43 +787,11 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
             weights = (w_rest,) + tuple(weights[1:])
             return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, add)
     if proj is not None:
-        # "Project, then gather": scalar_out is linear in its concatenated input, so the share of a GATHERED source
-        # (h[row], h[col] in a message GCP, reference gcpnet.py:907-917) is computed once per source row -- a plain
-        # [n_src, dim] x [dim, so] library GEMM on 16x fewer rows than edges -- and the kernel adds the gathered result
-        # rows to s_pre.  The per-edge reduction shrinks from K = si + H + 9 to the un-gathered columns.
-        gath, rest = proj
-        w_scalar = weights[0]
-        dims = [t.shape[1] for t in s_sources]
-        offs = [sum(dims[:k]) for k in range(len(dims))]
-        adds = [_Project.apply(s_sources[k], w_scalar[:, offs[k]:offs[k] + dims[k]]) for k in gath]
-        w_rest = torch.cat([w_scalar[:, offs[k]:offs[k] + dims[k]] for k in rest] + [w_scalar[:, spec.si:]], dim=1)
-        spec = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=None,
-                       add_plans=[spec.s_plans[k] for k in gath])
-        weights = (w_rest,) + tuple(weights[1:])
-        s_sources = [s_sources[k] for k in rest]
-        # The same for the vector inputs: vector_down and vector_down_frames are linear as well, so [vh | vf] of a gathered
-        # source (chi[row], chi[col]) is computed per source row -- [n_src, 3, V] x [V, H + 3] -- and the kernels add the
-        # gathered rows; the per-edge vector stage shrinks from V_in = 2 V + 4 to the un-gathered channels.
+        # "Project, then gather" (see _Gcp2Projected): the shares of GATHERED sources (h[row], h[col] / chi[row], chi[col] in a
+        # message GCP, reference gcpnet.py:907-917) in scalar_out / vector_down(.frames) are computed once per source row.
         vproj = _v_projectable(spec, v_sources)
-        vadds: List[Tensor] = []
-        if vproj is not None:
-            vg, vr = vproj
-            w_down, w_frames = weights[2], weights[3]
-            chans = [t.shape[1] for t in v_sources]
-            voffs = [sum(chans[:k]) for k in range(len(chans))]
-            H = spec.hidden
-            hfp = (H + 3 + 3) // 4 * 4
-            for k in vg:
-                wseg = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]], w_frames[:, voffs[k]:voffs[k] + chans[k]]], dim=0)
-                wseg = torch.nn.functional.pad(wseg, (0, 0, 0, hfp - (H + 3)))  # [HF', V], zero rows past H + 3
-                vadds.append(_ProjectV.apply(v_sources[k], wseg))  # [n_src, 3, HF']
-            pick = lambda m: torch.cat([m[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1) if len(vr) > 1 else \
-                m[:, voffs[vr[0]]:voffs[vr[0]] + chans[vr[0]]].contiguous()
-            weights = (weights[0], weights[1], pick(w_down), pick(w_frames)) + tuple(weights[4:])
-            spec = replace(spec, vi=sum(chans[k] for k in vr), v_plans=[spec.v_plans[k] for k in vr],
-                           vadd_plans=[spec.v_plans[k] for k in vg])
-            v_sources = [v_sources[k] for k in vr]
-        return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, *adds, *vadds)
+        return _Gcp2Projected.apply(spec, frames, list(proj[0]), list(vproj[0]) if vproj is not None else [], *s_sources,
+                                    *v_sources, res_s, res_v, *weights)
     return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights)
 
 
@@ -848,6 +831,198 @@ def _rows_matmul_small(x2d: Tensor, w: Tensor) -> Tensor:
     check(lib.gcpnet_rows_matmul_small(x2d.shape[0], K, J, _p(x2d), x2d.stride(0), _p(w), _p(out), J, _stream()),
           "rows_matmul_small")
     return out
+
+
+def _tn_weight_grad_into(a2d: Tensor, b2d: Tensor, out: Tensor) -> None:
+    """out[M, N] (any row stride, unit column stride) = a2d^T b2d through gcpnet_tn_gemm."""
+    lib = _lib.load()
+    rows, M = a2d.shape
+    N = b2d.shape[1]
+    assert out.shape == (M, N) and out.stride(1) == 1
+    a, b = Operand(), Operand()
+    a.n, b.n = 1, 1
+    a.ptr[0], a.dim[0], a.ld[0] = a2d.data_ptr(), M, a2d.stride(0)
+    b.ptr[0], b.dim[0], b.ld[0] = b2d.data_ptr(), N, b2d.stride(0)
+    pr = TnProblem()
+    pr.rows, pr.a, pr.b = rows, a, b
+    pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = out.data_ptr(), out.stride(0), 1, M, N
+    pr.out2, pr.out2_n = None, 0
+    pr.splits = lib.gcpnet_tn_splits(rows, M, N)
+    part = torch.empty((pr.splits, M, N), dtype=torch.float32, device=a2d.device)
+    pr.partial = part.data_ptr()
+    check(lib.gcpnet_tn_gemm(1, C.byref(pr), _stream()), "tn_gemm")
+
+
+class _Gcp2Projected(torch.autograd.Function):
+    """One GCP2 block whose GATHERED sources are projected at their source rows ("project, then gather").
+
+    scalar_out, vector_down and vector_down_frames are linear in their concatenated inputs, so the share of a gathered source
+    (h[row], h[col], chi[row], chi[col] in the first message GCP, reference gcpnet.py:907-917) is computed once per source
+    row -- [n_src, dim] x [dim, so] and [3 n_src, V] x [V, H + 3] products on 16x fewer rows than edges -- and the kernels
+    add the gathered result rows (gcpnet_gcp2_forward's s_add / v_add).  The per-edge reductions shrink from
+    K = 2 s + 32 + H + 9 to 32 + H + 9 and from V_in = 2 V + 4 to 4.
+    inputs: spec (all sources), frames, indices of the projected scalar / vector sources, then the tensors of _Gcp2
+    (sources, res_s, res_v, the 7 LEAF weights).  The backward assembles the full weight gradients itself -- kernel results
+    for the un-gathered columns, row-split TN GEMMs for the projected ones -- on the weight-gradient stream."""
+
+    @staticmethod
+    def forward(ctx, spec: Gcp2Spec, frames, sg, vg, *tensors):
+        n_s, n_v = len(spec.s_plans), len(spec.v_plans)
+        s_src, v_src = list(tensors[:n_s]), list(tensors[n_s:n_s + n_v])
+        res_s, res_v = tensors[n_s + n_v], tensors[n_s + n_v + 1]
+        w = tuple(tensors[n_s + n_v + 2:n_s + n_v + 9])
+        w_scalar, b_scalar, w_down, w_frames, w_up, w_gate, b_gate = w
+        dims = [t.shape[1] for t in s_src]
+        offs = [sum(dims[:k]) for k in range(n_s)]
+        rest = [k for k in range(n_s) if k not in sg]
+        wsegs = [w_scalar[:, offs[k]:offs[k] + dims[k]].contiguous() for k in sg]
+        adds = [torch.matmul(s_src[k], wk.t()) for k, wk in zip(sg, wsegs)]
+        w_rest = torch.cat([w_scalar[:, offs[k]:offs[k] + dims[k]] for k in rest] + [w_scalar[:, spec.si:]], dim=1)
+        chans = [t.shape[1] for t in v_src]
+        voffs = [sum(chans[:k]) for k in range(n_v)]
+        vr = [k for k in range(n_v) if k not in vg]
+        H = spec.hidden
+        hfp = (H + 3 + 3) // 4 * 4
+        wvs, vts, vadds = [], [], []
+        wd_rest, wf_rest = w_down, w_frames
+        if vg:
+            for k in vg:
+                wk = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]], w_frames[:, voffs[k]:voffs[k] + chans[k]]], dim=0)
+                wk = torch.nn.functional.pad(wk, (0, 0, 0, hfp - (H + 3)))  # [HF', V], zero rows past H + 3
+                vt = v_src[k].transpose(1, 2).contiguous()  # [n, 3, V]
+                wvs.append(wk); vts.append(vt)
+                vadds.append(_rows_matmul_small(vt.view(-1, chans[k]), wk.t().contiguous()).view(vt.shape[0], 3, hfp))
+            wd_rest = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
+            wf_rest = torch.cat([w_frames[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
+        spec2 = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=None,
+                        add_plans=[spec.s_plans[k] for k in sg], vi=sum(chans[k] for k in vr),
+                        v_plans=[spec.v_plans[k] for k in vr], vadd_plans=[spec.v_plans[k] for k in vg])
+        w2 = (w_rest, b_scalar, wd_rest, wf_rest, w_up, w_gate, b_gate)
+        need_grad = any(ctx.needs_input_grad)
+        rows, s_out, v_out, pack, s_pre, gate = _gcp2_forward_launch(spec2, frames, [s_src[k] for k in rest],
+                                                                     [v_src[k] for k in vr], res_s, res_v, w2, adds, vadds,
+                                                                     need_grad)
+        if need_grad:
+            ctx.spec, ctx.spec2, ctx.rows, ctx.frames, ctx.sg, ctx.vg = spec, spec2, rows, frames, list(sg), list(vg)
+            ctx.has_res = (res_s is not None, res_v is not None)
+            ctx.w_leaf = all(t is None or t.is_leaf for t in w)
+            ctx.n_w2 = [t is not None for t in w2]
+            ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre, gate, *wsegs, *wvs, *vts, *vadds)
+        if spec.vo:
+            return s_out, v_out
+        return s_out
+
+    @staticmethod
+    def backward(ctx, d_s_out, d_v_out=None):
+        spec, spec2, rows, sg, vg = ctx.spec, ctx.spec2, ctx.rows, ctx.sg, ctx.vg
+        n_s, n_v = len(spec.s_plans), len(spec.v_plans)
+        saved = list(ctx.saved_tensors)
+        s_src, v_src = saved[:n_s], saved[n_s:n_s + n_v]
+        pos = n_s + n_v
+        w2 = []
+        for present in ctx.n_w2:
+            w2.append(saved[pos] if present else None)
+            pos += 1 if present else 0
+        w2 = tuple(w2)
+        pack, s_pre, gate = saved[pos:pos + 3]
+        pos += 3
+        wsegs = saved[pos:pos + len(sg)]; pos += len(sg)
+        wvs = saved[pos:pos + len(vg)]; pos += len(vg)
+        vts = saved[pos:pos + len(vg)]; pos += len(vg)
+        vadds = saved[pos:pos + len(vg)]
+        f32 = dict(dtype=torch.float32, device=s_pre.device)
+        d_s_out = _req(d_s_out, "grad") if d_s_out is not None else torch.zeros((rows, spec.so), **f32)
+        if spec.vo:
+            d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
+        rest = [k for k in range(n_s) if k not in sg]
+        vr = [k for k in range(n_v) if k not in vg]
+        dims = [t.shape[1] for t in s_src]
+        offs = [sum(dims[:k]) for k in range(n_s)]
+        chans = [t.shape[1] for t in v_src]
+        voffs = [sum(chans[:k]) for k in range(n_v)]
+        base = 4  # index of the first tensor input in needs_input_grad
+        need_w = ctx.needs_input_grad[base + n_s + n_v + 2:base + n_s + n_v + 9]
+        s_rest, v_rest = [s_src[k] for k in rest], [v_src[k] for k in vr]
+        d_s_in, d_v_in, scr = gcp2_backward_data(spec2, rows, s_rest, v_rest, ctx.frames, w2, pack, s_pre, gate, d_s_out,
+                                                 d_v_out, need_w=any(need_w), vadds=vadds)
+        ds_pre = scr["ds_pre"]
+        # ---- input gradients ---------------------------------------------------------------------------------------------
+        grads_s: List[Optional[Tensor]] = [None] * n_s
+        off2 = 0
+        for k in rest:
+            pl = spec.s_plans[k]
+            if pl is not None:
+                grads_s[k] = _segment_reduce_raw(d_s_in, off2, dims[k], spec2.si, pl, False)
+            else:
+                grads_s[k] = d_s_in if len(rest) == 1 else d_s_in[:, off2:off2 + dims[k]]
+            off2 += dims[k]
+        dP = []
+        for k, wk in zip(sg, wsegs):  # projected sources: d(table) = ds_pre summed over the gathering rows, then the GEMM's adjoint
+            pl = spec.s_plans[k]
+            g = ds_pre if pl is None else _segment_reduce_raw(ds_pre, 0, spec.so, spec.so, pl, False)
+            dP.append(g)
+            if ctx.needs_input_grad[base + k]:
+                grads_s[k] = torch.matmul(g, wk)
+        grads_v: List[Optional[Tensor]] = [None] * n_v
+        off2 = 0
+        for k in vr:
+            pl = spec.v_plans[k]
+            if pl is not None:
+                grads_v[k] = _segment_reduce_raw(d_v_in, 3 * off2, 3 * chans[k], 3 * spec2.vi, pl, False).reshape(pl.n_src, chans[k], 3)
+            else:
+                grads_v[k] = d_v_in if len(vr) == 1 else d_v_in[:, off2:off2 + chans[k], :]
+            off2 += chans[k]
+        dQ = []
+        for k, wk in zip(vg, wvs):
+            pl = spec.v_plans[k]
+            dq = scr["dvhf"]
+            g = dq if pl is None else _segment_reduce_raw(dq, 0, dq.shape[1], dq.shape[1], pl, False)  # [n, 3 HF']
+            dQ.append(g)
+            if ctx.needs_input_grad[base + n_s + k]:
+                hfp = wk.shape[0]
+                grads_v[k] = _rows_matmul_small(g.view(-1, hfp), wk).view(g.shape[0], 3, chans[k]).transpose(1, 2)
+        # ---- weight gradients: un-gathered columns from the kernel's operands, projected columns by row-split TN GEMMs, all
+        #      assembled into the full-size tensors on the weight-gradient stream ------------------------------------------
+        wgrads: List[Optional[Tensor]] = [None] * 7
+        if any(need_w):
+            H = spec.hidden
+            job = _WeightGradJob(spec2, rows, s_rest, s_pre, scr)
+            gj = job.grads()
+            g0 = torch.empty((spec.so, spec.K), **f32)
+            gd = torch.empty((H, spec.vi), **f32) if vg else gj[2]
+            gf = torch.empty((3, spec.vi), **f32) if vg else gj[3]
+
+            def assemble():
+                run_weight_grad_jobs([job])
+                c = 0
+                for k in rest:
+                    g0[:, offs[k]:offs[k] + dims[k]].copy_(gj[0][:, c:c + dims[k]])
+                    c += dims[k]
+                g0[:, spec.si:].copy_(gj[0][:, c:])
+                for k, g in zip(sg, dP):
+                    _tn_weight_grad_into(g, s_src[k], g0[:, offs[k]:offs[k] + dims[k]])
+                if vg:
+                    c = 0
+                    for k in vr:
+                        gd[:, voffs[k]:voffs[k] + chans[k]].copy_(gj[2][:, c:c + chans[k]])
+                        gf[:, voffs[k]:voffs[k] + chans[k]].copy_(gj[3][:, c:c + chans[k]])
+                        c += chans[k]
+                    for k, g, vt in zip(vg, dQ, vts):
+                        hfp = g.shape[1] // 3
+                        tmp = _tn_weight_grad(g.view(-1, hfp), vt.view(-1, chans[k]))  # [HF', V]
+                        gd[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[:H])
+                        gf[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[H:H + 3])
+
+            keep = [job.keep, dP, dQ, list(s_src), list(vts), scr]
+            if ctx.w_leaf and WEIGHT_GRADS_ON_SIDE_STREAM:
+                _side_submit(assemble, keep)
+            else:
+                assemble()
+            full = [g0, gj[1], gd, gf, gj[4], gj[5], gj[6]]
+            wgrads = [g if need else None for g, need in zip(full, need_w)]
+        g_res_s = d_s_out if ctx.has_res[0] else None
+        g_res_v = d_v_out if ctx.has_res[1] else None
+        return (None, None, None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
 
 
 class _ProjectV(torch.autograd.Function):
