@@ -320,3 +320,45 @@ def test_interactions_large_vs_oracle(G, n, e, dims):
         close(gi[k].grad.cpu(), ci[k].grad, atol=1e-6, rtol=2e-3)
     for k, p in layer.named_parameters():
         close(p.grad.cpu(), P[k].grad, atol=1e-6, rtol=2e-3)
+
+
+def _layer_run(G, layer, ins, ei, fr):
+    gi = {k: t.clone().cuda().requires_grad_() for k, t in ins.items()}
+    for p in layer.parameters():
+        p.grad = None
+    gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
+    sq_loss(gh, gc).backward()
+    torch.cuda.synchronize()
+    out = {"h": gh.detach().cpu(), "chi": gc.detach().cpu()}
+    out.update({"d_" + k: t.grad.cpu() for k, t in gi.items()})
+    out.update({"w_" + k: p.grad.cpu().clone() for k, p in layer.named_parameters()})
+    return out
+
+
+def test_execution_variants_agree_and_are_deterministic(G):
+    """The host-side execution choices -- project-then-gather for gathered scalars / vectors, weight gradients on a second
+    stream -- change summation order at most: every variant matches the default to fp32 round-off, and the default is
+    bit-reproducible run to run (no atomics anywhere on the path)."""
+    from gcpnet_amd import ops
+    torch.manual_seed(5)
+    n, e = 700, 9000
+    layer = G.GCPInteractions((128, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
+                              dropout=0.0).cuda().eval()
+    ei, x = rand_graph(n, e, 12, sort_by_col=True)
+    fr = O.localize(x, ei)
+    g = torch.Generator().manual_seed(17)
+    ins = dict(h=torch.randn(n, 128, generator=g), chi=torch.randn(n, 16, 3, generator=g),
+               e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
+    ref = _layer_run(G, layer, ins, ei, fr)
+    again = _layer_run(G, layer, ins, ei, fr)
+    for k in ref:
+        assert torch.equal(ref[k], again[k]), f"{k} differs between two identical runs"
+    saved = (ops.PROJECT_GATHERED_SCALARS, ops.PROJECT_GATHERED_VECTORS, ops.WEIGHT_GRADS_ON_SIDE_STREAM)
+    try:
+        for flags in [(False, False, True), (True, False, True), (True, True, False)]:
+            ops.PROJECT_GATHERED_SCALARS, ops.PROJECT_GATHERED_VECTORS, ops.WEIGHT_GRADS_ON_SIDE_STREAM = flags
+            alt = _layer_run(G, layer, ins, ei, fr)
+            for k in ref:
+                close(alt[k], ref[k], atol=2e-5 if k in ("h", "chi") else 1e-6, rtol=2e-3)
+    finally:
+        ops.PROJECT_GATHERED_SCALARS, ops.PROJECT_GATHERED_VECTORS, ops.WEIGHT_GRADS_ON_SIDE_STREAM = saved
