@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
     const BlockWork w = locate(a);
     const gcp_tn_problem_t& P = a.p[w.pi];
     const int total_tiles = gcp_cdiv(w.mw, 32) * w.ntiles;
-    const int my_tiles = wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0;
+    const int my_tiles = __builtin_amdgcn_readfirstlane(wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0);  // wave-uniform
     const bool wave_active = my_tiles > 0;
     int aoff[5], boff[5];
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     const BlockWork w = locate(a);
     const gcp_tn_problem_t& P = a.p[w.pi];
     const int total_tiles = gcp_cdiv(w.mw, 32) * w.ntiles;
-    const int my_tiles = wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0;
+    const int my_tiles = __builtin_amdgcn_readfirstlane(wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0);  // wave-uniform
     const bool wave_active = my_tiles > 0;
     int aoff[5], boff[5];
 #pragma unroll
@@ -319,15 +319,30 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
             fetch_issue<TN_B_SLOTS>(sb, vb, rn, r_last, gb);
         }
         if (wave_active) {
-            const float* As = Abuf(cur) + col;
-            const float* Bs = Bbuf(cur) + col;
-#pragma unroll 4
+            // fragments of step ss + 1 are read (unconditionally: the offsets are clamped to valid tiles) before the MFMAs of
+            // step ss, so that an MFMA never waits for its own ds_read
+            const float* As = Abuf(cur) + col + hi * TN_BM;
+            const float* Bs = Bbuf(cur) + col + hi * TN_BN;
+            float fa[5], fb[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { fa[i] = As[aoff[i]]; fb[i] = Bs[boff[i]]; }
+#pragma unroll
             for (int ss = 0; ss < TN_RK / 2; ++ss) {
-                const float* arow = As + (2 * ss + hi) * TN_BM;
-                const float* brow = Bs + (2 * ss + hi) * TN_BN;
+                float na[5], nb[5];
+                if (ss + 1 < TN_RK / 2) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        na[i] = As[2 * (ss + 1) * TN_BM + aoff[i]];
+                        nb[i] = Bs[2 * (ss + 1) * TN_BN + boff[i]];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    if (i < my_tiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[aoff[i]], brow[boff[i]], acc[i], 0, 0, 0);
+                    if (i < my_tiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+                if (ss + 1 < TN_RK / 2) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+                }
             }
         }
         if (c + 1 < nchunks) {
