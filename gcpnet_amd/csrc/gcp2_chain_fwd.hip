@@ -160,6 +160,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
         // ---- scalar_out: acc = b + W[:, state] x^T + W[:, extras] ext^T --------------------------------------------------
         f32x16 acc[NT];
+        f32x16 gacc;     // vector-gate pre-activations (initialised with the bias while the extras tile is multiplied)
+        float gwa[16];   // first batch of the gate GEMM's weight fragments
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gacc[r] = 0.f; gwa[r] = 0.f; }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -195,29 +199,43 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE: hipcc otherwise sinks each load to its use
             }
             if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
+            // (the gate GEMM's first weight fragments and its bias are requested here, one phase ahead)
+            if (scalar_gate) {
+                const float* wg0 = it.pack + S.offC + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    gwa[r] = wg0[(int64_t)r * 64];
+                    gacc[r] = gcp_crow(r, hi) < vo ? it.b_gate[min(gcp_crow(r, hi), vo - 1)] : 0.f;
+                }
+            }
             // norms and frame scalars: ordinary B fragments from the 32 x 16 LDS tile, weights from section A
             const float* wa = it.pack + S.offA + (int64_t)lane * NT;
             const int kk0 = si / 2;
-            for (int x = 0; x < NX; ++x) {
-                WF<NT> a;
-                a.load(wa + (int64_t)(kk0 + x) * 64 * NT);
-                const float bv = ext[e * L.XS + 2 * x + hi];
+            for (int x0 = 0; x0 < NX; x0 += 8) {  // fragments of eight steps requested together (one L2 round trip, not eight)
+                WF<NT> a[8];
+                float bv[8];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], bv, acc[t], 0, 0, 0);
+                for (int u = 0; u < 8; ++u) {
+                    const int x = min(x0 + u, NX - 1);
+                    a[u].load(wa + (int64_t)(kk0 + x) * 64 * NT);
+                    bv[u] = ext[e * L.XS + 2 * x + hi];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (x0 + u < NX) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], bv[u], acc[t], 0, 0, 0);
+                    }
             }
         }
 
         if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
-        f32x16 gacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gacc[r] = (scalar_gate && gcp_crow(r, hi) < vo) ? it.b_gate[min(gcp_crow(r, hi), vo - 1)] : 0.f;
         if (scalar_gate) {
             const float* wg = it.pack + S.offC + lane;
-            float wa[16], wb[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) wa[r] = wg[(int64_t)r * 64];
-            __builtin_amdgcn_sched_barrier(0);
+            float(&wa)[16] = gwa;
+            float wb[16];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float(&cur)[16] = (t & 1) ? wb : wa;
