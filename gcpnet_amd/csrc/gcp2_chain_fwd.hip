@@ -7,10 +7,11 @@
 //     (weights packed for that pairing, section F of the packed image),
 //   * the layout scalar_out produces -> x += act(s_pre) is a plain register add,
 //   * the B fragment of the vector-gate GEMM,
-// so the scalar path needs NO LDS at all.  What is left in LDS is the 32 x 3V vector tile and a few hundred floats of
-// per-row scratch (~12 KB per wave), which is what lets two waves share a SIMD: one wave's VALU / LDS / store phases run
-// under the other's MFMAs.  The only per-row inputs of scalar_out that are not state, the H vector norms and 9 frame
-// scalars, go through a 32 x 16 LDS tile as ordinary B fragments.
+// so the scalar path needs NO LDS at all.  The small vector Linears run on the matrix cores as well (vec_mfma.h): the vector
+// state sits in a 32 x 3V LDS tile (B fragments of vector_down), everything downstream of it is register arithmetic in the C/D
+// layout, and the H norms and 9 frame scalars -- the only inputs of scalar_out that are not state -- go through a 32 x 16 LDS
+// tile as ordinary B fragments.  ~17 KB of LDS per wave (vector tile, frames, extras tile, a 4.6 KB transposition tile for
+// full-line stores) lets two waves share a SIMD: one wave's VALU / LDS / store phases run under the other's MFMAs.
 #include "common.h"
 #include "tile_io.h"
 #include "vec_mfma.h"

@@ -92,8 +92,8 @@ for need_grad in (False, True):
     t = buf.view(ntiles, 8).cpu().double()
     tot = t[:, 7] - t[:, 0]
     print(f"   last block total median {tot.median().item():.0f} ticks")
-    for i, lab in enumerate(["stage small weights", "vector prologue", "bias + mfma (state)", "mfma (norms/frames)", "gate gemm",
-                             "s_pre/s_out stores + x update", "vector epilogue + stores"]):
+    for i, lab in enumerate(["[vh|vf] = Wdf v (mfma)", "norms, frame scalars -> LDS", "bias + mfma (state)", "mfma (norms/frames)",
+                             "gate gemm", "s_pre/s_out stores + x update", "vector epilogue + stores"]):
         d = t[:, i + 1] - t[:, i]
         print(f"   {lab:30s} median {d.median().item():9.0f}  mean {d.mean().item():9.0f}")
 
@@ -117,8 +117,8 @@ lib.gcpnet_debug_set_phase_timing(None, 0)
 print(f"chain x7 backward (data kernel + weight-gradient GEMMs) {a.elapsed_time(b) * 1e3:.0f} us")
 t = buf.view(ntiles, 8).cpu().double()
 print(f"   chain bwd kernel: tile total median {(t[:, 7] - t[:, 0]).median().item():.0f} ticks")
-for i, lab in enumerate(["prologue (loads of the last block)", "blocks n-1 .. 1", "recompute vh (block 0)", "vector epilogue adjoint",
-                         "gate adjoint + ds_pre + W^T ds (mfma)", "requests for next + vector prologue adjoint",
-                         "small weight-gradient partials"]):
+for i, lab in enumerate(["prologue (loads of the last block)", "blocks n-1 .. 1", "A-C: recompute, epilogue adjoint, 1st partials (block 0)",
+                         "D-E: gate adjoint, ds_pre, W^T ds_pre (mfma)", "F: vector prologue adjoint", "G: 2nd partials, commit next",
+                         "end"]):
     d = t[:, i + 1] - t[:, i]
     print(f"   {lab:45s} median {d.median().item():9.0f}  mean {d.mean().item():9.0f}")
