@@ -60,6 +60,7 @@ def to_container(cfg: Any) -> dict:
 # the reference's dotted paths -> this package (drop-in `_target_` mapping)
 TARGET_MAP = {
     "src.models.components.gcpnet.GCP2": "gcpnet_amd.gcpnet.GCP2",
+    "src.models.components.gcpnet.GCP3": "gcpnet_amd.gcpnet.GCP3",
     "src.models.components.gcpnet.GCPInteractions": "gcpnet_amd.gcpnet.GCPInteractions",
     "src.models.components.gcpnet.GCPMessagePassing": "gcpnet_amd.gcpnet.GCPMessagePassing",
     "src.models.components.gcpnet.GCPEmbedding": "gcpnet_amd.gcpnet.GCPEmbedding",

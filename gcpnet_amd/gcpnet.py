@@ -160,6 +160,27 @@ class GCP2(nn.Module):
         return ScalarVector(s_out, v_out)
 
 
+class GCP3(GCP2):
+    """`GCP3` (:471-700) is `GCP2` with silu defaults and an optional two-layer `scalar_out` (`feedforward_out`, :529-533).
+    Without `feedforward_out` the two are the same computation with the same parameter names; that is what runs here."""
+
+    def __init__(self, input_dims, output_dims, nonlinearities: Tuple[Optional[str]] = ("silu", "silu"),
+                 scalar_out_nonlinearity: Optional[str] = "silu", scalar_gate: int = 0, vector_gate: bool = True,
+                 frame_gate: bool = False, sigma_frame_gate: bool = False, feedforward_out: bool = False, bottleneck: int = 1,
+                 vector_residual: bool = False, vector_frame_residual: bool = False, ablate_frame_updates: bool = False,
+                 ablate_scalars: bool = False, ablate_vectors: bool = False, enable_e3_equivariance: bool = False,
+                 scalarization_vectorization_output_dim: int = 3, **kwargs):
+        if feedforward_out:
+            _unsupported("GCP3(feedforward_out=True) (two-layer scalar_out)")
+        super().__init__(input_dims, output_dims, nonlinearities=nonlinearities, scalar_gate=scalar_gate, vector_gate=vector_gate,
+                         frame_gate=frame_gate, sigma_frame_gate=sigma_frame_gate, bottleneck=bottleneck,
+                         vector_residual=vector_residual, vector_frame_residual=vector_frame_residual,
+                         ablate_frame_updates=ablate_frame_updates, ablate_scalars=ablate_scalars, ablate_vectors=ablate_vectors,
+                         enable_e3_equivariance=enable_e3_equivariance,
+                         scalarization_vectorization_output_dim=scalarization_vectorization_output_dim, **kwargs)
+        self.scalar_out_nonlinearity = scalar_out_nonlinearity
+
+
 def get_GCP_with_custom_cfg(input_dims, output_dims, cfg, **kwargs):
     """:826-835 -- the whole module_cfg is forwarded; unknown keys are swallowed by GCP2's **kwargs."""
     cfg_dict = copy(to_container(cfg))

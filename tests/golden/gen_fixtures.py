@@ -77,9 +77,9 @@ def fx_geometry():
          ))
 
 
-def run_gcp2(name, in_dims, out_dims, rows_are_nodes, seed, n=20, e=64, **kw):
+def run_gcp2(name, in_dims, out_dims, rows_are_nodes, seed, n=20, e=64, cls="GCP2", **kw):
     torch.manual_seed(seed)
-    mod = gn.GCP2(SV(*in_dims), SV(*out_dims), **kw)
+    mod = getattr(gn, cls)(SV(*in_dims), SV(*out_dims), **kw)
     ei, x = rand_graph(n, e, seed + 100)
     frames = comp.localize(x, ei)
     rows = n if rows_are_nodes else e
@@ -124,6 +124,9 @@ def fx_gcp2():
     run_gcp2("gcp2_frame_gate_edge", (24, 8), (16, 4), False, 21, nonlinearities=("relu", "sigmoid"), frame_gate=True)
     run_gcp2("gcp2_ablate_frames", (24, 8), (16, 4), False, 22, nonlinearities=("relu", None), bottleneck=4,
              ablate_frame_updates=True)
+    # GCP3 (gcpnet.py:471-700) = GCP2 with silu defaults and an optional two-layer scalar_out (feedforward_out)
+    run_gcp2("gcp3_edge_default", (40, 8), (24, 8), False, 23, cls="GCP3", bottleneck=4)
+    run_gcp2("gcp3_node_default", (24, 8), (40, 12), True, 24, cls="GCP3", bottleneck=2)
 
 
 def fx_layernorm():

@@ -108,13 +108,17 @@ GCP2_CASES = {
     "gcp2_silu_sigmoid": dict(nonlinearities=("silu", "sigmoid"), bottleneck=2),
     "gcp2_selfgate": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False),
     "gcp2_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
+    "gcp3_edge_default": dict(bottleneck=4, cls="GCP3"),
+    "gcp3_node_default": dict(bottleneck=2, cls="GCP3"),
 }
 
 
 @pytest.mark.parametrize("name", sorted(GCP2_CASES))
 def test_gcp2_golden(G, name):
     f = Fixture(name)
-    mod = G.GCP2(tuple(int(d) for d in f.m["in_dims"]), tuple(int(d) for d in f.m["out_dims"]), **GCP2_CASES[name]).cuda()
+    kw = dict(GCP2_CASES[name])
+    cls = getattr(G, kw.pop("cls", "GCP2"))
+    mod = cls(tuple(int(d) for d in f.m["in_dims"]), tuple(int(d) for d in f.m["out_dims"]), **kw).cuda()
     mod.load_state_dict(f.p)
     s = f.i["s"].cuda().requires_grad_()
     ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()

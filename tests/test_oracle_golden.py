@@ -49,6 +49,9 @@ GCP2_CASES = {
     "gcp2_frame_gate": dict(nonlinearities=("silu", "silu"), frame_gate=True),
     "gcp2_frame_gate_edge": dict(nonlinearities=("relu", "sigmoid"), frame_gate=True),
     "gcp2_ablate_frames": dict(nonlinearities=("relu", None), ablate_frame_updates=True),
+    # GCP3 without feedforward_out is GCP2 with silu defaults (reference gcpnet.py:471-700)
+    "gcp3_edge_default": dict(nonlinearities=("silu", "silu")),
+    "gcp3_node_default": dict(nonlinearities=("silu", "silu")),
 }
 
 
