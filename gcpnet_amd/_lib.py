@@ -16,7 +16,7 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
-    "gcpnet_gcp2_chain_forward",
+    "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_headchain_forward",
     "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_debug_set_phase_timing",
@@ -43,6 +43,11 @@ class Gcp2Opts(C.Structure):
 class ChainItem(C.Structure):
     _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p),
                 ("gate", C.c_void_p)]
+
+
+class Head(C.Structure):
+    _fields_ = [("e_in", C.c_void_p), ("xi_in", C.c_void_p), ("s_add", Concat), ("v_add", Concat), ("w", Gcp2Weights),
+                ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p), ("gate", C.c_void_p)]
 
 
 class BwdScratch(C.Structure):
@@ -101,6 +106,7 @@ def load():
     lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), P(Concat), vp,
                                         vp, vp, vp, vp, vp, vp]
     lib.gcpnet_gcp2_chain_forward.argtypes = [i32, vp, vp, vp, i32, P(ChainItem), vp]
+    lib.gcpnet_gcp2_headchain_forward.argtypes = [i32, P(Head), vp, i32, P(ChainItem), vp]
     lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), vp, vp, vp,
                                          vp, vp, vp, P(BwdScratch), vp]
     lib.gcpnet_gcp2_chain_backward.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp]

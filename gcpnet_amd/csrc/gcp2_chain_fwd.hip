@@ -29,6 +29,17 @@ struct ChainItemF {
     int act_s, act_v;
 };
 
+// Optional head block in front of the chain: the first message GCP after project-then-gather, (se, vi0) -> (s, V) with the
+// gathered sources entering as addend tables (gcpnet_gcp2_forward's s_add / v_add).  Not residual: its output IS the chain's
+// initial state, so fusing it saves the state's round trip through HBM; with n == 0 the kernel is that block alone.
+struct HeadParams {
+    const float* e_in;   // [rows, se]
+    const float* xi_in;  // [rows, vi0, 3]
+    gcp_concat_t s_add, v_add;
+    ChainItemF it;
+    GcpShape sh;
+};
+
 struct ChainParams {
     int rows;
     const float* s0;
@@ -42,21 +53,31 @@ struct ChainParams {
     GcpShape sh;
 };
 
+struct ChainParamsH : ChainParams {  // kernel argument of the HEAD instantiations
+    HeadParams hd;
+};
+
 struct ChainLds {
     int VS, XS;
     int o_vt, o_fr, o_ext, o_ust, o_stage, total;
 };
 
-__host__ __device__ inline ChainLds chain_lds(const GcpShape& s) {
+__host__ __device__ inline ChainLds chain_lds(const GcpShape& s, const GcpShape* h = nullptr) {
     ChainLds l;
-    l.VS = gcp_odd(3 * s.vi);
-    l.XS = gcp_odd(gcp_round_up(s.H + s.nf, 2));
+    const int vmax = h && h->vi > s.vi ? h->vi : s.vi;
+    l.VS = gcp_odd(3 * vmax);
+    int xw = gcp_round_up(s.H + s.nf, 2);
+    if (h && h->KP - h->si > xw) xw = h->KP - h->si;  // the head reads its k padding from the extras tile too
+    l.XS = gcp_odd(xw);
     l.o_vt = 0;
     l.o_fr = l.o_vt + 32 * l.VS;
     l.o_ext = l.o_fr + 32 * 9;
     l.o_ust = l.o_ext + 32 * l.XS;
-    l.o_stage = l.o_ust + s.SVB * 3 * 64;  // (ust: vector_down outputs parked between the vector prologue and epilogue)
-    l.total = l.o_stage + GCP_ACC_STAGE_FLOATS;
+    const int svb = h && h->SVB > s.SVB ? h->SVB : s.SVB;
+    l.o_stage = l.o_ust + svb * 3 * 64;  // (ust: vector_down outputs parked between the vector prologue and epilogue)
+    int stage = GCP_ACC_STAGE_FLOATS;  // the head's scalar input tile shares the transposition tile's space
+    if (h && 32 * gcp_odd(h->si) > stage) stage = 32 * gcp_odd(h->si);
+    l.total = l.o_stage + stage;
     return l;
 }
 
@@ -80,11 +101,22 @@ struct WF<4> {
 };
 
 // NT = 32-wide tiles of the scalar state (so <= 32 * NT); PWL as in gcp2_fwd.hip.
-template <int NT, bool PWL>
-__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams p) {
+template <bool HEAD>
+struct ChainArg { typedef ChainParams type; };
+template <>
+struct ChainArg<true> { typedef ChainParamsH type; };
+
+// (head parameters of a kernel argument; the plain instantiations never evaluate the result)
+__device__ __forceinline__ const HeadParams& head_of(const ChainParamsH& p) { return p.hd; }
+__device__ __forceinline__ const HeadParams& head_of(const ChainParams& p) { return *reinterpret_cast<const HeadParams*>(&p); }
+
+// HEAD: a head block (HeadParams) runs first; ONLY: ... and nothing else (n == 0), so that the compiler sees one block shape.
+template <int NT, bool PWL, bool HEAD, bool ONLY = false>
+__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename ChainArg<HEAD>::type p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
-    const ChainLds L = chain_lds(S);
+    const HeadParams& HD = head_of(p);
+    const ChainLds L = chain_lds(S, HEAD ? &HD.sh : nullptr);
     int lane = threadIdx.x;
     int e = lane & 31, hi = lane >> 5;
     const int r0 = blockIdx.x * GCP_TILE_ROWS;
@@ -96,14 +128,23 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
     float* ext = lds + L.o_ext;
     float* ust = lds + L.o_ust;
     float* stage = lds + L.o_stage;
-    const int si = S.si, vi = S.vi, so = S.so, vo = S.vo, H = S.H;
+    const int vi = S.vi, so = S.so, vo = S.vo, H = S.H;
     const int NX = gcp_round_up(H + S.nf, 2) / 2;  // k-pair steps over the norms / frame scalars
     const float slope = p.o.slope;
     const bool scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;
     const bool vec_so = (so & 3) == 0;
     // ---- the tile: vectors + frames into LDS, scalars straight into the accumulator layout ---------------------------
     f32x16 xs[NT];
-    {
+    float* et = stage;  // HEAD: the head's scalar inputs [32][ES] (consumed before the first row-wise store needs the tile)
+    const int ES = HEAD ? gcp_odd(HD.sh.si) : 1;
+    if constexpr (HEAD) {
+        GcpSegBuf<8> vb0, eb0;
+        gcp_seg_issue(vb0, HD.xi_in, nullptr, 3 * HD.sh.vi, r0, rows, vt, L.VS, 0, lane);
+        gcp_seg_issue(eb0, HD.e_in, nullptr, HD.sh.si, r0, rows, et, ES, 0, lane);
+        if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
+        gcp_seg_commit(vb0, vt, L.VS, 0);
+        gcp_seg_commit(eb0, et, ES, 0);
+    } else {
         GcpSegBuf<8> vb0;
         gcp_seg_issue(vb0, p.v0, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
@@ -118,21 +159,77 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
     }
     for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
 
-    for (int ci = 0; ci < p.n; ++ci) {
+    const int n_blocks = ONLY ? 0 : p.n;
+    for (int ci = HEAD ? -1 : 0; ci < n_blocks; ++ci) {
         asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));  // keep per-lane addresses from being hoisted and spilled
         row = r0 + e;
         row_ok = row < rows;
-        const ChainItemF& it = p.it[ci];
+        const bool head = HEAD && (ONLY || ci < 0);  // (compile-time false in the plain instantiations, true with ONLY)
+        const ChainItemF& it = head ? HD.it : p.it[ci];
+        const GcpShape& B = head ? HD.sh : S;  // the block's own shape: dims, step counts, section offsets of its pack
+        const int Hb = B.H, vib = B.vi;
         const float ns_s = gcp_neg_slope(it.act_s, slope), ns_v = gcp_neg_slope(it.act_v, slope);
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
         gcp_wave_lds_sync();  // the previous block's vector tile update
+
+        // HEAD: the rows of the pre-projected tables this row gathers are requested first (accumulator layout for the scalar
+        // addends, four channels x xyz at a time for the vector ones) and added to the products below
+        f32x16 acc[NT];
+        float qa[4][12];
+        if (head) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 12; ++j) qa[q][j] = 0.f;
+            const int rc = min(row, rows - 1);
+            for (int k = 0; k < HD.s_add.n; ++k) {
+                const int32_t* ix = HD.s_add.idx[k];
+                const int64_t src = ix ? (int64_t)ix[rc] : (int64_t)rc;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = gcp_load4(HD.s_add.ptr[k], src, so, 32 * t + 8 * q + 4 * hi, true, vec_so);
+                        acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+                    }
+            }
+            const int HFP = gcp_round_up(B.HF, 4);
+            for (int k = 0; k < HD.v_add.n; ++k) {
+                const int32_t* ix = HD.v_add.idx[k];
+                const float* trow = HD.v_add.ptr[k] + (ix ? (int64_t)ix[rc] : (int64_t)rc) * 3 * HFP;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int x0 = 8 * q + 4 * hi;
+                    const bool on = x0 < B.HF;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(trow + d * HFP + (on ? x0 : 0));
+                        qa[q][4 * d + 0] += on ? t4.x : 0.f; qa[q][4 * d + 1] += on ? t4.y : 0.f;
+                        qa[q][4 * d + 2] += on ? t4.z : 0.f; qa[q][4 * d + 3] += on ? t4.w : 0.f;
+                    }
+                }
+            }
+        }
 
         // ---- vector prologue on the matrix cores: [vh | vf] = [vector_down ; vector_down_frames] v, then (element-wise,
         //      in registers) the norms of vh and the projections of vf onto the row's frame -> the 32 x XS extras tile ------
         {
             gcp_xyz_acc u;
-            gcp_vmm_down<16>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
-            if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+            gcp_vmm_down<16>(it.pack + B.offVA + lane, B.SVA, vib, vt + e * L.VS, hi, u);
+            if (head) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) u[d][4 * q + i] += qa[q][4 * d + i];
+                for (int i = Hb + B.nf + hi; i < B.KP - B.si; i += 2) ext[e * L.XS + i] = 0.f;  // the head's k padding
+            }
+            if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
             float f[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
@@ -140,27 +237,26 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
             for (int r = 0; r < 16; ++r) {
                 const int x = gcp_crow(r, hi);
                 const float u0 = u[0][r], u1 = u[1][r], u2 = u[2][r];
-                if (r < S.SVB) {  // parked for vector_up in the epilogue (wave-uniform guard)
+                if (r < B.SVB) {  // parked for vector_up in the epilogue (wave-uniform guard)
                     ust[(r * 3 + 0) * 64 + lane] = u0; ust[(r * 3 + 1) * 64 + lane] = u1; ust[(r * 3 + 2) * 64 + lane] = u2;
                 }
-                if (x < H) {
+                if (x < Hb) {
                     ext[e * L.XS + x] = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f;
-                } else if (x < S.HF) {
-                    const int k = x - H;
+                } else if (x < B.HF) {
+                    const int k = x - Hb;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         float pr = f[3 * a + 0] * u0 + f[3 * a + 1] * u1 + f[3 * a + 2] * u2;
                         if (p.o.e3 && a == 1) pr = fabsf(pr);
-                        ext[e * L.XS + H + 3 * k + a] = pr;
+                        ext[e * L.XS + Hb + 3 * k + a] = pr;
                     }
                 }
             }
         }
         gcp_wave_lds_sync();
 
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
         // ---- scalar_out: acc = b + W[:, state] x^T + W[:, extras] ext^T --------------------------------------------------
-        f32x16 acc[NT];
         f32x16 gacc;     // vector-gate pre-activations (initialised with the bias while the extras tile is multiplied)
         float gwa[16];   // first batch of the gate GEMM's weight fragments
 #pragma unroll
@@ -170,11 +266,35 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = 32 * t + gcp_crow(r, hi);
-                acc[t][r] = j < so ? it.b_scalar[j] : 0.f;
+                const float bj = j < so ? it.b_scalar[j] : 0.f;
+                acc[t][r] = head ? acc[t][r] + bj : bj;
             }
+        if (head) {
+            // the head's own scalar inputs: B fragments from its LDS tile, weights from section A of its pack
+            const float* wa0 = it.pack + B.offA + (int64_t)lane * NT;
+            const int KE = B.si / 2;
+            for (int k0 = 0; k0 < KE; k0 += 8) {
+                WF<NT> a[8];
+                float bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = min(k0 + u, KE - 1);
+                    a[u].load(wa0 + (int64_t)kk * 64 * NT);
+                    bv[u] = et[e * ES + 2 * kk + hi];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < KE) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], bv[u], acc[t], 0, 0, 0);
+                    }
+            }
+        }
         {
             const float* wf = it.pack + S.offF + (int64_t)lane * NT;  // [step][64][NT]
             constexpr int U = 4;
+            if (!head) {
             WF<NT> A0[U], A1[U], A2[U];
             auto ld = [&](WF<NT>(&a)[U], int st0) {
 #pragma unroll
@@ -199,10 +319,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
                 if ((b + 3) * U < NT * 16) ld(a, (b + 3) * U);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE: hipcc otherwise sinks each load to its use
             }
-            if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
+            }
+            if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
             // (the gate GEMM's first weight fragments and its bias are requested here, one phase ahead)
             if (scalar_gate) {
-                const float* wg0 = it.pack + S.offC + lane;
+                const float* wg0 = it.pack + B.offC + lane;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     gwa[r] = wg0[(int64_t)r * 64];
@@ -210,31 +331,32 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
                 }
             }
             // norms and frame scalars: ordinary B fragments from the 32 x 16 LDS tile, weights from section A
-            const float* wa = it.pack + S.offA + (int64_t)lane * NT;
-            const int kk0 = si / 2;
-            for (int x0 = 0; x0 < NX; x0 += 8) {  // fragments of eight steps requested together (one L2 round trip, not eight)
+            const float* wa = it.pack + B.offA + (int64_t)lane * NT;
+            const int kk0 = B.si / 2;
+            const int NXb = head ? (B.KP - B.si) / 2 : NX;
+            for (int x0 = 0; x0 < NXb; x0 += 8) {  // fragments of eight steps requested together (one L2 round trip, not eight)
                 WF<NT> a[8];
                 float bv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int x = min(x0 + u, NX - 1);
+                    const int x = min(x0 + u, NXb - 1);
                     a[u].load(wa + (int64_t)(kk0 + x) * 64 * NT);
                     bv[u] = ext[e * L.XS + 2 * x + hi];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (x0 + u < NX) {
+                    if (x0 + u < NXb) {
 #pragma unroll
                         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], bv[u], acc[t], 0, 0, 0);
                     }
             }
         }
 
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
         if (scalar_gate) {
-            const float* wg = it.pack + S.offC + lane;
+            const float* wg = it.pack + B.offC + lane;
             float(&wa)[16] = gwa;
             float wb[16];
 #pragma unroll
@@ -251,16 +373,19 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
                     gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[r], gcp_actf<PWL>(it.act_v, ns_v, slope, acc[t][r]), gacc, 0, 0, 0);
             }
         }
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
         if (it.s_pre) gcp_store_acc_rows<NT>(it.s_pre, so, 0, so, r0, rows, acc, stage, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xs[t][r] += gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][r]);
+            for (int r = 0; r < 16; ++r) {  // (the head is not residual: its output starts the state)
+                const float y = gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][r]);
+                xs[t][r] = head ? y : xs[t][r] + y;
+            }
         if (it.s_out) gcp_store_acc_rows<NT>(it.s_out, so, 0, so, r0, rows, xs, stage, lane);
 
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
         // ---- vector epilogue: vector_up on the matrix cores (B fragments = the parked vector_down outputs), then sigmoid
         //      gate, gating and residual element-wise in registers; the vector tile is updated in place ------------------
         {
@@ -268,16 +393,16 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
 #pragma unroll
             for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) uin[d][r] = r < S.SVB ? ust[(r * 3 + d) * 64 + lane] : 0.f;
+                for (int d = 0; d < 3; ++d) uin[d][r] = r < B.SVB ? ust[(r * 3 + d) * 64 + lane] : 0.f;
             gcp_xyz_zero(vu);
-            gcp_vmm_regs<16>(it.pack + S.offVB + lane, S.SVB, uin, vu);
+            gcp_vmm_regs<16>(it.pack + B.offVB + lane, B.SVB, uin, vu);
             float sg[16], x[16][3];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = min(gcp_crow(r, hi), vo - 1);
                 sg[r] = scalar_gate ? gcp_sigmoid(gacc[r]) : 1.f;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) x[r][d] = vt[e * L.VS + 3 * o + d];
+                for (int d = 0; d < 3; ++d) x[r][d] = head ? 0.f : vt[e * L.VS + 3 * o + d];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -301,15 +426,17 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(ChainParams
                                    row_ok, (vo & 3) == 0);
             }
         }
+        if (head)  // back to the chain blocks' extras layout: their k padding must read as zero
+            for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
         gcp_wave_lds_sync();
         if (it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
-        if (ci == p.n - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
     }
 }
 
-template <int NT, bool PWL>
-int launch_chain(const ChainParams& p, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
+template <int NT, bool PWL, bool HEAD = false, bool ONLY = false>
+int launch_chain(const typename ChainArg<HEAD>::type& p, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, HEAD, ONLY>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
                        lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
@@ -317,19 +444,7 @@ int launch_chain(const ChainParams& p, size_t lds_bytes, hipStream_t st) {
 
 }  // namespace
 
-// Returns GCPNET_E_UNSUPPORTED when the shape does not fit the register-resident kernel; the caller then uses the
-// LDS-resident chain of gcp2_fwd.hip.
-int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const float* frames, int n,
-                             const gcp2_chain_item_t* items, hipStream_t st) {
-    const gcp2_weights_t& w0 = items[0].w;
-    const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
-    if (S.NG != 1 || S.NTG < 2 || (w0.si & 1) || w0.vi <= 0 || w0.vo <= 0 || w0.vo > 32 || S.GT != 1) return GCPNET_E_UNSUPPORTED;
-    if (S.NTS != S.NTG || !S.vmm || w0.vi > 32) return GCPNET_E_UNSUPPORTED;
-    ChainParams p;
-    p.rows = rows; p.s0 = s0; p.v0 = v0; p.frames = frames;
-    p.o = items[0].o;
-    p.n = n;
-    bool pwl = true;
+static int fill_chain(ChainParams& p, const GcpShape& S, int n, const gcp2_chain_item_t* items, bool& pwl) {
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_item_t& c = items[k];
         ChainItemF& it = p.it[k];
@@ -338,10 +453,99 @@ int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const f
         it.gate = c.gate; it.act_s = c.o.act_s; it.act_v = c.o.act_v;
         pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
     }
+    (void)S;
+    return 0;
+}
+
+static bool chain_shape_ok(const GcpShape& S, const gcp2_weights_t& w0) {
+    if (S.NG != 1 || S.NTG < 2 || (w0.si & 1) || w0.vi <= 0 || w0.vo <= 0 || w0.vo > 32 || S.GT != 1) return false;
+    if (S.NTS != S.NTG || !S.vmm || w0.vi > 32) return false;
+    return true;
+}
+
+// Returns GCPNET_E_UNSUPPORTED when the shape does not fit the register-resident kernel; the caller then uses the
+// LDS-resident chain of gcp2_fwd.hip.
+int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const float* frames, int n,
+                             const gcp2_chain_item_t* items, hipStream_t st) {
+    const gcp2_weights_t& w0 = items[0].w;
+    const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
+    if (!chain_shape_ok(S, w0)) return GCPNET_E_UNSUPPORTED;
+    ChainParams p;
+    p.rows = rows; p.s0 = s0; p.v0 = v0; p.frames = frames;
+    p.o = items[0].o;
+    p.n = n;
+    bool pwl = true;
+    fill_chain(p, S, n, items, pwl);
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     p.sh = S;
     const size_t lds_bytes = (size_t)chain_lds(S).total * sizeof(float);
     if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
     if (S.NTG == 2) return pwl ? launch_chain<2, true>(p, lds_bytes, st) : launch_chain<2, false>(p, lds_bytes, st);
     return pwl ? launch_chain<4, true>(p, lds_bytes, st) : launch_chain<4, false>(p, lds_bytes, st);
+}
+
+// The first message GCP after project-then-gather (gcp2_head_t), alone (n == 0) or fused in front of the chain of residual
+// blocks it feeds (its outputs are then still written: the backward needs them).
+extern "C" int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, const float* frames, int n,
+                                             const gcp2_chain_item_t* items, void* stream) {
+    if (rows < 0 || !head || n < 0 || n > GCP_MAX_CHAIN || (n > 0 && !items)) return GCPNET_E_BADARG;
+    const gcp2_weights_t& hw = head->w;
+    if (!head->e_in || !head->xi_in || !hw.pack || !hw.b_scalar || !head->s_out || !head->v_out) return GCPNET_E_BADARG;
+    if (head->s_add.n < 0 || head->s_add.n > GCP_MAX_SEG || head->v_add.n < 0 || head->v_add.n > GCP_MAX_SEG) return GCPNET_E_BADARG;
+    const GcpShape S0 = gcp_shape(hw.si, hw.vi, hw.so, hw.vo, hw.hidden, hw.use_frames);
+    // the head must look like a chain block from its outputs' side, with a small plain input
+    if (S0.NG != 1 || S0.NTG < 2 || hw.so != 32 * S0.NTG || !S0.vmm || hw.vo > 32 || (hw.vo & 3) || S0.GT != 1) return GCPNET_E_UNSUPPORTED;
+    if ((hw.si & 3) || hw.si > 64 || hw.vi <= 0 || ((3 * hw.vi) & 3) || hw.vi > 20 || !hw.use_frames) return GCPNET_E_UNSUPPORTED;
+    if (head->o.vector_residual) return GCPNET_E_UNSUPPORTED;
+    if (head->o.vmode == GCP_VMODE_SCALAR_GATE && !hw.b_gate) return GCPNET_E_BADARG;
+    auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+    if (misaligned(head->e_in) || misaligned(head->xi_in) || misaligned(head->s_out) || misaligned(head->s_pre) ||
+        misaligned(head->gate))
+        return GCPNET_E_UNSUPPORTED;
+    const int hfp = gcp_round_up(S0.HF, 4);
+    for (int k = 0; k < head->s_add.n; ++k)
+        if (!head->s_add.ptr[k] || head->s_add.dim[k] != hw.so || misaligned(head->s_add.ptr[k])) return GCPNET_E_BADARG;
+    for (int k = 0; k < head->v_add.n; ++k)
+        if (!head->v_add.ptr[k] || head->v_add.dim[k] != hfp || misaligned(head->v_add.ptr[k])) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    ChainParamsH p;
+    GcpShape S;
+    bool pwl = gcp_is_pwl(head->o.act_s) && gcp_is_pwl(head->o.act_v);
+    if (n > 0) {
+        const gcp2_weights_t& w0 = items[0].w;
+        S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
+        if (!chain_shape_ok(S, w0) || w0.so != hw.so || w0.vo != hw.vo || S.nf != S0.nf) return GCPNET_E_UNSUPPORTED;
+        for (int k = 0; k < n; ++k) {
+            const gcp2_weights_t& w = items[k].w;
+            if (!w.pack || !w.b_scalar || w.si != w0.si || w.vi != w0.vi || w.so != w0.so || w.vo != w0.vo ||
+                w.hidden != w0.hidden || w.use_frames != w0.use_frames || items[k].o.vmode != head->o.vmode ||
+                items[k].o.vector_residual != 0 || items[k].o.e3 != head->o.e3 || items[k].o.slope != head->o.slope)
+                return GCPNET_E_UNSUPPORTED;
+        }
+        fill_chain(p, S, n, items, pwl);
+    } else {  // head alone: the "chain" shape only provides output dims and LDS strides
+        S = gcp_shape(hw.so, hw.vo, hw.so, hw.vo, hw.hidden < hw.vo ? hw.hidden : hw.vo, hw.use_frames);
+        if (S.NTS != S.NTG || !S.vmm) return GCPNET_E_UNSUPPORTED;
+    }
+    p.rows = rows; p.s0 = nullptr; p.v0 = nullptr; p.frames = frames;
+    p.o = head->o;
+    p.n = n;
+    p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
+    p.sh = S;
+    p.hd.e_in = head->e_in; p.hd.xi_in = head->xi_in;
+    p.hd.s_add = head->s_add; p.hd.v_add = head->v_add;
+    p.hd.sh = S0;
+    ChainItemF& it = p.hd.it;
+    it.pack = hw.pack; it.b_scalar = hw.b_scalar; it.b_gate = hw.b_gate;
+    it.s_out = head->s_out; it.v_out = head->v_out; it.s_pre = head->s_pre; it.gate = head->gate;
+    it.act_s = head->o.act_s; it.act_v = head->o.act_v;
+    const size_t lds_bytes = (size_t)chain_lds(S, &S0).total * sizeof(float);
+    if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (S.NTG == 2) return pwl ? launch_chain<2, true, true, true>(p, lds_bytes, st) : launch_chain<2, false, true, true>(p, lds_bytes, st);
+        return pwl ? launch_chain<4, true, true, true>(p, lds_bytes, st) : launch_chain<4, false, true, true>(p, lds_bytes, st);
+    }
+    if (S.NTG == 2) return pwl ? launch_chain<2, true, true>(p, lds_bytes, st) : launch_chain<2, false, true>(p, lds_bytes, st);
+    return pwl ? launch_chain<4, true, true>(p, lds_bytes, st) : launch_chain<4, false, true>(p, lds_bytes, st);
 }

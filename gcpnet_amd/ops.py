@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT, BwdScratch, ChainBwdItem, ChainItem, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
+from ._lib import (ACT, BwdScratch, ChainBwdItem, ChainItem, Head, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
                    VMODE_SELF_GATE, check)
 
 Tensor = torch.Tensor
@@ -441,11 +441,30 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
     s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
     gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
     gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
+    if ((adds or vadds) and len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
+            and not spec.residual and res_s is None and res_v is None and spec.vo > 0 and USE_HEAD_KERNEL):
+        # the first message GCP after project-then-gather: plain (e, xi) inputs + gathered addend tables -> the register-
+        # resident kernel of the chain, run for this one block (gcp2_chain_fwd.hip, HEAD)
+        hd = Head()
+        hd.e_in, hd.xi_in = s_src[0].data_ptr(), v_src[0].data_ptr()
+        hd.s_add = ac if ac is not None else Concat()
+        hd.v_add = vac if vac is not None else Concat()
+        hd.w, hd.o = ws, opts
+        hd.s_out, hd.v_out = s_out.data_ptr(), v_out.data_ptr()
+        hd.s_pre = s_pre.data_ptr() if s_pre is not None else None
+        hd.gate = gate.data_ptr() if gate is not None else None
+        rc = lib.gcpnet_gcp2_headchain_forward(rows, C.byref(hd), _p(frames), 0, None, _stream())
+        if rc != _lib.E_UNSUPPORTED:
+            check(rc, "gcp2_headchain_forward")
+            return rows, s_out, v_out, pack, s_pre, gate
     check(lib.gcpnet_gcp2_forward(rows, C.byref(sc), C.byref(vc), _p(frames), C.byref(ws), C.byref(opts),
                                   C.byref(ac) if ac is not None else None, C.byref(vac) if vac is not None else None,
                                   _p(res_s), _p(res_v), _p(s_out), _p(v_out), _p(s_pre), _p(gate), _stream()),
           "gcp2_forward")
     return rows, s_out, v_out, pack, s_pre, gate
+
+
+USE_HEAD_KERNEL = True  # module switch
 
 
 def _vadd_concat(tables: Sequence[Tensor], plans: Sequence[Optional[GatherPlan]]) -> Concat:

@@ -118,6 +118,25 @@ typedef struct {
 int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const float* frames, int n,
                               const gcp2_chain_item_t* items, void* stream);
 
+/* ---- the first message GCP after project-then-gather, alone (n == 0) or fused in front of the chain it feeds:
+ * scalar input e_in [rows, w.si] and vector input xi_in [rows, w.vi, 3] are plain (un-gathered) tensors, the gathered
+ * sources enter through s_add / v_add as in gcpnet_gcp2_forward; the block is not residual and its outputs (s_out, v_out;
+ * s_pre / gate when non-NULL) are written in any case.  Returns GCPNET_E_UNSUPPORTED outside the register-resident kernel's
+ * shapes (so in {64, 128}, w.si <= 64, w.vi <= 20, vo <= 32, frames in use); the caller then uses gcpnet_gcp2_forward. */
+typedef struct {
+    const float* e_in;
+    const float* xi_in;
+    gcp_concat_t s_add, v_add;
+    gcp2_weights_t w;
+    gcp2_opts_t o;
+    float* s_out;
+    float* v_out;
+    float* s_pre;
+    float* gate;
+} gcp2_head_t;
+int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, const float* frames, int n,
+                                  const gcp2_chain_item_t* items, void* stream);
+
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
  * concatenated layout, plus what the weight gradients need:
