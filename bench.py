@@ -110,7 +110,7 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/README.md); None when not collected."""
-    path = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
     try:
         with open(path) as f:
             return json.load(f).get(kernel)
