@@ -804,7 +804,21 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
             s_sources = list(s_sources[:k]) + [src[:, cut:].contiguous()] + list(s_sources[k + 1:])
             spec = replace(spec, si=spec.si - cut, pack_cache=None, add_plans=[spec.s_plans[k]])
             weights = (w_rest,) + tuple(weights[1:])
-            return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, add)
+            vadds = []
+            if _head_shaped_after_split(spec, s_sources, v_sources, rows):
+                # few rows and a block that then fits the register-resident head kernel (so <= 128): project all but four
+                # vector channels as well ([n, 3, V] x [V, H + 3] at the rows themselves, added un-gathered)
+                v = v_sources[0]
+                vc = v.shape[1] - 4
+                w_down, w_frames = weights[2], weights[3]
+                H = spec.hidden
+                hfp = (H + 3 + 3) // 4 * 4
+                wseg = torch.nn.functional.pad(torch.cat([w_down[:, :vc], w_frames[:, :vc]], dim=0), (0, 0, 0, hfp - (H + 3)))
+                vadds = [_ProjectV.apply(v[:, :vc], wseg)]
+                weights = (weights[0], weights[1], w_down[:, vc:].contiguous(), w_frames[:, vc:].contiguous()) + tuple(weights[4:])
+                v_sources = [v[:, vc:].contiguous()]
+                spec = replace(spec, vi=4, vadd_plans=[None])
+            return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, add, *vadds)
     if proj is not None:
         # "Project, then gather" (see _Gcp2Projected): the shares of GATHERED sources (h[row], h[col] / chi[row], chi[col] in a
         # message GCP, reference gcpnet.py:907-917) in scalar_out / vector_down(.frames) are computed once per source row.
@@ -815,7 +829,7 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
 
 
 PROJECT_GATHERED_SCALARS = True  # module switches (tests compare both paths)
-PROJECT_SMALL_LAUNCHES = False  # measured: no gain at 10 000 node rows (extra small launches cost what the shorter k loop saves)
+PROJECT_SMALL_LAUNCHES = False  # measured at 10 000 node rows: no gain (the extra small launches cost what the shorter k loop saves)
 
 
 def _tn_weight_grad(a2d: Tensor, b2d: Tensor) -> Tensor:
@@ -1130,13 +1144,22 @@ def _too_wide(spec: Gcp2Spec, s_sources, rows: int):
     dims = [t.shape[1] for t in s_sources]
     k = max(range(len(dims)), key=lambda i: dims[i])
     if need(spec.si) <= LDS_LIMIT:
-        if PROJECT_SMALL_LAUNCHES and rows <= SMALL_LAUNCH_ROWS and dims[k] >= 3 * SPLIT_KEEP_COLUMNS and dims[k] % 4 == 0:
+        # (only where the remainder then runs in the register-resident head kernel: so <= 128; measured: no gain otherwise)
+        if (PROJECT_SMALL_LAUNCHES and rows <= SMALL_LAUNCH_ROWS and dims[k] >= 3 * SPLIT_KEEP_COLUMNS and dims[k] % 4 == 0
+                and spec.so in (64, 128) and len(s_sources) == 1 and spec.s_plans[0] is None):
             return k, (dims[k] - SPLIT_KEEP_COLUMNS) // 32 * 32
         return None
     cut = 0
     while cut + 32 < dims[k] and need(spec.si - cut) > LDS_LIMIT // 2:  # leave room for two waves per CU
         cut += 32
     return (k, cut) if cut > 0 and need(spec.si - cut) <= LDS_LIMIT else None
+
+
+def _head_shaped_after_split(spec: Gcp2Spec, s_sources, v_sources, rows: int) -> bool:
+    return (PROJECT_SMALL_LAUNCHES and rows <= SMALL_LAUNCH_ROWS and len(s_sources) == 1 and len(v_sources) == 1
+            and spec.s_plans[0] is None and spec.v_plans[0] is None and spec.so in (64, 128) and spec.si <= 64
+            and spec.vi > 4 and 0 < spec.vo <= 32 and spec.vo % 4 == 0 and spec.use_frames and spec.hidden + 3 <= 32
+            and not spec.vector_residual)
 
 
 PROJECT_GATHERED_VECTORS = True
