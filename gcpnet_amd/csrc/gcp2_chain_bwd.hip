@@ -101,11 +101,13 @@ struct WFragC<4> {
 
 // NTG: 32-wide tiles of the scalar state (si == so == 32 * NTG); VQ: register quads of the vector state (vi == vo <= 8 * VQ);
 // PWL: all activations are identity / relu / leakyrelu.
-template <int NTG, int VQ, bool PWL>
+// HC: hidden vector channels as a compile-time constant (0 = run-time value): with it the tests "channel < H" of the element-wise
+// register code fold, and only the registers that can hold a [vh | vf] channel are walked.
+template <int NTG, int VQ, bool PWL, int HC>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 4 * VQ;  // registers per xyz component of a vector-channel quantity
-    constexpr int NX = 8;       // registers per xyz component of a [vh | vf] quantity (H + 3 <= 16)
+    constexpr int NX = HC ? 4 * ((HC + 3 + 7) / 8) : 8;  // registers per xyz component of a [vh | vf] quantity (H + 3 <= 16)
     const GcpShape& S = p.sh;
     const CbLds L = cb_lds(S);
     int lane = threadIdx.x;
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     float* dext = lds + L.o_dext;  // d(norms | frame scalars): from the lanes of the scalar_out adjoint to the vh / vf channels' lanes
     float* e3t = lds + L.o_e3;     // signs of the x_cross projections (e3 variant only)
     float* stage = lds + L.o_stage;  // transposition tile of the row-wise stores (tile_io.h, gcp_store_acc_rows)
-    const int so = S.so, vi = S.vi, H = S.H, HF = S.HF;  // si == so, vo == vi
+    const int so = S.so, vi = S.vi;  // si == so, vo == vi
+    const int H = HC ? HC : S.H, HF = HC ? HC + 3 : S.HF;  // (frames are in use whenever HC is given)
+    const int SVB = HC ? 4 * ((HC + 7) / 8) : S.SVB, SVD = HC ? 4 * ((HC + 3 + 7) / 8) : S.SVD;
     const int EP = gcp_round_up(S.H + S.nf, 4), VOP = gcp_round_up(vi, 4);
     const float slope = p.o.slope;
     const bool scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             // ---- B. vu = vector_up(vh), B fragments = the registers just produced ------------------------------------
             gcp_xyz_acc vu;
             gcp_xyz_zero(vu);
-            gcp_vmm_regs<NX>(it.pack + S.offVB + lane, S.SVB, u, vu);
+            gcp_vmm_regs<NX>(it.pack + S.offVB + lane, SVB, u, vu);
             // ---- C. adjoint of the vector epilogue (gcpnet.py:364-391), element-wise: d(vector_up output), d(gate) ------
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             }
             gcp_xyz_acc dv;
             gcp_xyz_zero(dv);
-            gcp_vmm_regs<NX>(it.pack + S.offVD + lane, S.SVD, dacc, dv);
+            gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
             float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
             load_state(st);
 #pragma unroll
@@ -486,7 +490,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 
 template <int NTG, int VQ, bool PWL>
 int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
+    if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4): hidden channel count known at compile time
+        hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)),
+                           dim3(GCP_WAVE), lds_bytes, st, p);
+        GCP_HIP_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
                        lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;

@@ -298,10 +298,12 @@ def test_model_lba_golden(G):
     close(pred.cpu(), f.o["pred"], atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("n,e,dims", [(2000, 32000, (128, 16)), (600, 6000, (256, 32))], ids=["C2-dims", "C5-dims"])
+@pytest.mark.parametrize("n,e,dims", [(2000, 32000, (128, 16)), (600, 6000, (256, 32)), (600, 6000, (64, 8))],
+                         ids=["C2-dims", "C5-dims", "small-V"])
 def test_interactions_large_vs_oracle(G, n, e, dims):
     """Bench-shaped (but smaller) layers, col-sorted edges, edge dims (32,4), fwd + bwd: BASELINE configs[1] dims (128,16)
-    (register-resident chain kernels) and configs[4] dims (256,32) (two output groups: block-by-block kernels)."""
+    (register-resident chain kernels), configs[4] dims (256,32) (two output groups: block-by-block kernels), and (64,8):
+    H = 2, one register quad per vector quantity (the chain kernels' run-time-H instantiations)."""
     torch.manual_seed(11)
     layer = G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
                               dropout=0.0).cuda().eval()
