@@ -111,8 +111,11 @@ __device__ __forceinline__ const HeadParams& head_of(const ChainParamsH& p) { re
 __device__ __forceinline__ const HeadParams& head_of(const ChainParams& p) { return *reinterpret_cast<const HeadParams*>(&p); }
 
 // HEAD: a head block (HeadParams) runs first; ONLY: ... and nothing else (n == 0), so that the compiler sees one block shape.
-template <int NT, bool PWL, bool HEAD, bool ONLY = false>
+// HC: hidden vector channels of the chain blocks as a compile-time constant (0 = run-time; plain instantiations only).
+template <int NT, bool PWL, bool HEAD, bool ONLY = false, int HC = 0>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename ChainArg<HEAD>::type p) {
+    static_assert(!(HEAD && HC), "the head block has its own shape");
+    constexpr int NXR = HC ? 4 * ((HC + 3 + 7) / 8) : 16;  // registers that can hold a [vh | vf] channel
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
     const HeadParams& HD = head_of(p);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
     float* ext = lds + L.o_ext;
     float* ust = lds + L.o_ust;
     float* stage = lds + L.o_stage;
-    const int vi = S.vi, so = S.so, vo = S.vo, H = S.H;
+    const int vi = S.vi, so = S.so, vo = S.vo, H = HC ? HC : S.H;
     const int NX = gcp_round_up(H + S.nf, 2) / 2;  // k-pair steps over the norms / frame scalars
     const float slope = p.o.slope;
     const bool scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;
@@ -167,7 +170,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         const bool head = HEAD && (ONLY || ci < 0);  // (compile-time false in the plain instantiations, true with ONLY)
         const ChainItemF& it = head ? HD.it : p.it[ci];
         const GcpShape& B = head ? HD.sh : S;  // the block's own shape: dims, step counts, section offsets of its pack
-        const int Hb = B.H, vib = B.vi;
+        const int Hb = HC ? HC : B.H, vib = B.vi;
+        const int HFb = HC ? HC + 3 : B.HF, SVBb = HC ? 4 * ((HC + 7) / 8) : B.SVB;
         const float ns_s = gcp_neg_slope(it.act_s, slope), ns_v = gcp_neg_slope(it.act_v, slope);
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
         gcp_wave_lds_sync();  // the previous block's vector tile update
@@ -234,15 +238,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #pragma unroll
             for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NXR; ++r) {
                 const int x = gcp_crow(r, hi);
                 const float u0 = u[0][r], u1 = u[1][r], u2 = u[2][r];
-                if (r < B.SVB) {  // parked for vector_up in the epilogue (wave-uniform guard)
+                if (r < SVBb) {  // parked for vector_up in the epilogue (wave-uniform guard)
                     ust[(r * 3 + 0) * 64 + lane] = u0; ust[(r * 3 + 1) * 64 + lane] = u1; ust[(r * 3 + 2) * 64 + lane] = u2;
                 }
                 if (x < Hb) {
                     ext[e * L.XS + x] = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f;
-                } else if (x < B.HF) {
+                } else if (x < HFb) {
                     const int k = x - Hb;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
@@ -393,9 +397,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #pragma unroll
             for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) uin[d][r] = r < B.SVB ? ust[(r * 3 + d) * 64 + lane] : 0.f;
+                for (int d = 0; d < 3; ++d) uin[d][r] = r < SVBb ? ust[(r * 3 + d) * 64 + lane] : 0.f;
             gcp_xyz_zero(vu);
-            gcp_vmm_regs<16>(it.pack + B.offVB + lane, B.SVB, uin, vu);
+            gcp_vmm_regs<16>(it.pack + B.offVB + lane, SVBb, uin, vu);
             float sg[16], x[16][3];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -436,6 +440,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 
 template <int NT, bool PWL, bool HEAD = false, bool ONLY = false>
 int launch_chain(const typename ChainArg<HEAD>::type& p, size_t lds_bytes, hipStream_t st) {
+    if constexpr (!HEAD) {
+        if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4)
+            hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, false, false, 4>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)),
+                               dim3(GCP_WAVE), lds_bytes, st, p);
+            GCP_HIP_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, HEAD, ONLY>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
                        lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
