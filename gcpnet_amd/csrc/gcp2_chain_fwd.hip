@@ -116,6 +116,7 @@ template <int NT, bool PWL, bool HEAD, bool ONLY = false, int HC = 0>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename ChainArg<HEAD>::type p) {
     static_assert(!(HEAD && HC), "the head block has its own shape");
     constexpr int NXR = HC ? 4 * ((HC + 3 + 7) / 8) : 16;  // registers that can hold a [vh | vf] channel
+    constexpr int NVR = HC ? 8 : 16;  // registers that can hold an output vector channel (the HC instantiations: vo <= 16)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GcpShape& S = p.sh;
     const HeadParams& HD = head_of(p);
@@ -400,16 +401,16 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 for (int d = 0; d < 3; ++d) uin[d][r] = r < SVBb ? ust[(r * 3 + d) * 64 + lane] : 0.f;
             gcp_xyz_zero(vu);
             gcp_vmm_regs<16>(it.pack + B.offVB + lane, SVBb, uin, vu);
-            float sg[16], x[16][3];
+            float sg[NVR], x[NVR][3];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NVR; ++r) {
                 const int o = min(gcp_crow(r, hi), vo - 1);
                 sg[r] = scalar_gate ? gcp_sigmoid(gacc[r]) : 1.f;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) x[r][d] = head ? 0.f : vt[e * L.VS + 3 * o + d];
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NVR; ++r) {
                 const int o = gcp_crow(r, hi);
                 if (o < vo) {
                     float u0 = vu[0][r], u1 = vu[1][r], u2 = vu[2][r];
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             }
             if (scalar_gate && it.gate) {  // saved for the backward, straight from the registers (accumulator-layout rows)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NVR / 4; ++q)
                     if (8 * q < vo)
                         gcp_store4(it.gate, row, vo, 8 * q + 4 * hi, make_float4(sg[4 * q], sg[4 * q + 1], sg[4 * q + 2], sg[4 * q + 3]),
                                    row_ok, (vo & 3) == 0);
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 template <int NT, bool PWL, bool HEAD = false, bool ONLY = false>
 int launch_chain(const typename ChainArg<HEAD>::type& p, size_t lds_bytes, hipStream_t st) {
     if constexpr (!HEAD) {
-        if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4)
+        if (p.sh.H == 4 && p.sh.nf && p.sh.vo <= 16) {  // the shipped shape (V = 16, bottleneck 4)
             hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, false, false, 4>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)),
                                dim3(GCP_WAVE), lds_bytes, st, p);
             GCP_HIP_CHECK_LAUNCH();
