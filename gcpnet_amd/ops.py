@@ -604,7 +604,17 @@ class _WeightGradJob:
         return g
 
 
-WEIGHT_GRADS_ON_SIDE_STREAM = True  # module switch
+WEIGHT_GRADS_ON_SIDE_STREAM = True  # module switch, see set_weight_grad_stream()
+
+
+def set_weight_grad_stream(enabled: bool) -> None:
+    """Weight gradients on a second HIP stream (default on).  They are complete when `backward()` returns (the caller's stream
+    joins in an end-of-backward callback), but NOT while it is still running: code that reads a parameter's gradient from
+    inside the backward pass -- `torch.nn.parallel.DistributedDataParallel`'s bucket hooks, `register_hook` /
+    `register_post_accumulate_grad_hook` on parameters -- must switch this off (or use `gcpnet_amd.parallel.GradAllReducer`,
+    which runs after the backward pass)."""
+    global WEIGHT_GRADS_ON_SIDE_STREAM
+    WEIGHT_GRADS_ON_SIDE_STREAM = bool(enabled)
 _side_streams: dict = {}
 _side_pending: list = []
 
