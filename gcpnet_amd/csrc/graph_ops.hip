@@ -366,6 +366,138 @@ extern "C" int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float*
     return 0;
 }
 
+// ---- inter-node force term of the position update (reference gcpnet.py:1143-1153): per edge
+//        z = act(A[row] + B[col]),  coef = W3 z  (3 values),  force = coef[0] x_diff + coef[1] x_cross + coef[2] x_vertical
+//      with A = phi_force_i(h), B = phi_force_j(h) computed per node by the caller (library GEMMs) and the frame rows of f_ij.
+//      One wave per edge at a time, lanes over the s columns (float4 pieces), wave-level dot products.
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define EF_MAX_CHUNKS 4  // s <= 1024
+__global__ __launch_bounds__(256) void edge_force_fwd_kernel(int64_t E, int s, const float* __restrict__ A,
+                                                             const float* __restrict__ B, const int32_t* __restrict__ row,
+                                                             const int32_t* __restrict__ col, const float* __restrict__ W3,
+                                                             const float* __restrict__ frames, int act, float slope,
+                                                             float* __restrict__ force) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t e = wave; e < E; e += nwaves) {
+        const float* a = A + (int64_t)row[e] * s;
+        const float* b = B + (int64_t)col[e] * s;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        for (int j = 4 * lane; j < s; j += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(a + j), y = *reinterpret_cast<const float4*>(b + j);
+            const float4 w0 = *reinterpret_cast<const float4*>(W3 + j), w1 = *reinterpret_cast<const float4*>(W3 + s + j),
+                         w2 = *reinterpret_cast<const float4*>(W3 + 2 * s + j);
+            const float z0 = gcp_act(act, x.x + y.x, slope), z1 = gcp_act(act, x.y + y.y, slope),
+                        z2 = gcp_act(act, x.z + y.z, slope), z3 = gcp_act(act, x.w + y.w, slope);
+            c0 += z0 * w0.x + z1 * w0.y + z2 * w0.z + z3 * w0.w;
+            c1 += z0 * w1.x + z1 * w1.y + z2 * w1.z + z3 * w1.w;
+            c2 += z0 * w2.x + z1 * w2.y + z2 * w2.z + z3 * w2.w;
+        }
+        c0 = wave_sum64(c0); c1 = wave_sum64(c1); c2 = wave_sum64(c2);
+        if (lane < 3) {
+            const float* f = frames + e * 9;
+            force[e * 3 + lane] = c0 * f[lane] + c1 * f[3 + lane] + c2 * f[6 + lane];
+        }
+    }
+}
+
+// Adjoint: d_pre[e, :] = act'(A[row] + B[col]) * (W3^T dcoef) with dcoef[k] = <f_ij[e, k, :], d_force[e, :]>, and this block's share
+// of d W3[k, j] = sum_e dcoef[k] z[j] in part[block, 3 s] (summed over blocks by gcpnet_reduce_partials).
+__global__ __launch_bounds__(256) void edge_force_bwd_kernel(int64_t E, int s, const float* __restrict__ A,
+                                                             const float* __restrict__ B, const int32_t* __restrict__ row,
+                                                             const int32_t* __restrict__ col, const float* __restrict__ W3,
+                                                             const float* __restrict__ frames, int act, float slope,
+                                                             const float* __restrict__ d_force, float* __restrict__ d_pre,
+                                                             float* __restrict__ part) {
+    __shared__ float red[4][3 * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    float pw[EF_MAX_CHUNKS][3][4];
+#pragma unroll
+    for (int i = 0; i < EF_MAX_CHUNKS; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) pw[i][k][x] = 0.f;
+    for (int64_t e = wave; e < E; e += nwaves) {
+        const float* a = A + (int64_t)row[e] * s;
+        const float* b = B + (int64_t)col[e] * s;
+        const float* f = frames + e * 9;
+        const float g0 = d_force[e * 3], g1 = d_force[e * 3 + 1], g2 = d_force[e * 3 + 2];
+        const float dc0 = f[0] * g0 + f[1] * g1 + f[2] * g2, dc1 = f[3] * g0 + f[4] * g1 + f[5] * g2,
+                    dc2 = f[6] * g0 + f[7] * g1 + f[8] * g2;
+#pragma unroll
+        for (int i = 0; i < EF_MAX_CHUNKS; ++i) {
+            const int j = 4 * lane + 256 * i;
+            if (j < s) {
+                const float4 x = *reinterpret_cast<const float4*>(a + j), y = *reinterpret_cast<const float4*>(b + j);
+                const float4 w0 = *reinterpret_cast<const float4*>(W3 + j), w1 = *reinterpret_cast<const float4*>(W3 + s + j),
+                             w2 = *reinterpret_cast<const float4*>(W3 + 2 * s + j);
+                const float p[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+                const float ww[3][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}};
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float z = gcp_act(act, p[q], slope);
+                    o[q] = (dc0 * ww[0][q] + dc1 * ww[1][q] + dc2 * ww[2][q]) * gcp_act_grad(act, p[q], slope);
+                    pw[i][0][q] += dc0 * z; pw[i][1][q] += dc1 * z; pw[i][2][q] += dc2 * z;
+                }
+                *reinterpret_cast<float4*>(d_pre + e * s + j) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    float* mine = part + (int64_t)blockIdx.x * 3 * s;
+#pragma unroll
+    for (int i = 0; i < EF_MAX_CHUNKS; ++i) {  // combine the four waves, 256 columns at a time, in a fixed order
+        if (256 * i >= s) break;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[w][k * 256 + 4 * lane + q] = pw[i][k][q];
+        __syncthreads();
+        for (int c = threadIdx.x; c < 3 * 256; c += 256) {
+            const int k = c >> 8, j = 256 * i + (c & 255);
+            if (j < s) mine[k * s + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        }
+        __syncthreads();
+    }
+}
+
+static inline int ef_blocks(int64_t E) { return (int)(E < 4 * 2048 ? (E + 3) / 4 > 0 ? (E + 3) / 4 : 1 : 2048); }
+
+extern "C" int gcpnet_edge_force_bwd_blocks(int64_t E) { return E <= 0 ? 1 : ef_blocks(E); }
+
+extern "C" int gcpnet_edge_force_forward(int64_t E, int s, const float* A, const float* B, const int32_t* row, const int32_t* col,
+                                         const float* W3, const float* frames, int act, float slope, float* force, void* stream) {
+    if (E < 0 || s <= 0 || (s & 3) || s > 256 * EF_MAX_CHUNKS || !A || !B || !row || !col || !W3 || !frames || !force)
+        return GCPNET_E_BADARG;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(W3)) return GCPNET_E_BADARG;
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(edge_force_fwd_kernel, dim3(ef_blocks(E)), dim3(256), 0, (hipStream_t)stream, E, s, A, B, row, col, W3,
+                       frames, act, slope, force);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_edge_force_backward(int64_t E, int s, const float* A, const float* B, const int32_t* row, const int32_t* col,
+                                          const float* W3, const float* frames, int act, float slope, const float* d_force,
+                                          float* d_pre, float* part, void* stream) {
+    if (E < 0 || s <= 0 || (s & 3) || s > 256 * EF_MAX_CHUNKS || !A || !B || !row || !col || !W3 || !frames || !d_force ||
+        !d_pre || !part)
+        return GCPNET_E_BADARG;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(W3) || !aligned16(d_pre)) return GCPNET_E_BADARG;
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(edge_force_bwd_kernel, dim3(ef_blocks(E)), dim3(256), 0, (hipStream_t)stream, E, s, A, B, row, col, W3,
+                       frames, act, slope, d_force, d_pre, part);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi,
                                  float* y, void* stream) {
     if (n < 0 || !b || !y) return GCPNET_E_BADARG;

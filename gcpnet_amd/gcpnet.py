@@ -384,17 +384,34 @@ class GCPInteractions(nn.Module):
             self.node_position_update_network = nn.ModuleList([
                 ff_without_res_GCP(node_dims, (node_dims.scalar, 1), nonlinearities=cfg.nonlinearities,
                                    enable_e3_equivariance=cfg.enable_e3_equivariance)])
-            if not self.ablate_x_force_update:
-                _unsupported("GCPInteractions with ablate_x_force_update=False (force update)")
-            self.phi_force_i = self.phi_force_j = self.phi_force_ij = None
+            # node position force-update layers (:1052-1063), created in the reference's order
+            s_dim = node_dims.scalar
+            self.force_act = canonical_act(cfg.nonlinearities[0])
+            self.force_slope = float(getattr(layer_cfg, "nonlinearity_slope", 1e-2))
+            if self.ablate_x_force_update:
+                self.phi_force_i = self.phi_force_j = self.phi_force_ij = None
+            else:
+                self.phi_force_i = nn.Linear(s_dim, s_dim)
+                self.phi_force_j = nn.Linear(s_dim, s_dim)
+                last = nn.Linear(s_dim, 3, bias=False)
+                torch.nn.init.xavier_uniform_(last.weight, gain=0.001)
+                # (index 0 of the reference's Sequential is the parameter-free nonlinearity; it is applied inside the kernel)
+                self.phi_force_ij = nn.Sequential(nn.Identity(), last)
 
     def derive_x_update(self, node_rep, edge_index, f_ij, node_mask=None):
-        """:1119-1158 with the force term ablated (every shipped config).  Returns the un-weighted vector update;
-        the weight and clamp are applied together with the position add."""
+        """:1119-1158.  Returns the un-weighted update (vector channel + inter-node force term); the weight and clamp are
+        applied together with the position add."""
         h_v, chi_v = node_rep
         for gcp in self.node_position_update_network:
             h_v, chi_v = gcp((h_v, chi_v), edge_index, f_ij, node_inputs=True, node_mask=node_mask)
-        return chi_v.reshape(chi_v.shape[0], 3)
+        upd = chi_v.reshape(chi_v.shape[0], 3)
+        if not self.ablate_x_force_update:  # :1143-1153: per-node Linears (library GEMMs), per-edge force, mean over in-edges
+            plan = GraphPlan.get(edge_index, h_v.shape[0])
+            a = torch.nn.functional.linear(h_v, self.phi_force_i.weight, self.phi_force_i.bias)
+            b = torch.nn.functional.linear(h_v, self.phi_force_j.weight, self.phi_force_j.bias)
+            force = ops.edge_force(a, b, self.phi_force_ij[1].weight, f_ij, plan, self.force_act, self.force_slope)
+            upd = ops.axpy(upd, ops.segment_reduce(force, plan.col, mean=True), 1.0)
+        return upd
 
     def forward(self, node_rep, edge_rep, edge_index, frames, node_rep_regressive=None, node_mask=None, node_pos=None):
         if node_rep_regressive is not None:

@@ -1068,6 +1068,49 @@ class _Gcp2Projected(torch.autograd.Function):
         return (None, None, None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
 
 
+class _EdgeForce(torch.autograd.Function):
+    """force[e] = sum_k coef[e, k] f_ij[e, k, :] with coef = W3 act(A[row] + B[col]) (reference gcpnet.py:1143-1150).
+    A, B: per-node tables [N, s]; W3 [3, s]; frames [E, 3, 3] (constants of the step)."""
+
+    @staticmethod
+    def forward(ctx, A, B, W3, frames, plan: GraphPlan, act, slope: float):
+        lib = _lib.load()
+        E, s = plan.n_edges, A.shape[1]
+        force = torch.empty((E, 3), dtype=torch.float32, device=A.device)
+        check(lib.gcpnet_edge_force_forward(E, s, _p(A), _p(B), _p(plan.row.idx), _p(plan.col.idx), _p(W3), _p(frames),
+                                            ACT[act], float(slope), _p(force), _stream()), "edge_force_forward")
+        ctx.save_for_backward(A, B, W3, frames)
+        ctx.plan, ctx.act, ctx.slope = plan, act, float(slope)
+        return force
+
+    @staticmethod
+    def backward(ctx, d_force):
+        lib = _lib.load()
+        A, B, W3, frames = ctx.saved_tensors
+        plan = ctx.plan
+        E, s = plan.n_edges, A.shape[1]
+        f32 = dict(dtype=torch.float32, device=A.device)
+        d_force = _req(d_force, "grad")
+        d_pre = torch.empty((E, s), **f32)
+        nb = lib.gcpnet_edge_force_bwd_blocks(E)
+        part = torch.empty((nb, 3 * s), **f32)
+        check(lib.gcpnet_edge_force_backward(E, s, _p(A), _p(B), _p(plan.row.idx), _p(plan.col.idx), _p(W3), _p(frames),
+                                             ACT[ctx.act], ctx.slope, _p(d_force), _p(d_pre), _p(part), _stream()),
+              "edge_force_backward")
+        dA = _segment_reduce_raw(d_pre, 0, s, s, plan.row, False)
+        dB = _segment_reduce_raw(d_pre, 0, s, s, plan.col, False)
+        dW3 = torch.empty((3, s), **f32)
+        tmp = torch.empty((lib.gcpnet_reduce_partials_groups(nb), 3 * s), **f32)
+        job = ReduceJob()
+        job.parts, job.n_parts, job.width, job.tmp, job.out = part.data_ptr(), nb, 3 * s, tmp.data_ptr(), dW3.data_ptr()
+        check(lib.gcpnet_reduce_partials(1, C.byref(job), _stream()), "reduce_partials")
+        return dA, dB, dW3, None, None, None, None
+
+
+def edge_force(A: Tensor, B: Tensor, W3: Tensor, frames: Tensor, plan: GraphPlan, act, slope: float) -> Tensor:
+    return _EdgeForce.apply(_req(A, "A"), _req(B, "B"), _req(W3, "W3"), _req(frames.detach(), "frames"), plan, act, slope)
+
+
 class _ProjectV(torch.autograd.Function):
     """Q[n, d, x] = sum_c W[x, c] v[n, c, d] for v [n, V, 3], W [HF', V]: [vector_down ; vector_down_frames] applied at the
     source rows.  Forward and input gradient are plain library GEMMs on the xyz-major copy of v; the weight gradient reduces

@@ -256,6 +256,19 @@ int64_t gcpnet_layernorm_bwd_scratch_floats(int rows, int sdim);
 int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi, float* y,
                       void* stream);
 
+/* ---- inter-node force term of the position update (components/gcpnet.py:1143-1153, `ablate_x_force_update: false`):
+ * per edge z = act(A[row] + B[col]) with A = phi_force_i(h), B = phi_force_j(h) [N, s] (computed per node by the caller),
+ * coef = W3 z (W3 = phi_force_ij.1.weight [3, s]), force[e] = coef[0] x_diff + coef[1] x_cross + coef[2] x_vertical (rows of
+ * frames[e]); the scatter-mean over `col` that follows is gcpnet_segment_reduce.  Backward: d_pre [E, s] (to be summed per
+ * row -> dA and per col -> dB) and per-block shares of d W3 in part [gcpnet_edge_force_bwd_blocks(E), 3 s]
+ * (gcpnet_reduce_partials). */
+int gcpnet_edge_force_forward(int64_t E, int s, const float* A, const float* B, const int32_t* row, const int32_t* col,
+                              const float* W3, const float* frames, int act, float slope, float* force, void* stream);
+int gcpnet_edge_force_backward(int64_t E, int s, const float* A, const float* B, const int32_t* row, const int32_t* col,
+                               const float* W3, const float* frames, int act, float slope, const float* d_force,
+                               float* d_pre, float* part, void* stream);
+int gcpnet_edge_force_bwd_blocks(int64_t E);
+
 /* out[r, j] = sum_k in[r, k] W[k, j], rows x K times a tiny row-major W [K, J] (K * J <= 4096): the per-source-row side of
  * the vector projections of gcpnet_gcp2_forward's v_add tables ([vector_down ; vector_down_frames] applied at the source rows). */
 int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,

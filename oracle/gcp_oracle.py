@@ -378,13 +378,13 @@ def gcp_interactions(
     if not updating:
         return h, chi
     # derive_x_update, gcpnet.py:1119-1158 (force term ablated in every shipped config)
-    _, xv = gcp2(P, pre + "node_position_update_network.0.", h, chi, edge_index, frames, node_inputs=True,
-                 **_gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])))
+    hv, xv = gcp2(P, pre + "node_position_update_network.0.", h, chi, edge_index, frames, node_inputs=True,
+                  **_gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])))
     upd = xv.squeeze(1)
-    if (pre + "phi_force_i.weight") in P:
+    if (pre + "phi_force_i.weight") in P:  # force term (:1143-1153): uses the scalar OUTPUT of the position-update GCP
         row, col = edge_index[0], edge_index[1]
-        hi = h[row] @ P[pre + "phi_force_i.weight"].t() + P[pre + "phi_force_i.bias"]
-        hj = h[col] @ P[pre + "phi_force_j.weight"].t() + P[pre + "phi_force_j.bias"]
+        hi = hv[row] @ P[pre + "phi_force_i.weight"].t() + P[pre + "phi_force_i.bias"]
+        hj = hv[col] @ P[pre + "phi_force_j.weight"].t() + P[pre + "phi_force_j.bias"]
         coef = nonlinearity(cfg["nonlinearities"][0], hi + hj, layer_cfg["nonlinearity_slope"]) \
             @ P[pre + "phi_force_ij.1.weight"].t()
         force = torch.einsum("ea,ead->ed", coef, frames)

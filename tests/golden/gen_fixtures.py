@@ -219,6 +219,24 @@ def fx_interactions():
         save(name, params=layer.state_dict(),
              inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames, x=x), outputs=outs, grads=grads)
 
+    # position update WITH the inter-node force term (ablate_x_force_update: false, gcpnet.py:1143-1153); the reference
+    # initialises phi_force_ij with gain 0.001 -- re-drawn larger here so that the term is visible at fp32 tolerances
+    cfgf = ref_stubs.make_cfg(ablate_x_force_update=False)
+    torch.manual_seed(62)
+    layer = gn.GCPInteractions(nd, ed, cfg=cfgf, layer_cfg=lc, dropout=0.0, updating_node_positions=True)
+    layer.eval()
+    with torch.no_grad():
+        layer.phi_force_ij[1].weight.copy_(randn(3, nd[0], seed=63) * 0.2)
+    for t in (h, chi, e, xi):
+        t.grad = None
+    (ho, co), xo = layer((h, chi), (e, xi), ei, frames, node_pos=x)
+    outs = dict(h=ho, chi=co, x=xo)
+    sq_loss(*outs.values()).backward()
+    grads = dict(h=h.grad, chi=chi.grad, e=e.grad, xi=xi.grad)
+    grads.update({"w." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+    save("interactions_force", params=layer.state_dict(),
+         inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames, x=x), outputs=outs, grads=grads)
+
     # pre-norm ordering, 3 message layers / 3 FF layers, small dims
     lc2 = ref_stubs.make_layer_cfg(pre_norm=True, num_feedforward_layers=3, num_message_layers=3)
     cfg2 = ref_stubs.make_cfg(scalar_nonlinearity="silu", vector_nonlinearity="silu")

@@ -207,9 +207,9 @@ def test_embedding_golden(G, name):
         close(t.detach().cpu(), f.o[k], **FWD)
 
 
-def _load_layer(G, f, upd):
-    layer = G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0,
-                              updating_node_positions=upd).cuda()
+def _load_layer(G, f, upd, force=False):
+    layer = G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(ablate_x_force_update=not force),
+                              layer_cfg=G.default_layer_cfg(), dropout=0.0, updating_node_positions=upd).cuda()
     layer.load_state_dict(f.p)
     return layer.eval()
 
@@ -233,11 +233,11 @@ def test_message_passing_golden(G):
         close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=5e-4)
 
 
-@pytest.mark.parametrize("name", ["interactions", "interactions_posupd"])
+@pytest.mark.parametrize("name", ["interactions", "interactions_posupd", "interactions_force"])
 def test_interactions_golden(G, name):
     f = Fixture(name)
-    upd = name.endswith("posupd")
-    layer = _load_layer(G, f, upd)
+    upd = name != "interactions"
+    layer = _load_layer(G, f, upd, force=name == "interactions_force")
     ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
     ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
     if upd:

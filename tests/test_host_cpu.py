@@ -44,10 +44,11 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.gcpnet_localize(5, None, None, None, 1, None, None) == -1
 
 
-@pytest.mark.parametrize("name,upd", [("interactions", False), ("interactions_posupd", True)])
+@pytest.mark.parametrize("name,upd", [("interactions", False), ("interactions_posupd", True), ("interactions_force", True)])
 def test_state_dict_names_match_reference(name, upd):
     f = Fixture(name)
-    layer = G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
+    cfg = G.default_module_cfg(ablate_x_force_update=name != "interactions_force")
+    layer = G.GCPInteractions((64, 16), (32, 4), cfg=cfg, layer_cfg=G.default_layer_cfg(),
                               dropout=0.0, updating_node_positions=upd)
     sd = layer.state_dict()
     assert list(sd) == list(f.p)

@@ -109,16 +109,17 @@ def test_message_passing():
         close(g, f.g[n], atol=5e-6, rtol=5e-4)
 
 
-@pytest.mark.parametrize("name", ["interactions", "interactions_posupd"])
+@pytest.mark.parametrize("name", ["interactions", "interactions_posupd", "interactions_force"])
 def test_interactions(name):
     f = Fixture(name)
     i = f.i
     P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
     ins = {k: i[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
     cfg, lc = O.default_module_cfg(), O.default_layer_cfg()
+    upd = name != "interactions"  # ("interactions_force": position update with the inter-node force term, :1143-1153)
     out = O.gcp_interactions(P, "", ins["h"], ins["chi"], ins["e"], ins["xi"], i["edge_index"], i["frames"], cfg, lc,
-                             node_pos=i["x"] if name.endswith("posupd") else None)
-    outs = dict(h=out[0][0], chi=out[0][1], x=out[1]) if name.endswith("posupd") else dict(h=out[0], chi=out[1])
+                             node_pos=i["x"] if upd else None)
+    outs = dict(h=out[0][0], chi=out[0][1], x=out[1]) if upd else dict(h=out[0], chi=out[1])
     for k, t in outs.items():
         close(t, f.o[k], atol=5e-6, rtol=5e-5)
     names = list(ins) + ["w." + k for k in P]
