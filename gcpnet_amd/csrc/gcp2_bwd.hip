@@ -59,7 +59,7 @@ __host__ __device__ inline BwdLds bwd_lds(const GcpShape& s) {
     l.o_dvhf = l.o_dext + 32 * l.DS;
     l.o_fr = l.o_dvhf + 32 * l.FS;
     l.o_sw = l.o_fr + 32 * 9;
-    l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
+    l.total = l.o_sw + gcp_small_w_lds_floats(s.vi, s.H, s.vo, s.nf);
     return l;
 }
 

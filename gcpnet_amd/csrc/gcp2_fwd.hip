@@ -87,7 +87,7 @@ __host__ __device__ inline FwdLds fwd_lds(const GcpShape& s) {
     l.o_gt = l.o_vht + (vht > ust ? vht : ust);
     l.o_fr = l.o_gt + 32 * l.GS;
     l.o_sw = l.o_fr + 32 * 9;
-    l.total = l.o_sw + gcp_small_w_floats(s.vi, s.H, s.vo, s.nf);
+    l.total = l.o_sw + gcp_small_w_lds_floats(s.vi, s.H, s.vo, s.nf);
     return l;
 }
 

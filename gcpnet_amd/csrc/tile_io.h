@@ -197,8 +197,20 @@ __device__ __forceinline__ void gcp_copy_to_lds(const float* __restrict__ src, f
     }
 }
 
+// Small weights above this many floats are not copied: the loops read them from global memory (L2-resident, wave-uniform
+// addresses) -- slower per access, but the LDS budget of wide-vector shapes (V_in = 68, H = 68: 28 KB) goes to the tiles.
+#define GCP_SMALL_W_LDS_MAX 2048
+__host__ __device__ inline int gcp_small_w_lds_floats(int vi, int H, int vo, int nf) {
+    const int n = gcp_small_w_floats(vi, H, vo, nf);
+    return n <= GCP_SMALL_W_LDS_MAX ? n : 0;
+}
+
 __device__ __forceinline__ GcpSmallW gcp_stage_small_weights(const gcp2_weights_t& w, int H, int nf, float* area, int lane) {
     GcpSmallW r;
+    if (gcp_small_w_floats(w.vi, H, w.vo, nf) > GCP_SMALL_W_LDS_MAX) {
+        r.wd = w.w_down; r.wf = w.w_frames; r.wu = w.w_up;
+        return r;
+    }
     r.wd = area;
     r.wf = area + H * w.vi;
     r.wu = r.wf + (nf ? 3 * w.vi : 0);

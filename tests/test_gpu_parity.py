@@ -320,12 +320,17 @@ def test_interactions_large_vs_oracle(G, n, e, dims):
     gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
     close(gh.detach().cpu(), wh.detach(), atol=2e-5, rtol=2e-5)
     close(gc.detach().cpu(), wc.detach(), atol=2e-5, rtol=2e-5)
-    sq_loss(wh, wc).backward()
-    sq_loss(gh, gc).backward()
+    # a random linear functional of the outputs: |LayerNorm(x)|^2 is constant for gamma = 1, beta = 0, so a squared loss on
+    # this post-norm layer would have (analytically) zero gradient through the scalar path and only compare round-off
+    lh, lc = torch.randn(wh.shape, generator=g), torch.randn(wc.shape, generator=g)
+    ((wh * lh).sum() + (wc * lc).sum()).backward()
+    ((gh * lh.cuda()).sum() + (gc * lc.cuda()).sum()).backward()
     for k in ins:
-        close(gi[k].grad.cpu(), ci[k].grad, atol=1e-6, rtol=2e-3)
+        scale = float(ci[k].grad.abs().max())
+        close(gi[k].grad.cpu(), ci[k].grad, atol=2e-5 * scale, rtol=1e-4)
     for k, p in layer.named_parameters():
-        close(p.grad.cpu(), P[k].grad, atol=1e-6, rtol=2e-3)
+        scale = float(P[k].grad.abs().max())
+        close(p.grad.cpu(), P[k].grad, atol=2e-5 * scale, rtol=1e-4)
 
 
 def _layer_run(G, layer, ins, ei, fr):

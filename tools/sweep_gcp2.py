@@ -1,0 +1,56 @@
+"""Randomised parity sweep of single GCP2 blocks (edge rows) against the CPU oracle: dims, bottleneck, gating mode, activations,
+vector residual, e3, frames on/off.  usage: python tools/sweep_gcp2.py [n_cases] [seed]   (needs a GPU)"""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gcpnet_amd as G  # noqa: E402
+from oracle import gcp_oracle as O  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+acts = ["relu", "leakyrelu", "silu", "selu", "sigmoid", None]
+bad = 0
+for case in range(n_cases):
+    vi = rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 20, 32, 36])
+    same = rng.random() < 0.4
+    vo = vi if same else rng.choice([1, 2, 4, 6, 8, 16, 24, 32])
+    si = rng.choice([3, 8, 17, 32, 45, 64, 100, 128, 160, 288])
+    so = si if same else rng.choice([5, 16, 32, 64, 100, 128, 200, 256])
+    divs = [b for b in (1, 2, 4) if vi % b == 0]
+    kw = dict(nonlinearities=(rng.choice(acts), rng.choice(acts)), bottleneck=rng.choice(divs), vector_gate=rng.random() < 0.7,
+              vector_residual=same and rng.random() < 0.4, enable_e3_equivariance=rng.random() < 0.25,
+              ablate_frame_updates=rng.random() < 0.15)
+    rows = rng.choice([1, 31, 32, 33, 64, 200, 1000])
+    torch.manual_seed(case)
+    mod = G.GCP2((si, vi), (so, vo), **kw).cuda()
+    g = torch.Generator().manual_seed(case + 1000)
+    ei = torch.stack((torch.arange(rows), torch.arange(rows)))
+    fr = torch.randn(rows, 3, 3, generator=g)
+    s = torch.randn(rows, si, generator=g).requires_grad_()
+    v = torch.randn(rows, vi, 3, generator=g).requires_grad_()
+    P = {k: t.detach().cpu().clone().requires_grad_() for k, t in mod.state_dict().items()}
+    okw = {k: kw[k] for k in ("nonlinearities", "vector_gate", "vector_residual", "enable_e3_equivariance", "ablate_frame_updates")}
+    ws, wv = O.gcp2(P, "", s, v, ei, fr, **okw)
+    sg, vg = s.detach().cuda().requires_grad_(), v.detach().cuda().requires_grad_()
+    gs, gv = mod((sg, vg), ei.cuda(), fr.cuda())
+    (ws.square().mean() + wv.square().mean()).backward()
+    (gs.square().mean() + gv.square().mean()).backward()
+
+    def err(a, b):
+        return ((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-6)).item()
+
+    errs = dict(s=err(gs, ws), v=err(gv, wv), ds=err(sg.grad, s.grad), dv=err(vg.grad, v.grad))
+    for k, p in mod.named_parameters():
+        if P[k].grad is not None and p.grad is not None:
+            errs["w." + k] = err(p.grad, P[k].grad)
+    worst = max(errs.values())
+    flag = "" if worst < 2e-3 else "   <-- MISMATCH"
+    bad += worst >= 2e-3
+    print(f"{case:3d} rows {rows:4d} ({si},{vi})->({so},{vo}) {kw['nonlinearities']} b={kw['bottleneck']} gate={kw['vector_gate']} "
+          f"vres={kw['vector_residual']} e3={kw['enable_e3_equivariance']} nofr={kw['ablate_frame_updates']}: worst rel err "
+          f"{worst:.1e} ({max(errs, key=errs.get)}){flag}")
+print("mismatches:", bad)

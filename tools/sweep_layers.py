@@ -1,0 +1,70 @@
+"""Randomised parity sweep of whole GCPInteractions layers against the CPU oracle: node dims, bottleneck, activations, pre/post
+norm, number of message / feed-forward blocks, position update with and without the force term.
+usage: python tools/sweep_layers.py [n_cases] [seed]   (needs a GPU)"""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gcpnet_amd as G  # noqa: E402
+from oracle import gcp_oracle as O  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n_cases):
+    dims = rng.choice([(32, 4), (64, 8), (64, 16), (128, 16), (128, 8), (96, 12), (100, 16), (128, 32), (256, 16)])
+    act_s, act_v = rng.choice(["relu", "silu", "leakyrelu"]), rng.choice([None, "sigmoid", "silu"])
+    bott = rng.choice([b for b in (1, 2, 4) if dims[1] % b == 0 and (2 * dims[1] + 4) % b == 0])
+    upd = rng.random() < 0.4
+    force = upd and rng.random() < 0.5
+    over = dict(scalar_nonlinearity=act_s, vector_nonlinearity=act_v, bottleneck=bott, ablate_x_force_update=not force,
+                enable_e3_equivariance=False)
+    # (num_feedforward_layers = 1 is broken in the reference itself: gcpnet.py:1014)
+    lover = dict(pre_norm=rng.random() < 0.3, num_message_layers=rng.choice([2, 4, 8]), num_feedforward_layers=rng.choice([2, 3]))
+    cfg, lc = G.default_module_cfg(**over), G.default_layer_cfg(**lover)
+    ocfg = O.default_module_cfg(**dict(over, nonlinearities=(act_s, act_v)))
+    olc = O.default_layer_cfg(**lover)
+    n, e = rng.choice([(40, 300), (300, 4000), (33, 64)])
+    torch.manual_seed(case)
+    layer = G.GCPInteractions(dims, (32, 4), cfg=cfg, layer_cfg=lc, dropout=0.0, updating_node_positions=upd).cuda().eval()
+    if force:
+        with torch.no_grad():
+            layer.phi_force_ij[1].weight.normal_(0, 0.2)
+    g = torch.Generator().manual_seed(case + 500)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei = ei[:, torch.argsort(ei[1], stable=True)]
+    x = torch.randn(n, 3, generator=g)
+    fr = O.localize(x, ei)
+    ins = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g),
+               e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
+    P = {k: t.detach().cpu().clone().requires_grad_() for k, t in layer.state_dict().items()}
+    ci = {k: t.clone().requires_grad_() for k, t in ins.items()}
+    gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
+    ro = O.gcp_interactions(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], ei, fr, ocfg, olc, node_pos=x if upd else None)
+    go = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda(), node_pos=x.cuda() if upd else None)
+    flat = lambda o: [o[0][0], o[0][1], o[1]] if upd else [o[0], o[1]]
+    # a random linear functional of the outputs: |LayerNorm(x)|^2 is constant for gamma = 1, beta = 0, so a squared loss on a
+    # post-norm layer has (analytically) zero gradient through the scalar path and only compares round-off
+    lw = [torch.randn(t.shape, generator=g) for t in flat(ro)]
+    sum((t * w).sum() for t, w in zip(flat(ro), lw)).backward()
+    sum((t * w.cuda()).sum() for t, w in zip(flat(go), lw)).backward()
+
+    def err(a, b):
+        return ((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-6)).item()
+
+    errs = {f"out{i}": err(a, b) for i, (a, b) in enumerate(zip(flat(go), flat(ro)))}
+    errs.update({"d" + k: err(gi[k].grad, ci[k].grad) for k in ins})
+    for k, p in layer.named_parameters():
+        if P[k].grad is not None and p.grad is not None:
+            errs["w." + k] = err(p.grad, P[k].grad)
+    worst = max(errs.values())
+    if os.environ.get("SWEEP_VERBOSE") == str(case):
+        for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:25]:
+            print(f"      {k:60s} {v:.2e}")
+    bad += worst >= 3e-3
+    print(f"{case:3d} N={n} E={e} dims={dims} acts=({act_s},{act_v}) b={bott} {lover} upd={upd} force={force}: worst rel err "
+          f"{worst:.1e} ({max(errs, key=errs.get)})" + ("   <-- MISMATCH" if worst >= 3e-3 else ""))
+print("mismatches:", bad)
