@@ -298,14 +298,15 @@ def test_model_lba_golden(G):
     close(pred.cpu(), f.o["pred"], atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("act", ["silu", "relu"])
 @pytest.mark.parametrize("n,e,dims", [(2000, 32000, (128, 16)), (600, 6000, (256, 32)), (600, 6000, (64, 8))],
                          ids=["C2-dims", "C5-dims", "small-V"])
-def test_interactions_large_vs_oracle(G, n, e, dims):
+def test_interactions_large_vs_oracle(G, n, e, dims, act):
     """Bench-shaped (but smaller) layers, col-sorted edges, edge dims (32,4), fwd + bwd: BASELINE configs[1] dims (128,16)
     (register-resident chain kernels), configs[4] dims (256,32) (two output groups: block-by-block kernels), and (64,8):
     H = 2, one register quad per vector quantity (the chain kernels' run-time-H instantiations)."""
     torch.manual_seed(11)
-    layer = G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(),
+    layer = G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(scalar_nonlinearity=act), layer_cfg=G.default_layer_cfg(),
                               dropout=0.0).cuda().eval()
     ei, x = rand_graph(n, e, 12, sort_by_col=True)
     fr = O.localize(x, ei)
@@ -314,8 +315,8 @@ def test_interactions_large_vs_oracle(G, n, e, dims):
                e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
     P = {k: t.detach().cpu().clone().requires_grad_() for k, t in layer.state_dict().items()}
     ci = {k: t.clone().requires_grad_() for k, t in ins.items()}
-    wh, wc = O.gcp_interactions(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], ei, fr, O.default_module_cfg(),
-                                O.default_layer_cfg())
+    wh, wc = O.gcp_interactions(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], ei, fr,
+                                O.default_module_cfg(scalar_nonlinearity=act, nonlinearities=(act, None)), O.default_layer_cfg())
     gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
     gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
     close(gh.detach().cpu(), wh.detach(), atol=2e-5, rtol=2e-5)
@@ -325,12 +326,22 @@ def test_interactions_large_vs_oracle(G, n, e, dims):
     lh, lc = torch.randn(wh.shape, generator=g), torch.randn(wc.shape, generator=g)
     ((wh * lh).sum() + (wc * lc).sum()).backward()
     ((gh * lh.cuda()).sum() + (gc * lc.cuda()).sum()).backward()
+    # silu: smooth, so the two fp32 implementations must agree tightly everywhere.  relu: a pre-activation within round-off of
+    # zero (expected for a few of the ~1e7 units here) takes a different branch in the two implementations and changes the
+    # gradient of its row by O(1/s) (and every weight gradient a little): agreement in the L2 sense, loose element-wise bound.
+    def grads_close(a, b):
+        scale = float(b.abs().max())
+        if act == "silu":
+            close(a, b, atol=2e-5 * scale, rtol=1e-4)
+        else:
+            rel_l2 = float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+            assert rel_l2 < 2e-3, f"relative L2 error {rel_l2:.2e}"
+            close(a, b, atol=5e-2 * scale, rtol=0.0)
+
     for k in ins:
-        scale = float(ci[k].grad.abs().max())
-        close(gi[k].grad.cpu(), ci[k].grad, atol=2e-5 * scale, rtol=1e-4)
+        grads_close(gi[k].grad.cpu(), ci[k].grad)
     for k, p in layer.named_parameters():
-        scale = float(P[k].grad.abs().max())
-        close(p.grad.cpu(), P[k].grad, atol=2e-5 * scale, rtol=1e-4)
+        grads_close(p.grad.cpu(), P[k].grad)
 
 
 def _layer_run(G, layer, ins, ei, fr):
