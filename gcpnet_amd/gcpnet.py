@@ -8,6 +8,7 @@ behaviour; the arithmetic is launched on the MI355X through gcpnet_amd.ops.  Cit
 from __future__ import annotations
 
 from copy import copy
+from dataclasses import replace
 from functools import partial
 from typing import Any, List, Optional, Sequence, Tuple, Union
 
@@ -161,8 +162,11 @@ class GCP2(nn.Module):
 
 
 class GCP3(GCP2):
-    """`GCP3` (:471-700) is `GCP2` with silu defaults and an optional two-layer `scalar_out` (`feedforward_out`, :529-533).
-    Without `feedforward_out` the two are the same computation with the same parameter names; that is what runs here."""
+    """`GCP3` (:471-700) is `GCP2` with silu defaults and an optional two-layer `scalar_out` (`feedforward_out`, :529-533,
+    :552-556).  Without `feedforward_out` the two are the same computation with the same parameter names.  With it,
+    `scalar_out = Linear -> act -> Linear` runs as two launches of the same kernels: a scalar-only block (first Linear over
+    [s | norms | frame projections], `scalar_out_nonlinearity`) and a block whose scalar input is that result (second Linear;
+    its norm / frame columns carry zero weights) and which produces the gated vectors."""
 
     def __init__(self, input_dims, output_dims, nonlinearities: Tuple[Optional[str]] = ("silu", "silu"),
                  scalar_out_nonlinearity: Optional[str] = "silu", scalar_gate: int = 0, vector_gate: bool = True,
@@ -170,8 +174,6 @@ class GCP3(GCP2):
                  vector_residual: bool = False, vector_frame_residual: bool = False, ablate_frame_updates: bool = False,
                  ablate_scalars: bool = False, ablate_vectors: bool = False, enable_e3_equivariance: bool = False,
                  scalarization_vectorization_output_dim: int = 3, **kwargs):
-        if feedforward_out:
-            _unsupported("GCP3(feedforward_out=True) (two-layer scalar_out)")
         super().__init__(input_dims, output_dims, nonlinearities=nonlinearities, scalar_gate=scalar_gate, vector_gate=vector_gate,
                          frame_gate=frame_gate, sigma_frame_gate=sigma_frame_gate, bottleneck=bottleneck,
                          vector_residual=vector_residual, vector_frame_residual=vector_frame_residual,
@@ -179,6 +181,38 @@ class GCP3(GCP2):
                          enable_e3_equivariance=enable_e3_equivariance,
                          scalarization_vectorization_output_dim=scalarization_vectorization_output_dim, **kwargs)
         self.scalar_out_nonlinearity = scalar_out_nonlinearity
+        self.feedforward_out = bool(feedforward_out)
+        if self.feedforward_out:
+            self.act_mid = canonical_act(scalar_out_nonlinearity)
+            first = self.scalar_out  # same slot in the module order, so state_dict keys line up with the reference's
+            self.scalar_out = nn.Sequential(first, nn.Identity(),  # (the activation itself runs inside the kernel)
+                                            nn.Linear(self.scalar_output_dim, self.scalar_output_dim))
+            self._pack_cache_first: dict = {}
+
+    def apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool = False):
+        if not self.feedforward_out:
+            return super().apply_rows(s_sources, s_plans, v_sources, v_plans, row_frames, residual)
+        first, second = self.scalar_out[0], self.scalar_out[2]
+        g = lambda name: getattr(self, name).weight if hasattr(self, name) else None
+        spec = self.make_spec(s_plans, v_plans, False)
+        frames = row_frames if spec.use_frames else None
+        spec_a = replace(spec, vo=0, act_s=self.act_mid, vmode=VMODE_NONE, vector_residual=False,
+                         pack_cache=self._pack_cache_first)
+        s_mid = ops.gcp2(spec_a, s_sources, v_sources, frames,
+                         (first.weight, first.bias, g("vector_down"), g("vector_down_frames"), None, None, None))
+        extra = spec.K - spec.si  # the norm / frame-projection columns, already consumed by the first Linear
+        w_second = torch.cat((second.weight, second.weight.new_zeros(self.scalar_output_dim, extra)), dim=1) if extra \
+            else second.weight
+        gate = getattr(self, "vector_out_scale", None)
+        spec_b = replace(spec, si=self.scalar_output_dim, s_plans=[None], pack_cache=None)
+        out = ops.gcp2(spec_b, [s_mid], v_sources, frames,
+                       (w_second, second.bias, g("vector_down"), g("vector_down_frames"), g("vector_up"),
+                        None if gate is None else gate.weight, None if gate is None else gate.bias))
+        if residual:  # ResGCP: x + GCP(x) for the single ungathered source
+            if isinstance(out, tuple):
+                return out[0] + s_sources[0], out[1] + v_sources[0]
+            return out + s_sources[0]
+        return out
 
 
 def get_GCP_with_custom_cfg(input_dims, output_dims, cfg, **kwargs):
@@ -304,7 +338,7 @@ class GCPMessagePassing(nn.Module):
         return m
 
     def _chainable(self, mods) -> bool:
-        if not self.use_residual_message_gcp or len(mods) > 8:
+        if not self.use_residual_message_gcp or len(mods) > 8 or any(getattr(m, "feedforward_out", False) for m in mods):
             return False
         a = mods[0]
         if a.scalar_output_dim > 128 or not a.vector_input_dim or not a.vector_output_dim or a.vector_output_dim > 64:

@@ -158,6 +158,7 @@ def gcp2(
     enable_e3_equivariance: bool = False,
     vector_output_dim: Optional[int] = None,
     slope: float = 1e-2,
+    scalar_out_nonlinearity: Optional[str] = "silu",
 ):
     """One geometry-complete perceptron.  Returns (s_out, v_out) or just s_out when there is no vector output.
 
@@ -169,7 +170,9 @@ def gcp2(
     act_s, act_v = nonlinearities
     has_vin = (pre + "vector_down.weight") in P
     has_vout = (pre + "vector_up.weight") in P
-    W_s, b_s = P[pre + "scalar_out.weight"], P[pre + "scalar_out.bias"]
+    two_layer = (pre + "scalar_out.0.weight") in P  # GCP3(feedforward_out=True), gcpnet.py:529-533
+    W_s, b_s = (P[pre + "scalar_out.0.weight"], P[pre + "scalar_out.0.bias"]) if two_layer \
+        else (P[pre + "scalar_out.weight"], P[pre + "scalar_out.bias"])
 
     vh = None
     if has_vin:  # gcpnet.py:414-436
@@ -187,6 +190,9 @@ def gcp2(
         merged = s
 
     s_pre = merged @ W_s.t() + b_s  # gcpnet.py:441
+    if two_layer:  # Linear -> act -> Linear
+        s_pre = nonlinearity(scalar_out_nonlinearity, s_pre, slope) @ P[pre + "scalar_out.2.weight"].t() \
+            + P[pre + "scalar_out.2.bias"]
 
     if not has_vout and not vector_output_dim:  # gcpnet.py:443-446
         if ablate_scalars:

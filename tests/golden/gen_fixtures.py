@@ -127,6 +127,11 @@ def fx_gcp2():
     # GCP3 (gcpnet.py:471-700) = GCP2 with silu defaults and an optional two-layer scalar_out (feedforward_out)
     run_gcp2("gcp3_edge_default", (40, 8), (24, 8), False, 23, cls="GCP3", bottleneck=4)
     run_gcp2("gcp3_node_default", (24, 8), (40, 12), True, 24, cls="GCP3", bottleneck=2)
+    run_gcp2("gcp3_feedforward", (40, 8), (24, 8), False, 25, cls="GCP3", bottleneck=4, feedforward_out=True)
+    run_gcp2("gcp3_feedforward_node", (64, 8), (16, 4), True, 26, cls="GCP3", bottleneck=2, feedforward_out=True,
+             nonlinearities=(None, None))  # the last feed-forward GCP of GCPInteractions (gcpnet.py:1335-1343)
+    run_gcp2("gcp3_feedforward_scalar", (12, 0), (8, 0), True, 27, cls="GCP3", feedforward_out=True,
+             scalar_out_nonlinearity="relu")
 
 
 def fx_layernorm():

@@ -110,6 +110,9 @@ GCP2_CASES = {
     "gcp2_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
     "gcp3_edge_default": dict(bottleneck=4, cls="GCP3"),
     "gcp3_node_default": dict(bottleneck=2, cls="GCP3"),
+    "gcp3_feedforward": dict(bottleneck=4, cls="GCP3", feedforward_out=True),
+    "gcp3_feedforward_node": dict(bottleneck=2, cls="GCP3", feedforward_out=True, nonlinearities=(None, None)),
+    "gcp3_feedforward_scalar": dict(cls="GCP3", feedforward_out=True, scalar_out_nonlinearity="relu"),
 }
 
 

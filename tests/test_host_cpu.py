@@ -57,6 +57,13 @@ def test_state_dict_names_match_reference(name, upd):
     layer.load_state_dict(f.p)  # strict
 
 
+def test_gcp3_feedforward_state_dict_names_match_reference():
+    f = Fixture("gcp3_feedforward")  # scalar_out.0.* / scalar_out.2.* (reference gcpnet.py:529-533)
+    mod = G.GCP3((40, 8), (24, 8), bottleneck=4, feedforward_out=True)
+    assert list(mod.state_dict()) == list(f.p)
+    mod.load_state_dict(f.p)
+
+
 def test_model_state_dict_names_match_reference():
     f = Fixture("model_lba_small")
     model_cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=20, chi_hidden_dim=4, e_hidden_dim=8,

@@ -52,6 +52,10 @@ GCP2_CASES = {
     # GCP3 without feedforward_out is GCP2 with silu defaults (reference gcpnet.py:471-700)
     "gcp3_edge_default": dict(nonlinearities=("silu", "silu")),
     "gcp3_node_default": dict(nonlinearities=("silu", "silu")),
+    # feedforward_out: scalar_out = Linear -> act -> Linear (gcpnet.py:529-533, :552-556)
+    "gcp3_feedforward": dict(nonlinearities=("silu", "silu")),
+    "gcp3_feedforward_node": dict(nonlinearities=(None, None)),
+    "gcp3_feedforward_scalar": dict(nonlinearities=("silu", "silu"), scalar_out_nonlinearity="relu"),
 }
 
 
