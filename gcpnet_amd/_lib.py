@@ -20,7 +20,8 @@ EXPORTS = [
     "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
-    "gcpnet_edge_force_bwd_blocks", "gcpnet_debug_set_phase_timing",
+    "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
+    "gcpnet_debug_set_phase_timing",
 ]
 
 
@@ -128,6 +129,9 @@ def load():
     lib.gcpnet_edge_force_forward.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
     lib.gcpnet_edge_force_backward.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp]
     lib.gcpnet_edge_force_bwd_blocks.argtypes = [i64]
+    lib.gcpnet_row_gate_forward.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
+    lib.gcpnet_row_gate_backward.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.gcpnet_row_gate_bwd_blocks.argtypes = [i64]
     lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
     for name in EXPORTS:
         fn = getattr(lib, name)

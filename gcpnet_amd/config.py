@@ -62,6 +62,7 @@ TARGET_MAP = {
     "src.models.components.gcpnet.GCP2": "gcpnet_amd.gcpnet.GCP2",
     "src.models.components.gcpnet.GCP3": "gcpnet_amd.gcpnet.GCP3",
     "src.models.components.gcpnet.GCPInteractions": "gcpnet_amd.gcpnet.GCPInteractions",
+    "src.models.components.gcpnet.GCPInteractions2": "gcpnet_amd.gcpnet.GCPInteractions2",
     "src.models.components.gcpnet.GCPMessagePassing": "gcpnet_amd.gcpnet.GCPMessagePassing",
     "src.models.components.gcpnet.GCPEmbedding": "gcpnet_amd.gcpnet.GCPEmbedding",
     "src.models.gcpnet_nms_module.GCPNetNMSLitModule": "gcpnet_amd.models.GCPNetNMS",

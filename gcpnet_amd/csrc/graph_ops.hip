@@ -498,6 +498,118 @@ extern "C" int gcpnet_edge_force_backward(int64_t E, int s, const float* A, cons
     return 0;
 }
 
+// ---- learnable scalar message gate (reference gcpnet.py:892-896,932-934): att[r] = sigmoid(<x[r, :], w> + b), out = x * att.
+//      One wave per row at a time, lanes over the columns (float4 pieces); same structure as the force kernels above.
+__global__ __launch_bounds__(256) void row_gate_fwd_kernel(int64_t rows, int s, const float* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ out, float* __restrict__ att) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const float bias = b[0];
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float* xr = x + r * s;
+        float4 v[EF_MAX_CHUNKS];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < EF_MAX_CHUNKS; ++i) {
+            const int j = 4 * lane + 256 * i;
+            if (j < s) {
+                v[i] = *reinterpret_cast<const float4*>(xr + j);
+                const float4 ww = *reinterpret_cast<const float4*>(w + j);
+                dot += v[i].x * ww.x + v[i].y * ww.y + v[i].z * ww.z + v[i].w * ww.w;
+            }
+        }
+        const float a = gcp_sigmoid(wave_sum64(dot) + bias);
+#pragma unroll
+        for (int i = 0; i < EF_MAX_CHUNKS; ++i) {
+            const int j = 4 * lane + 256 * i;
+            if (j < s) *reinterpret_cast<float4*>(out + r * s + j) = make_float4(v[i].x * a, v[i].y * a, v[i].z * a, v[i].w * a);
+        }
+        if (lane == 0) att[r] = a;
+    }
+}
+
+// Adjoint: dl = <d_out[r], x[r]> att (1 - att);  d_x = d_out att + dl w;  this block's share of (d_w[j] = sum_r dl x[r, j],
+// d_b = sum_r dl) in part[block, s + 4] (d_b in column s), summed over blocks by gcpnet_reduce_partials.
+__global__ __launch_bounds__(256) void row_gate_bwd_kernel(int64_t rows, int s, const float* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ att,
+                                                           const float* __restrict__ d_out, float* __restrict__ d_x,
+                                                           float* __restrict__ part) {
+    __shared__ float red[4][256 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    float pw[EF_MAX_CHUNKS][4], pb = 0.f;
+#pragma unroll
+    for (int i = 0; i < EF_MAX_CHUNKS; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pw[i][q] = 0.f;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float a = att[r];
+        float4 v[EF_MAX_CHUNKS], g[EF_MAX_CHUNKS];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < EF_MAX_CHUNKS; ++i) {
+            const int j = 4 * lane + 256 * i;
+            if (j < s) {
+                v[i] = *reinterpret_cast<const float4*>(x + r * s + j);
+                g[i] = *reinterpret_cast<const float4*>(d_out + r * s + j);
+                dot += v[i].x * g[i].x + v[i].y * g[i].y + v[i].z * g[i].z + v[i].w * g[i].w;
+            }
+        }
+        const float dl = wave_sum64(dot) * a * (1.f - a);
+        pb += dl;
+#pragma unroll
+        for (int i = 0; i < EF_MAX_CHUNKS; ++i) {
+            const int j = 4 * lane + 256 * i;
+            if (j < s) {
+                const float4 ww = *reinterpret_cast<const float4*>(w + j);
+                *reinterpret_cast<float4*>(d_x + r * s + j) = make_float4(g[i].x * a + dl * ww.x, g[i].y * a + dl * ww.y,
+                                                                          g[i].z * a + dl * ww.z, g[i].w * a + dl * ww.w);
+                pw[i][0] += dl * v[i].x; pw[i][1] += dl * v[i].y; pw[i][2] += dl * v[i].z; pw[i][3] += dl * v[i].w;
+            }
+        }
+    }
+    float* mine = part + (int64_t)blockIdx.x * (s + 4);
+#pragma unroll
+    for (int i = 0; i < EF_MAX_CHUNKS; ++i) {  // combine the four waves, 256 columns at a time, in a fixed order
+        if (256 * i >= s) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wv][4 * lane + q] = pw[i][q];
+        if (i == 0 && lane == 0) red[wv][256] = pb;  // (every lane of a wave holds the same d_b share)
+        __syncthreads();
+        {
+            const int c = threadIdx.x, j = 256 * i + c;
+            if (j < s) mine[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (i == 0 && c < 4) mine[s + c] = c == 0 ? (red[0][256] + red[1][256]) + (red[2][256] + red[3][256]) : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int gcpnet_row_gate_bwd_blocks(int64_t rows) { return rows <= 0 ? 1 : ef_blocks(rows); }
+
+extern "C" int gcpnet_row_gate_forward(int64_t rows, int s, const float* x, const float* w, const float* b, float* out, float* att,
+                                       void* stream) {
+    if (rows < 0 || s <= 0 || (s & 3) || s > 256 * EF_MAX_CHUNKS || !x || !w || !b || !out || !att) return GCPNET_E_BADARG;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(out)) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(row_gate_fwd_kernel, dim3(ef_blocks(rows)), dim3(256), 0, (hipStream_t)stream, rows, s, x, w, b, out, att);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_row_gate_backward(int64_t rows, int s, const float* x, const float* w, const float* att, const float* d_out,
+                                        float* d_x, float* part, void* stream) {
+    if (rows < 0 || s <= 0 || (s & 3) || s > 256 * EF_MAX_CHUNKS || !x || !w || !att || !d_out || !d_x || !part)
+        return GCPNET_E_BADARG;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(d_out) || !aligned16(d_x)) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(row_gate_bwd_kernel, dim3(ef_blocks(rows)), dim3(256), 0, (hipStream_t)stream, rows, s, x, w, att, d_out,
+                       d_x, part);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, float alpha, int clamp, float lo, float hi,
                                  float* y, void* stream) {
     if (n < 0 || !b || !y) return GCPNET_E_BADARG;

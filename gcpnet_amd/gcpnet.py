@@ -292,8 +292,6 @@ class GCPMessagePassing(nn.Module):
         self.aggregate_with_row = aggregate_with_row
         if reduce_function not in ("mean", "sum", "add"):
             raise NotImplementedError(reduce_function)
-        if use_scalar_message_attention:
-            _unsupported("GCPMessagePassing(use_scalar_message_attention=True)")
 
         scalars_in_dim = 2 * self.scalar_input_dim + self.edge_scalar_dim
         vectors_in_dim = 2 * self.vector_input_dim + self.edge_vector_dim
@@ -312,8 +310,17 @@ class GCPMessagePassing(nn.Module):
             modules.append(primary(output_dims, output_dims, nonlinearities=(None, None),
                                    enable_e3_equivariance=cfg.enable_e3_equivariance))
         self.message_fusion = nn.ModuleList(modules)
+        if use_scalar_message_attention:  # :892-896
+            self.scalar_message_attention = nn.Sequential(nn.Linear(output_dims.scalar, 1), nn.Sigmoid())
 
     def _messages(self, node_rep, edge_rep, edge_index, frames) -> ScalarVector:
+        m = self._fused_messages(node_rep, edge_rep, edge_index, frames)
+        if self.use_scalar_message_attention:  # :932-934, one fused kernel (dot product, sigmoid, scale)
+            lin = self.scalar_message_attention[0]
+            m = ScalarVector(ops.row_gate(m[0], lin.weight, lin.bias), m[1])
+        return m
+
+    def _fused_messages(self, node_rep, edge_rep, edge_index, frames) -> ScalarVector:
         h, chi = node_rep
         e, xi = edge_rep
         plan = GraphPlan.get(edge_index, h.shape[0])
@@ -480,3 +487,82 @@ class GCPInteractions(nn.Module):
         upd = self.derive_x_update(node_rep, edge_index, frames)
         node_pos = ops.axpy_clamp(node_pos, upd, float(self.node_positions_weight), -100.0, 100.0)  # :1156-1158,1258
         return node_rep, node_pos
+
+
+class GCPInteractions2(nn.Module):
+    """:1265-1451 (unmasked call path): the AR / EQ layer.  Sum-aggregated messages (optionally over `row`, with the learnable
+    scalar message gate), a feed-forward network on [aggregate | node] whose last GCP has a two-layer `scalar_out`
+    (`feedforward_out`, GCP3), one residual + one GCPLayerNorm, and an un-clamped position update without force term."""
+
+    def __init__(self, node_dims, edge_dims, cfg, layer_cfg, dropout: float = 0.1,
+                 nonlinearities: Optional[Tuple[Any, Any]] = None, updating_node_positions: bool = False):
+        super().__init__()
+        node_dims, edge_dims = ScalarVector(*node_dims), ScalarVector(*edge_dims)
+        if nonlinearities is None:
+            nonlinearities = cfg.nonlinearities
+        self.pre_norm = layer_cfg.pre_norm
+        self.updating_node_positions = updating_node_positions
+        self.node_positions_weight = getattr(cfg, "node_positions_weight", 1.0)
+
+        self.interaction = GCPMessagePassing(
+            node_dims, node_dims, edge_dims, cfg=cfg, mp_cfg=layer_cfg.mp_cfg, reduce_function="sum",
+            use_scalar_message_attention=getattr(layer_cfg, "use_scalar_message_attention", False),
+            aggregate_with_row=getattr(layer_cfg, "aggregate_with_row", False))
+
+        ff_cfg = copy(cfg)  # :1303-1309
+        ff_cfg.nonlinearities = nonlinearities
+        ff_without_res_cfg = copy(cfg)
+        ff_without_res_cfg.vector_residual = False
+        ff_GCP = partial(get_GCP_with_custom_cfg, cfg=ff_cfg)
+        ff_without_res_GCP = partial(get_GCP_with_custom_cfg, cfg=ff_without_res_cfg)
+
+        self.gcp_norm = nn.ModuleList([GCPLayerNorm(node_dims)])
+        self.gcp_dropout = nn.ModuleList([GCPDropout(dropout)])
+
+        n_ff = layer_cfg.num_feedforward_layers
+        hidden_dims = ((node_dims.scalar, node_dims.vector) if n_ff == 1
+                       else (4 * node_dims.scalar, 2 * node_dims.vector))  # :1315-1319
+        ff = [ff_without_res_GCP((node_dims.scalar * 2, node_dims.vector * 2), hidden_dims,
+                                 nonlinearities=(None, None) if n_ff == 1 else cfg.nonlinearities,
+                                 feedforward_out=n_ff == 1, enable_e3_equivariance=cfg.enable_e3_equivariance)]
+        ff.extend(ff_GCP(hidden_dims, hidden_dims, enable_e3_equivariance=cfg.enable_e3_equivariance)
+                  for _ in range(n_ff - 2))
+        if n_ff > 1:
+            ff.append(ff_without_res_GCP(hidden_dims, node_dims, nonlinearities=(None, None), feedforward_out=True,
+                                         enable_e3_equivariance=cfg.enable_e3_equivariance))
+        self.feedforward_network = nn.ModuleList(ff)
+
+        if updating_node_positions:  # :1346-1353
+            self.node_position_update_gcp = ff_without_res_GCP(node_dims, (node_dims.scalar, 1),
+                                                               nonlinearities=cfg.nonlinearities,
+                                                               enable_e3_equivariance=cfg.enable_e3_equivariance)
+
+    def derive_x_update(self, node_rep, edge_index, f_ij, node_mask=None):
+        """:1356-1378.  Returns the un-weighted update."""
+        if node_mask is not None:
+            _unsupported("GCPInteractions2(node_mask=...)")
+        _, chi_v = self.node_position_update_gcp(node_rep, edge_index, f_ij, node_inputs=True)
+        return chi_v.reshape(chi_v.shape[0], 3)
+
+    def forward(self, node_rep, edge_rep, edge_index, frames, node_mask=None, node_pos=None):
+        if node_mask is not None:
+            _unsupported("GCPInteractions2(node_mask=...)")
+        node_rep = ScalarVector(node_rep[0], node_rep[1])
+        edge_rep = ScalarVector(edge_rep[0], edge_rep[1])
+        if self.pre_norm:
+            node_rep = self.gcp_norm[0](node_rep)
+        hidden = self.interaction(node_rep, edge_rep, edge_index, frames)
+        hidden = ScalarVector(*hidden.concat((node_rep,)))  # [aggregate | node] (:1414)
+        for module in self.feedforward_network:
+            hidden = module(hidden, edge_index, frames, node_inputs=True)
+        if self.gcp_dropout[0].active:
+            hidden = self.gcp_dropout[0](hidden)
+        if self.pre_norm:  # :1427-1431
+            node_rep = _sv_add(node_rep, hidden)
+        else:
+            node_rep = self.gcp_norm[0](node_rep, residual=hidden)
+        if not self.updating_node_positions:
+            return node_rep
+        upd = self.derive_x_update(node_rep, edge_index, frames)
+        return node_rep, ops.axpy(node_pos, upd, float(self.node_positions_weight))  # :1442-1444
+

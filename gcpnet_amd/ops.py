@@ -1111,6 +1111,44 @@ def edge_force(A: Tensor, B: Tensor, W3: Tensor, frames: Tensor, plan: GraphPlan
     return _EdgeForce.apply(_req(A, "A"), _req(B, "B"), _req(W3, "W3"), _req(frames.detach(), "frames"), plan, act, slope)
 
 
+class _RowGate(torch.autograd.Function):
+    """out = x * sigmoid(x w^T + b) per row (reference gcpnet.py:932-934); x [rows, s], w [1, s], b [1]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        rows, s = x.shape
+        out = torch.empty_like(x)
+        att = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        check(lib.gcpnet_row_gate_forward(rows, s, _p(x), _p(w), _p(b), _p(out), _p(att), _stream()), "row_gate_forward")
+        ctx.save_for_backward(x, w, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        x, w, att = ctx.saved_tensors
+        rows, s = x.shape
+        f32 = dict(dtype=torch.float32, device=x.device)
+        d_out = _req(d_out, "grad")
+        d_x = torch.empty_like(x)
+        nb = lib.gcpnet_row_gate_bwd_blocks(rows)
+        part = torch.empty((nb, s + 4), **f32)
+        check(lib.gcpnet_row_gate_backward(rows, s, _p(x), _p(w), _p(att), _p(d_out), _p(d_x), _p(part), _stream()),
+              "row_gate_backward")
+        dwb = torch.zeros((s + 4,), **f32)
+        if rows:
+            tmp = torch.empty((lib.gcpnet_reduce_partials_groups(nb), s + 4), **f32)
+            job = ReduceJob()
+            job.parts, job.n_parts, job.width, job.tmp, job.out = part.data_ptr(), nb, s + 4, tmp.data_ptr(), dwb.data_ptr()
+            check(lib.gcpnet_reduce_partials(1, C.byref(job), _stream()), "reduce_partials")
+        return d_x, dwb[:s].view(1, s), dwb[s:s + 1]
+
+
+def row_gate(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    return _RowGate.apply(_req(x, "x"), _req(w, "w"), _req(b, "b"))
+
+
 class _ProjectV(torch.autograd.Function):
     """Q[n, d, x] = sum_c W[x, c] v[n, c, d] for v [n, V, 3], W [HF', V]: [vector_down ; vector_down_frames] applied at the
     source rows.  Forward and input gradient are plain library GEMMs on the xyz-major copy of v; the weight gradient reduces

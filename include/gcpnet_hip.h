@@ -269,6 +269,16 @@ int gcpnet_edge_force_backward(int64_t E, int s, const float* A, const float* B,
                                float* d_pre, float* part, void* stream);
 int gcpnet_edge_force_bwd_blocks(int64_t E);
 
+/* ---- learnable scalar message gate (components/gcpnet.py:892-896,932-934, `use_scalar_message_attention`, GCPInteractions2):
+ * att[r] = sigmoid(<x[r, :], w> + b[0]) with w = scalar_message_attention.0.weight [1, s]; out[r, :] = x[r, :] att[r].
+ * s a multiple of 4, <= 1024; x, out, w 16-byte aligned.  Backward: d_x [rows, s] and per-block shares of (d_w [s], d_b in
+ * column s) in part [gcpnet_row_gate_bwd_blocks(rows), s + 4] (gcpnet_reduce_partials). */
+int gcpnet_row_gate_forward(int64_t rows, int s, const float* x, const float* w, const float* b, float* out, float* att,
+                            void* stream);
+int gcpnet_row_gate_backward(int64_t rows, int s, const float* x, const float* w, const float* att, const float* d_out,
+                             float* d_x, float* part, void* stream);
+int gcpnet_row_gate_bwd_blocks(int64_t rows);
+
 /* out[r, j] = sum_k in[r, k] W[k, j], rows x K times a tiny row-major W [K, J] (K * J <= 4096): the per-source-row side of
  * the vector projections of gcpnet_gcp2_forward's v_add tables ([vector_down ; vector_down_frames] applied at the source rows). */
 int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,

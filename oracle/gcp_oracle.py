@@ -305,6 +305,7 @@ def message_passing(
     mp_cfg: Mapping,
     reduce_function: str = "mean",
     return_messages: bool = False,
+    aggregate_with_row: bool = False,
 ):
     row, col = edge_index[0], edge_index[1]
     n_msg = mp_cfg["num_message_layers"]
@@ -331,7 +332,7 @@ def message_passing(
                             + P[pre + "scalar_message_attention.0.bias"])
         ms = ms * att
     msg = flatten_sv(ms, mv)
-    agg = scatter(msg, col, dim_size=h.shape[0], reduce=reduce_function)  # gcpnet.py:939-947
+    agg = scatter(msg, row if aggregate_with_row else col, dim_size=h.shape[0], reduce=reduce_function)  # gcpnet.py:939-947
     out = recover_sv(agg, mv.shape[1])
     return (out, msg) if return_messages else out
 
@@ -397,6 +398,54 @@ def gcp_interactions(
         upd = upd + scatter(force, col, reduce="mean")
     upd = (upd * cfg.get("node_positions_weight", 1.0)).clamp(min=-100, max=100)
     return (h, chi), node_pos + upd
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GCPInteractions2 -- components/gcpnet.py:1265-1451 (unmasked): the AR / EQ layer
+# ----------------------------------------------------------------------------------------------------------
+def gcp_interactions2(
+    P: Params,
+    pre: str,
+    h: Tensor,
+    chi: Tensor,
+    e: Tensor,
+    xi: Tensor,
+    edge_index: Tensor,
+    frames: Tensor,
+    cfg: Mapping,
+    layer_cfg: Mapping,
+    node_pos: Optional[Tensor] = None,
+    nonlinearities: Optional[Sequence[Optional[str]]] = None,
+):
+    """Eval-mode forward.  Returns (h, chi) or ((h, chi), node_pos).  The two-layer `scalar_out` of the GCP3 blocks and the
+    scalar message gate are picked up from the parameter names."""
+    if nonlinearities is None:
+        nonlinearities = cfg["nonlinearities"]
+    pre_norm = layer_cfg["pre_norm"]
+    n_ff = layer_cfg["num_feedforward_layers"]
+    if pre_norm:  # gcpnet.py:1402-1403
+        h, chi = gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
+    rs, rv = message_passing(P, pre + "interaction.", h, chi, e, xi, edge_index, frames, cfg, layer_cfg["mp_cfg"],
+                             reduce_function="sum", aggregate_with_row=layer_cfg.get("aggregate_with_row", False))
+    fs, fv = torch.cat((rs, h), dim=-1), torch.cat((rv, chi), dim=1)  # gcpnet.py:1414
+    no_res = dict(cfg)
+    no_res["vector_residual"] = False
+    ff_cfg = dict(cfg)
+    ff_cfg["nonlinearities"] = nonlinearities
+    kws = [_gcp_kwargs(no_res, nonlinearities=(None, None) if n_ff == 1 else tuple(cfg["nonlinearities"]))]
+    kws += [_gcp_kwargs(ff_cfg)] * (n_ff - 2)
+    if n_ff > 1:
+        kws.append(_gcp_kwargs(no_res, nonlinearities=(None, None)))
+    for k, kw in enumerate(kws):  # gcpnet.py:1417-1424
+        fs, fv = gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, edge_index, frames, node_inputs=True, **kw)
+    h, chi = h + fs, chi + fv  # gcpnet.py:1427
+    if not pre_norm:
+        h, chi = gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
+    if (pre + "node_position_update_gcp.scalar_out.weight") not in P:
+        return h, chi
+    _, xv = gcp2(P, pre + "node_position_update_gcp.", h, chi, edge_index, frames, node_inputs=True,
+                 **_gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])))
+    return (h, chi), node_pos + xv.squeeze(1) * cfg.get("node_positions_weight", 1.0)  # gcpnet.py:1356-1378,1442
 
 
 # ----------------------------------------------------------------------------------------------------------

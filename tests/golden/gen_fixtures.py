@@ -311,6 +311,40 @@ def fx_models():
          meta=dict(num_layers=2, num_message_layers=4))
 
 
+def fx_interactions2():
+    """GCPInteractions2 (gcpnet.py:1265-1451) as configs/model/gcpnet_eq.yaml builds it: GCP3 blocks, sum aggregation over
+    `row`, learnable scalar message gate, one feed-forward GCP with a two-layer scalar_out; and a two-FF-layer variant with the
+    position update."""
+    import functools
+    cfg = ref_stubs.make_cfg(selected_GCP=functools.partial(gn.GCP3))
+    nd, ed = SV(64, 16), SV(32, 4)
+    ei, x = rand_graph(24, 96, 70)
+    frames = comp.localize(x, ei)
+    h, chi = randn(24, 64, seed=72).requires_grad_(), randn(24, 16, 3, seed=73).requires_grad_()
+    e, xi = randn(96, 32, seed=74).requires_grad_(), randn(96, 4, 3, seed=75).requires_grad_()
+    cases = (("interactions2_eq", False, ref_stubs.make_layer_cfg(use_scalar_message_attention=True, aggregate_with_row=True,
+                                                                  num_feedforward_layers=1)),
+             ("interactions2_posupd", True, ref_stubs.make_layer_cfg(use_scalar_message_attention=True, num_message_layers=4,
+                                                                     num_feedforward_layers=2)))
+    for name, upd, lc in cases:
+        torch.manual_seed(76)
+        layer = gn.GCPInteractions2(nd, ed, cfg=cfg, layer_cfg=lc, dropout=0.0, updating_node_positions=upd)
+        layer.eval()
+        for t in (h, chi, e, xi):
+            t.grad = None
+        if upd:
+            (ho, co), xo = layer((h, chi), (e, xi), ei, frames, node_pos=x)
+            outs = dict(h=ho, chi=co, x=xo)
+        else:
+            ho, co = layer((h, chi), (e, xi), ei, frames)
+            outs = dict(h=ho, chi=co)
+        sq_loss(*outs.values()).backward()
+        grads = dict(h=h.grad, chi=chi.grad, e=e.grad, xi=xi.grad)
+        grads.update({"w." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+        save(name, params=layer.state_dict(),
+             inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames, x=x), outputs=outs, grads=grads)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     fx_geometry()
@@ -318,4 +352,5 @@ if __name__ == "__main__":
     fx_layernorm()
     fx_embedding()
     fx_interactions()
+    fx_interactions2()
     fx_models()

@@ -144,6 +144,19 @@ def test_gcp_interactions(G, data):
                                        random_rotation(SEED).cuda())
 
 
+def test_gcp_interactions2_with_gcp3(G, data):
+    """The AR / EQ layer (reference gcpnet.py:1265-1451 with GCP3 blocks, configs/model/gcpnet_eq.yaml): sum aggregation
+    over `row`, scalar message gate, two-layer scalar_out; same checker as GCPInteractions."""
+    import functools
+    torch.manual_seed(SEED)
+    cfg = G.default_module_cfg(selected_GCP=functools.partial(G.GCP3))
+    lc = G.default_layer_cfg(use_scalar_message_attention=True, aggregate_with_row=True, num_feedforward_layers=1)
+    layer = G.GCPInteractions2(NODE_DIM, EDGE_DIM, cfg=cfg, layer_cfg=lc, dropout=0.1).cuda().eval()
+    with torch.no_grad():
+        check_rotation_and_permutation(lambda n, e, ei, fr: layer(n, e, ei, fr), data, _frames(G, data),
+                                       random_rotation(SEED).cuda())
+
+
 def _random_batch(G, int_types, seed):
     """construct_batch_from_random_data_list (:1490-1507): 8 graphs of 37 nodes / 1250 random edges each
     (self-loops and duplicate edges possible), block-diagonal collation."""

@@ -259,6 +259,63 @@ def test_interactions_golden(G, name):
             close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=1e-3)
 
 
+@pytest.mark.parametrize("rows,s", [(1, 4), (37, 128), (5000, 64), (9000, 260), (33, 1024)])
+def test_row_gate_vs_torch(G, rows, s):
+    """Scalar message gate kernel (reference gcpnet.py:932-934) against the same formula in fp64 on the CPU."""
+    from gcpnet_amd import ops
+    g = torch.Generator().manual_seed(rows + s)
+    x = torch.randn(rows, s, generator=g)
+    w, b = torch.randn(1, s, generator=g) / s ** 0.5, torch.randn(1, generator=g)
+    dy = torch.randn(rows, s, generator=g)
+    xc, wc, bc = (t.double().requires_grad_() for t in (x, w, b))
+    yc = xc * torch.sigmoid(xc @ wc.t() + bc)
+    yc.backward(dy.double())
+    xg, wg, bg = (t.cuda().requires_grad_() for t in (x, w, b))
+    yg = ops.row_gate(xg, wg, bg)
+    yg.backward(dy.cuda())
+    close(yg.detach().cpu(), yc.detach().float(), atol=1e-6, rtol=1e-5)
+    close(xg.grad.cpu(), xc.grad.float(), atol=2e-6, rtol=1e-5)
+    scale = max(1.0, float(wc.grad.abs().max()))
+    close(wg.grad.cpu(), wc.grad.float(), atol=2e-5 * scale, rtol=1e-4)
+    close(bg.grad.cpu(), bc.grad.float(), atol=2e-5 * scale, rtol=1e-4)
+
+
+INTERACTIONS2 = {
+    "interactions2_eq": dict(use_scalar_message_attention=True, aggregate_with_row=True, num_feedforward_layers=1),
+    "interactions2_posupd": dict(use_scalar_message_attention=True, num_message_layers=4, num_feedforward_layers=2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(INTERACTIONS2))
+def test_interactions2_golden(G, name):
+    """GCPInteractions2 (reference gcpnet.py:1265-1451) with GCP3 blocks: sum aggregation (over row), scalar message gate,
+    two-layer scalar_out in the last feed-forward GCP, un-clamped position update."""
+    import functools
+    f = Fixture(name)
+    upd = name == "interactions2_posupd"
+    cfg = G.default_module_cfg(selected_GCP=functools.partial(G.GCP3))
+    layer = G.GCPInteractions2((64, 16), (32, 4), cfg=cfg, layer_cfg=G.default_layer_cfg(**INTERACTIONS2[name]), dropout=0.0,
+                               updating_node_positions=upd).cuda().eval()
+    assert list(layer.state_dict()) == list(f.p)
+    layer.load_state_dict(f.p)
+    ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
+    if upd:
+        (h, chi), x = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, node_pos=f.i["x"].cuda())
+        outs = dict(h=h, chi=chi, x=x)
+    else:
+        h, chi = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
+        outs = dict(h=h, chi=chi)
+    for k, t in outs.items():
+        close(t.detach().cpu(), f.o[k], atol=2e-5, rtol=2e-5)
+    sq_loss(*outs.values()).backward()
+    for k, t in ins.items():
+        close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=1e-3)
+    for k, p in layer.named_parameters():
+        if "w." + k in f.g:
+            close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=1e-3)
+
+
 def test_interactions_prenorm_silu_golden(G):
     f = Fixture("interactions_prenorm_silu")
     cfg = G.default_module_cfg(scalar_nonlinearity="silu", vector_nonlinearity="silu")

@@ -64,6 +64,20 @@ def test_gcp3_feedforward_state_dict_names_match_reference():
     mod.load_state_dict(f.p)
 
 
+def test_interactions2_state_dict_names_match_reference():
+    import functools
+    for name, kw, upd in (("interactions2_eq", dict(use_scalar_message_attention=True, aggregate_with_row=True,
+                                                   num_feedforward_layers=1), False),
+                          ("interactions2_posupd", dict(use_scalar_message_attention=True, num_message_layers=4,
+                                                       num_feedforward_layers=2), True)):
+        f = Fixture(name)
+        cfg = G.default_module_cfg(selected_GCP=functools.partial(G.GCP3))
+        layer = G.GCPInteractions2((64, 16), (32, 4), cfg=cfg, layer_cfg=G.default_layer_cfg(**kw), dropout=0.0,
+                                   updating_node_positions=upd)
+        assert list(layer.state_dict()) == list(f.p)
+        layer.load_state_dict(f.p)
+
+
 def test_model_state_dict_names_match_reference():
     f = Fixture("model_lba_small")
     model_cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=20, chi_hidden_dim=4, e_hidden_dim=8,

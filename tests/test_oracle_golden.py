@@ -133,6 +133,32 @@ def test_interactions(name):
             close(g, f.g[n], atol=5e-6, rtol=1e-3)
 
 
+INTERACTIONS2 = {  # GCPInteractions2 as gcpnet_eq.yaml builds it (GCP3, gate, sum over row, 1 FF GCP); 2-FF variant + positions
+    "interactions2_eq": dict(use_scalar_message_attention=True, aggregate_with_row=True, num_feedforward_layers=1),
+    "interactions2_posupd": dict(use_scalar_message_attention=True, num_message_layers=4, num_feedforward_layers=2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(INTERACTIONS2))
+def test_interactions2(name):
+    f = Fixture(name)
+    i = f.i
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    ins = {k: i[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    cfg, lc = O.default_module_cfg(), O.default_layer_cfg(**INTERACTIONS2[name])
+    upd = name == "interactions2_posupd"
+    out = O.gcp_interactions2(P, "", ins["h"], ins["chi"], ins["e"], ins["xi"], i["edge_index"], i["frames"], cfg, lc,
+                              node_pos=i["x"] if upd else None)
+    outs = dict(h=out[0][0], chi=out[0][1], x=out[1]) if upd else dict(h=out[0], chi=out[1])
+    for k, t in outs.items():
+        close(t, f.o[k], atol=5e-6, rtol=5e-5)
+    names = list(ins) + ["w." + k for k in P]
+    gr = _grads(sq_loss(*outs.values()), list(ins.values()) + list(P.values()))
+    for n, g in zip(names, gr):
+        if n in f.g:
+            close(g, f.g[n], atol=5e-6, rtol=1e-3)
+
+
 def test_interactions_prenorm_silu():
     f = Fixture("interactions_prenorm_silu")
     i = f.i
