@@ -181,6 +181,21 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         // addends, four channels x xyz at a time for the vector ones) and added to the products below
         f32x16 acc[NT];
         float qa[4][12];
+        // scalar_out's bias in the accumulator layout (columns 32 t + 8 q + 4 hi .. + 3 of a lane are contiguous: one 16-byte load
+        // per register quad).  Plain blocks request it here, a whole phase before the GEMM that starts from it; the head block,
+        // whose accumulators already collect the gathered addends, where it is added.
+        f32x16 bias[NT];
+        auto load_bias = [&]() {
+            const bool vec_b = vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = gcp_load4(it.b_scalar, 0, so, 32 * t + 8 * q + 4 * hi, true, vec_b);
+                    bias[t][4 * q] = b4.x; bias[t][4 * q + 1] = b4.y; bias[t][4 * q + 2] = b4.z; bias[t][4 * q + 3] = b4.w;
+                }
+        };
+        if constexpr (!HEAD) load_bias();
         if (head) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -266,14 +281,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         float gwa[16];   // first batch of the gate GEMM's weight fragments
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gacc[r] = 0.f; gwa[r] = 0.f; }
+        if constexpr (HEAD) load_bias();
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = 32 * t + gcp_crow(r, hi);
-                const float bj = j < so ? it.b_scalar[j] : 0.f;
-                acc[t][r] = head ? acc[t][r] + bj : bj;
-            }
+            for (int r = 0; r < 16; ++r) acc[t][r] = head ? acc[t][r] + bias[t][r] : bias[t][r];
+#ifdef GCP_FWD_FINE
+        if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
+#endif
         if (head) {
             // the head's own scalar inputs: B fragments from its LDS tile, weights from section A of its pack
             const float* wa0 = it.pack + B.offA + (int64_t)lane * NT;
@@ -305,6 +320,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #pragma unroll
                 for (int u = 0; u < U; ++u) a[u].load(wf + (int64_t)min(st0 + u, NT * 16 - 1) * 64 * NT);
             };
+#ifdef GCP_FWD_FINE
+            if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
+#endif
             ld(A0, 0);
             ld(A1, U);
             ld(A2, 2 * U);
@@ -323,16 +341,24 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 }
                 if ((b + 3) * U < NT * 16) ld(a, (b + 3) * U);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE: hipcc otherwise sinks each load to its use
+#ifdef GCP_FWD_FINE
+                if (b == 0 && ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
+                if (b == 7 && ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
+                if (b == 15 && ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
+#endif
             }
             }
+#ifndef GCP_FWD_FINE
             if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
+#endif
             // (the gate GEMM's first weight fragments and its bias are requested here, one phase ahead)
             if (scalar_gate) {
                 const float* wg0 = it.pack + B.offC + lane;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     gwa[r] = wg0[(int64_t)r * 64];
-                    gacc[r] = gcp_crow(r, hi) < vo ? it.b_gate[min(gcp_crow(r, hi), vo - 1)] : 0.f;
+                    const float bg = it.b_gate[min(gcp_crow(r, hi), vo - 1)];  // unconditional (clamped) load, then select:
+                    gacc[r] = gcp_crow(r, hi) < vo ? bg : 0.f;                   // a guarded load is waited for on the spot
                 }
             }
             // norms and frame scalars: ordinary B fragments from the 32 x 16 LDS tile, weights from section A
@@ -358,7 +384,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             }
         }
 
+#ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
+#endif
         // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
         if (scalar_gate) {
             const float* wg = it.pack + B.offC + lane;
@@ -378,7 +406,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                     gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[r], gcp_actf<PWL>(it.act_v, ns_v, slope, acc[t][r]), gacc, 0, 0, 0);
             }
         }
+#ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
+#endif
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
         if (it.s_pre) gcp_store_acc_rows<NT>(it.s_pre, so, 0, so, r0, rows, acc, stage, lane);
 #pragma unroll
@@ -390,7 +420,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             }
         if (it.s_out) gcp_store_acc_rows<NT>(it.s_out, so, 0, so, r0, rows, xs, stage, lane);
 
+#ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
+#endif
         // ---- vector epilogue: vector_up on the matrix cores (B fragments = the parked vector_down outputs), then sigmoid
         //      gate, gating and residual element-wise in registers; the vector tile is updated in place ------------------
         {
@@ -435,7 +467,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
         gcp_wave_lds_sync();
         if (it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
+#ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
+#endif
     }
 }
 

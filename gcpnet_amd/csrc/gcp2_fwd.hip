@@ -290,14 +290,15 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
 
+        const bool vec_b = vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0);
         for (int g = 0; g < S.NG; ++g) {
             f32x16 acc[NTG];
 #pragma unroll
             for (int t = 0; t < NTG; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = 32 * (g * NTG + t) + gcp_crow(r, hi);
-                    acc[t][r] = j < so ? it.b_scalar[j] : 0.f;
+                for (int q = 0; q < 4; ++q) {  // (a lane's columns 8 q + 4 hi .. + 3 of a tile are contiguous: one 16-byte load)
+                    const float4 b4 = gcp_load4(it.b_scalar, 0, so, 32 * (g * NTG + t) + 8 * q + 4 * hi, true, vec_b);
+                    acc[t][4 * q] = b4.x; acc[t][4 * q + 1] = b4.y; acc[t][4 * q + 2] = b4.z; acc[t][4 * q + 3] = b4.w;
                 }
             // Pre-projected inputs (node-level GEMMs done by the caller): their gathered rows are requested here, in the
             // accumulator layout, and added after the k loop -- the gather latency is spent under the MFMAs.
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int oo = 32 * a + gcp_crow(r, hi);
-                    if (oo < vo) gt[e * L.GS + oo] = gcp_sigmoid(gacc[a][r] + it.b_gate[oo]);
+                    const float bg = it.b_gate[min(oo, vo - 1)];  // unconditional (clamped) load: a guarded one is waited for on the spot
+                    if (oo < vo) gt[e * L.GS + oo] = gcp_sigmoid(gacc[a][r] + bg);
                 }
         }
         gcp_wave_lds_sync();
@@ -469,10 +471,15 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
             gcp_vmm_regs<16>(it.pack + S.offVB + lane, S.SVB, uin, vu);
             float sg[16], x[16][3];
             const bool need_x = p.o.vector_residual || p.fused_res;
+            float bg[16];  // the gate bias, requested in one go (a load inside the conditional below would be waited for on the spot)
+            if (scalar_gate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bg[r] = it.b_gate[min(gcp_crow(r, hi), vo - 1)];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = min(gcp_crow(r, hi), vo - 1);
-                sg[r] = scalar_gate ? gcp_sigmoid(gacc[0][r] + it.b_gate[o]) : 1.f;
+                sg[r] = scalar_gate ? gcp_sigmoid(gacc[0][r] + bg[r]) : 1.f;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) x[r][d] = need_x ? vt[e * L.VS + 3 * o + d] : 0.f;
             }
