@@ -160,16 +160,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     // phase 1 has to wait for: vmcnt retires in order), in the accumulator layout, and stay in flight
     // under phases 1-2; d(s_out) later doubles as the ResGCP pass-through term of the accumulator.
     if constexpr (SINGLE) {
-#pragma unroll
-        for (int t = 0; t < NTG; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j0 = 32 * t + 8 * q + 4 * hi;
-                const float4 a = load4(sp_ptr, row, so, j0, row_ok, vec_so);
-                const float4 b = load4(dso_ptr, row, so, j0, row_ok, vec_so);
-                spr[t][4 * q] = a.x; spr[t][4 * q + 1] = a.y; spr[t][4 * q + 2] = a.z; spr[t][4 * q + 3] = a.w;
-                dyr[t][4 * q] = b.x; dyr[t][4 * q + 1] = b.y; dyr[t][4 * q + 2] = b.z; dyr[t][4 * q + 3] = b.w;
-            }
+        gcp_load_acc_layout<NTG, false>(sp_ptr, row, so, 0, hi, row_ok, vec_so, spr);
+        gcp_load_acc_layout<NTG, false>(dso_ptr, row, so, 0, hi, row_ok, vec_so, dyr);
     }
     gcp_wave_lds_sync();
     FSTAMP(3);
@@ -184,9 +176,45 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
             vq[k] = p.v_add.ptr[k] + (p.v_add.idx[k] ? (int64_t)p.v_add.idx[k][rc] : (int64_t)rc) * 3 * HFPQ;
         }
     }
+    // Shares of the pre-projected (gathered) sources in [vh | vf]: every value this lane will need (channels hi, hi + 2, ..),
+    // requested in ONE go -- loads inside the run-time channel loops below would each be waited for on the spot, one gather
+    // round trip per channel.  Up to two tables and 2 * QH channels (HF <= 16); anything else takes the loads in the loops.
+    constexpr int QH = 8;
+    const bool q_fast = p.v_add.n > 0 && p.v_add.n <= 2 && HF <= 2 * QH;  // wave-uniform
+    float qsum[QH][3], qfsum[2][3];  // vector_down channels hi + 2 i; frame channels H + hi + 2 j
+    if (q_fast) {
+        float qa[2][QH][3], qf[2][2][3];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float* t = vq[k < p.v_add.n ? k : 0];
+#pragma unroll
+            for (int i = 0; i < QH; ++i) {
+                const int x = min(hi + 2 * i, HFPQ - 1);  // (clamped: always inside the row)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) qa[k][i][d] = t[d * HFPQ + x];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int x = min(H + hi + 2 * j, HFPQ - 1);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) qf[k][j][d] = t[d * HFPQ + x];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool two = p.v_add.n > 1;
+#pragma unroll
+        for (int i = 0; i < QH; ++i)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) qsum[i][d] = qa[0][i][d] + (two ? qa[1][i][d] : 0.f);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) qfsum[j][d] = qf[0][j][d] + (two ? qf[1][j][d] : 0.f);
+    }
     if (has_vec) {
         const float* vrow = vt + e * L.VS;
-        for (int h = hi; h < H; h += 2) {
+#pragma unroll 1
+        for (int h = hi, hidx = 0; h < H; h += 2, ++hidx) {
             const float* wd = sw.wd + h * vi;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int c = 0; c < vi; ++c) {
@@ -195,8 +223,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 a1 = fmaf(w, vrow[3 * c + 1], a1);
                 a2 = fmaf(w, vrow[3 * c + 2], a2);
             }
-            for (int k = 0; k < p.v_add.n; ++k) {  // shares of the pre-projected (gathered) sources
-                a0 += vq[k][0 * HFPQ + h]; a1 += vq[k][1 * HFPQ + h]; a2 += vq[k][2 * HFPQ + h];
+            if (q_fast) {
+#pragma unroll
+                for (int i = 0; i < QH; ++i)  // (static register index: select)
+                    if (i == hidx) { a0 += qsum[i][0]; a1 += qsum[i][1]; a2 += qsum[i][2]; }
+            } else {
+                for (int k = 0; k < p.v_add.n; ++k) {
+                    a0 += vq[k][0 * HFPQ + h]; a1 += vq[k][1 * HFPQ + h]; a2 += vq[k][2 * HFPQ + h];
+                }
             }
             vht[e * L.HS + 3 * h + 0] = a0;
             vht[e * L.HS + 3 * h + 1] = a1;
@@ -222,8 +256,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                     a1 = fmaf(w, vrow[3 * c + 1], a1);
                     a2 = fmaf(w, vrow[3 * c + 2], a2);
                 }
-                for (int q = 0; q < p.v_add.n; ++q) {
-                    a0 += vq[q][0 * HFPQ + H + k]; a1 += vq[q][1 * HFPQ + H + k]; a2 += vq[q][2 * HFPQ + H + k];
+                if (q_fast) {  // frame channel k = hi + 2 j
+                    const int j = (k - hi) >> 1;
+                    a0 += j ? qfsum[1][0] : qfsum[0][0]; a1 += j ? qfsum[1][1] : qfsum[0][1]; a2 += j ? qfsum[1][2] : qfsum[0][2];
+                } else {
+                    for (int q = 0; q < p.v_add.n; ++q) {
+                        a0 += vq[q][0 * HFPQ + H + k]; a1 += vq[q][1 * HFPQ + H + k]; a2 += vq[q][2 * HFPQ + H + k];
+                    }
                 }
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -442,15 +481,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[uu][r] = p.o.fused_residual ? dyr[uu < NTG ? uu : 0][r] : 0.f;
         } else {
+            if (p.o.fused_residual) {  // (si == so there: columns past si read as zero)
+                gcp_load_acc_layout<NUG, false>(dso_ptr, row, so, 32 * ug * NUG, hi, row_ok, vec_so, acc2);
+            } else {
 #pragma unroll
-            for (int uu = 0; uu < NUG; ++uu)
+                for (int uu = 0; uu < NUG; ++uu)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k0 = 32 * (ug * NUG + uu) + 8 * q + 4 * hi;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.o.fused_residual && k0 < si) v = load4(dso_ptr, row, so, k0, row_ok, vec_so);
-                    acc2[uu][4 * q + 0] = v.x; acc2[uu][4 * q + 1] = v.y; acc2[uu][4 * q + 2] = v.z; acc2[uu][4 * q + 3] = v.w;
-                }
+                    for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
+            }
         }
         for (int g = 0; g < S.NG; ++g) {
             if (ug == 0) {  // first pass over this output group: build ds_pre and keep a copy in HBM
@@ -482,16 +520,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
 #pragma unroll
                 for (int t = 0; t < NTG; ++t) {
                     float4 sp[4], dy[4];  // one tile's loads in flight together
+                    if (single) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
-                        if (single) {
+                        for (int q = 0; q < 4; ++q) {
                             sp[q] = make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]);
                             dy[q] = make_float4(dyr[t][4 * q], dyr[t][4 * q + 1], dyr[t][4 * q + 2], dyr[t][4 * q + 3]);
-                        } else {
-                            sp[q] = load4(sp_ptr, row, so, j0, row_ok, vec_so);
-                            dy[q] = load4(dso_ptr, row, so, j0, row_ok, vec_so);
                         }
+                    } else {
+                        gcp_load_tile4(sp_ptr, row, so, 32 * (g * NTG + t), hi, row_ok, vec_so, sp);
+                        gcp_load_tile4(dso_ptr, row, so, 32 * (g * NTG + t), hi, row_ok, vec_so, dy);
                     }
                     float4 d[4];
 #pragma unroll
@@ -517,15 +554,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                     }
                 }
             } else if (!single) {  // later merged-axis groups: re-read this lane's own ds_pre stores
-#pragma unroll
-                for (int t = 0; t < NTG; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j0 = 32 * (g * NTG + t) + 8 * q + 4 * hi;
-                        const float4 d = load4(dsp_ptr, row, so, j0, row_ok, vec_so);
-                        dsr[t][4 * q + 0] = d.x; dsr[t][4 * q + 1] = d.y;
-                        dsr[t][4 * q + 2] = d.z; dsr[t][4 * q + 3] = d.w;
-                    }
+                gcp_load_acc_layout<NTG, false>(dsp_ptr, row, so, 32 * g * NTG, hi, row_ok, vec_so, dsr);
             }
             // scalar_out adjoint for this (merged group, output group): 16 * NTG k-pair steps
             const float* wq = p.w.pack + S.offB + (((int64_t)ug * S.NS + (int64_t)g * NTG * 16) * 64 + lane) * NUG;

@@ -152,13 +152,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         GcpSegBuf<8> vb0;
         gcp_seg_issue(vb0, p.v0, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = gcp_load4(p.s0, row, so, 32 * t + 8 * q + 4 * hi, row_ok, vec_so);
-                xs[t][4 * q] = v.x; xs[t][4 * q + 1] = v.y; xs[t][4 * q + 2] = v.z; xs[t][4 * q + 3] = v.w;
-            }
+        gcp_load_acc_layout<NT, false>(p.s0, row, so, 0, hi, row_ok, vec_so, xs);
         gcp_seg_commit(vb0, vt, L.VS, 0);
     }
     for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
@@ -187,13 +181,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         f32x16 bias[NT];
         auto load_bias = [&]() {
             const bool vec_b = vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b4 = gcp_load4(it.b_scalar, 0, so, 32 * t + 8 * q + 4 * hi, true, vec_b);
-                    bias[t][4 * q] = b4.x; bias[t][4 * q + 1] = b4.y; bias[t][4 * q + 2] = b4.z; bias[t][4 * q + 3] = b4.w;
-                }
+            gcp_load_acc_layout<NT, false>(it.b_scalar, 0, so, 0, hi, true, vec_b, bias);
         };
         if constexpr (!HEAD) load_bias();
         if (head) {
@@ -209,13 +197,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             for (int k = 0; k < HD.s_add.n; ++k) {
                 const int32_t* ix = HD.s_add.idx[k];
                 const int64_t src = ix ? (int64_t)ix[rc] : (int64_t)rc;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = gcp_load4(HD.s_add.ptr[k], src, so, 32 * t + 8 * q + 4 * hi, true, vec_so);
-                        acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
-                    }
+                gcp_load_acc_layout<NT, true>(HD.s_add.ptr[k], src, so, 0, hi, true, vec_so, acc);
             }
             const int HFP = gcp_round_up(B.HF, 4);
             for (int k = 0; k < HD.v_add.n; ++k) {

@@ -293,13 +293,8 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
         const bool vec_b = vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0);
         for (int g = 0; g < S.NG; ++g) {
             f32x16 acc[NTG];
-#pragma unroll
-            for (int t = 0; t < NTG; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {  // (a lane's columns 8 q + 4 hi .. + 3 of a tile are contiguous: one 16-byte load)
-                    const float4 b4 = gcp_load4(it.b_scalar, 0, so, 32 * (g * NTG + t) + 8 * q + 4 * hi, true, vec_b);
-                    acc[t][4 * q] = b4.x; acc[t][4 * q + 1] = b4.y; acc[t][4 * q + 2] = b4.z; acc[t][4 * q + 3] = b4.w;
-                }
+            // (a lane's columns 8 q + 4 hi .. + 3 of a tile are contiguous: one 16-byte load per register quad)
+            gcp_load_acc_layout<NTG, false>(it.b_scalar, 0, so, 32 * g * NTG, hi, true, vec_b, acc);
             // Pre-projected inputs (node-level GEMMs done by the caller): their gathered rows are requested here, in the
             // accumulator layout, and added after the k loop -- the gather latency is spent under the MFMAs.
             f32x16 pre[NTG];
@@ -313,13 +308,7 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
                     const int32_t* ix = p.s_add.idx[k];
                     const int rc = min(row, rows - 1);
                     const int64_t src = ix ? (int64_t)ix[rc] : (int64_t)rc;
-#pragma unroll
-                    for (int t = 0; t < NTG; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 v = gcp_load4(p.s_add.ptr[k], src, so, 32 * (g * NTG + t) + 8 * q + 4 * hi, true, vec_so);
-                            pre[t][4 * q] += v.x; pre[t][4 * q + 1] += v.y; pre[t][4 * q + 2] += v.z; pre[t][4 * q + 3] += v.w;
-                        }
+                    gcp_load_acc_layout<NTG, true>(p.s_add.ptr[k], src, so, 32 * g * NTG, hi, true, vec_so, pre);
                 }
             }
             const float* wp = it.pack + S.offA + ((int64_t)g * S.KK * 64 + lane) * NTG;

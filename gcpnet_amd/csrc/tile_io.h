@@ -241,6 +241,60 @@ __device__ __forceinline__ float4 gcp_load4(const float* base, int64_t row, int 
     return v;
 }
 
+// Batched forms of gcp_load4 for the accumulator layout.  gcp_load4 with a RUN-TIME `vec` compiles to a branch around each
+// load whose two sides merge right behind it, so hipcc waits (vmcnt(0)) for every load where it is issued: a loop of N calls
+// costs N memory round trips.  Here the wave-uniform test is made once and all the loads of a tile (or of all NT tiles) sit in
+// one basic block, requested together.
+//   v[q] = base[row, c0 + 8 q + 4 hi .. + 3], q < 4: the 16 columns of one 32-wide tile this lane holds.
+__device__ __forceinline__ void gcp_load_tile4(const float* __restrict__ base, int64_t row, int ld, int c0, int hi, bool ok, bool vec,
+                                               float4 (&v)[4]) {
+    if (vec) {
+        const float* rp = base + (ok ? row : 0) * (int64_t)ld;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(rp + min(c0 + 8 * q + 4 * hi, ld - 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = ok && c0 + 8 * q + 4 * hi + 3 < ld;
+            v[q] = make_float4(in ? v[q].x : 0.f, in ? v[q].y : 0.f, in ? v[q].z : 0.f, in ? v[q].w : 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gcp_load4(base, row, ld, c0 + 8 * q + 4 * hi, ok, false);
+    }
+}
+//   x[t][r] (+)= base[row, col0 + 32 t + crow(r, hi)] for all NT tiles of an accumulator-layout register set.
+template <int NT, bool ADD>
+__device__ __forceinline__ void gcp_load_acc_layout(const float* __restrict__ base, int64_t row, int ld, int col0, int hi, bool ok,
+                                                    bool vec, f32x16 (&x)[NT]) {
+    float4 v[NT][4];
+    if (vec) {  // raw (clamped, unconditional) requests only; the out-of-range selects come after all of them
+        const float* rp = base + (ok ? row : 0) * (int64_t)ld;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[t][q] = *reinterpret_cast<const float4*>(rp + min(col0 + 32 * t + 8 * q + 4 * hi, ld - 4));
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[t][q] = gcp_load4(base, row, ld, col0 + 32 * t + 8 * q + 4 * hi, ok, false);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all requests first: hipcc otherwise sinks each load to its use through one temporary
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = !vec || (ok && col0 + 32 * t + 8 * q + 4 * hi + 3 < ld);
+            const float4 w = make_float4(in ? v[t][q].x : 0.f, in ? v[t][q].y : 0.f, in ? v[t][q].z : 0.f, in ? v[t][q].w : 0.f);
+            if constexpr (ADD) {
+                x[t][4 * q] += w.x; x[t][4 * q + 1] += w.y; x[t][4 * q + 2] += w.z; x[t][4 * q + 3] += w.w;
+            } else {
+                x[t][4 * q] = w.x; x[t][4 * q + 1] = w.y; x[t][4 * q + 2] = w.z; x[t][4 * q + 3] = w.w;
+            }
+        }
+}
+
 __device__ __forceinline__ void gcp_store4(float* base, int64_t row, int ld, int j0, float4 v, bool ok, bool vec) {
     if (!ok) return;
     float* p = base + row * ld + j0;

@@ -55,5 +55,9 @@ torch.autograd.backward([m[0], m[1]], [torch.randn_like(m[0]), torch.randn_like(
 b.record()
 torch.cuda.synchronize()
 print(f"backward (kernel + weight-gradient GEMMs + projections) {a.elapsed_time(b) * 1e3:.0f} us")
-report("bwd", 5, ["load + recompute vh", "vector epilogue adjoint", "ds_pre + W^T ds (mfma)", "vector prologue adjoint"])
+if os.environ.get("GCP_BWD_FINE"):  # library built with GCPNET_HIPCC_EXTRA=-DGCP_BWD_FINE
+    report("bwd(fine)", 8, ["tile loads committed", "small weights staged", "s_pre/d_s_out requested", "vh recompute + scratch",
+                            "frame scalars", "transposed v copy", "vector epilogue adjoint"])
+else:
+    report("bwd", 5, ["load + recompute vh", "vector epilogue adjoint", "ds_pre + W^T ds (mfma)", "vector prologue adjoint"])
 lib.gcpnet_debug_set_phase_timing(None, 0)
