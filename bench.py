@@ -65,20 +65,24 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     ws = [tuple(None if t is None else t.detach().requires_grad_() for t in b._weights()) for b in blocks]
 
     def timeit(f):
-        for _ in range(3):
+        """Median launch duration, one HIP event pair per launch (a launch that has to grow the caching allocator's pool --
+        ~1.4 GB of saved activations per forward launch -- takes milliseconds on the host and must not enter the figure)."""
+        for _ in range(5):
             f()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         torch.cuda.synchronize()
-        a.record()
-        for _ in range(iters):
+        for a, b in ev:
+            a.record()
             f()
-        b.record()
+            b.record()
         torch.cuda.synchronize()
-        return a.elapsed_time(b) / iters * 1e-3
+        ts = sorted(a.elapsed_time(b) for a, b in ev)
+        return ts[len(ts) // 2] * 1e-3
 
     keep = {}
 
     def fwd():
+        keep.pop("out", None)  # (the previous launch's saved activations go back to the allocator first)
         keep["out"] = ops.gcp2_chain(specs, s, v, frames, ws)  # training mode: s_pre / gates / states are saved
 
     t_fwd = timeit(fwd)
@@ -108,14 +112,22 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
                 bytes=dict(fwd=bytes_fwd, bwd=bytes_bwd, tn=bytes_tn))
 
 
+def _pmc_file():
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_e_traffic.json")) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/README.md); None when not collected."""
-    path = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel)
-    except OSError:
-        return None
+    return _pmc_file().get(kernel)
+
+
+def pmc_mfma_busy(kernel):
+    """Fraction of SIMD cycles with the MFMA pipe busy, from the committed SQ_VALU_MFMA_BUSY_CYCLES pass; None when not collected."""
+    return _pmc_file().get("mfma_busy_frac", {}).get(kernel)
 
 
 def aggregate_roofline(G, ops, n_nodes, n_edges, width, label, iters=30):
@@ -235,7 +247,7 @@ def main():
             "roofline": {
                 "kernel": f"{dom} on the {kr['n_blocks']}-block residual message chain (s,V)->(s,V) of one layer, E rows",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom), "mfma_busy_frac_pmc": pmc_mfma_busy(dom),
                 "avg_launch_ms": times[dom] * 1e3, "flop_per_launch": kr["flops"],
                 "algorithmic_hbm_gbs": kbytes[dom] / times[dom] / 1e9,
                 "algorithmic_hbm_frac": kbytes[dom] / times[dom] / 1e9 / PEAK_HBM_GBS,
