@@ -160,8 +160,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     // phase 1 has to wait for: vmcnt retires in order), in the accumulator layout, and stay in flight
     // under phases 1-2; d(s_out) later doubles as the ResGCP pass-through term of the accumulator.
     if constexpr (SINGLE) {
-        gcp_load_acc_layout<NTG, false>(sp_ptr, row, so, 0, hi, row_ok, vec_so, spr);
-        gcp_load_acc_layout<NTG, false>(dso_ptr, row, so, 0, hi, row_ok, vec_so, dyr);
+        gcp_request_acc_layout<NTG>(sp_ptr, row, so, 0, hi, row_ok, vec_so, spr);
+        gcp_request_acc_layout<NTG>(dso_ptr, row, so, 0, hi, row_ok, vec_so, dyr);
     }
     gcp_wave_lds_sync();
     FSTAMP(3);
@@ -345,6 +345,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     // ---- 4. dmerged = W^T ds_pre, accumulated over the output groups, per merged-axis group ---------------------
     // keep the address arithmetic of the phases below from being hoisted above (and spilled across) phases 1-2
     asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
+    if constexpr (SINGLE) {  // first use of the s_pre / d(s_out) requests made before phase 1: zero what was out of range
+        const bool okr = r0 + e < rows;
+        gcp_mask_acc_layout<NTG>(so, 0, hi, okr, vec_so, spr);
+        gcp_mask_acc_layout<NTG>(so, 0, hi, okr, vec_so, dyr);
+    }
     row = r0 + e;
     row_ok = row < rows;
     // epilogue of one merged-axis group: d_s_in columns go to HBM, the vector extras (norm / frame-scalar adjoints) to LDS

@@ -103,6 +103,35 @@ struct WFragC<4> {
 // PWL: all activations are identity / relu / leakyrelu.
 // HC: hidden vector channels as a compile-time constant (0 = run-time value): with it the tests "channel < H" of the element-wise
 // register code fold, and only the registers that can hold a [vh | vf] channel are walked.
+// sigmoid(gate) of a row in the register-quad layout (channels 8 q + 4 hi .. + 3, q < VQ): one wave-uniform test, all VQ
+// requests together, then the out-of-range selects (tile_io.h, gcp_load_tile4: a gcp_load4 call per quad is waited for on the
+// spot).  Consumed here -- keeping raw requests in flight into step C costs the backward kernel 90 more spilled registers.
+template <int VQ, int NV>
+__device__ __forceinline__ void gcp_load_gate(const float* __restrict__ gate, int row, int vo, int hi, bool ok, bool vec,
+                                              float (&sg)[NV]) {
+    static_assert(NV >= 4 * VQ, "one register quad per 8 channels");
+    float4 g[VQ];
+    if (!gate) {
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) g[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (vec) {
+        const float* rp = gate + (int64_t)(ok ? row : 0) * vo;
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) g[q] = *reinterpret_cast<const float4*>(rp + min(8 * q + 4 * hi, vo - 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+            const bool in = ok && 8 * q + 4 * hi + 3 < vo;
+            g[q] = make_float4(in ? g[q].x : 0.f, in ? g[q].y : 0.f, in ? g[q].z : 0.f, in ? g[q].w : 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) g[q] = gcp_load4(gate, row, vo, 8 * q + 4 * hi, ok, false);
+    }
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) { sg[4 * q] = g[q].x; sg[4 * q + 1] = g[q].y; sg[4 * q + 2] = g[q].z; sg[4 * q + 3] = g[q].w; }
+}
+
 template <int NTG, int VQ, bool PWL, int HC>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -142,12 +171,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         GcpSegBuf<8> vb;
         gcp_seg_issue(vb, it.v_in, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
-#pragma unroll
-        for (int q = 0; q < VQ; ++q) {
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (scalar_gate) g = gcp_load4(it.gate, row, vi, 8 * q + 4 * hi, row_ok, vec_vo);
-            sg[4 * q] = g.x; sg[4 * q + 1] = g.y; sg[4 * q + 2] = g.z; sg[4 * q + 3] = g.w;
-        }
+        gcp_load_gate<VQ>(scalar_gate ? it.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
 #pragma unroll
         for (int t = 0; t < NTG; ++t)
 #pragma unroll
@@ -464,12 +488,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         //         partial-sum pass -------------------------------------------------------------------------------------------
         if (k > 0) {
             const ChainItemB& nx = p.it[k - 1];
-#pragma unroll
-            for (int q = 0; q < VQ; ++q) {
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (scalar_gate) g = gcp_load4(nx.gate, row, vi, 8 * q + 4 * hi, row_ok, vec_vo);
-                sg[4 * q] = g.x; sg[4 * q + 1] = g.y; sg[4 * q + 2] = g.z; sg[4 * q + 3] = g.w;
-            }
+            gcp_load_gate<VQ>(scalar_gate ? nx.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
         }
         GcpSegBuf<8> vb;
         if (k > 0) {

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         f32x16 bias[NT];
         auto load_bias = [&]() {
             const bool vec_b = vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0);
-            gcp_load_acc_layout<NT, false>(it.b_scalar, 0, so, 0, hi, true, vec_b, bias);
+            gcp_request_acc_layout<NT>(it.b_scalar, 0, so, 0, hi, true, vec_b, bias);
         };
         if constexpr (!HEAD) load_bias();
         if (head) {
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gacc[r] = 0.f; gwa[r] = 0.f; }
         if constexpr (HEAD) load_bias();
+        gcp_mask_acc_layout<NT>(so, 0, hi, true, vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0), bias);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll

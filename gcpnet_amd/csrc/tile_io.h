@@ -295,6 +295,45 @@ __device__ __forceinline__ void gcp_load_acc_layout(const float* __restrict__ ba
         }
 }
 
+// Split form for loads that should stay in flight under other work: gcp_request_acc_layout issues the raw (clamped,
+// unconditional) requests straight into the destination registers -- nothing consumes them, so neither the wave-uniform
+// `vec` branch nor anything else makes hipcc wait -- and gcp_mask_acc_layout, called where the values are first needed,
+// zeroes what was out of range.
+template <int NT>
+__device__ __forceinline__ void gcp_request_acc_layout(const float* __restrict__ base, int64_t row, int ld, int col0, int hi, bool ok,
+                                                       bool vec, f32x16 (&x)[NT]) {
+    if (vec) {
+        const float* rp = base + (ok ? row : 0) * (int64_t)ld;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(rp + min(col0 + 32 * t + 8 * q + 4 * hi, ld - 4));
+                x[t][4 * q] = v.x; x[t][4 * q + 1] = v.y; x[t][4 * q + 2] = v.z; x[t][4 * q + 3] = v.w;
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = gcp_load4(base, row, ld, col0 + 32 * t + 8 * q + 4 * hi, ok, false);
+                x[t][4 * q] = v.x; x[t][4 * q + 1] = v.y; x[t][4 * q + 2] = v.z; x[t][4 * q + 3] = v.w;
+            }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void gcp_mask_acc_layout(int ld, int col0, int hi, bool ok, bool vec, f32x16 (&x)[NT]) {
+    if (!vec) return;  // (the scalar path has masked already)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = ok && col0 + 32 * t + 8 * q + 4 * hi + 3 < ld;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[t][4 * q + i] = in ? x[t][4 * q + i] : 0.f;
+        }
+}
+
 __device__ __forceinline__ void gcp_store4(float* base, int64_t row, int ld, int j0, float4 v, bool ok, bool vec) {
     if (!ok) return;
     float* p = base + row * ld + j0;
