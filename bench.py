@@ -268,6 +268,12 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # orderly teardown: nothing in flight and no module-level stream objects left for interpreter shutdown to destroy
+    # after the HIP runtime has gone
+    torch.cuda.synchronize()
+    ops._side_pending.clear()
+    ops._side_streams.clear()
+    sys.stdout.flush()
 
 
 def cpu_baseline(layers, host, args):

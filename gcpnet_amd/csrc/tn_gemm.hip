@@ -293,6 +293,12 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     fetch_issue<TN_B_SLOTS>(sb, vb, w.r_begin, r_last, gb);
     fetch_finish<TN_A_SLOTS>(sa, va, ra, w.r_begin, r_last, ga);
     fetch_finish<TN_B_SLOTS>(sb, vb, rb, w.r_begin, r_last, gb);
+    // every source row resolved BEFORE the first piece goes out: hipcc otherwise sinks each select into the (conditional) issue
+    // of its piece and drains vmcnt(0) -- the previous piece -- in front of every one
+#pragma unroll
+    for (int k = 0; k < TN_A_SLOTS; ++k) asm volatile("" : "+v"(ra[k]));
+#pragma unroll
+    for (int k = 0; k < TN_B_SLOTS; ++k) asm volatile("" : "+v"(rb[k]));
     stage(0, 0);
     fetch_issue<TN_A_SLOTS>(sa, va, w.r_begin + TN_RK, r_last, ga);
     fetch_issue<TN_B_SLOTS>(sb, vb, w.r_begin + TN_RK, r_last, gb);
