@@ -52,8 +52,16 @@ for case in range(n_cases):
     sum((t * w).sum() for t, w in zip(flat(ro), lw)).backward()
     sum((t * w.cuda()).sum() for t, w in zip(flat(go), lw)).backward()
 
+    # smooth activations: element-wise (max error over max magnitude).  relu / leakyrelu: a pre-activation within round-off of
+    # zero takes the other branch in one of the two fp32 implementations (expected for ~1 of the ~1e6 units of the larger cases)
+    # and moves the gradients of that row by O(1): judged in the L2 sense, as tests/test_gpu_parity.py does
+    kinked = act_s in ("relu", "leakyrelu") or act_v in ("relu", "leakyrelu")
+
     def err(a, b):
-        return ((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-6)).item()
+        a, b = a.detach().cpu().double(), b.detach().double()
+        if kinked:
+            return ((a - b).norm() / (b.norm() + 1e-12)).item()
+        return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
 
     errs = {f"out{i}": err(a, b) for i, (a, b) in enumerate(zip(flat(go), flat(ro)))}
     errs.update({"d" + k: err(gi[k].grad, ci[k].grad) for k in ins})
