@@ -160,11 +160,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test hooks (a 1-GPU box can rehearse the N > 1 code path): BENCH_SHARE_GPU=1 puts every rank on cuda:0,
+    # BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import gcpnet_amd as G
     from gcpnet_amd import ops
