@@ -136,6 +136,18 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     const float* __restrict__ dso_ptr = p.d_s_out;
     float* __restrict__ dsp_ptr = p.sc.ds_pre;
     f32x16 spr[NTG], dyr[NTG];
+    // rows of the pre-projected vector tables this lane's row gathers ([n_src, 3, HF'] each): the gather indices are requested
+    // first of all, so that they arrive with the tile
+    const int HFPQ = gcp_round_up(HF, 4);
+    const float* vq[GCP_MAX_SEG];
+#pragma unroll
+    for (int k = 0; k < GCP_MAX_SEG; ++k) {
+        vq[k] = nullptr;
+        if (k < p.v_add.n) {
+            const int rc = min(row, rows - 1);
+            vq[k] = p.v_add.ptr[k] + (p.v_add.idx[k] ? (int64_t)p.v_add.idx[k][rc] : (int64_t)rc) * 3 * HFPQ;
+        }
+    }
     // ---- 1. stage vectors / frames, recompute vh, its norms and the frame scalars ---------------------------
     if (has_vec) {  // inputs, upstream vector gradients, gates and frames: one memory round trip
         GcpSegBuf<8> vb0, gb0, tb0;
@@ -159,31 +171,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
     // Single output group (so <= 128): s_pre and d(s_out) of the tile are requested here (after every load
     // phase 1 has to wait for: vmcnt retires in order), in the accumulator layout, and stay in flight
     // under phases 1-2; d(s_out) later doubles as the ResGCP pass-through term of the accumulator.
-    if constexpr (SINGLE) {
-        gcp_request_acc_layout<NTG>(sp_ptr, row, so, 0, hi, row_ok, vec_so, spr);
-        gcp_request_acc_layout<NTG>(dso_ptr, row, so, 0, hi, row_ok, vec_so, dyr);
-    }
-    gcp_wave_lds_sync();
-    FSTAMP(3);
-    // rows of the pre-projected vector tables this lane's row gathers ([n_src, 3, HF'] each)
-    const int HFPQ = gcp_round_up(HF, 4);
-    const float* vq[GCP_MAX_SEG];
-#pragma unroll
-    for (int k = 0; k < GCP_MAX_SEG; ++k) {
-        vq[k] = nullptr;
-        if (k < p.v_add.n) {
-            const int rc = min(row, rows - 1);
-            vq[k] = p.v_add.ptr[k] + (p.v_add.idx[k] ? (int64_t)p.v_add.idx[k][rc] : (int64_t)rc) * 3 * HFPQ;
-        }
-    }
     // Shares of the pre-projected (gathered) sources in [vh | vf]: every value this lane will need (channels hi, hi + 2, ..),
     // requested in ONE go -- loads inside the run-time channel loops below would each be waited for on the spot, one gather
     // round trip per channel.  Up to two tables and 2 * QH channels (HF <= 16); anything else takes the loads in the loops.
     constexpr int QH = 8;
     const bool q_fast = p.v_add.n > 0 && p.v_add.n <= 2 && HF <= 2 * QH;  // wave-uniform
-    float qsum[QH][3], qfsum[2][3];  // vector_down channels hi + 2 i; frame channels H + hi + 2 j
+    float qa[2][QH][3], qf[2][2][3];
     if (q_fast) {
-        float qa[2][QH][3], qf[2][2][3];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float* t = vq[k < p.v_add.n ? k : 0];
@@ -200,7 +194,17 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_bwd_kernel(BwdParams p) {
                 for (int d = 0; d < 3; ++d) qf[k][j][d] = t[d * HFPQ + x];
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (SINGLE) {
+        gcp_request_acc_layout<NTG>(sp_ptr, row, so, 0, hi, row_ok, vec_so, spr);
+        gcp_request_acc_layout<NTG>(dso_ptr, row, so, 0, hi, row_ok, vec_so, dyr);
+    }
+    gcp_wave_lds_sync();
+    FSTAMP(3);
+    // (the gathered shares of the pre-projected vector tables were requested before s_pre / d(s_out): they are older in the
+    // in-order vmcnt queue, so consuming them here does not wait for those)
+    float qsum[QH][3], qfsum[2][3];  // vector_down channels hi + 2 i; frame channels H + hi + 2 j
+    if (q_fast) {
         const bool two = p.v_add.n > 1;
 #pragma unroll
         for (int i = 0; i < QH; ++i)

@@ -27,7 +27,7 @@ def report(name, nst, labels):
     d = t[:, 1:nst] - t[:, : nst - 1]
     tot = t[:, nst - 1] - t[:, 0]
     span = t[:, nst - 1].max() - t[:, 0].min()
-    print(f"{name}: {ntiles} tiles, whole-launch span {span.item():.0f} ticks (100 MHz), tile total median {tot.median().item():.0f}")
+    print(f"{name}: {ntiles} tiles, whole-launch span {span.item():.0f} ticks (shader clock), tile total median {tot.median().item():.0f}")
     for i, lab in enumerate(labels):
         print(f"   {lab:28s} median {d[:, i].median().item():9.0f}  mean {d[:, i].mean().item():9.0f}  max {d[:, i].max().item():9.0f}")
     buf.zero_()
