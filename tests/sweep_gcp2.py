@@ -1,5 +1,5 @@
 """Randomised parity sweep of single GCP2 blocks (edge rows) against the CPU oracle: dims, bottleneck, gating mode, activations,
-vector residual, e3, frames on/off.  usage: python tools/sweep_gcp2.py [n_cases] [seed]   (needs a GPU)"""
+vector residual, e3, frames on/off.  usage: python tests/sweep_gcp2.py [n_cases] [seed]   (needs a GPU)"""
 import os
 import random
 import sys

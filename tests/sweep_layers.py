@@ -1,6 +1,6 @@
 """Randomised parity sweep of whole GCPInteractions layers against the CPU oracle: node dims, bottleneck, activations, pre/post
 norm, number of message / feed-forward blocks, position update with and without the force term.
-usage: python tools/sweep_layers.py [n_cases] [seed]   (needs a GPU)"""
+usage: python tests/sweep_layers.py [n_cases] [seed]   (needs a GPU)"""
 import os
 import random
 import sys
