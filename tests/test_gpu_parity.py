@@ -316,6 +316,45 @@ def test_interactions2_golden(G, name):
             close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=1e-3)
 
 
+@pytest.mark.parametrize("upd", [False, True], ids=["eq", "posupd"])
+def test_interactions2_large_vs_oracle(G, upd):
+    """GCPInteractions2 with GCP3 blocks at chain-kernel dims (128,16) on a col-sorted 6000-edge graph, silu (smooth: tight
+    element-wise agreement), fwd + bwd with a random linear functional of the outputs."""
+    import functools
+    torch.manual_seed(21)
+    n, e, dims = 600, 6000, (128, 16)
+    kw = dict(use_scalar_message_attention=True, aggregate_with_row=not upd, num_feedforward_layers=2 if upd else 1)
+    cfg = G.default_module_cfg(selected_GCP=functools.partial(G.GCP3), scalar_nonlinearity="silu")
+    layer = G.GCPInteractions2(dims, (32, 4), cfg=cfg, layer_cfg=G.default_layer_cfg(**kw), dropout=0.0,
+                               updating_node_positions=upd).cuda().eval()
+    ei, x = rand_graph(n, e, 22, sort_by_col=True)
+    fr = O.localize(x, ei)
+    g = torch.Generator().manual_seed(23)
+    ins = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g),
+               e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
+    P = {k: t.detach().cpu().clone().requires_grad_() for k, t in layer.state_dict().items()}
+    ci = {k: t.clone().requires_grad_() for k, t in ins.items()}
+    ocfg = O.default_module_cfg(scalar_nonlinearity="silu", nonlinearities=("silu", None))
+    want = O.gcp_interactions2(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], ei, fr, ocfg, O.default_layer_cfg(**kw),
+                               node_pos=x if upd else None)
+    gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
+    got = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda(), node_pos=x.cuda() if upd else None)
+    wl = [want[0][0], want[0][1], want[1]] if upd else list(want)
+    gl = [got[0][0], got[0][1], got[1]] if upd else list(got)
+    for a, b in zip(gl, wl):
+        close(a.detach().cpu(), b.detach(), atol=2e-5 * max(1.0, float(b.detach().abs().max())), rtol=2e-5)
+    lw = [torch.randn(t.shape, generator=g) for t in wl]
+    sum((t * w).sum() for t, w in zip(wl, lw)).backward()
+    sum((t * w.cuda()).sum() for t, w in zip(gl, lw)).backward()
+    for k in ins:
+        b = ci[k].grad
+        close(gi[k].grad.cpu(), b, atol=2e-5 * float(b.abs().max()), rtol=1e-4)
+    for k, p in layer.named_parameters():
+        b = P[k].grad
+        if b is not None and p.grad is not None:
+            close(p.grad.cpu(), b, atol=2e-5 * max(float(b.abs().max()), 1e-6), rtol=1e-4)
+
+
 def test_interactions_prenorm_silu_golden(G):
     f = Fixture("interactions_prenorm_silu")
     cfg = G.default_module_cfg(scalar_nonlinearity="silu", vector_nonlinearity="silu")
