@@ -22,6 +22,7 @@ EXPORTS = [
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing",
+    "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_forward",
 ]
 
 
@@ -50,6 +51,14 @@ class ChainItem(C.Structure):
 class Head(C.Structure):
     _fields_ = [("e_in", C.c_void_p), ("xi_in", C.c_void_p), ("s_add", Concat), ("v_add", Concat), ("w", Gcp2Weights),
                 ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p), ("gate", C.c_void_p)]
+
+
+class WgBlock(C.Structure):
+    _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p),
+                ("gate", C.c_void_p), ("residual", C.c_int)]
+
+
+WG_MAX_BLOCKS = 9
 
 
 class BwdScratch(C.Structure):
@@ -133,9 +142,14 @@ def load():
     lib.gcpnet_row_gate_backward.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.gcpnet_row_gate_bwd_blocks.argtypes = [i64]
     lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
+    lib.gcpnet_wg_pack_floats.restype = i64
+    lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
+    lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]
+    lib.gcpnet_wg_forward.argtypes = [i32, vp, vp, vp, P(Concat), P(Concat), i32, P(WgBlock), vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes"):
+        if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",
+                        "gcpnet_wg_pack_floats"):
             fn.restype = i32
     if lib.gcpnet_abi_version() != 1:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")

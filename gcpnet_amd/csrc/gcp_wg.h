@@ -1,0 +1,66 @@
+// Multi-wave workgroup GCP2 kernels (gcp_wg_fwd.hip / gcp_wg_bwd.hip): shared shapes, packed-weight layout and helpers.
+//
+// One WORKGROUP of NW wavefronts owns a 32-row tile (edges or nodes).  Every dense Linear of the block is computed
+// transposed, out^T[cols, 32 rows] = W[cols, K] . in^T[K, 32 rows], with the OUTPUT columns split across the waves: wave w
+// holds the 32-column output tiles ot = w, w + NW, ...; the reduction operand (the tile's merged input [s | norms | frame
+// scalars]) sits ONCE in LDS as X[32][KS] and every wave reads its B fragments from there with one ds_read_b128 per four
+// k-pair steps; the A fragments (weights) stream from L2 in a fragment-ordered image, 16 bytes per lane per four steps.
+// A wave therefore carries 16 accumulator registers per output tile and almost nothing else, so 3-4 waves share a SIMD and
+// the VALU / LDS / store phases of one workgroup run under the MFMAs of the others.
+//
+// k-pair steps: step 4 g + i of group g pairs the columns (8 g + i, 8 g + 4 + i) for the lane halves (hi = 0, 1): a lane
+// (row e, half hi) reads X[e][8 g + 4 hi .. + 3] -- which is also the layout of an accumulator register quad
+// (column 8 q + 4 hi + i of row e), so accumulators feed the next GEMM without any data movement.
+#pragma once
+#include "common.h"
+
+// (GCP_WG_MAX_BLOCKS = 9: head + 8 residual blocks, include/gcpnet_hip.h)
+
+// Packed image of one block's dense weights (floats; all sections are [..][64 lanes][4]):
+//   A1 [NT][KG]   forward scalar_out:       W[32 ot + m][8 g + 4 hi + i]
+//   G1 [4 NT]     forward gate Linear:      Wg[m][8 g + 4 hi + i]                 (m < vo, reduction over so)
+//   A2 [NKT][4 NT] backward-data scalar_out: W[8 g + 4 hi + i][32 kt + m]          (reduction over so, output tile kt of K)
+//   G2 [NT][VG]   backward gate Linear:     Wg[8 g + 4 hi + i][32 ot + m]         (reduction over vo)
+// with m = lane & 31, hi = lane >> 5, zeros outside the matrices.
+struct WgShape {
+    int si, vi, so, vo, H, nf;
+    int K, KG, KP;   // merged width, groups of 8 columns, KG * 8
+    int NT;          // 32-wide tiles of so
+    int NKT;         // 32-wide tiles of K
+    int VG;          // groups of 8 gate outputs
+    int gated;
+    int64_t offA1, offG1, offA2, offG2, total;
+};
+
+__host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int H, int use_frames, int gated) {
+    WgShape s;
+    s.si = si; s.vi = vi; s.so = so; s.vo = vo; s.H = vi > 0 ? H : 0;
+    s.nf = (vi > 0 && use_frames) ? 9 : 0;
+    s.K = si + s.H + s.nf;
+    s.KG = gcp_cdiv(s.K, 8);
+    s.KP = s.KG * 8;
+    s.NT = gcp_cdiv(so, 32);
+    s.NKT = gcp_cdiv(s.K, 32);
+    s.VG = gcp_cdiv(vo, 8);
+    s.gated = (gated && vo > 0 && vi > 0) ? 1 : 0;
+    s.offA1 = 0;
+    s.offG1 = s.offA1 + (int64_t)s.NT * s.KG * 256;
+    s.offA2 = s.offG1 + (s.gated ? (int64_t)4 * s.NT * 256 : 0);
+    s.offG2 = s.offA2 + (int64_t)s.NKT * 4 * s.NT * 256;
+    s.total = s.offG2 + (s.gated ? (int64_t)s.NT * s.VG * 256 : 0);
+    return s;
+}
+
+// LDS row stride (floats) of a [32][width] tile read with ds_read_b128 by lanes (row e, half hi): a multiple of 4 (16-byte
+// alignment) that is an ODD multiple of 4, so that the 16 lanes of one LDS access group (distinct e mod 16) hit distinct
+// 4-bank groups of the 64 banks.
+__host__ __device__ inline int wg_stride(int width) {
+    int q = gcp_cdiv(width, 4);
+    return 4 * (q | 1);
+}
+
+// Workgroup barrier for LDS hand-offs: waits for this wave's DS operations only (__syncthreads() would also drain vmcnt, i.e.
+// every outstanding global store and prefetched load of the wave).
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}

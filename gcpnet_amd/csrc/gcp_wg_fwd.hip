@@ -1,0 +1,638 @@
+// GCP2 forward for a 32-row tile per WORKGROUP (NW wavefronts), see gcp_wg.h: one block (any dims: embeddings, feed-forward
+// and position-update GCPs on node rows, the first message GCP after project-then-gather) or a whole chain
+// x_k = x_{k-1} + GCP_k(x_{k-1}) (ResGCP, reference src/models/components/gcpnet.py:921-924) behind an optional non-residual
+// first block, in ONE launch with the (s, V) state of the tile on chip.  Replaces GCP2.forward (gcpnet.py:394-468).
+//
+// Per block and tile:
+//   prologue (VALU, thread = (row, hidden channel)): [vh | vf] = [vector_down ; vector_down_frames] v (+ gathered addends),
+//             norms of vh and frame projections of vf -> the extras columns of X; vh parked in LDS            -> barrier B1
+//   GEMM (MFMA, wave = 32-column output tiles): s_pre = b + W [s | norms | frame scalars] (+ gathered addends);
+//             gate partial = Wg[:, own columns] act_v(s_pre) -> LDS; s_pre and the new scalars leave through a wave-private
+//             staging tile as full 64-byte row pieces                                                           -> barrier B2
+//   epilogue (VALU, thread = (row, output channel)): vector_up, gate = sigmoid(sum of partials), gating, residual; the
+//             wave's slice of the new scalar state goes back to X                                              -> barrier B3
+#include "gcp_wg.h"
+
+namespace {
+
+struct WgBlk {
+    const float* pk;
+    const float* b_scalar;
+    const float* b_gate;
+    const float* w_down;
+    const float* w_frames;
+    const float* w_up;
+    float* s_out;
+    float* v_out;
+    float* s_pre;
+    float* gate;
+    int64_t offG1;
+    int act_s, act_v;
+    int si, vi, H, K, KG;
+    int residual;
+};
+
+struct WgFwdParams {
+    int rows;
+    const float* s_in;
+    const float* v_in;
+    const float* frames;
+    gcp_concat_t s_add, v_add;  // block 0 only
+    int so, vo, nf, e3, vmode, vres;
+    float slope;
+    int NT, NG;
+    int n;
+    int KS, VS, HS, GS;
+    int o_x, o_v, o_vh, o_fr, o_gp, o_ws, o_st, ws_floats;
+    WgBlk blk[GCP_WG_MAX_BLOCKS];
+};
+
+__device__ __forceinline__ bool wg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int NW, int MT, bool PWL>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NTH = 64 * NW, TPR = NTH / 32, U = 4 / MT;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, e = lane & 31, hi = lane >> 5;
+    const int r0 = blockIdx.x * 32;
+    const int rows = p.rows;
+    const int nvalid = min(32, rows - r0);
+    const int prow = tid / TPR, psub = tid - prow * TPR;  // (row, sub-index) of the VALU phases
+    float* X = lds + p.o_x;
+    float* V = lds + p.o_v;
+    float* VH = lds + p.o_vh;
+    float* FR = lds + p.o_fr;
+    float* GP = lds + p.o_gp;
+    float* ST = lds + p.o_st + w * (32 * 20);
+    const int KS = p.KS, VS = p.VS, HS = p.HS, GS = p.GS;
+    const int so = p.so, vo = p.vo, nf = p.nf, NT = p.NT;
+    const bool scalar_gate = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;
+    const float slope = p.slope;
+
+    // small weights of block b -> LDS buffer b & 1: [vector_down ; vector_down_frames] rows (stride vi | 1), vector_up rows
+    // (stride H | 1), gate bias, scalar_out bias.  Split in a request (global loads into registers, issued before a block's GEMM) and a commit
+    // (LDS writes, after it): the round trip to L2 stays under the MFMAs.
+    constexpr int WSR = 4;
+    float wsr[WSR];
+    auto ws_src = [&](const WgBlk& B, int i, int& dst) -> const float* {  // flat index over [down ; frames | up | gate bias]
+        const int H = B.H, vi = B.vi, HF = H + (nf ? 3 : 0), WSV = vi | 1, WSU = H | 1;
+        const int n1 = HF * vi, n2 = n1 + vo * H;
+        if (i < n1) {
+            const int x = i / vi, c = i - x * vi;
+            dst = x * WSV + c;
+            return x < H ? B.w_down + i : B.w_frames + (i - H * vi);
+        }
+        if (i < n2) {
+            const int j = i - n1, o = j / H, h = j - o * H;
+            dst = HF * WSV + o * WSU + h;
+            return B.w_up + j;
+        }
+        const int n3 = n2 + (scalar_gate ? vo : 0);
+        if (i < n3) {
+            dst = HF * WSV + vo * WSU + (i - n2);
+            return B.b_gate + (i - n2);
+        }
+        dst = gcp_round_up(HF * WSV + vo * WSU + vo, 4) + (i - n3);
+        return B.b_scalar + (i - n3);
+    };
+    auto ws_count = [&](const WgBlk& B) { return (B.H + (nf ? 3 : 0)) * B.vi + vo * B.H + (scalar_gate ? vo : 0) + so; };
+    auto ws_request = [&](int b) {
+        const WgBlk& B = p.blk[b];
+        const int n = ws_count(B);
+#pragma unroll
+        for (int k = 0; k < WSR; ++k) {
+            int dst;
+            wsr[k] = *ws_src(B, min(tid + k * NTH, n - 1), dst);
+        }
+    };
+    auto ws_commit = [&](int b) {
+        const WgBlk& B = p.blk[b];
+        float* ws = lds + p.o_ws + (b & 1) * p.ws_floats;
+        const int n = ws_count(B);
+#pragma unroll
+        for (int k = 0; k < WSR; ++k) {
+            int dst;
+            const int i = tid + k * NTH;
+            ws_src(B, min(i, n - 1), dst);
+            if (i < n) ws[dst] = wsr[k];
+        }
+        for (int i = tid + WSR * NTH; i < n; i += NTH) {  // (shapes with more than WSR * NTH small weights)
+            int dst;
+            const float* s = ws_src(B, i, dst);
+            ws[dst] = *s;
+        }
+    };
+
+    // ---- the tile: scalars -> X[:, 0:si0), vectors -> V, frames -> FR (flat, coalesced copies: tile rows are contiguous) ----
+    {
+        const WgBlk& B0 = p.blk[0];
+        const int si0 = B0.si, vw = 3 * B0.vi;
+        const float* src = p.s_in + (int64_t)r0 * si0;
+        if ((si0 & 3) == 0 && wg_aligned16(p.s_in)) {
+            const int q = si0 >> 2, n4 = nvalid * q;
+            for (int i0 = 0; i0 < 32 * q; i0 += 4 * NTH) {
+                f32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + 4 * (int64_t)min(i0 + tid + k * NTH, n4 - 1));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + tid + k * NTH;
+                    if (i < 32 * q) {
+                        const int r = i / q, c4 = i - r * q;
+                        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4*>(X + r * KS + 4 * c4) = i < n4 ? v[k] : z;
+                    }
+                }
+            }
+        } else {
+            const int n1 = nvalid * si0;
+            for (int i0 = 0; i0 < 32 * si0; i0 += 4 * NTH) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + tid + k * NTH, n1 - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + tid + k * NTH;
+                    if (i < 32 * si0) {
+                        const int r = i / si0, c = i - r * si0;
+                        X[r * KS + c] = i < n1 ? v[k] : 0.f;
+                    }
+                }
+            }
+        }
+        const float* vsrc = p.v_in + (int64_t)r0 * vw;
+        const int nv = nvalid * vw;
+        for (int i0 = 0; i0 < 32 * vw; i0 += 4 * NTH) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = vsrc[min(i0 + tid + k * NTH, nv - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + tid + k * NTH;
+                if (i < 32 * vw) {
+                    const int r = i / vw, c = i - r * vw;
+                    V[r * VS + c] = i < nv ? v[k] : 0.f;
+                }
+            }
+        }
+        if (nf) {
+            const float* fsrc = p.frames + (int64_t)r0 * 9;
+            for (int i = tid; i < 32 * 9; i += NTH) FR[i] = fsrc[min(i, nvalid * 9 - 1)];
+        }
+        ws_request(0);
+        ws_commit(0);
+    }
+    wg_barrier();
+
+    auto run_block = [&](auto first_tag, const int b) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const WgBlk& B = p.blk[b];
+        const float* ws = lds + p.o_ws + (b & 1) * p.ws_floats;
+        const int H = B.H, vi = B.vi, si = B.si, HF = H + (nf ? 3 : 0), WSV = vi | 1, WSU = H | 1;
+        const float* wu = ws + HF * WSV;
+        const float* bg = wu + vo * WSU;
+        const float* bs = ws + gcp_round_up(HF * WSV + vo * WSU + vo, 4);
+        const int KG = B.KG, K = B.K, KP = 8 * KG;
+        const float ns_s = gcp_neg_slope(B.act_s, slope), ns_v = gcp_neg_slope(B.act_v, slope);
+
+        // ---- prologue ----------------------------------------------------------------------------------------------------
+        {
+            const float* vrow = V + prow * VS;
+            const int grow = min(r0 + prow, rows - 1);
+            const int HFP = gcp_round_up(HF, 4);
+            for (int x = psub; x < HF; x += TPR) {
+                float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                if constexpr (FIRST) {  // shares of the pre-projected (gathered) vector sources
+                    for (int k = 0; k < p.v_add.n; ++k) {
+                        const int32_t* ix = p.v_add.idx[k];
+                        const float* t = p.v_add.ptr[k] + (int64_t)(ix ? ix[grow] : grow) * 3 * HFP;
+                        q0 += t[x]; q1 += t[HFP + x]; q2 += t[2 * HFP + x];
+                    }
+                }
+                const float* wr = ws + x * WSV;
+                float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                for (int c = 0; c < vi; ++c) {
+                    const float wv = wr[c];
+                    u0 = fmaf(wv, vrow[3 * c + 0], u0);
+                    u1 = fmaf(wv, vrow[3 * c + 1], u1);
+                    u2 = fmaf(wv, vrow[3 * c + 2], u2);
+                }
+                u0 += q0; u1 += q1; u2 += q2;
+                if (x < H) {
+                    VH[prow * HS + 3 * x + 0] = u0; VH[prow * HS + 3 * x + 1] = u1; VH[prow * HS + 3 * x + 2] = u2;
+                    X[prow * KS + si + x] = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f;
+                } else {
+                    const int k = x - H;
+                    const float* f = FR + prow * 9;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float pr = f[3 * a + 0] * u0 + f[3 * a + 1] * u1 + f[3 * a + 2] * u2;
+                        if (p.e3 && a == 1) pr = fabsf(pr);
+                        X[prow * KS + si + H + 3 * k + a] = pr;
+                    }
+                }
+            }
+            const int npad = KP - K;  // k padding of this block's merged axis reads as zero
+            for (int i = tid; i < 32 * npad; i += NTH) {
+                const int r = i / npad, c = i - r * npad;
+                X[r * KS + K + c] = 0.f;
+            }
+        }
+        wg_barrier();  // B1
+        if (b + 1 < p.n) ws_request(b + 1);
+
+        // ---- scalar_out (+ gate partial) per output group ---------------------------------------------------------------
+        f32x16 ynew[MT];  // the wave's slice of the block output (accumulator layout); the chain state when NG == 1
+        f32x16 gacc;      // this wave's partial gate pre-activations (its columns of the reduction over so)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+        for (int og = 0; og < p.NG; ++og) {
+            const int ot0 = og * NW * MT + w;
+            if (ot0 >= NT) continue;  // (wave-uniform) nothing for this wave in this group
+            int otc[MT];
+            bool tv[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                tv[t] = ot0 + NW * t < NT;
+                otc[t] = min(ot0 + NW * t, NT - 1);
+            }
+            f32x16 acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            {
+                const float* pkA = B.pk + (int64_t)lane * 4;
+                const float* xb = X + e * KS + 4 * hi;
+                auto ldA = [&](f32x4(&a)[U][MT], f32x4(&bb)[U], int g0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int g = min(g0 + u, KG - 1);
+                        bb[u] = *reinterpret_cast<const f32x4*>(xb + 8 * g);
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            a[u][t] = *reinterpret_cast<const f32x4*>(pkA + ((int64_t)otc[t] * KG + g) * 256);
+                    }
+                };
+                auto mm = [&](f32x4(&a)[U][MT], f32x4(&bb)[U], int g0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (g0 + u < KG) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int t = 0; t < MT; ++t)
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t][i], bb[u][i], acc[t], 0, 0, 0);
+                        }
+                };
+                f32x4 a0[U][MT], a1[U][MT], b0[U], b1[U];
+                ldA(a0, b0, 0);
+                for (int g0 = 0; g0 < KG; g0 += 2 * U) {
+                    ldA(a1, b1, g0 + U);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE (hipcc otherwise sinks loads to their use)
+                    mm(a0, b0, g0);
+                    ldA(a0, b0, g0 + 2 * U);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(a1, b1, g0 + U);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool in = 32 * otc[t] + 8 * q + 4 * hi + 3 < so;
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + min(32 * otc[t] + 8 * q + 4 * hi, so - 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][4 * q + i] += in ? bq[i] : 0.f;
+                }
+            if constexpr (FIRST) {
+                // shares of the pre-projected (gathered) scalar sources: rows of [n_src, so] tables in the accumulator layout.
+                // Requested only now (one exposed round trip per tile, first block only) -- held across the reduction they
+                // would cost 16 registers per table.
+                const int grow = min(r0 + e, rows - 1);
+                for (int k = 0; k < p.s_add.n; ++k) {
+                    const int32_t* ix = p.s_add.idx[k];
+                    const float* base = p.s_add.ptr[k] + (int64_t)(ix ? ix[grow] : grow) * so;
+                    f32x4 ad[MT][4];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ad[t][q] = *reinterpret_cast<const f32x4*>(base + min(32 * otc[t] + 8 * q + 4 * hi, so - 4));
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool in = 32 * otc[t] + 8 * q + 4 * hi + 3 < so;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[t][4 * q + i] += in ? ad[t][q][i] : 0.f;
+                        }
+                }
+            }
+
+            // gate partial over this wave's columns: B fragments = act_v(s_pre) straight from the accumulators
+            if (scalar_gate) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (tv[t]) {
+                        f32x4 ag[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ag[q] = *reinterpret_cast<const f32x4*>(B.pk + B.offG1 + ((int64_t)(4 * otc[t] + q) * 64 + lane) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    ag[q][i], gcp_actf<PWL>(B.act_v, ns_v, slope, acc[t][4 * q + i]), gacc, 0, 0, 0);
+                    }
+            }
+
+            // full-row-piece stores through the wave-private staging tile (32 x 20: half a tile at a time)
+            auto store_acc = [&](float* dst, const f32x16& a, int otile) {
+                const int sub = lane >> 2, c4 = 4 * (lane & 3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    gcp_wave_lds_sync();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 v = {a[8 * h + 4 * q], a[8 * h + 4 * q + 1], a[8 * h + 4 * q + 2], a[8 * h + 4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(ST + e * 20 + 8 * q + 4 * hi) = v;
+                    }
+                    gcp_wave_lds_sync();
+                    f32x4 wv[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) wv[j] = *reinterpret_cast<const f32x4*>(ST + (16 * j + sub) * 20 + c4);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int r = 16 * j + sub, c = 32 * otile + 16 * h + c4;
+                        if (r < nvalid && c < so) *reinterpret_cast<f32x4*>(dst + (int64_t)(r0 + r) * so + c) = wv[j];
+                    }
+                }
+            };
+            if (B.s_pre) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (tv[t]) store_acc(B.s_pre, acc[t], otc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 old = {0.f, 0.f, 0.f, 0.f};  // ResGCP: the block's input slice is still in X (until B2)
+                    if (B.residual) old = *reinterpret_cast<const f32x4*>(X + e * KS + min(32 * otc[t] + 8 * q + 4 * hi, so - 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ynew[t][4 * q + i] = old[i] + gcp_actf<PWL>(B.act_s, ns_s, slope, acc[t][4 * q + i]);
+                }
+            if (B.s_out) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (tv[t]) store_acc(B.s_out, ynew[t], otc[t]);
+            }
+        }
+        if (scalar_gate) {
+            // partial gate pre-activations -> GP[w & 3][32][vo]; with eight waves the upper four add theirs in a second step
+            // (half the LDS: the partials of a (256+, 32+) block would not fit otherwise)
+            auto gp_quad = [&](int q) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // (static register index)
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) sacc = qq == q ? gacc[4 * qq + i] : sacc;
+                    v[i] = sacc;
+                }
+                return v;
+            };
+            if (w < 4)
+                for (int q = 0; 8 * q < vo; ++q) *reinterpret_cast<f32x4*>(GP + (w * 32 + e) * GS + 8 * q + 4 * hi) = gp_quad(q);
+            if constexpr (NW == 8) {
+                wg_barrier();
+                if (w >= 4)
+                    for (int q = 0; 8 * q < vo; ++q) {
+                        float* gp = GP + ((w - 4) * 32 + e) * GS + 8 * q + 4 * hi;
+                        const f32x4 v = gp_quad(q);
+                        f32x4 o = *reinterpret_cast<const f32x4*>(gp);
+                        o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+                        *reinterpret_cast<f32x4*>(gp) = o;
+                    }
+            }
+        }
+        if (b + 1 < p.n) ws_commit(b + 1);
+        wg_barrier();  // B2: every wave is done reading X; the gate partials are complete
+
+        if (b + 1 < p.n && w < NT) {  // new scalar state -> X (B operand of the next block)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int ot = w + NW * t;
+                if (ot < NT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 32 * ot + 8 * q + 4 * hi;
+                        if (c + 3 < so) {
+                            f32x4 v = {ynew[t][4 * q], ynew[t][4 * q + 1], ynew[t][4 * q + 2], ynew[t][4 * q + 3]};
+                            *reinterpret_cast<f32x4*>(X + e * KS + c) = v;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue -----------------------------------------------------------------------------------------------------
+        if (vo > 0) {
+            for (int o = psub; o < vo; o += TPR) {
+                float g = 1.f;
+                if (scalar_gate) {
+                    float s = bg[o];
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) s += GP[(ww * 32 + prow) * GS + o];
+                    g = gcp_sigmoid(s);
+                }
+                float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                for (int h = 0; h < H; ++h) {
+                    const float wv = wu[o * WSU + h];
+                    u0 = fmaf(wv, VH[prow * HS + 3 * h + 0], u0);
+                    u1 = fmaf(wv, VH[prow * HS + 3 * h + 1], u1);
+                    u2 = fmaf(wv, VH[prow * HS + 3 * h + 2], u2);
+                }
+                float* vp = V + prow * VS + 3 * o;
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+                if (p.vres || B.residual) { x0 = vp[0]; x1 = vp[1]; x2 = vp[2]; }
+                if (p.vres) { u0 += x0; u1 += x1; u2 += x2; }
+                if (p.vmode == GCP_VMODE_SELF_GATE)
+                    g = gcp_actf<PWL>(B.act_v, ns_v, slope, sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f) + 1e-8f);
+                u0 *= g; u1 *= g; u2 *= g;
+                if (B.residual) { u0 += x0; u1 += x1; u2 += x2; }
+                vp[0] = u0; vp[1] = u1; vp[2] = u2;
+                if (scalar_gate && B.gate && prow < nvalid) B.gate[(int64_t)(r0 + prow) * vo + o] = g;
+            }
+        }
+        wg_barrier();  // B3: the vector tile is updated
+        if (vo > 0 && B.v_out) {
+            const int vw = 3 * vo, nv = nvalid * vw;
+            float* dst = B.v_out + (int64_t)r0 * vw;
+            for (int i = tid; i < nv; i += NTH) {
+                const int r = i / vw, c = i - r * vw;
+                dst[i] = V[r * VS + c];
+            }
+        }
+    };
+
+    run_block(std::true_type{}, 0);
+    for (int b = 1; b < p.n; ++b) run_block(std::false_type{}, b);
+}
+
+__global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, const float* __restrict__ W, const float* __restrict__ Wg,
+                                                      float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= S.total) return;
+    const int i = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const int m = lane & 31, hi = lane >> 5;
+    const int G4 = 4 * S.NT;
+    float v = 0.f;
+    if (idx < S.offG1) {
+        const int64_t blk = idx >> 8;
+        const int ot = (int)(blk / S.KG), g = (int)(blk - (int64_t)ot * S.KG);
+        const int r = 32 * ot + m, c = 8 * g + 4 * hi + i;
+        if (r < S.so && c < S.K) v = W[(int64_t)r * S.K + c];
+    } else if (idx < S.offA2) {
+        const int g = (int)((idx - S.offG1) >> 8);
+        const int c = 8 * g + 4 * hi + i;
+        if (m < S.vo && c < S.so) v = Wg[(int64_t)m * S.so + c];
+    } else if (idx < S.offG2) {
+        const int64_t blk = (idx - S.offA2) >> 8;
+        const int kt = (int)(blk / G4), g = (int)(blk - (int64_t)kt * G4);
+        const int r = 8 * g + 4 * hi + i, c = 32 * kt + m;
+        if (r < S.so && c < S.K) v = W[(int64_t)r * S.K + c];
+    } else {
+        const int64_t blk = (idx - S.offG2) >> 8;
+        const int ot = (int)(blk / S.VG), g = (int)(blk - (int64_t)ot * S.VG);
+        const int r = 8 * g + 4 * hi + i, c = 32 * ot + m;
+        if (r < S.vo && c < S.so) v = Wg[(int64_t)r * S.so + c];
+    }
+    out[idx] = v;
+}
+
+template <int NW, int MT>
+int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st) {
+    auto go = [&](auto kern) -> int {
+        if (lds_bytes > 64 * 1024) {
+            hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (err != hipSuccess) return (int)err;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)gcp_cdiv(p.rows, 32)), dim3(64 * NW), lds_bytes, st, p);
+        GCP_HIP_CHECK_LAUNCH();
+        return 0;
+    };
+    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true>) : go(gcp_wg_fwd_kernel<NW, MT, false>);
+}
+
+}  // namespace
+
+extern "C" int64_t gcpnet_wg_pack_floats(int si, int vi, int so, int vo, int hidden, int use_frames, int gated) {
+    return wg_shape(si, vi, so, vo, hidden, use_frames, gated).total;
+}
+
+extern "C" int gcpnet_wg_pack(const gcp2_weights_t* w, int gated, float* out, void* stream) {
+    if (!w || !out || !w->w_scalar) return GCPNET_E_BADARG;
+    const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
+    if (S.gated && !w->w_gate) return GCPNET_E_BADARG;
+    hipLaunchKernelGGL(wg_pack_kernel, dim3((unsigned)gcp_cdiv((int)S.total, 256)), dim3(256), 0, (hipStream_t)stream, S, w->w_scalar,
+                       w->w_gate, out);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Waves per workgroup / output tiles per wave for an output width (shared with the Python side through gcpnet_wg_config).
+static void wg_pick(int so, int& NW, int& MT) {
+    if (so <= 128) { NW = 4; MT = 1; }
+    else if (so <= 256) { NW = 8; MT = 1; }
+    else { NW = 8; MT = 2; }
+}
+
+extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in, const float* frames, const gcp_concat_t* s_add,
+                                 const gcp_concat_t* v_add, int n, const gcp_wg_block_t* blocks, void* stream) {
+    if (rows < 0 || n <= 0 || n > GCP_WG_MAX_BLOCKS || !blocks || !s_in) return GCPNET_E_BADARG;
+    const gcp2_weights_t& w0 = blocks[0].w;
+    const int so = w0.so, vo = w0.vo;
+    if (w0.vi <= 0 || !v_in) return GCPNET_E_UNSUPPORTED;
+    if ((so & 3) || so < 4) return GCPNET_E_UNSUPPORTED;
+    WgFwdParams p;
+    p.rows = rows; p.s_in = s_in; p.v_in = v_in; p.frames = frames;
+    p.s_add.n = 0; p.v_add.n = 0;
+    if (s_add) p.s_add = *s_add;
+    if (v_add) p.v_add = *v_add;
+    if (p.s_add.n < 0 || p.s_add.n > GCP_MAX_SEG || p.v_add.n < 0 || p.v_add.n > GCP_MAX_SEG) return GCPNET_E_BADARG;
+    const gcp2_opts_t& o0 = blocks[0].o;
+    p.so = so; p.vo = vo; p.nf = (w0.use_frames ? 9 : 0); p.e3 = o0.e3; p.vmode = vo > 0 ? o0.vmode : GCP_VMODE_NONE;
+    p.vres = o0.vector_residual; p.slope = o0.slope;
+    if (p.nf && !frames) return GCPNET_E_BADARG;
+    int NW, MT;
+    wg_pick(so, NW, MT);
+    p.NT = gcp_cdiv(so, 32);
+    p.NG = gcp_cdiv(p.NT, NW * MT);
+    p.n = n;
+    const bool gated = p.vmode == GCP_VMODE_SCALAR_GATE;
+    bool pwl = true;
+    int kmax = 0, vmax = vo, hmax = 1, wsmax = 0;
+    auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+    for (int b = 0; b < n; ++b) {
+        const gcp_wg_block_t& c = blocks[b];
+        const gcp2_weights_t& w = c.w;
+        if (!w.pack || !w.b_scalar || !w.w_down || (w.vo > 0 && !w.w_up)) return GCPNET_E_BADARG;
+        if (w.so != so || w.vo != vo || w.vi <= 0 || (w.use_frames ? 9 : 0) != p.nf) return GCPNET_E_UNSUPPORTED;
+        if (p.nf && !w.w_frames) return GCPNET_E_BADARG;
+        if (c.o.vmode != o0.vmode || c.o.e3 != o0.e3 || c.o.vector_residual != o0.vector_residual || c.o.slope != o0.slope)
+            return GCPNET_E_UNSUPPORTED;
+        if (b > 0 && (w.si != so || w.vi != vo)) return GCPNET_E_UNSUPPORTED;  // later blocks run on the state
+        if (c.residual && (w.si != so || w.vi != vo)) return GCPNET_E_BADARG;
+        if (o0.vector_residual && w.vi != vo) return GCPNET_E_BADARG;
+        if (gated && !w.b_gate) return GCPNET_E_BADARG;
+        if (misaligned(c.s_out) || misaligned(c.s_pre) || misaligned(w.pack) || misaligned(w.b_scalar)) return GCPNET_E_UNSUPPORTED;
+        const WgShape S = wg_shape(w.si, w.vi, so, vo, w.hidden, w.use_frames, gated);
+        WgBlk& k = p.blk[b];
+        k.pk = w.pack; k.b_scalar = w.b_scalar; k.b_gate = w.b_gate; k.w_down = w.w_down; k.w_frames = w.w_frames; k.w_up = w.w_up;
+        k.s_out = c.s_out; k.v_out = c.v_out; k.s_pre = c.s_pre; k.gate = c.gate;
+        k.offG1 = S.offG1;
+        k.act_s = c.o.act_s; k.act_v = c.o.act_v;
+        k.si = w.si; k.vi = w.vi; k.H = S.H; k.K = S.K; k.KG = S.KG;
+        k.residual = c.residual;
+        pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
+        kmax = max(kmax, S.KP);
+        vmax = max(vmax, w.vi);
+        hmax = max(hmax, S.H);
+        const int HF = S.H + (p.nf ? 3 : 0);
+        wsmax = max(wsmax, gcp_round_up(HF * (w.vi | 1) + vo * (S.H | 1) + vo, 4) + gcp_round_up(so, 4));
+    }
+    if ((n > 1 || blocks[0].residual) && p.NG != 1) return GCPNET_E_UNSUPPORTED;
+    if (n > 1) kmax = max(kmax, gcp_round_up(so, 4));
+    for (int k = 0; k < p.s_add.n; ++k)
+        if (!p.s_add.ptr[k] || p.s_add.dim[k] != so || misaligned(p.s_add.ptr[k])) return GCPNET_E_BADARG;
+    {
+        const WgShape S0 = wg_shape(w0.si, w0.vi, so, vo, w0.hidden, w0.use_frames, gated);
+        const int hfp = gcp_round_up(S0.H + (p.nf ? 3 : 0), 4);
+        for (int k = 0; k < p.v_add.n; ++k)
+            if (!p.v_add.ptr[k] || p.v_add.dim[k] != hfp) return GCPNET_E_BADARG;
+    }
+    if (rows == 0) return 0;
+    p.KS = wg_stride(kmax);
+    p.VS = gcp_odd(3 * vmax);
+    p.HS = gcp_odd(3 * hmax);
+    p.GS = wg_stride(gcp_round_up(max(vo, 1), 8));
+    p.ws_floats = gcp_round_up(wsmax, 4);
+    int off = 0;
+    p.o_x = off; off += 32 * p.KS;
+    p.o_st = off; off += NW * 32 * 20;
+    p.o_gp = off; off += gated ? 4 * 32 * p.GS : 0;
+    p.o_ws = off; off += (n > 1 ? 2 : 1) * p.ws_floats;
+    p.o_v = off; off += gcp_round_up(32 * p.VS, 4);
+    p.o_vh = off; off += gcp_round_up(32 * p.HS, 4);
+    p.o_fr = off; off += 32 * 9;
+    const size_t lds_bytes = (size_t)off * sizeof(float);
+    if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (NW == 4) return launch_fwd<4, 1>(p, pwl, lds_bytes, st);
+    if (MT == 1) return launch_fwd<8, 1>(p, pwl, lds_bytes, st);
+    return launch_fwd<8, 2>(p, pwl, lds_bytes, st);
+}

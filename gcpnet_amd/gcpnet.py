@@ -348,7 +348,7 @@ class GCPMessagePassing(nn.Module):
         if not self.use_residual_message_gcp or len(mods) > 8 or any(getattr(m, "feedforward_out", False) for m in mods):
             return False
         a = mods[0]
-        if a.scalar_output_dim > 128 or not a.vector_input_dim or not a.vector_output_dim or a.vector_output_dim > 64:
+        if a.scalar_output_dim > (512 if ops.USE_WG_KERNELS else 128) or not a.vector_input_dim or not a.vector_output_dim or a.vector_output_dim > 64:
             return False
         key = lambda m: (m.scalar_input_dim, m.vector_input_dim, m.scalar_output_dim, m.vector_output_dim, m.hidden_dim,
                          m.ablate_frame_updates, m._vmode(), bool(m.vector_residual), bool(m.enable_e3_equivariance),

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, BwdScratch, ChainBwdItem, ChainItem, Head, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
-                   VMODE_SELF_GATE, check)
+                   VMODE_SELF_GATE, WgBlock, check)
 
 Tensor = torch.Tensor
 
@@ -336,6 +336,42 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
     return pack
 
 
+USE_WG_KERNELS = True  # module switch: multi-wave workgroup kernels (gcp_wg_*.hip) where the shape fits, else the wave-per-tile ones
+WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
+
+
+def _gated(spec: Gcp2Spec) -> bool:
+    return spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
+
+
+def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
+    """Packed image of scalar_out / vector_out_scale for the workgroup kernels (gcpnet_wg_pack), cached per weight version."""
+    lib = _lib.load()
+    w_scalar, w_gate = w[0], w[5]
+    key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
+    cache = spec.pack_cache
+    if cache is not None and cache.get("wg_key") == key:
+        return cache["wg_pack"]
+    gated = int(_gated(spec))
+    n = lib.gcpnet_wg_pack_floats(spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames), gated)
+    pack = torch.empty(int(n), dtype=torch.float32, device=w_scalar.device)
+    ws = _weights_struct(spec, w, pack)
+    check(lib.gcpnet_wg_pack(C.byref(ws), gated, _p(pack), _stream()), "wg_pack")
+    if cache is not None:
+        cache["wg_key"], cache["wg_pack"] = key, pack
+    return pack
+
+
+def _wg_block(spec: Gcp2Spec, w, s_out, v_out, s_pre, gate, residual: bool) -> WgBlock:
+    blk = WgBlock()
+    blk.w = _weights_struct(spec, w, _pack_wg(spec, w))
+    blk.o = _opts_struct(spec)
+    blk.s_out, blk.v_out = _p(s_out), _p(v_out)
+    blk.s_pre, blk.gate = _p(s_pre), _p(gate)
+    blk.residual = int(residual)
+    return blk
+
+
 class _Gcp2(torch.autograd.Function):
     """inputs: spec, frames, then n_s scalar sources, n_v vector sources, res_s, res_v, 7 weights, the scalar addend tables
     (len(spec.add_plans)) and the vector addend tables (len(spec.vadd_plans))."""
@@ -441,6 +477,16 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
     s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
     gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
     gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
+    plain = len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
+    if USE_WG_KERNELS and plain and (spec.residual or (res_s is None and res_v is None)) and spec.vi > 0:
+        # one workgroup per 32-row tile, output columns split over its waves (gcp_wg_fwd.hip)
+        blk = _wg_block(spec, w, s_out, v_out, s_pre, gate, spec.residual)
+        rc = lib.gcpnet_wg_forward(rows, _p(s_src[0]), _p(v_src[0]), _p(frames), C.byref(ac) if ac is not None else None,
+                                   C.byref(vac) if vac is not None else None, 1, C.byref(blk), _stream())
+        if rc != _lib.E_UNSUPPORTED:
+            check(rc, "wg_forward")
+            WG_STATS["fwd"] += 1
+            return rows, s_out, v_out, pack, s_pre, gate
     if ((adds or vadds) and len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
             and not spec.residual and res_s is None and res_v is None and spec.vo > 0 and USE_HEAD_KERNEL):
         # the first message GCP after project-then-gather: plain (e, xi) inputs + gathered addend tables -> the register-
@@ -700,7 +746,15 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
             items[k].gate = gate.data_ptr() if gate is not None else None
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
-        check(lib.gcpnet_gcp2_chain_forward(rows, _p(s0), _p(v0), _p(frames), n, items, _stream()), "gcp2_chain_forward")
+        rc = _lib.E_UNSUPPORTED
+        if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS:
+            blks = (WgBlock * n)(*[_wg_block(spec, w, *outs[k], True) for k, (spec, w) in enumerate(zip(specs, ws))])
+            rc = lib.gcpnet_wg_forward(rows, _p(s0), _p(v0), _p(frames), None, None, n, blks, _stream())
+            if rc != _lib.E_UNSUPPORTED:
+                check(rc, "wg_forward")
+                WG_STATS["fwd_chain"] += 1
+        if rc == _lib.E_UNSUPPORTED:
+            check(lib.gcpnet_gcp2_chain_forward(rows, _p(s0), _p(v0), _p(frames), n, items, _stream()), "gcp2_chain_forward")
         if need_grad:
             ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
             ctx.state = (s0, v0, ws, packs, outs)

@@ -137,6 +137,35 @@ typedef struct {
 int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, const float* frames, int n,
                                   const gcp2_chain_item_t* items, void* stream);
 
+/* ---- multi-wave workgroup kernels (gcp_wg_*.hip): one WORKGROUP of 4 or 8 wavefronts per 32-row tile, output columns
+ * split across the waves, the tile's merged input [s | norms | frame scalars] once in LDS.  They cover any output width (so a
+ * multiple of 4) with a plain (un-gathered) input: the first message GCP after project-then-gather, the residual message
+ * chain (ResGCP, components/gcpnet.py:921-924) and the node-row GCPs (embeddings, feed-forward, position update;
+ * components/gcpnet.py:394-468 on N rows), at every shipped hidden size including (256, 32).
+ * Weights go through their own packed image (gcpnet_wg_pack into gcp2_weights_t.pack; `gated` = the block has a
+ * vector_out_scale Linear). */
+int64_t gcpnet_wg_pack_floats(int si, int vi, int so, int vo, int hidden, int use_frames, int gated);
+int gcpnet_wg_pack(const gcp2_weights_t* w, int gated, float* pack_out, void* stream);
+
+typedef struct {
+    gcp2_weights_t w;   /* dims of THIS block, reference-layout weights, w.pack = image of gcpnet_wg_pack */
+    gcp2_opts_t o;
+    float* s_out;       /* [rows, so]     block output (the chain state after this block); may be NULL when nobody reads it */
+    float* v_out;       /* [rows, vo, 3]  */
+    float* s_pre;       /* [rows, so]     saved for the backward (NULL in inference) */
+    float* gate;        /* [rows, vo]     sigmoid of the vector gate, saved for the backward */
+    int residual;       /* out = in + GCP(in) (needs si == so, vi == vo) */
+} gcp_wg_block_t;
+
+/* Forward of n blocks on `rows` rows in one launch: block 0 reads s_in [rows, w.si] / v_in [rows, w.vi, 3] (plus the
+ * pre-projected gathered tables s_add / v_add as in gcpnet_gcp2_forward, may be NULL); blocks 1.. run on the previous block's
+ * output, which stays on chip (their si == so, vi == vo).  All blocks share so, vo, frames, gating mode and options.
+ * Returns GCPNET_E_UNSUPPORTED for shapes outside the kernel (vi == 0, so not a multiple of 4, tiles above 160 KB of LDS,
+ * chains wider than 512 scalars); the caller then uses gcpnet_gcp2_forward. */
+#define GCP_WG_MAX_BLOCKS 9
+int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in, const float* frames, const gcp_concat_t* s_add,
+                      const gcp_concat_t* v_add, int n, const gcp_wg_block_t* blocks, void* stream);
+
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
  * concatenated layout, plus what the weight gradients need:
