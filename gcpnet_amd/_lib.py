@@ -22,7 +22,8 @@ EXPORTS = [
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing",
-    "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_forward",
+    "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
+    "gcpnet_wg_reduce",
 ]
 
 
@@ -59,6 +60,18 @@ class WgBlock(C.Structure):
 
 
 WG_MAX_BLOCKS = 9
+
+
+class WgBwdPlan(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nw", "kt", "fused", "split", "grid", "kw", "n_small", "ext_w", "dgate_w")]
+
+
+class WgBwdArgs(C.Structure):
+    _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("residual", C.c_int), ("s_in", C.c_void_p), ("v_in", C.c_void_p),
+                ("frames", C.c_void_p), ("v_add", C.POINTER(Concat)), ("s_pre", C.c_void_p), ("gate", C.c_void_p),
+                ("d_s_out", C.c_void_p), ("d_v_out", C.c_void_p), ("d_s_in", C.c_void_p), ("d_v_in", C.c_void_p),
+                ("ds_pre", C.c_void_p), ("dvhf", C.c_void_p), ("ext", C.c_void_p), ("dgate", C.c_void_p),
+                ("dw_part", C.c_void_p), ("dwg_part", C.c_void_p), ("wsm_part", C.c_void_p)]
 
 
 class BwdScratch(C.Structure):
@@ -146,6 +159,9 @@ def load():
     lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
     lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]
     lib.gcpnet_wg_forward.argtypes = [i32, vp, vp, vp, P(Concat), P(Concat), i32, P(WgBlock), vp]
+    lib.gcpnet_wg_backward_plan.argtypes = [i32, P(Gcp2Weights), P(Gcp2Opts), i32, P(WgBwdPlan)]
+    lib.gcpnet_wg_backward.argtypes = [i32, P(WgBwdArgs), vp]
+    lib.gcpnet_wg_reduce.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",

@@ -64,3 +64,88 @@ __host__ __device__ inline int wg_stride(int width) {
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+__device__ __forceinline__ bool wg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// tile[r * stride + c] = src[r * width + c] for r < 32, c < width (rows of a 32-row tile are contiguous in memory: a flat,
+// coalesced copy); rows >= nvalid read as zero.  Loads are unconditional (clamped) and batched four deep per thread.
+// `vec`: width % 4 == 0, stride % 4 == 0 and src 16-byte aligned -> 16-byte accesses.
+template <int NTH>
+__device__ __forceinline__ void wg_tile_load(float* tile, int stride, const float* __restrict__ src, int width, int nvalid, int tid,
+                                             bool vec) {
+    if (vec) {
+        const int q = width >> 2, n4 = nvalid * q, tot = 32 * q;
+        for (int i0 = 0; i0 < tot; i0 += 4 * NTH) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + 4 * (int64_t)min(i0 + tid + k * NTH, n4 - 1));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + tid + k * NTH;
+                if (i < tot) {
+                    const int r = i / q, c4 = i - r * q;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(tile + r * stride + 4 * c4) = i < n4 ? v[k] : z;
+                }
+            }
+        }
+    } else {
+        const int n1 = nvalid * width, tot = 32 * width;
+        for (int i0 = 0; i0 < tot; i0 += 4 * NTH) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + tid + k * NTH, n1 - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + tid + k * NTH;
+                if (i < tot) {
+                    const int r = i / width, c = i - r * width;
+                    tile[r * stride + c] = i < n1 ? v[k] : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// dst[r * width + c] = tile[r * stride + c] for r < nvalid (flat, coalesced).
+template <int NTH>
+__device__ __forceinline__ void wg_tile_store(float* __restrict__ dst, const float* tile, int stride, int width, int nvalid, int tid,
+                                              bool vec) {
+    if (vec) {
+        const int q = width >> 2, n4 = nvalid * q;
+        for (int i = tid; i < n4; i += NTH) {
+            const int r = i / q, c4 = i - r * q;
+            *reinterpret_cast<f32x4*>(dst + 4 * (int64_t)i) = *reinterpret_cast<const f32x4*>(tile + r * stride + 4 * c4);
+        }
+    } else {
+        const int n1 = nvalid * width;
+        for (int i = tid; i < n1; i += NTH) {
+            const int r = i / width, c = i - r * width;
+            dst[i] = tile[r * stride + c];
+        }
+    }
+}
+
+// One 32 x 32 accumulator tile (C/D layout) -> dst[(r0 + row) * ld + c0 + col] as full 128-byte row pieces, through a
+// wave-private 32 x 36 LDS staging tile (why: tile_io.h, gcp_store_acc_rows).  ld % 4 == 0, c0 % 32 == 0, dst 16-byte aligned.
+#define WG_STAGE_FLOATS (32 * 36)
+__device__ __forceinline__ void wg_store_acc(float* __restrict__ dst, int ld, int c0, int width, int r0, int nvalid, const f32x16& a,
+                                             float* st, int lane) {
+    const int e = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 3, c4 = 4 * (lane & 7);
+    gcp_wave_lds_sync();  // (the staging tile's previous reads are done)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(st + e * 36 + 8 * q + 4 * hi) = v;
+    }
+    gcp_wave_lds_sync();
+    f32x4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = *reinterpret_cast<const f32x4*>(st + (8 * j + sub) * 36 + c4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + sub, c = c0 + c4;
+        if (r < nvalid && c < width) *reinterpret_cast<f32x4*>(dst + (int64_t)(r0 + r) * ld + c) = wv[j];
+    }
+}

@@ -1,0 +1,842 @@
+// GCP2 backward for a 32-row tile per WORKGROUP (NW wavefronts), the adjoint of gcp_wg_fwd.hip's block: given d(s_out),
+// d(v_out) and the saved s_pre / gate it writes d(s_in), d(v_in) and the weight gradients (autograd through GCP2.forward,
+// reference src/models/components/gcpnet.py:394-468; with `residual` the block was x + GCP(x), gcpnet.py:921-924).
+//
+// Persistent workgroups loop over the tiles.  Phases per tile (barriers between them):
+//   load   v_in, d(v_out), gate, frames (and s_in when the weight gradient is fused) -> LDS; s_pre / d(s_out) slices requested
+//   P1     (VALU, thread = (row, hidden channel)) recompute [vh | vf], norms, frame scalars
+//   P2     (VALU, thread = (row, output channel)) adjoint of the vector epilogue: d(vector_up out), d(gate pre-activation)
+//   P3     (MFMA, wave = its 32-column tiles of so) gate adjoint Wg^T dgate, ds_pre -> LDS tile DS
+//   P4     (MFMA, wave = 32-column tiles of the merged axis K) d[s | norms | frame scalars] = W^T ds_pre; a lone last tile is
+//          reduced split-K across the waves
+//   P5/P6  (MFMA, fused mode) dW[so, K + 1] += ds_pre^T [s | norms | frame scalars | 1], dWg[vo, so] += dgate^T act_v(s_pre):
+//          the reduction runs over the tile's rows; the accumulators stay in registers across ALL tiles of the workgroup and
+//          leave once, as per-workgroup partial sums (summed in a fixed order by wg_reduce_kernel: deterministic, no atomics)
+//   P7/P8  (VALU) adjoint of the vector prologue: d vh, d vf, d(v_in)
+//   P9     (VALU) per-thread partial sums of the small vector weight gradients
+// Without the fusion (node rows: few tiles, wide blocks) ds_pre / norms / dgate go to HBM for gcpnet_tn_gemm instead.
+#include "gcp_wg.h"
+
+namespace {
+
+struct WgBwdParams {
+    int rows, ntiles;
+    const float* s_in;
+    const float* v_in;
+    const float* frames;
+    const float* s_pre;
+    const float* gate;
+    const float* d_s_out;
+    const float* d_v_out;
+    gcp_concat_t v_add;
+    float* d_s_in;
+    float* d_v_in;
+    const float* pk;
+    int64_t offA2, offG2;
+    const float* w_down;
+    const float* w_frames;
+    const float* w_up;
+    float* ds_pre;
+    float* dvhf;
+    float* ext;
+    float* dgate;
+    float* dw_part;
+    float* dwg_part;
+    float* wsm_part;
+    int si, vi, so, vo, H, nf, K, NT, NKT, SG, VG, HF;
+    int act_s, act_v, vmode, vres, e3, residual;
+    float slope;
+    int split, LW;
+    int KW, NNT;
+    int EP, VOP, HFP;
+    int KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, WSV, WSU, WTV, WTU;
+    int o_x, o_ds, o_v, o_dvo, o_dvu, o_vh, o_dvhf, o_fr, o_dg, o_rn, o_sgn, o_dext, o_epart, o_ws;
+    int n_up, n_sm;  // small weight gradients: vector_up entries, all entries
+};
+
+constexpr int NSW = 4;  // small-weight-gradient accumulators per thread
+
+// NW waves; KT = full K tiles per wave in P4; FN = 32-wide tiles of the fused weight gradient's K + 1 columns (0 = not fused)
+template <int NW, int KT, int FN, bool PWL>
+__global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NTH = 64 * NW, TPR = NTH / 32;
+    constexpr bool FUSED = FN > 0;
+    constexpr int FNR = FUSED ? FN : 1;
+    int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63, e = lane & 31, hi = lane >> 5;
+    int prow = tid / TPR, psub = tid - prow * TPR;
+    // Per-lane addresses are loop-invariant in the persistent tile loop: hipcc hoists them all out of it and spills them.
+    // Laundering the lane indices at every phase boundary makes each phase recompute the few it needs.
+#define WG_LAUNDER() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub))
+    const int rows = p.rows;
+    float* X = lds + p.o_x;
+    float* DS = lds + p.o_ds;
+    float* V = lds + p.o_v;
+    float* DVO = lds + p.o_dvo;
+    float* DVU = lds + p.o_dvu;
+    float* VH = lds + p.o_vh;
+    float* DVHF = lds + p.o_dvhf;
+    float* FR = lds + p.o_fr;
+    float* DG = lds + p.o_dg;
+    float* RN = lds + p.o_rn;
+    float* SGN = lds + p.o_sgn;
+    float* DEXT = lds + p.o_dext;
+    float* EPART = lds + p.o_epart;
+    float* ST = EPART + w * 32 * p.EPS;  // wave-private staging (half tiles, 32 x 20) shares the wave's split-K partial slot
+    const float* WD = lds + p.o_ws;                 // [HF][WSV]   [vector_down ; vector_down_frames]
+    const float* WDT = WD + p.HF * p.WSV;           // [vi][WTV]   transposed
+    const float* WU = WDT + p.vi * p.WTV;           // [vo][WSU]   vector_up
+    const float* WUT = WU + p.vo * p.WSU;           // [H][WTU]    transposed
+    const int KS = p.KS, DSS = p.DSS, VS = p.VS, US = p.US, HS = p.HS, FS = p.FS, DGS = p.DGS, EXS = p.EXS, EPS = p.EPS;
+    const int si = p.si, vi = p.vi, so = p.so, vo = p.vo, H = p.H, nf = p.nf, K = p.K, HF = p.HF, NT = p.NT, SG = p.SG;
+    const bool gated = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;
+    const float slope = p.slope;
+    const float ns_s = gcp_neg_slope(p.act_s, slope), ns_v = gcp_neg_slope(p.act_v, slope);
+    float* extp = FUSED ? X + si : DEXT;  // where P1 leaves [norms | frame scalars]: X's extras columns, or (not fused) a tile
+    const int exs = FUSED ? KS : EXS;     //   of its own that goes to HBM (it doubles as the d(extras) tile later)
+
+    // ---- once per workgroup: small weights (both orientations) -> LDS, zero the never-written paddings ------------------
+    {
+        float* wd = lds + p.o_ws;
+        float* wdt = wd + HF * p.WSV;
+        float* wu = wdt + vi * p.WTV;
+        float* wut = wu + vo * p.WSU;
+        for (int i = tid; i < HF * vi; i += NTH) {
+            const int x = i / vi, c = i - x * vi;
+            const float v = x < H ? p.w_down[i] : p.w_frames[i - H * vi];
+            wd[x * p.WSV + c] = v;
+            wdt[c * p.WTV + x] = v;
+        }
+        for (int i = tid; i < vo * H; i += NTH) {
+            const int o = i / H, h = i - o * H;
+            const float v = p.w_up[i];
+            wu[o * p.WSU + h] = v;
+            wut[h * p.WTU + o] = v;
+        }
+        for (int i = tid; i < 32 * DGS; i += NTH) DG[i] = 0.f;
+        for (int i = tid; i < 32 * DSS; i += NTH) DS[i] = 0.f;
+    }
+    // persistent accumulators
+    f32x16 dW[FNR], dWg;
+#pragma unroll
+    for (int n = 0; n < FNR; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[n][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dWg[r] = 0.f;
+    float wsm[NSW] = {0.f, 0.f, 0.f, 0.f};
+    float dbg = 0.f;
+    wg_barrier();
+
+    const bool vec_v = (vi & 3) == 0, vec_o = (vo & 3) == 0, vec_h = (H & 3) == 0;
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        WG_LAUNDER();
+        const int r0 = tile * 32;
+        const int nvalid = min(32, rows - r0);
+        const bool row_ok = e < nvalid;
+        const int64_t rowc = min(r0 + e, rows - 1);
+        // ---- s_pre / d(s_out) slices of this wave's first tile: requested now, used in P3 -------------------------------
+        f32x4 spq[4], dyq[4];
+        {
+            const int ot = min(w, NT - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = min(32 * ot + 8 * q + 4 * hi, so - 4);
+                spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + rowc * so + c);
+                dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + c);
+            }
+        }
+        // ---- tile loads ---------------------------------------------------------------------------------------------------
+        wg_tile_load<NTH>(V, VS, p.v_in + (int64_t)r0 * 3 * vi, 3 * vi, nvalid, tid, ((3 * vi) & 3) == 0 && wg_aligned16(p.v_in));
+        if (vo > 0) {
+            wg_tile_load<NTH>(DVO, US, p.d_v_out + (int64_t)r0 * 3 * vo, 3 * vo, nvalid, tid,
+                              ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out));
+            if (gated) wg_tile_load<NTH>(DG, DGS, p.gate + (int64_t)r0 * vo, vo, nvalid, tid, vec_o && wg_aligned16(p.gate));
+        }
+        if (nf) {
+            const float* fsrc = p.frames + (int64_t)r0 * 9;
+            for (int i = tid; i < 32 * 9; i += NTH) FR[i] = fsrc[min(i, nvalid * 9 - 1)];
+        }
+        if constexpr (FUSED) {
+            wg_tile_load<NTH>(X, KS, p.s_in + (int64_t)r0 * si, si, nvalid, tid, (si & 3) == 0 && wg_aligned16(p.s_in));
+            const int npad = 8 * gcp_cdiv(p.KW, 8) - K;  // ones column (bias gradient) + zero padding
+            for (int i = tid; i < 32 * npad; i += NTH) {
+                const int r = i / npad, c = i - r * npad;
+                X[r * KS + K + c] = (c == 0 && r < nvalid) ? 1.f : 0.f;
+            }
+        }
+        wg_barrier();
+
+        WG_LAUNDER();
+        // ---- P1: recompute [vh | vf], norms, frame scalars ---------------------------------------------------------------
+        {
+            const float* vrow = V + prow * VS;
+            const int grow = min(r0 + prow, rows - 1);
+            for (int x = psub; x < HF; x += TPR) {
+                float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                for (int k = 0; k < p.v_add.n; ++k) {  // shares of the pre-projected (gathered) vector sources
+                    const int32_t* ix = p.v_add.idx[k];
+                    const float* t = p.v_add.ptr[k] + (int64_t)(ix ? ix[grow] : grow) * 3 * p.HFP;
+                    q0 += t[x]; q1 += t[p.HFP + x]; q2 += t[2 * p.HFP + x];
+                }
+                const float* wr = WD + x * p.WSV;
+                float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                if (vec_v) {
+                    for (int c = 0; c < vi; c += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(vrow + 3 * c);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(vrow + 3 * c + 4);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(vrow + 3 * c + 8);
+                        u0 = fmaf(wv[0], a[0], u0); u1 = fmaf(wv[0], a[1], u1); u2 = fmaf(wv[0], a[2], u2);
+                        u0 = fmaf(wv[1], a[3], u0); u1 = fmaf(wv[1], b[0], u1); u2 = fmaf(wv[1], b[1], u2);
+                        u0 = fmaf(wv[2], b[2], u0); u1 = fmaf(wv[2], b[3], u1); u2 = fmaf(wv[2], d[0], u2);
+                        u0 = fmaf(wv[3], d[1], u0); u1 = fmaf(wv[3], d[2], u1); u2 = fmaf(wv[3], d[3], u2);
+                    }
+                } else {
+                    for (int c = 0; c < vi; ++c) {
+                        const float wv = wr[c];
+                        u0 = fmaf(wv, vrow[3 * c + 0], u0); u1 = fmaf(wv, vrow[3 * c + 1], u1); u2 = fmaf(wv, vrow[3 * c + 2], u2);
+                    }
+                }
+                u0 += q0; u1 += q1; u2 += q2;
+                if (x < H) {
+                    VH[prow * HS + 3 * x + 0] = u0; VH[prow * HS + 3 * x + 1] = u1; VH[prow * HS + 3 * x + 2] = u2;
+                    const float nr = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
+                    RN[prow * (H | 1) + x] = 1.0f / nr;
+                    extp[prow * exs + x] = nr + 1e-8f;
+                } else {
+                    const int k = x - H;
+                    const float* f = FR + prow * 9;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float pr = f[3 * a + 0] * u0 + f[3 * a + 1] * u1 + f[3 * a + 2] * u2;
+                        if (p.e3 && a == 1) {
+                            SGN[prow * 3 + k] = pr < 0.f ? -1.f : 1.f;
+                            pr = fabsf(pr);
+                        }
+                        extp[prow * exs + H + 3 * k + a] = pr;
+                    }
+                }
+            }
+            if constexpr (!FUSED) {
+                const int npad = p.EP - (H + nf);  // stride padding of the ext rows that go to HBM
+                for (int i = tid; i < 32 * npad; i += NTH) {
+                    const int r = i / npad, c = i - r * npad;
+                    DEXT[r * EXS + H + nf + c] = 0.f;
+                }
+            }
+        }
+        wg_barrier();
+        if constexpr (!FUSED) {
+            if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * p.EP, DEXT, EXS, p.EP, nvalid, tid, wg_aligned16(p.ext));
+        }
+
+        WG_LAUNDER();
+        // ---- P2: adjoint of the vector epilogue (gcpnet.py:364-391) --------------------------------------------------------
+        if (vo > 0) {
+            for (int o = psub; o < vo; o += TPR) {
+                const float* wu = WU + o * p.WSU;
+                const float* vh = VH + prow * HS;
+                float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+                if (vec_h) {
+                    for (int h = 0; h < H; h += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wu + h);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(vh + 3 * h);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(vh + 3 * h + 4);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(vh + 3 * h + 8);
+                        u0 = fmaf(wv[0], a[0], u0); u1 = fmaf(wv[0], a[1], u1); u2 = fmaf(wv[0], a[2], u2);
+                        u0 = fmaf(wv[1], a[3], u0); u1 = fmaf(wv[1], b[0], u1); u2 = fmaf(wv[1], b[1], u2);
+                        u0 = fmaf(wv[2], b[2], u0); u1 = fmaf(wv[2], b[3], u1); u2 = fmaf(wv[2], d[0], u2);
+                        u0 = fmaf(wv[3], d[1], u0); u1 = fmaf(wv[3], d[2], u1); u2 = fmaf(wv[3], d[3], u2);
+                    }
+                } else {
+                    for (int h = 0; h < H; ++h) {
+                        const float wv = wu[h];
+                        u0 = fmaf(wv, vh[3 * h + 0], u0); u1 = fmaf(wv, vh[3 * h + 1], u1); u2 = fmaf(wv, vh[3 * h + 2], u2);
+                    }
+                }
+                if (p.vres) { u0 += V[prow * VS + 3 * o + 0]; u1 += V[prow * VS + 3 * o + 1]; u2 += V[prow * VS + 3 * o + 2]; }
+                const float g0 = DVO[prow * US + 3 * o + 0], g1 = DVO[prow * US + 3 * o + 1], g2 = DVO[prow * US + 3 * o + 2];
+                float d0 = g0, d1 = g1, d2 = g2;
+                const float dot = g0 * u0 + g1 * u1 + g2 * u2;
+                if (gated) {
+                    const float sg = DG[prow * DGS + o];
+                    d0 = g0 * sg; d1 = g1 * sg; d2 = g2 * sg;
+                    DG[prow * DGS + o] = dot * sg * (1.f - sg);
+                } else if (p.vmode == GCP_VMODE_SELF_GATE) {
+                    const float rs = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
+                    const float n = rs + 1e-8f;
+                    const float a = gcp_actf<PWL>(p.act_v, ns_v, slope, n), da = gcp_dactf<PWL>(p.act_v, ns_v, slope, n);
+                    const float coef = dot * da / rs;
+                    d0 = g0 * a + coef * u0; d1 = g1 * a + coef * u1; d2 = g2 * a + coef * u2;
+                }
+                DVU[prow * US + 3 * o + 0] = d0; DVU[prow * US + 3 * o + 1] = d1; DVU[prow * US + 3 * o + 2] = d2;
+            }
+        }
+        wg_barrier();
+        if constexpr (!FUSED) {
+            if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * p.VOP, DG, DGS, p.VOP, nvalid, tid, wg_aligned16(p.dgate));
+        }
+
+        WG_LAUNDER();
+        // ---- P3: ds_pre = d(s_out) act_s'(s_pre) + act_v'(s_pre) (Wg^T dgate), this wave's tiles of so -> DS ---------------
+        f32x16 spa;  // act_v(s_pre) of the wave's tile (fused: B operand of the gate weight gradient)
+        for (int t = 0; w + NW * t < NT; ++t) {
+            const int ot = w + NW * t;
+            if (t > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = min(32 * ot + 8 * q + 4 * hi, so - 4);
+                    spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + rowc * so + c);
+                    dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + c);
+                }
+            }
+            f32x16 gacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+            if (gated) {
+                const float* pg = p.pk + p.offG2 + ((int64_t)ot * p.VG * 64 + lane) * 4;
+                for (int g = 0; g < p.VG; ++g) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(pg + (int64_t)g * 256);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(DG + e * DGS + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], gacc, 0, 0, 0);
+                }
+            }
+            f32x16 dsp;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = row_ok && 32 * ot + 8 * q + 4 * hi + 3 < so;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sp = spq[q][i];
+                    float d = dyq[q][i] * gcp_dactf<PWL>(p.act_s, ns_s, slope, sp);
+                    if (gated) d += gcp_dactf<PWL>(p.act_v, ns_v, slope, sp) * gacc[4 * q + i];
+                    dsp[4 * q + i] = in ? d : 0.f;
+                    spa[4 * q + i] = in ? gcp_actf<PWL>(p.act_v, ns_v, slope, sp) : 0.f;
+                }
+                const f32x4 v = {dsp[4 * q], dsp[4 * q + 1], dsp[4 * q + 2], dsp[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * ot + 8 * q + 4 * hi) = v;
+            }
+            if (p.ds_pre) {  // (head block: summed per source node afterwards; not fused: operand of gcpnet_tn_gemm)
+                const int sub = lane >> 2, c4 = 4 * (lane & 3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    gcp_wave_lds_sync();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 v = {dsp[8 * h + 4 * q], dsp[8 * h + 4 * q + 1], dsp[8 * h + 4 * q + 2], dsp[8 * h + 4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(ST + e * 20 + 8 * q + 4 * hi) = v;
+                    }
+                    gcp_wave_lds_sync();
+                    f32x4 wv[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) wv[j] = *reinterpret_cast<const f32x4*>(ST + (16 * j + sub) * 20 + c4);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int r = 16 * j + sub, c = 32 * ot + 16 * h + c4;
+                        if (r < nvalid && c < so) *reinterpret_cast<f32x4*>(p.ds_pre + (int64_t)(r0 + r) * so + c) = wv[j];
+                    }
+                }
+            }
+        }
+        wg_barrier();
+
+        WG_LAUNDER();
+        // ---- P4: d[s | norms | frame scalars]^T = W^T ds_pre^T ------------------------------------------------------------
+        {
+            const int NFT = p.split ? p.NKT - 1 : p.NKT;  // tiles handed out whole, round-robin
+            if (w < NFT) {
+                int ktc[KT];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) ktc[j] = min(w + NW * j, NFT - 1);
+                f32x4 res[KT][4];  // ResGCP pass-through d(out) (requested now, added after the reduction)
+                if (p.residual) {
+#pragma unroll
+                    for (int j = 0; j < KT; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            res[j][q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + min(32 * ktc[j] + 8 * q + 4 * hi, so - 4));
+                }
+                f32x16 acc2[KT];
+#pragma unroll
+                for (int j = 0; j < KT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+                constexpr int U = KT == 1 ? 4 : 1;
+                const float* pa = p.pk + p.offA2 + (int64_t)lane * 4;
+                const float* db = DS + e * DSS + 4 * hi;
+                auto ld = [&](f32x4(&a)[U][KT], f32x4(&bb)[U], int g0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int g = min(g0 + u, SG - 1);
+                        bb[u] = *reinterpret_cast<const f32x4*>(db + 8 * g);
+#pragma unroll
+                        for (int j = 0; j < KT; ++j) a[u][j] = *reinterpret_cast<const f32x4*>(pa + ((int64_t)ktc[j] * SG + g) * 256);
+                    }
+                };
+                auto mm = [&](f32x4(&a)[U][KT], f32x4(&bb)[U], int g0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (g0 + u < SG) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < KT; ++j)
+                                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j][i], bb[u][i], acc2[j], 0, 0, 0);
+                        }
+                };
+                f32x4 a0[U][KT], a1[U][KT], b0[U], b1[U];
+                ld(a0, b0, 0);
+                for (int g0 = 0; g0 < SG; g0 += 2 * U) {
+                    ld(a1, b1, g0 + U);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(a0, b0, g0);
+                    ld(a0, b0, g0 + 2 * U);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(a1, b1, g0 + U);
+                }
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    const int kt = w + NW * j;
+                    if (kt < NFT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = 32 * kt + 8 * q + 4 * hi;
+                            f32x4 v = {acc2[j][4 * q], acc2[j][4 * q + 1], acc2[j][4 * q + 2], acc2[j][4 * q + 3]};
+                            if (p.residual && c + 3 < so) { v[0] += res[j][q][0]; v[1] += res[j][q][1]; v[2] += res[j][q][2]; v[3] += res[j][q][3]; }
+                            if (c + 3 < si) {
+                                if (row_ok) *reinterpret_cast<f32x4*>(p.d_s_in + (int64_t)(r0 + e) * si + c) = v;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int cc = c + i;
+                                    if (cc < si) {
+                                        if (row_ok) p.d_s_in[(int64_t)(r0 + e) * si + cc] = v[i];
+                                    } else if (cc < K) {
+                                        DEXT[e * EXS + cc - si] = v[i];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            WG_LAUNDER();
+            if (p.split) {  // the last tile of K: every wave reduces over its share of so, partial sums -> EPART[w]
+                const int kt = p.NKT - 1;
+                const int gs = gcp_cdiv(SG, NW), g_lo = w * gs, g_hi = min(SG, g_lo + gs);
+                f32x16 acc3;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+                const float* pa = p.pk + p.offA2 + ((int64_t)kt * SG * 64 + lane) * 4;
+                const float* db = DS + e * DSS + 4 * hi;
+                for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
+                    f32x4 a[4], bb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int g = min(g0 + u, g_hi - 1);
+                        a[u] = *reinterpret_cast<const f32x4*>(pa + (int64_t)g * 256);
+                        bb[u] = *reinterpret_cast<const f32x4*>(db + 8 * g);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (g0 + u < g_hi) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][i], acc3, 0, 0, 0);
+                        }
+                }
+                gcp_wave_lds_sync();  // (ST shares this slot: its reads are done)
+                for (int q = 0; 8 * q < p.LW; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) sacc = qq == q ? acc3[4 * qq + i] : sacc;
+                        v[i] = sacc;
+                    }
+                    *reinterpret_cast<f32x4*>(EPART + (w * 32 + e) * EPS + 8 * q + 4 * hi) = v;
+                }
+            }
+        }
+        wg_barrier();
+
+        WG_LAUNDER();
+        if constexpr (FUSED) {
+            // ---- P5: dW[own 32 rows of so][K + 1] += ds_pre^T [s | norms | frame scalars | 1] (reduction over the 32 rows) ---
+            if (w < NT) {
+                const float* da = DS + hi * DSS + 32 * w + e;
+                const float* xb = X + hi * KS + e;
+                float a_n = da[0];
+                float b_n[FN];
+#pragma unroll
+                for (int n = 0; n < FN; ++n) b_n[n] = xb[32 * min(n, p.NNT - 1)];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float a_c = a_n;
+                    float b_c[FN];
+#pragma unroll
+                    for (int n = 0; n < FN; ++n) b_c[n] = b_n[n];
+                    if (j + 1 < 16) {
+                        a_n = da[2 * (j + 1) * DSS];
+#pragma unroll
+                        for (int n = 0; n < FN; ++n) b_n[n] = xb[2 * (j + 1) * KS + 32 * min(n, p.NNT - 1)];
+                    }
+#pragma unroll
+                    for (int n = 0; n < FN; ++n)
+                        if (n < p.NNT) dW[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[n], dW[n], 0, 0, 0);
+                }
+            }
+            // ---- P6: dWg[vo][own 32 columns of so] += dgate^T act_v(s_pre) -------------------------------------------------
+            if (gated) {
+                wg_barrier();  // everybody is done with ds_pre in DS
+                if (w < NT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {spa[4 * q], spa[4 * q + 1], spa[4 * q + 2], spa[4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * w + 8 * q + 4 * hi) = v;
+                    }
+                }
+                wg_barrier();
+                if (w < NT) {
+                    const float* ga = DG + hi * DGS + min(e, DGS - 1);
+                    const float* sb = DS + hi * DSS + 32 * w + e;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float a = e < vo ? ga[2 * j * DGS] : 0.f;
+                        const float b = sb[2 * j * DSS];
+                        dWg = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dWg, 0, 0, 0);
+                    }
+                }
+                if (tid < vo) {  // gate bias gradient: column sums of dgate
+                    float sacc = 0.f;
+                    for (int r = 0; r < 32; ++r) sacc += DG[r * DGS + tid];
+                    dbg += sacc;
+                }
+            }
+        }
+
+        WG_LAUNDER();
+        // ---- P7: adjoint of the vector prologue: d vh, d vf ---------------------------------------------------------------
+        {
+            auto dext = [&](int x) -> float {  // d(extras column x) of this thread's row
+                const int c = si + x;
+                if (p.split && c >= 32 * (p.NKT - 1)) {
+                    const int cc = c - 32 * (p.NKT - 1);
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) sacc += EPART[(ww * 32 + prow) * EPS + cc];
+                    return sacc;
+                }
+                return DEXT[prow * EXS + x];
+            };
+            for (int x = psub; x < HF; x += TPR) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                if (x < H) {
+                    if (vo > 0) {
+                        const float* wt = WUT + x * p.WTU;
+                        const float* du = DVU + prow * US;
+                        if (vec_o) {
+                            for (int o = 0; o < vo; o += 4) {
+                                const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + o);
+                                const f32x4 a = *reinterpret_cast<const f32x4*>(du + 3 * o);
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(du + 3 * o + 4);
+                                const f32x4 d = *reinterpret_cast<const f32x4*>(du + 3 * o + 8);
+                                a0 = fmaf(wv[0], a[0], a0); a1 = fmaf(wv[0], a[1], a1); a2 = fmaf(wv[0], a[2], a2);
+                                a0 = fmaf(wv[1], a[3], a0); a1 = fmaf(wv[1], b[0], a1); a2 = fmaf(wv[1], b[1], a2);
+                                a0 = fmaf(wv[2], b[2], a0); a1 = fmaf(wv[2], b[3], a1); a2 = fmaf(wv[2], d[0], a2);
+                                a0 = fmaf(wv[3], d[1], a0); a1 = fmaf(wv[3], d[2], a1); a2 = fmaf(wv[3], d[3], a2);
+                            }
+                        } else {
+                            for (int o = 0; o < vo; ++o) {
+                                const float wv = wt[o];
+                                a0 = fmaf(wv, du[3 * o + 0], a0); a1 = fmaf(wv, du[3 * o + 1], a1); a2 = fmaf(wv, du[3 * o + 2], a2);
+                            }
+                        }
+                    }
+                    const float dn = dext(x) * RN[prow * (H | 1) + x];
+                    a0 += dn * VH[prow * HS + 3 * x + 0]; a1 += dn * VH[prow * HS + 3 * x + 1]; a2 += dn * VH[prow * HS + 3 * x + 2];
+                } else if (nf) {
+                    const int k = x - H;
+                    const float* f = FR + prow * 9;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float ds = dext(H + 3 * k + a);
+                        if (p.e3 && a == 1) ds *= SGN[prow * 3 + k];
+                        a0 = fmaf(f[3 * a + 0], ds, a0); a1 = fmaf(f[3 * a + 1], ds, a1); a2 = fmaf(f[3 * a + 2], ds, a2);
+                    }
+                }
+                DVHF[prow * FS + 3 * x + 0] = a0; DVHF[prow * FS + 3 * x + 1] = a1; DVHF[prow * FS + 3 * x + 2] = a2;
+            }
+            if (p.split) {  // scalar-input columns inside the split tile: summed over the waves' partials and stored
+                const int c0 = 32 * (p.NKT - 1), ns = min(si, K) - c0;  // (> 0 only when the last tile holds scalar columns)
+                for (int i = tid; i < 32 * max(ns, 0); i += NTH) {
+                    const int r = i / ns, c = i - r * ns;
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) sacc += EPART[(ww * 32 + r) * EPS + c];
+                    if (p.residual) sacc += r < nvalid ? p.d_s_out[(int64_t)(r0 + r) * so + c0 + c] : 0.f;
+                    if (r < nvalid) p.d_s_in[(int64_t)(r0 + r) * si + c0 + c] = sacc;
+                }
+            }
+        }
+        wg_barrier();
+
+        WG_LAUNDER();
+        // ---- P8: d(v_in) = [vector_down ; vector_down_frames]^T d[vh | vf] (+ pass-through terms) ----------------------------
+        for (int c = psub; c < vi; c += TPR) {
+            const float* wt = WDT + c * p.WTV;
+            const float* dq = DVHF + prow * FS;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int x = 0; x < HF; ++x) {
+                const float wv = wt[x];
+                a0 = fmaf(wv, dq[3 * x + 0], a0); a1 = fmaf(wv, dq[3 * x + 1], a1); a2 = fmaf(wv, dq[3 * x + 2], a2);
+            }
+            if (p.vres && vo > 0) { a0 += DVU[prow * US + 3 * c + 0]; a1 += DVU[prow * US + 3 * c + 1]; a2 += DVU[prow * US + 3 * c + 2]; }
+            if (prow < nvalid) {
+                if (p.residual) {  // ResGCP pass-through (the LDS copy of d(v_out) has been recycled: L2 still has the tile)
+                    const float* g = p.d_v_out + ((int64_t)(r0 + prow) * vo + c) * 3;
+                    a0 += g[0]; a1 += g[1]; a2 += g[2];
+                }
+                float* dp = p.d_v_in + ((int64_t)(r0 + prow) * vi + c) * 3;
+                dp[0] = a0; dp[1] = a1; dp[2] = a2;
+            }
+        }
+        if (p.dvhf) {  // d[vh | vf] per row, [3, HF'] xyz-major: the gradient of the pre-projected vector tables' gathered rows
+            const int wdt = 3 * p.HFP;
+            for (int i = tid; i < nvalid * wdt; i += NTH) {
+                const int r = i / wdt, j = i - r * wdt, d = j / p.HFP, x = j - d * p.HFP;
+                p.dvhf[(int64_t)r0 * wdt + i] = x < HF ? DVHF[r * FS + 3 * x + d] : 0.f;
+            }
+        }
+        WG_LAUNDER();
+        // ---- P9: small vector weight gradients, per-thread partial sums over the tile's rows ------------------------------
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) {
+            const int idx = tid + j * NTH;
+            if (idx < p.n_sm) {
+                const float* pa;
+                const float* pb;
+                int sa, sb;
+                if (idx < p.n_up) {  // d vector_up[o, h] = sum dvu[row, o, :] . vh[row, h, :]
+                    const int o = idx / H, h = idx - o * H;
+                    pa = DVU + 3 * o; sa = US; pb = VH + 3 * h; sb = HS;
+                } else {             // d [vector_down ; vector_down_frames][x, c] = sum d[vh | vf][row, x, :] . v[row, c, :]
+                    const int i2 = idx - p.n_up, x = i2 / vi, c = i2 - x * vi;
+                    pa = DVHF + 3 * x; sa = FS; pb = V + 3 * c; sb = VS;
+                }
+                float sacc = 0.f;
+#pragma unroll 4
+                for (int r = 0; r < 32; ++r)
+                    sacc += pa[r * sa] * pb[r * sb] + pa[r * sa + 1] * pb[r * sb + 1] + pa[r * sa + 2] * pb[r * sb + 2];
+                wsm[j] += sacc;
+            }
+        }
+        wg_barrier();  // the tiles are free for the next iteration's loads
+    }
+
+    WG_LAUNDER();
+    // ---- partial weight gradients of this workgroup ---------------------------------------------------------------------------
+    if constexpr (FUSED) {
+        if (w < NT) {
+            float* out = p.dw_part + (int64_t)blockIdx.x * so * p.KW;
+#pragma unroll
+            for (int n = 0; n < FN; ++n)
+                if (n < p.NNT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = 32 * w + gcp_crow(r, hi), c = 32 * n + e;
+                        if (m < so && c < p.KW) out[(int64_t)m * p.KW + c] = dW[n][r];
+                    }
+                }
+            if (gated) {
+                float* og = p.dwg_part + (int64_t)blockIdx.x * vo * (so + 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = gcp_crow(r, hi), c = 32 * w + e;
+                    if (o < vo && c < so) og[(int64_t)o * (so + 1) + c] = dWg[r];
+                }
+            }
+        }
+        if (gated && tid < vo) p.dwg_part[(int64_t)blockIdx.x * vo * (so + 1) + (int64_t)tid * (so + 1) + so] = dbg;
+    }
+    if (p.wsm_part) {
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) {
+            const int idx = tid + j * NTH;
+            if (idx < p.n_sm) p.wsm_part[(int64_t)blockIdx.x * p.n_sm + idx] = wsm[j];
+        }
+    }
+}
+
+// out[...] = sum over parts, fixed order.  parts[g][r * C + c] for r < R, c < C; columns c < CW of row r go to
+// out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].
+__global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ parts, int G, int R, int C, int CW,
+                                                        float* __restrict__ out_w, float* __restrict__ out_b) {
+    const int64_t n = (int64_t)R * C;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+        a0 += parts[(int64_t)g * n + i];
+        a1 += parts[(int64_t)(g + 1) * n + i];
+        a2 += parts[(int64_t)(g + 2) * n + i];
+        a3 += parts[(int64_t)(g + 3) * n + i];
+    }
+    for (; g < G; ++g) a0 += parts[(int64_t)g * n + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+    if (c < CW) out_w[(int64_t)r * CW + c] = v;
+    else if (out_b) out_b[r] = v;
+}
+
+int g_wg_cus = 0;
+
+template <int NW, int KT, int FN>
+int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipStream_t st) {
+    auto go = [&](auto kern) -> int {
+        if (lds_bytes > 64 * 1024) {
+            hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (err != hipSuccess) return (int)err;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds_bytes, st, p);
+        GCP_HIP_CHECK_LAUNCH();
+        return 0;
+    };
+    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false>);
+}
+
+}  // namespace
+
+extern "C" int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, int CW, float* out_w, float* out_b, void* stream) {
+    if (!parts || n_parts <= 0 || R <= 0 || C <= 0 || CW < 0 || CW > C || !out_w) return GCPNET_E_BADARG;
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)gcp_cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, parts, n_parts, R, C,
+                       CW, out_w, out_b);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Plan of one backward launch: workgroup count (= rows of the partial buffers), fused or not, scratch widths.
+extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const gcp2_opts_t* o, int want_fused, gcp_wg_bwd_plan_t* plan) {
+    if (!w || !o || !plan) return GCPNET_E_BADARG;
+    if (w->vi <= 0 || (w->so & 3) || w->so < 4) return GCPNET_E_UNSUPPORTED;
+    const bool gated = o->vmode == GCP_VMODE_SCALAR_GATE && w->vo > 0;
+    if (gated && w->vo > 32) return GCPNET_E_UNSUPPORTED;  // (one 32-row tile of gate outputs)
+    const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
+    const int NW = (w->so > 160 || S.K > 160) ? 8 : 4;
+    if (gcp_cdiv(S.NT, NW) > 4) return GCPNET_E_UNSUPPORTED;
+    const int rem = S.NKT % NW;
+    const int split = (rem == 1 && S.NKT > 1) ? 1 : 0;
+    const int NFT = split ? S.NKT - 1 : S.NKT;
+    const int KTn = gcp_cdiv(NFT, NW);
+    if (KTn > 4) return GCPNET_E_UNSUPPORTED;
+    const int HF = S.H + (S.nf ? 3 : 0);
+    const int n_sm = w->vo * S.H + HF * w->vi;
+    if (n_sm > NSW * 64 * NW) return GCPNET_E_UNSUPPORTED;
+    const int KW = S.K + 1, NNT = gcp_cdiv(KW, 32);
+    const int fused = want_fused && S.NT <= NW && KTn == 1 && NNT <= 5;
+    if (!g_wg_cus) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g_wg_cus = cus;
+    }
+    const int ntiles = gcp_cdiv(rows, 32);
+    plan->nw = NW;
+    plan->kt = KTn == 1 ? 1 : 4;
+    plan->fused = fused;
+    plan->grid = ntiles <= 0 ? 1 : min(ntiles, 2 * g_wg_cus);
+    plan->kw = KW;
+    plan->n_small = n_sm;
+    plan->ext_w = gcp_round_up(S.H + S.nf, 4);
+    plan->dgate_w = gcp_round_up(w->vo, 4);
+    plan->split = split;
+    return 0;
+}
+
+extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* stream) {
+    if (rows < 0 || !a) return GCPNET_E_BADARG;
+    const gcp2_weights_t& w = a->w;
+    const gcp2_opts_t& o = a->o;
+    gcp_wg_bwd_plan_t pl;
+    if (int rc = gcpnet_wg_backward_plan(rows, &w, &o, a->dw_part != nullptr, &pl)) return rc;
+    if ((a->dw_part != nullptr) != (pl.fused != 0)) return GCPNET_E_BADARG;  // the caller sizes its buffers from the same plan
+    if (!w.pack || !w.w_down || (w.vo > 0 && !w.w_up) || !a->v_in || !a->s_pre || !a->d_s_out || !a->d_s_in || !a->d_v_in)
+        return GCPNET_E_BADARG;
+    if (w.vo > 0 && !a->d_v_out) return GCPNET_E_BADARG;
+    const bool gated = o.vmode == GCP_VMODE_SCALAR_GATE && w.vo > 0;
+    if (gated && !a->gate) return GCPNET_E_BADARG;
+    if (a->residual && (w.si != w.so || w.vi != w.vo)) return GCPNET_E_BADARG;
+    if (o.vector_residual && w.vi != w.vo) return GCPNET_E_BADARG;
+    auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+    if (misaligned(a->s_pre) || misaligned(a->d_s_out) || misaligned(a->d_s_in) || misaligned(w.pack) || misaligned(a->ds_pre))
+        return GCPNET_E_UNSUPPORTED;
+    if (a->residual && (w.si & 3)) return GCPNET_E_UNSUPPORTED;
+    const WgShape S = wg_shape(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated);
+    if (S.nf && (!a->frames || !w.w_frames)) return GCPNET_E_BADARG;
+    if (pl.fused && (!a->s_in || (gated && !a->dwg_part))) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    WgBwdParams p;
+    p.rows = rows; p.ntiles = gcp_cdiv(rows, 32);
+    p.s_in = a->s_in; p.v_in = a->v_in; p.frames = a->frames; p.s_pre = a->s_pre; p.gate = a->gate;
+    p.d_s_out = a->d_s_out; p.d_v_out = a->d_v_out;
+    p.v_add.n = 0;
+    if (a->v_add) p.v_add = *a->v_add;
+    if (p.v_add.n < 0 || p.v_add.n > GCP_MAX_SEG) return GCPNET_E_BADARG;
+    p.d_s_in = a->d_s_in; p.d_v_in = a->d_v_in;
+    p.pk = w.pack; p.offA2 = S.offA2; p.offG2 = S.offG2;
+    p.w_down = w.w_down; p.w_frames = w.w_frames; p.w_up = w.w_up;
+    p.ds_pre = a->ds_pre; p.dvhf = a->dvhf; p.ext = a->ext; p.dgate = a->dgate;
+    p.dw_part = a->dw_part; p.dwg_part = a->dwg_part; p.wsm_part = a->wsm_part;
+    p.si = w.si; p.vi = w.vi; p.so = w.so; p.vo = w.vo; p.H = S.H; p.nf = S.nf; p.K = S.K; p.NT = S.NT; p.NKT = S.NKT;
+    p.SG = 4 * S.NT; p.VG = S.VG; p.HF = S.H + (S.nf ? 3 : 0);
+    p.act_s = o.act_s; p.act_v = o.act_v; p.vmode = w.vo > 0 ? o.vmode : GCP_VMODE_NONE; p.vres = o.vector_residual; p.e3 = o.e3;
+    p.residual = a->residual; p.slope = o.slope;
+    p.split = pl.split; p.LW = S.K - 32 * (S.NKT - 1);
+    p.KW = pl.kw; p.NNT = gcp_cdiv(pl.kw, 32);
+    p.EP = pl.ext_w; p.VOP = pl.dgate_w; p.HFP = gcp_round_up(p.HF, 4);
+    for (int k = 0; k < p.v_add.n; ++k)
+        if (!p.v_add.ptr[k] || p.v_add.dim[k] != p.HFP) return GCPNET_E_BADARG;
+    p.n_up = w.vo * S.H; p.n_sm = pl.n_small;
+    const int NW = pl.nw;
+    const int xw = pl.fused ? 8 * gcp_cdiv(pl.kw, 8) : 0;
+    p.KS = wg_stride(max(xw, 4));
+    p.DSS = wg_stride(32 * S.NT);
+    p.VS = wg_stride(3 * w.vi); p.US = wg_stride(3 * max(w.vo, 1)); p.HS = wg_stride(3 * max(S.H, 1)); p.FS = wg_stride(3 * p.HF);
+    p.DGS = wg_stride(gcp_round_up(max(w.vo, 1), 8));
+    p.EXS = wg_stride(max(p.EP, S.K - w.si));
+    p.EPS = max(20, wg_stride(gcp_round_up(p.LW, 8)));
+    p.WSV = wg_stride(w.vi); p.WTV = wg_stride(p.HF); p.WSU = wg_stride(max(S.H, 1)); p.WTU = wg_stride(max(w.vo, 1));
+    int off = 0;
+    p.o_x = off; off += pl.fused ? 32 * p.KS : 0;
+    p.o_ds = off; off += 32 * p.DSS;
+    p.o_epart = off; off += NW * 32 * p.EPS;
+    p.o_v = off; off += 32 * p.VS;
+    p.o_dvu = off; off += 32 * p.US;
+    p.o_vh = off; off += 32 * p.HS;
+    p.o_fr = off; off += 32 * 9;
+    p.o_dg = off; off += 32 * p.DGS;
+    p.o_rn = off; off += gcp_round_up(32 * (S.H | 1), 4);
+    p.o_sgn = off; off += 32 * 3 + 32;
+    p.o_ws = off; off += p.HF * p.WSV + w.vi * p.WTV + w.vo * p.WSU + S.H * p.WTU;
+    off = gcp_round_up(off, 4);
+    // d(v_out) is dead after P2; its space then holds d[vh | vf] and (not fused: from P1 on) the extras tile.  The extras tile
+    // must not overlap d(v_out) when it is written in P1, so it sits behind it in that case.
+    p.o_dvo = off;
+    const int dvo = 32 * p.US, dq = 32 * p.FS, dx = 32 * p.EXS;
+    p.o_dvhf = off;
+    if (pl.fused) { p.o_dext = off + dq; off += max(dvo, dq + dx); }
+    else { p.o_dext = off + max(dvo, dq); off += max(dvo, dq) + dx; }
+    const size_t lds_bytes = (size_t)off * sizeof(float);
+    if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
+    const bool pwl = gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = pl.grid;
+    if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);
+    if (NW == 4) return pl.kt == 1 ? launch_bwd<4, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<4, 4, 0>(p, pwl, grid, lds_bytes, st);
+    return pl.kt == 1 ? launch_bwd<8, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 4, 0>(p, pwl, grid, lds_bytes, st);
+}

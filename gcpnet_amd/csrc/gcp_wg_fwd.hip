@@ -44,10 +44,12 @@ struct WgFwdParams {
     int n;
     int KS, VS, HS, GS;
     int o_x, o_v, o_vh, o_fr, o_gp, o_ws, o_st, ws_floats;
+    unsigned long long* stamps;  // profiling hook (gcpnet_debug_set_phase_timing): s_memtime stamps of wave 0, last block
+    long long stamp_cap;
     WgBlk blk[GCP_WG_MAX_BLOCKS];
 };
 
-__device__ __forceinline__ bool wg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 
 template <int NW, int MT, bool PWL>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p) {
@@ -189,6 +191,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     auto run_block = [&](auto first_tag, const int b) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const WgBlk& B = p.blk[b];
+        auto stamp = [&](int k) {
+            if (b == p.n - 1 && w == 0) gcp_stamp(p.stamps, p.stamp_cap, k, lane);
+        };
+        stamp(0);
         const float* ws = lds + p.o_ws + (b & 1) * p.ws_floats;
         const int H = B.H, vi = B.vi, si = B.si, HF = H + (nf ? 3 : 0), WSV = vi | 1, WSU = H | 1;
         const float* wu = ws + HF * WSV;
@@ -240,7 +246,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 X[r * KS + K + c] = 0.f;
             }
         }
+        stamp(1);
         wg_barrier();  // B1
+        stamp(2);
         if (b + 1 < p.n) ws_request(b + 1);
 
         // ---- scalar_out (+ gate partial) per output group ---------------------------------------------------------------
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                     mm(a1, b1, g0 + U);
                 }
             }
+            stamp(3);
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                     if (tv[t]) store_acc(B.s_out, ynew[t], otc[t]);
             }
         }
+        stamp(4);
         if (scalar_gate) {
             // partial gate pre-activations -> GP[w & 3][32][vo]; with eight waves the upper four add theirs in a second step
             // (half the LDS: the partials of a (256+, 32+) block would not fit otherwise)
@@ -422,6 +432,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         }
         if (b + 1 < p.n) ws_commit(b + 1);
         wg_barrier();  // B2: every wave is done reading X; the gate partials are complete
+        stamp(5);
 
         if (b + 1 < p.n && w < NT) {  // new scalar state -> X (B operand of the next block)
 #pragma unroll
@@ -468,6 +479,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 if (scalar_gate && B.gate && prow < nvalid) B.gate[(int64_t)(r0 + prow) * vo + o] = g;
             }
         }
+        stamp(6);
         wg_barrier();  // B3: the vector tile is updated
         if (vo > 0 && B.v_out) {
             const int vw = 3 * vo, nv = nvalid * vw;
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 dst[i] = V[r * VS + c];
             }
         }
+        stamp(7);
     };
 
     run_block(std::true_type{}, 0);
@@ -558,6 +571,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     const int so = w0.so, vo = w0.vo;
     if (w0.vi <= 0 || !v_in) return GCPNET_E_UNSUPPORTED;
     if ((so & 3) || so < 4) return GCPNET_E_UNSUPPORTED;
+    if (vo > 32 && blocks[0].o.vmode == GCP_VMODE_SCALAR_GATE) return GCPNET_E_UNSUPPORTED;  // (one 32-row tile of gate outputs)
     WgFwdParams p;
     p.rows = rows; p.s_in = s_in; p.v_in = v_in; p.frames = frames;
     p.s_add.n = 0; p.v_add.n = 0;
@@ -631,6 +645,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     p.o_fr = off; off += 32 * 9;
     const size_t lds_bytes = (size_t)off * sizeof(float);
     if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
+    p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
     if (NW == 4) return launch_fwd<4, 1>(p, pwl, lds_bytes, st);
     if (MT == 1) return launch_fwd<8, 1>(p, pwl, lds_bytes, st);

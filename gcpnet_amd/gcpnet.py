@@ -197,14 +197,14 @@ class GCP3(GCP2):
         spec = self.make_spec(s_plans, v_plans, False)
         frames = row_frames if spec.use_frames else None
         spec_a = replace(spec, vo=0, act_s=self.act_mid, vmode=VMODE_NONE, vector_residual=False,
-                         pack_cache=self._pack_cache_first)
+                         pack_cache=self._pack_cache_first, shared_weights=True)
         s_mid = ops.gcp2(spec_a, s_sources, v_sources, frames,
                          (first.weight, first.bias, g("vector_down"), g("vector_down_frames"), None, None, None))
         extra = spec.K - spec.si  # the norm / frame-projection columns, already consumed by the first Linear
         w_second = torch.cat((second.weight, second.weight.new_zeros(self.scalar_output_dim, extra)), dim=1) if extra \
             else second.weight
         gate = getattr(self, "vector_out_scale", None)
-        spec_b = replace(spec, si=self.scalar_output_dim, s_plans=[None], pack_cache=None)
+        spec_b = replace(spec, si=self.scalar_output_dim, s_plans=[None], pack_cache=None, shared_weights=True)
         out = ops.gcp2(spec_b, [s_mid], v_sources, frames,
                        (w_second, second.bias, g("vector_down"), g("vector_down_frames"), g("vector_up"),
                         None if gate is None else gate.weight, None if gate is None else gate.bias))

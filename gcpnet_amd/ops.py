@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT, BwdScratch, ChainBwdItem, ChainItem, Head, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
+from ._lib import (ACT, WgBwdArgs, WgBwdPlan, BwdScratch, ChainBwdItem, ChainItem, Head, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
                    VMODE_SELF_GATE, WgBlock, check)
 
 Tensor = torch.Tensor
@@ -284,6 +284,10 @@ class Gcp2Spec:
     add_plans: List[Optional[GatherPlan]] = field(default_factory=list)
     # same for vector inputs: one plan per [n_src, 3, HF'] table ([vector_down ; vector_down_frames] applied at the source rows)
     vadd_plans: List[Optional[GatherPlan]] = field(default_factory=list)
+    # some weight of this block is also an input of ANOTHER autograd Function in the same graph (GCP3 feedforward_out runs the
+    # block as two launches sharing vector_down / vector_down_frames): autograd then sums two gradients inside the backward
+    # pass, so this block's weight gradients must be complete on the caller's stream when its backward returns
+    shared_weights: bool = False
 
     @property
     def K(self):
@@ -308,7 +312,7 @@ def _weights_struct(spec: Gcp2Spec, w, pack: Tensor) -> Gcp2Weights:
     ws.w_scalar, ws.b_scalar = w_scalar.data_ptr(), b_scalar.data_ptr()
     ws.w_gate = w_gate.data_ptr() if w_gate is not None else None
     ws.b_gate = b_gate.data_ptr() if b_gate is not None else None
-    ws.pack = pack.data_ptr()
+    ws.pack = pack.data_ptr() if pack is not None else None
     return ws
 
 
@@ -337,6 +341,7 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
 
 
 USE_WG_KERNELS = True  # module switch: multi-wave workgroup kernels (gcp_wg_*.hip) where the shape fits, else the wave-per-tile ones
+USE_WG_BACKWARD = True  # (separately for the backward; both need USE_WG_KERNELS)
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
 
@@ -362,9 +367,13 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
     return pack
 
 
-def _wg_block(spec: Gcp2Spec, w, s_out, v_out, s_pre, gate, residual: bool) -> WgBlock:
+def _wg_block(spec: Gcp2Spec, w, s_out, v_out, s_pre, gate, residual: bool, keep: list) -> WgBlock:
+    """`keep` receives the packed-weight tensor: it must stay referenced until the launch is enqueued (specs without a pack
+    cache get a fresh image per call; released earlier, the caching allocator may hand its memory to the next torch.empty)."""
     blk = WgBlock()
-    blk.w = _weights_struct(spec, w, _pack_wg(spec, w))
+    pack = _pack_wg(spec, w)
+    keep.append(pack)
+    blk.w = _weights_struct(spec, w, pack)
     blk.o = _opts_struct(spec)
     blk.s_out, blk.v_out = _p(s_out), _p(v_out)
     blk.s_pre, blk.gate = _p(s_pre), _p(gate)
@@ -395,7 +404,8 @@ class _Gcp2(torch.autograd.Function):
             ctx.spec, ctx.rows, ctx.n_s, ctx.n_v = spec, rows, n_s, n_v
             ctx.frames = frames
             ctx.has_res = (tensors[n_s + n_v] is not None, tensors[n_s + n_v + 1] is not None)
-            ctx.w_leaf = all(t is None or t.is_leaf for t in w)  # nothing downstream of the weight gradients in this backward
+            ctx.w_leaf = not spec.shared_weights  # (checked again, against the live tensors, in the backward: _side_stream_ok)
+            ctx.weights = w
             ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate, *vadds)
         if spec.vo:
             return s_out, v_out
@@ -419,7 +429,8 @@ class _Gcp2(torch.autograd.Function):
                                                  d_v_out, need_w=any(need_w), vadds=vadds)
         wgrads = [None] * 7
         if any(need_w):
-            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr, in_backward_of_leaves=ctx.w_leaf)
+            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr,
+                                       in_backward_of_leaves=ctx.w_leaf and _side_stream_ok(ctx.weights))
 
         # ---- input gradients: un-concatenate, scatter-add the gathered sources back to their rows -----------------
         grads_s: List[Optional[Tensor]] = []
@@ -480,7 +491,8 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
     plain = len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
     if USE_WG_KERNELS and plain and (spec.residual or (res_s is None and res_v is None)) and spec.vi > 0:
         # one workgroup per 32-row tile, output columns split over its waves (gcp_wg_fwd.hip)
-        blk = _wg_block(spec, w, s_out, v_out, s_pre, gate, spec.residual)
+        keep: list = []
+        blk = _wg_block(spec, w, s_out, v_out, s_pre, gate, spec.residual, keep)
         rc = lib.gcpnet_wg_forward(rows, _p(s_src[0]), _p(v_src[0]), _p(frames), C.byref(ac) if ac is not None else None,
                                    C.byref(vac) if vac is not None else None, 1, C.byref(blk), _stream())
         if rc != _lib.E_UNSUPPORTED:
@@ -529,6 +541,11 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=s_pre.device)
     si, vi, vo = spec.si, spec.vi, spec.vo
+    if (USE_WG_KERNELS and USE_WG_BACKWARD and len(s_src) == 1 and spec.s_plans[0] is None and len(v_src) == 1
+            and spec.v_plans[0] is None and vi > 0 and rows > 0):
+        res = _wg_backward(spec, rows, s_src[0], v_src[0], frames, w, s_pre, gate, d_s_out, d_v_out, need_w, vadds)
+        if res is not None:
+            return res
     d_s_in = torch.empty((rows, si), **f32)
     d_v_in = torch.empty((rows, vi, 3), **f32) if vi > 0 else None
     scr, t = _alloc_bwd_scratch(spec, rows, need_w, s_pre.device)
@@ -545,6 +562,96 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
                                    C.byref(vac) if vac is not None else None, _p(s_pre), _p(gate), _p(d_s_out),
                                    _p(d_v_out) if vo else None, _p(d_s_in), _p(d_v_in), C.byref(scr), _stream()),
           "gcp2_backward")
+    return d_s_in, d_v_in, t
+
+
+def _wg_backward_supported(spec: Gcp2Spec, rows: int, w) -> bool:
+    lib = _lib.load()
+    if spec.vi <= 0:
+        return False
+    ws = _weights_struct(spec, w, None)  # (the plan depends on dims and options only)
+    opts = _opts_struct(spec)
+    plan = WgBwdPlan()
+    return lib.gcpnet_wg_backward_plan(rows, C.byref(ws), C.byref(opts), 1, C.byref(plan)) == 0
+
+
+def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, d_s_out, d_v_out, need_w: bool, vadds):
+    """Backward of one block through the workgroup kernel (gcp_wg_bwd.hip).  Returns (d_s_in, d_v_in, scratch dict) like
+    gcp2_backward_data, or None when the shape is outside that kernel.  In fused mode the scratch dict carries the finished
+    weight gradients under "fused" (summed over the persistent workgroups' partials in a fixed order); otherwise the per-row
+    operands of the TN GEMMs, as the wave-per-tile kernel leaves them."""
+    lib = _lib.load()
+    f32 = dict(dtype=torch.float32, device=s_pre.device)
+    si, vi, so, vo, H = spec.si, spec.vi, spec.so, spec.vo, spec.hidden
+    wg_pack = _pack_wg(spec, w)  # (stays referenced until the launch below is enqueued)
+    ws = _weights_struct(spec, w, wg_pack)
+    opts = _opts_struct(spec)
+    plan = WgBwdPlan()
+    rc = lib.gcpnet_wg_backward_plan(rows, C.byref(ws), C.byref(opts), int(need_w), C.byref(plan))
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "wg_backward_plan")
+    gated = _gated(spec)
+    nf = 9 if spec.use_frames else 0
+    a = WgBwdArgs()
+    a.w, a.o, a.residual = ws, opts, int(spec.residual)
+    a.s_in, a.v_in, a.frames = _p(s_in), _p(v_in), _p(frames)
+    vac = _vadd_concat(vadds, spec.vadd_plans) if len(vadds) else None
+    a.v_add = C.pointer(vac) if vac is not None else None
+    a.s_pre, a.gate, a.d_s_out, a.d_v_out = _p(s_pre), _p(gate), _p(d_s_out), _p(d_v_out) if vo else None
+    d_s_in = torch.empty((rows, si), **f32)
+    d_v_in = torch.empty((rows, vi, 3), **f32)
+    a.d_s_in, a.d_v_in = _p(d_s_in), _p(d_v_in)
+    t = {}
+    fused = bool(plan.fused)
+    if (not fused and need_w) or spec.add_plans:
+        t["ds_pre"] = torch.empty((rows, so), **f32)
+        a.ds_pre = _p(t["ds_pre"])
+    else:
+        t["ds_pre"] = None
+    if len(vadds):
+        t["dvhf"] = torch.empty((rows, 3 * vadds[0].shape[2]), **f32)
+        a.dvhf = _p(t["dvhf"])
+    grid = plan.grid
+    if need_w:
+        t["w_part"] = torch.empty((grid, plan.n_small), **f32)
+        a.wsm_part = _p(t["w_part"])
+    if fused:
+        dw_part = torch.empty((grid, so * plan.kw), **f32)
+        a.dw_part = _p(dw_part)
+        dwg_part = torch.empty((grid, vo * (so + 1)), **f32) if gated else None
+        a.dwg_part = _p(dwg_part)
+    elif need_w:
+        t["ext"] = torch.empty((rows, plan.ext_w), **f32)
+        a.ext = _p(t["ext"])
+        if gated:
+            t["dgate"] = torch.empty((rows, plan.dgate_w), **f32)
+            a.dgate = _p(t["dgate"])
+    rc = lib.gcpnet_wg_backward(rows, C.byref(a), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "wg_backward")
+    del wg_pack
+    WG_STATS["bwd"] += 1
+    if fused:
+        st = _stream()
+        K = spec.K
+        g: List[Optional[Tensor]] = [None] * 7
+        g[0], g[1] = torch.empty((so, K), **f32), torch.empty((so,), **f32)
+        check(lib.gcpnet_wg_reduce(_p(dw_part), grid, so, plan.kw, K, _p(g[0]), _p(g[1]), st), "wg_reduce")
+        if gated:
+            g[5], g[6] = torch.empty((vo, so), **f32), torch.empty((vo,), **f32)
+            check(lib.gcpnet_wg_reduce(_p(dwg_part), grid, vo, so + 1, so, _p(g[5]), _p(g[6]), st), "wg_reduce")
+        wv = torch.empty((plan.n_small,), **f32)
+        check(lib.gcpnet_wg_reduce(_p(t["w_part"]), grid, 1, plan.n_small, plan.n_small, _p(wv), None, st), "wg_reduce")
+        o1, o2 = vo * H, vo * H + H * vi
+        if vo:
+            g[4] = wv[:o1].view(vo, H)
+        g[2] = wv[o1:o2].view(H, vi)
+        if nf:
+            g[3] = wv[o2:].view(3, vi)
+        t["fused"] = g
+        t["keep"] = (dw_part, dwg_part)
     return d_s_in, d_v_in, t
 
 
@@ -581,6 +688,9 @@ class _WeightGradJob:
         H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
         nf = 9 if (spec.use_frames and vi > 0) else 0
         self.spec, self.nf = spec, nf
+        if "fused" in t:  # the workgroup backward kernel has produced the gradients itself
+            self.probs, self.keep, self.reduce, self.g = [], [t], None, t["fused"]
+            return
         self.has_vec, self.has_vout = vi > 0, vi > 0 and vo > 0
         self.gated = spec.vmode == VMODE_SCALAR_GATE and self.has_vout
         self.probs, self.keep = [], [t, s_pre, list(s_src)]
@@ -665,6 +775,26 @@ _side_streams: dict = {}
 _side_pending: list = []
 
 
+def _side_stream_ok(weights) -> bool:
+    """The weight-gradient stream may be used only when nothing can READ the returned gradients before the end-of-backward join:
+    every weight is a leaf that autograd will simply adopt as .grad -- no existing .grad to accumulate into (gradient
+    accumulation, zero_grad(set_to_none=False)), no tensor hooks -- and no distributed wrapper is reducing gradients from inside
+    the backward pass (DistributedDataParallel's bucket hooks; gcpnet_amd.parallel.GradAllReducer runs after it and opts in)."""
+    if not WEIGHT_GRADS_ON_SIDE_STREAM:
+        return False
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and not SIDE_STREAM_UNDER_DISTRIBUTED:
+        return False
+    for t in weights:
+        if t is None:
+            continue
+        if not t.is_leaf or t.grad is not None or t._backward_hooks or getattr(t, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+SIDE_STREAM_UNDER_DISTRIBUTED = False  # set by gcpnet_amd.parallel.GradAllReducer (it reduces after the backward pass)
+
+
 def _join_side_stream():
     """End-of-backward callback: the caller's stream waits for the weight-gradient stream; scratch is released."""
     for main, side in {(m, s) for m, s, _ in _side_pending}:
@@ -695,7 +825,10 @@ def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: 
     parameters), so from inside autograd they are enqueued on a second HIP stream: they then run concurrently with the data-path
     kernels of the following blocks, which on their own leave most CUs idle for node-row launches.  The caller's stream
     joins that stream in a callback at the end of the backward pass (before any optimizer / all-reduce can touch .grad)."""
-    if in_backward_of_leaves and WEIGHT_GRADS_ON_SIDE_STREAM and jobs:
+    jobs = [j for j in jobs if j.probs or j.reduce is not None]  # (fused blocks have produced their gradients already)
+    if not jobs:
+        return
+    if in_backward_of_leaves and WEIGHT_GRADS_ON_SIDE_STREAM:
         _side_submit(lambda: run_weight_grad_jobs(jobs), [j.keep for j in jobs])  # operands / partials alive until the join
         return
     lib = _lib.load()
@@ -748,7 +881,8 @@ class _Gcp2Chain(torch.autograd.Function):
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         rc = _lib.E_UNSUPPORTED
         if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS:
-            blks = (WgBlock * n)(*[_wg_block(spec, w, *outs[k], True) for k, (spec, w) in enumerate(zip(specs, ws))])
+            keep: list = []
+            blks = (WgBlock * n)(*[_wg_block(spec, w, *outs[k], True, keep) for k, (spec, w) in enumerate(zip(specs, ws))])
             rc = lib.gcpnet_wg_forward(rows, _p(s0), _p(v0), _p(frames), None, None, n, blks, _stream())
             if rc != _lib.E_UNSUPPORTED:
                 check(rc, "wg_forward")
@@ -758,7 +892,8 @@ class _Gcp2Chain(torch.autograd.Function):
         if need_grad:
             ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
             ctx.state = (s0, v0, ws, packs, outs)
-            ctx.w_leaf = all(t is None or t.is_leaf for t in weights)
+            ctx.w_leaf = not any(sp.shared_weights for sp in specs)
+            ctx.weights = weights
         return outs[-1][0], outs[-1][1]
 
     @staticmethod
@@ -773,8 +908,10 @@ class _Gcp2Chain(torch.autograd.Function):
         jobs: List[Optional[_WeightGradJob]] = [None] * n
         ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
         nws = [any(need_w[7 * k:7 * k + 7]) for k in range(n)]
-        # one launch for the whole chain (gradient state on chip); shapes outside that kernel go block by block
-        res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
+        # workgroup kernels: block by block with the weight gradients fused; else one launch of the wave-per-tile chain kernel
+        # (gradient state on chip); shapes outside both go block by block through the generic kernel
+        use_wg = USE_WG_KERNELS and USE_WG_BACKWARD and rows > 0 and _wg_backward_supported(specs[0], rows, ws[0])
+        res = None if use_wg else gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
         if res is not None:
             d_s, d_v, scrs = res
             for k in range(n):
@@ -790,7 +927,7 @@ class _Gcp2Chain(torch.autograd.Function):
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
         if live:
-            run_weight_grad_jobs(live, in_backward_of_leaves=ctx.w_leaf)
+            run_weight_grad_jobs(live, in_backward_of_leaves=ctx.w_leaf and _side_stream_ok(ctx.weights))
         wgrads: List[Optional[Tensor]] = []
         for k in range(n):
             g = jobs[k].grads() if jobs[k] is not None else [None] * 7
@@ -1002,7 +1139,8 @@ class _Gcp2Projected(torch.autograd.Function):
         if need_grad:
             ctx.spec, ctx.spec2, ctx.rows, ctx.frames, ctx.sg, ctx.vg = spec, spec2, rows, frames, list(sg), list(vg)
             ctx.has_res = (res_s is not None, res_v is not None)
-            ctx.w_leaf = all(t is None or t.is_leaf for t in w)
+            ctx.w_leaf = not spec.shared_weights
+            ctx.weights = w
             ctx.n_w2 = [t is not None for t in w2]
             ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre, gate, *wsegs, *wvs, *vts, *vadds)
         if spec.vo:
@@ -1111,7 +1249,7 @@ class _Gcp2Projected(torch.autograd.Function):
                         gf[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[H:H + 3])
 
             keep = [job.keep, dP, dQ, list(s_src), list(vts), scr]
-            if ctx.w_leaf and WEIGHT_GRADS_ON_SIDE_STREAM:
+            if ctx.w_leaf and _side_stream_ok(ctx.weights):
                 _side_submit(assemble, keep)
             else:
                 assemble()

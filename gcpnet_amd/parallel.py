@@ -20,6 +20,9 @@ class GradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        from . import ops  # this reducer reads the gradients AFTER the backward pass: the weight-gradient stream stays usable
+
+        ops.SIDE_STREAM_UNDER_DISTRIBUTED = True
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)

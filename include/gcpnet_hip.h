@@ -166,6 +166,52 @@ typedef struct {
 int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in, const float* frames, const gcp_concat_t* s_add,
                       const gcp_concat_t* v_add, int n, const gcp_wg_block_t* blocks, void* stream);
 
+/* Backward of ONE block in the workgroup form (the adjoint of one gcp_wg_block_t; a chain is walked block by block, last to
+ * first, the state gradient travelling through d_s_in / d_v_in).  Two modes, chosen by gcpnet_wg_backward_plan():
+ *   fused   (edge-row blocks whose K + 1 <= 160 / 288 columns fit the accumulators): the weight gradients of scalar_out and
+ *           vector_out_scale are accumulated on chip over all tiles of a persistent workgroup and leave as per-workgroup partial
+ *           sums dw_part [grid, so, K + 1] (bias gradient in the last column) and dwg_part [grid, vo, so + 1], to be summed by
+ *           gcpnet_wg_reduce; needs s_in;
+ *   plain   ds_pre / ext / dgate are written per row for gcpnet_tn_gemm, exactly as gcpnet_gcp2_backward does.
+ * In both modes wsm_part [grid, vo*H + (H+3)*vi] receives per-workgroup partial sums of d vector_up [vo, H], d vector_down [H, vi]
+ * and d vector_down_frames [3, vi] (in this order).  ds_pre / dvhf are optional outputs in fused mode (the first message GCP:
+ * gradients of the gathered addend tables). */
+typedef struct {
+    int nw, kt, fused, split;
+    int grid;      /* workgroups = leading dimension of the *_part buffers */
+    int kw;        /* K + 1 */
+    int n_small;   /* width of wsm_part */
+    int ext_w;     /* row width of `ext`   ((H + 9) rounded up to 4) */
+    int dgate_w;   /* row width of `dgate` (vo rounded up to 4) */
+} gcp_wg_bwd_plan_t;
+int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const gcp2_opts_t* o, int want_fused, gcp_wg_bwd_plan_t* plan);
+
+typedef struct {
+    gcp2_weights_t w;     /* w.pack = image of gcpnet_wg_pack */
+    gcp2_opts_t o;
+    int residual;
+    const float* s_in;    /* [rows, si]  (fused mode only) */
+    const float* v_in;    /* [rows, vi, 3] */
+    const float* frames;
+    const gcp_concat_t* v_add;  /* as in the forward (NULL = none) */
+    const float* s_pre;
+    const float* gate;
+    const float* d_s_out;
+    const float* d_v_out;
+    float* d_s_in;
+    float* d_v_in;
+    float* ds_pre;        /* optional [rows, so] */
+    float* dvhf;          /* optional [rows, 3, HF'] */
+    float* ext;           /* plain mode [rows, ext_w] */
+    float* dgate;         /* plain mode [rows, dgate_w] */
+    float* dw_part;       /* fused mode */
+    float* dwg_part;      /* fused mode, scalar-gated blocks */
+    float* wsm_part;
+} gcp_wg_bwd_args_t;
+int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* args, void* stream);
+/* out_w[r, c] = sum_g parts[g, r, c] for c < CW, out_b[r] = sum_g parts[g, r, CW] when C == CW + 1; fixed summation order. */
+int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, int CW, float* out_w, float* out_b, void* stream);
+
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the
  * concatenated layout, plus what the weight gradients need:
