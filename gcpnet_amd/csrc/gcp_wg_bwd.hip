@@ -52,6 +52,8 @@ struct WgBwdParams {
     int KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, WSV, WSU, WTV, WTU;
     int o_x, o_ds, o_v, o_dvo, o_dvu, o_vh, o_dvhf, o_fr, o_dg, o_rn, o_sgn, o_dext, o_epart, o_ws;
     int n_up, n_sm;  // small weight gradients: vector_up entries, all entries
+    unsigned long long* stamps;  // profiling hook: s_memtime stamps of wave 0 at the phase boundaries (last tile of the workgroup)
+    long long stamp_cap;
 };
 
 constexpr int NSW = 4;  // small-weight-gradient accumulators per thread
@@ -133,6 +135,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
     const bool vec_v = (vi & 3) == 0, vec_o = (vo & 3) == 0, vec_h = (H & 3) == 0;
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         WG_LAUNDER();
+        auto stamp = [&](int k) {
+            if (w == 0) gcp_stamp(p.stamps, p.stamp_cap, k, lane);
+        };
+        stamp(0);
         const int r0 = tile * 32;
         const int nvalid = min(32, rows - r0);
         const bool row_ok = e < nvalid;
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             }
         }
         wg_barrier();
+        stamp(1);
 
         WG_LAUNDER();
         // ---- P1: recompute [vh | vf], norms, frame scalars ---------------------------------------------------------------
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * p.EP, DEXT, EXS, p.EP, nvalid, tid, wg_aligned16(p.ext));
         }
 
+        stamp(2);
         WG_LAUNDER();
         // ---- P2: adjoint of the vector epilogue (gcpnet.py:364-391) --------------------------------------------------------
         if (vo > 0) {
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * p.VOP, DG, DGS, p.VOP, nvalid, tid, wg_aligned16(p.dgate));
         }
 
+        stamp(3);
         WG_LAUNDER();
         // ---- P3: ds_pre = d(s_out) act_s'(s_pre) + act_v'(s_pre) (Wg^T dgate), this wave's tiles of so -> DS ---------------
         f32x16 spa;  // act_v(s_pre) of the wave's tile (fused: B operand of the gate weight gradient)
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         }
         wg_barrier();
 
+        stamp(4);
         WG_LAUNDER();
         // ---- P4: d[s | norms | frame scalars]^T = W^T ds_pre^T ------------------------------------------------------------
         {
@@ -464,6 +474,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         }
         wg_barrier();
 
+        stamp(5);
         WG_LAUNDER();
         if constexpr (FUSED) {
             // ---- P5: dW[own 32 rows of so][K + 1] += ds_pre^T [s | norms | frame scalars | 1] (reduction over the 32 rows) ---
@@ -519,6 +530,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             }
         }
 
+        stamp(6);
         WG_LAUNDER();
         // ---- P7: adjoint of the vector prologue: d vh, d vf ---------------------------------------------------------------
         {
@@ -636,6 +648,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             }
         }
         wg_barrier();  // the tiles are free for the next iteration's loads
+        stamp(7);
     }
 
     WG_LAUNDER();
@@ -673,25 +686,36 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 }
 
 // out[...] = sum over parts, fixed order.  parts[g][r * C + c] for r < R, c < C; columns c < CW of row r go to
-// out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].
+// out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].  A block sums 64 consecutive entries: its 256 threads are four
+// slices of the parts axis (16 loads in flight each), combined through LDS in a fixed order -- a few hundred parts of a small
+// matrix are otherwise one dependent load chain per thread.
 __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ parts, int G, int R, int C, int CW,
                                                         float* __restrict__ out_w, float* __restrict__ out_b) {
+    __shared__ float red[4][64];
     const int64_t n = (int64_t)R * C;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int g = 0;
-    for (; g + 3 < G; g += 4) {
-        a0 += parts[(int64_t)g * n + i];
-        a1 += parts[(int64_t)(g + 1) * n + i];
-        a2 += parts[(int64_t)(g + 2) * n + i];
-        a3 += parts[(int64_t)(g + 3) * n + i];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    const int per = (G + 3) / 4, g0 = sl * per, g1 = min(G, g0 + per);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int g = g0;
+        for (; g + 15 < g1; g += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = parts[(int64_t)(g + k) * n + i];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k & 7] += v[k];
+        }
+        for (; g < g1; ++g) acc[0] += parts[(int64_t)g * n + i];
     }
-    for (; g < G; ++g) a0 += parts[(int64_t)g * n + i];
-    const float v = (a0 + a1) + (a2 + a3);
-    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
-    if (c < CW) out_w[(int64_t)r * CW + c] = v;
-    else if (out_b) out_b[r] = v;
+    red[sl][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+        if (c < CW) out_w[(int64_t)r * CW + c] = v;
+        else if (out_b) out_b[r] = v;
+    }
 }
 
 int g_wg_cus = 0;
@@ -714,7 +738,7 @@ int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipSt
 
 extern "C" int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, int CW, float* out_w, float* out_b, void* stream) {
     if (!parts || n_parts <= 0 || R <= 0 || C <= 0 || CW < 0 || CW > C || !out_w) return GCPNET_E_BADARG;
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)gcp_cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, parts, n_parts, R, C,
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)gcp_cdiv(R * C, 64)), dim3(256), 0, (hipStream_t)stream, parts, n_parts, R, C,
                        CW, out_w, out_b);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
@@ -834,6 +858,7 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     const size_t lds_bytes = (size_t)off * sizeof(float);
     if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
     const bool pwl = gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
+    p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
     const int grid = pl.grid;
     if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);

@@ -342,6 +342,8 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
 
 USE_WG_KERNELS = True  # module switch: multi-wave workgroup kernels (gcp_wg_*.hip) where the shape fits, else the wave-per-tile ones
 USE_WG_BACKWARD = True  # (separately for the backward; both need USE_WG_KERNELS)
+PREFER_WG_CHAIN_BACKWARD = True  # chains wider than 128 scalars: block by block through the workgroup backward kernel
+FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains the wave-per-tile chain kernel covers
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
 
@@ -910,8 +912,14 @@ class _Gcp2Chain(torch.autograd.Function):
         nws = [any(need_w[7 * k:7 * k + 7]) for k in range(n)]
         # workgroup kernels: block by block with the weight gradients fused; else one launch of the wave-per-tile chain kernel
         # (gradient state on chip); shapes outside both go block by block through the generic kernel
-        use_wg = USE_WG_KERNELS and USE_WG_BACKWARD and rows > 0 and _wg_backward_supported(specs[0], rows, ws[0])
-        res = None if use_wg else gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
+        # The wave-per-tile chain kernel (one launch, gradient state on chip, so <= 128) is the faster one where it applies
+        # (measured at (128,16): 1.2 ms + 0.76 ms of weight-gradient GEMMs per 7 blocks against 7 x 0.33 ms); wider chains --
+        # (256,32) -- go block by block through the workgroup kernel; shapes outside both through the generic kernel.
+        res = None
+        if not (USE_WG_KERNELS and USE_WG_BACKWARD and PREFER_WG_CHAIN_BACKWARD):
+            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
+        elif specs[0].so <= 128 and not FORCE_WG_CHAIN_BACKWARD:
+            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
         if res is not None:
             d_s, d_v, scrs = res
             for k in range(n):

@@ -40,3 +40,21 @@ def rand_graph(n, e, seed, sort_by_col=False):
         row, col = row[order], col[order]
     x = torch.randn(n, 3, generator=g)
     return torch.stack((row, col)), x
+
+
+def as_accurate(got, cpu32, cpu64, name="", factor=4.0, floor=1e-3):
+    """`got` (the HIP path, fp32) is as close to the float64 result as the reference's own fp32 CPU arithmetic is, up to
+    `factor` (L2 over the tensor), with a floor of `floor` x the tensor's norm (a handful of flips more or fewer on one side
+    moves a small weight gradient by a few 1e-4 of its norm; the smooth-activation variants of the same tests, which run the
+    same kernels, are held to 1e-4 element-wise, and the small ReLU fixtures to 1e-4 .. 1e-5).
+
+    Why not element-wise at 1e-5: with ReLU a pre-activation within round-off of zero takes a different branch in ANY two fp32
+    evaluations (different summation orders); each flip moves an isolated row of a gradient by O(1/s).  Both fp32 results then
+    differ from the exact one by the same kind of sparse O(1e-3) perturbations; what can be demanded is that the HIP path is not
+    worse than the CPU path the reference itself runs.  Smooth activations are checked element-wise by the callers."""
+    got, cpu32, cpu64 = (torch.as_tensor(t).double() for t in (got, cpu32, cpu64))
+    assert got.shape == cpu64.shape, (name, got.shape, cpu64.shape)
+    ref = float(cpu64.norm())
+    e_got, e_cpu = float((got - cpu64).norm()), float((cpu32 - cpu64).norm())
+    bound = max(factor * e_cpu, floor * max(ref, 1e-30))
+    assert e_got <= bound, f"{name}: |hip - f64| = {e_got:.3e} > max({factor} x |cpu32 - f64| ({e_cpu:.3e}), {floor} x |f64| ({ref:.3e}))"

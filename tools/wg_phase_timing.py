@@ -51,3 +51,27 @@ for need_grad in (False, True):
     lib.gcpnet_debug_set_phase_timing(None, 0)
     print(f"chain forward launch {a.elapsed_time(b) * 1e3:.0f} us (need_grad={need_grad}), wg launches so far: {ops.WG_STATS}")
     report(f"wg chain fwd, last block, need_grad={need_grad}")
+
+# ---- backward of one residual block (fused weight gradients), stamps of wave 0 on the last tile of every workgroup ----------
+wreq = [mods[0]._weights()]  # (parameters: the weight gradients are needed, so the fused mode runs)
+sx = s.clone().requires_grad_(True)
+BL = ["loads + barrier", "P1 recompute", "P2 epilogue adjoint", "P3 gate adj + ds_pre", "P4 W^T ds_pre", "P5/P6 weight grads", "P7-P9 prologue adj, small w"]
+for it in range(3):
+    out_s, out_v = ops.gcp2_chain(specs[:1], sx, v, fr, wreq)
+    ds, dv = torch.randn_like(out_s), torch.randn_like(out_v)
+    buf.zero_()
+    if it == 2:
+        lib.gcpnet_debug_set_phase_timing(C.c_void_p(buf.data_ptr()), ntiles)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    torch.autograd.backward([out_s, out_v], [ds, dv])
+    b.record()
+    torch.cuda.synchronize()
+lib.gcpnet_debug_set_phase_timing(None, 0)
+print(f"one-block backward (incl. reduces) {a.elapsed_time(b) * 1e3:.0f} us; wg launches: {ops.WG_STATS}")
+t = buf.view(ntiles, 8).cpu().double()
+t = t[t[:, 7] > 0]
+d = t[:, 1:8] - t[:, :7]
+print(f"workgroups with stamps: {t.shape[0]}, tile total median {(t[:, 7] - t[:, 0]).median().item():.0f} cycles")
+for i, lab in enumerate(BL):
+    print(f"   {lab:28s} median {d[:, i].median().item():9.0f}  mean {d[:, i].mean().item():9.0f}  max {d[:, i].max().item():9.0f}")
