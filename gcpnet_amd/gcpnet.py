@@ -82,7 +82,7 @@ class GCP2(nn.Module):
                                else max(self.vector_input_dim, self.vector_output_dim))
             frame_dim = 9 if not ablate_frame_updates else 0
             self.vector_down = nn.Linear(self.vector_input_dim, self.hidden_dim, bias=False)
-            self.scalar_out = nn.Linear(self.hidden_dim + self.scalar_input_dim + frame_dim, self.scalar_output_dim)
+            self.scalar_out = self._make_scalar_out(self.hidden_dim + self.scalar_input_dim + frame_dim, self.scalar_output_dim)
             if not ablate_frame_updates:
                 self.vector_down_frames = nn.Linear(self.vector_input_dim, 3, bias=False)
             if self.vector_output_dim:
@@ -93,8 +93,11 @@ class GCP2(nn.Module):
                 elif self.vector_gate:
                     self.vector_out_scale = nn.Linear(self.scalar_output_dim, self.vector_output_dim)
         else:
-            self.scalar_out = nn.Linear(self.scalar_input_dim, self.scalar_output_dim)
+            self.scalar_out = self._make_scalar_out(self.scalar_input_dim, self.scalar_output_dim)
         self._pack_cache: dict = {}
+
+    def _make_scalar_out(self, in_dim: int, out_dim: int) -> nn.Module:
+        return nn.Linear(in_dim, out_dim)
 
     # ---- kernel dispatch ------------------------------------------------------------------------------------
     def _vmode(self) -> int:
@@ -126,9 +129,39 @@ class GCP2(nn.Module):
                    row_frames: Optional[torch.Tensor], residual: bool = False):
         """Runs the block on rows whose inputs are concatenations of (optionally gathered) sources.  `row_frames`
         holds one frame per row.  With `residual` the result is x + GCP(x) for the single source x (ResGCP)."""
+        ablating = self.ablate_scalars or self.ablate_vectors
+        if not ablating:
+            return self._apply_rows(s_sources, s_plans, v_sources, v_plans, row_frames, residual)
+        # ablations (:416-417, :466-467): the block sees zero inputs and returns zero outputs for the ablated kind; a ResGCP
+        # (:921-924) still adds the block's result to the UN-ablated message, so the residual add is done outside the kernel
+        zin = bool(self.vector_input_dim)  # (a block without vector input passes its scalars through un-ablated, :439-441)
+        zs = [torch.zeros_like(t) for t in s_sources] if (self.ablate_scalars and zin) else s_sources
+        zv = [torch.zeros_like(t) for t in v_sources] if (self.ablate_vectors and zin) else v_sources
+        out = self._ablate_outputs(self._apply_rows(zs, s_plans, zv, v_plans, row_frames, False))
+        if residual:
+            if isinstance(out, tuple):
+                return ops.axpy(s_sources[0], out[0], 1.0), ops.axpy(v_sources[0], out[1], 1.0)
+            return ops.axpy(s_sources[0], out, 1.0)
+        return out
+
+    def _apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool):
         spec = self.make_spec(s_plans, v_plans, residual)
-        use_frames = spec.use_frames
-        return ops.gcp2(spec, s_sources, v_sources, row_frames if use_frames else None, self._weights())
+        return ops.gcp2(spec, s_sources, v_sources, row_frames if spec.use_frames else None, self._weights())
+
+    def _ablate_outputs(self, out):
+        """:443-446, :466-467 -- ablated outputs are zeros (of the right shape)."""
+        if not (self.ablate_scalars or self.ablate_vectors):
+            return out
+        if not isinstance(out, tuple):  # no vector output: the nonlinearity is applied to the zeroed pre-activation (:443-446)
+            if not self.ablate_scalars:
+                return out
+            return torch.full_like(out, 0.5) if self.act_s == "sigmoid" else torch.zeros_like(out)
+        s_out, v_out = out
+        if self.ablate_scalars:
+            s_out = torch.zeros_like(s_out)
+        if self.ablate_vectors:
+            v_out = torch.zeros_like(v_out)
+        return s_out, v_out
 
     def forward(self, s_maybe_v, edge_index, frames, node_inputs: bool = False, node_mask=None):
         """:394-468.  Returns ScalarVector, or a Tensor when the block has no vector output."""
@@ -136,10 +169,6 @@ class GCP2(nn.Module):
             _unsupported("GCP2.forward(node_mask=...)")
         if self.vector_input_dim:
             s, v = s_maybe_v
-            if self.ablate_scalars:
-                s = torch.zeros_like(s)
-            if self.ablate_vectors:
-                v = torch.zeros_like(v)
             row_frames = None
             if not self.ablate_frame_updates:
                 if node_inputs:
@@ -152,13 +181,8 @@ class GCP2(nn.Module):
         else:
             out = self.apply_rows([s_maybe_v], [None], [], [], None)
         if not self.vector_output_dim:
-            return torch.zeros_like(out) if self.ablate_scalars else out
-        s_out, v_out = out
-        if self.ablate_scalars:
-            s_out = torch.zeros_like(s_out)
-        if self.ablate_vectors:
-            v_out = torch.zeros_like(v_out)
-        return ScalarVector(s_out, v_out)
+            return out
+        return ScalarVector(*out)
 
 
 class GCP3(GCP2):
@@ -174,6 +198,7 @@ class GCP3(GCP2):
                  vector_residual: bool = False, vector_frame_residual: bool = False, ablate_frame_updates: bool = False,
                  ablate_scalars: bool = False, ablate_vectors: bool = False, enable_e3_equivariance: bool = False,
                  scalarization_vectorization_output_dim: int = 3, **kwargs):
+        object.__setattr__(self, "_ff_out", bool(feedforward_out))  # (read by _make_scalar_out during the base constructor)
         super().__init__(input_dims, output_dims, nonlinearities=nonlinearities, scalar_gate=scalar_gate, vector_gate=vector_gate,
                          frame_gate=frame_gate, sigma_frame_gate=sigma_frame_gate, bottleneck=bottleneck,
                          vector_residual=vector_residual, vector_frame_residual=vector_frame_residual,
@@ -184,14 +209,19 @@ class GCP3(GCP2):
         self.feedforward_out = bool(feedforward_out)
         if self.feedforward_out:
             self.act_mid = canonical_act(scalar_out_nonlinearity)
-            first = self.scalar_out  # same slot in the module order, so state_dict keys line up with the reference's
-            self.scalar_out = nn.Sequential(first, nn.Identity(),  # (the activation itself runs inside the kernel)
-                                            nn.Linear(self.scalar_output_dim, self.scalar_output_dim))
             self._pack_cache_first: dict = {}
 
-    def apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool = False):
+    def _make_scalar_out(self, in_dim: int, out_dim: int) -> nn.Module:
+        """:529-533 / :552-556 -- both Linears are created here, at the reference's position in the construction order (same
+        state_dict keys AND the same RNG consumption, so the same seed gives the same initial weights)."""
+        if not self._ff_out:
+            return nn.Linear(in_dim, out_dim)
+        return nn.Sequential(nn.Linear(in_dim, out_dim), nn.Identity(),  # (the activation itself runs inside the kernel)
+                             nn.Linear(out_dim, out_dim))
+
+    def _apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool = False):
         if not self.feedforward_out:
-            return super().apply_rows(s_sources, s_plans, v_sources, v_plans, row_frames, residual)
+            return super()._apply_rows(s_sources, s_plans, v_sources, v_plans, row_frames, residual)
         first, second = self.scalar_out[0], self.scalar_out[2]
         g = lambda name: getattr(self, name).weight if hasattr(self, name) else None
         spec = self.make_spec(s_plans, v_plans, False)

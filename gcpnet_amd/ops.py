@@ -88,12 +88,16 @@ class GraphPlan:
         """Mean frame over each node's out-edges (row == node); zero for nodes without out-edges.
         scalarize(node_inputs=True) (components/__init__.py:286,302,314-323) is linear in the frame, so the
         gather-by-row / project / scatter-mean-by-row sequence equals one projection onto this mean frame."""
-        key = (frames.data_ptr(), frames._version)
-        if self._fbar_key != key:
+        import weakref
+
+        # keyed on the tensor OBJECT (weak reference) and its version: a frames tensor that was dropped and recomputed may
+        # come back at the same address (caching allocator), and tensors filled through a raw pointer keep version 0
+        hit = self._fbar_key
+        if hit is None or hit[0]() is not frames or hit[1] != frames._version:
             with torch.no_grad():
                 flat = _req(frames, "frames").reshape(self.n_edges, 9)
                 self._fbar = segment_reduce(flat, self.row, mean=True).reshape(self.n_nodes, 3, 3)
-            self._fbar_key = key
+            self._fbar_key = (weakref.ref(frames), frames._version)
         return self._fbar
 
 
@@ -162,6 +166,11 @@ def gather_rows(x: Tensor, plan: GatherPlan) -> Tensor:
 # ==============================================================================================================
 def localize(x: Tensor, plan: GraphPlan, norm_x_diff: bool = True) -> Tensor:
     lib = _lib.load()
+    if x.requires_grad and torch.is_grad_enabled():
+        # the reference's frames are differentiable w.r.t. the positions; every shipped pipeline builds them from data
+        # (no gradient), and they are constants of the step here
+        raise NotImplementedError("gcpnet_amd.localize: frames are constants of the step; positions that require grad are "
+                                  "not differentiated through (call it under torch.no_grad() or on x.detach())")
     x = _req(x.detach(), "x")
     frames = torch.empty((plan.n_edges, 3, 3), dtype=torch.float32, device=x.device)
     check(lib.gcpnet_localize(plan.n_edges, _p(plan.row.idx), _p(plan.col.idx), _p(x), int(norm_x_diff), _p(frames),
@@ -324,10 +333,21 @@ def _opts_struct(spec: Gcp2Spec, fused_residual: bool = False) -> Gcp2Opts:
     return o
 
 
+_PACK_EPOCH = 0
+
+
+def invalidate_packs() -> None:
+    """Forces every packed-weight image to be rebuilt at its next use.  The caches are keyed on (data_ptr, _version) of the
+    weights, which in-place updates through `p.data` (legacy optimizers, EMA / SWA weight swaps, `p.data.copy_`) do not
+    change: code that updates weights that way calls this after the update."""
+    global _PACK_EPOCH
+    _PACK_EPOCH += 1
+
+
 def _pack(spec: Gcp2Spec, w) -> Tensor:
     lib = _lib.load()
     w_scalar, w_gate = w[0], w[5]
-    key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate, w[2], w[3], w[4]))
+    key = (_PACK_EPOCH,) + tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate, w[2], w[3], w[4]))
     cache = spec.pack_cache
     if cache is not None and cache.get("key") == key:
         return cache["pack"]
@@ -355,7 +375,7 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
     """Packed image of scalar_out / vector_out_scale for the workgroup kernels (gcpnet_wg_pack), cached per weight version."""
     lib = _lib.load()
     w_scalar, w_gate = w[0], w[5]
-    key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
+    key = (_PACK_EPOCH,) + tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
     cache = spec.pack_cache
     if cache is not None and cache.get("wg_key") == key:
         return cache["wg_pack"]
