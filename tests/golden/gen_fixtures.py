@@ -149,25 +149,7 @@ def fx_layernorm():
                 "w.scalar_norm.bias": ln.scalar_norm.bias.grad})
 
 
-def nms_like_batch(n_graphs, n_body, seed, h_dim=1, chi_dim=3, e_dim=17, xi_dim=1, int_h=False, n_types=9):
-    """Batch of fully-connected n-body graphs (block-diagonal collation as PyG does), seeded random features."""
-    g = torch.Generator().manual_seed(seed)
-    rows, cols, bidx = [], [], []
-    for k in range(n_graphs):
-        idx = torch.arange(n_body)
-        r, c = torch.meshgrid(idx, idx, indexing="ij")
-        keep = r != c
-        rows.append(r[keep] + k * n_body)
-        cols.append(c[keep] + k * n_body)
-        bidx += [k] * n_body
-    ei = torch.stack((torch.cat(rows), torch.cat(cols)))
-    n, e = n_graphs * n_body, ei.shape[1]
-    h = torch.randint(0, n_types, (n,), generator=g) if int_h else torch.randn(n, h_dim, generator=g)
-    return dict(
-        h=h, chi=torch.randn(n, chi_dim, 3, generator=g), e=torch.randn(e, e_dim, generator=g),
-        xi=torch.randn(e, xi_dim, 3, generator=g), x=torch.randn(n, 3, generator=g) * 2 + 1.5,
-        edge_index=ei, batch=torch.tensor(bidx),
-    )
+from gen_helpers import nms_like_batch  # noqa: E402  (shared with tests/test_full_size.py)
 
 
 def fx_embedding():
@@ -267,6 +249,9 @@ def fx_models():
         gn.GCPInteractions(nd, ed, cfg=cfg, layer_cfg=lc, dropout=0.0, updating_node_positions=True)
         for _ in range(2))
     b = nms_like_batch(3, 5, 71)
+    b["label"] = b["x"] + 0.3 * randn(15, 3, seed=77)  # step(): MSELoss(x_pred, label), gcpnet_nms_module.py:153-158
+    for k in ("h", "chi", "e", "xi"):
+        b[k] = b[k].requires_grad_()
     bag = ref_stubs.Bag(**b)
     cen, bag.x = comp.centralize(bag, "x", bag.batch)
     bag.f_ij = comp.localize(bag.x, bag.edge_index, norm_x_diff=True)
@@ -276,8 +261,13 @@ def fx_models():
     x_out = comp.decentralize(bag, "x", bag.batch, cen)
     params = {"gcp_embedding." + k: v for k, v in emb.state_dict().items()}
     params.update({"interaction_layers." + k: v for k, v in layers.state_dict().items()})
-    save("model_nms_small", params=params, inputs=b, outputs=dict(h=h, chi=chi, e=e, xi=xi, x=x_out, f_ij=bag.f_ij),
-         meta=dict(num_layers=2, num_message_layers=4))
+    loss = torch.nn.functional.mse_loss(x_out, b["label"])
+    loss.backward()
+    grads = {k: b[k].grad for k in ("h", "chi", "e", "xi")}
+    grads.update({"w.gcp_embedding." + k: p.grad for k, p in emb.named_parameters() if p.grad is not None})
+    grads.update({"w.interaction_layers." + k: p.grad for k, p in layers.named_parameters() if p.grad is not None})
+    save("model_nms_small", params=params, inputs=b, outputs=dict(h=h, chi=chi, e=e, xi=xi, x=x_out, f_ij=bag.f_ij, loss=loss),
+         grads=grads, meta=dict(num_layers=2, num_message_layers=4))
 
     # --- LBA-style: int atom types -> (20,4)/(8,4), 2 layers, readout
     torch.manual_seed(72)
@@ -292,6 +282,9 @@ def fx_models():
     dense = torch.nn.Sequential(torch.nn.Linear(20, 40), torch.nn.ReLU(), torch.nn.Dropout(0.1),
                                 torch.nn.Linear(40, 1)).eval()
     b = nms_like_batch(4, 6, 73, chi_dim=2, e_dim=16, xi_dim=1, int_h=True)
+    b["label"] = randn(4, seed=78)  # step(): MSELoss(pred, label), gcpnet_lba_module.py:188-193
+    for k in ("chi", "e", "xi"):
+        b[k] = b[k].requires_grad_()
     bag = ref_stubs.Bag(**b)
     _, bag.x = comp.centralize(bag, "x", bag.batch)
     bag.f_ij = comp.localize(bag.x, bag.edge_index, norm_x_diff=True)
@@ -307,7 +300,13 @@ def fx_models():
     params.update({"invariant_node_projection.0." + k: v for k, v in proj_norm.state_dict().items()})
     params.update({"invariant_node_projection.1." + k: v for k, v in proj.state_dict().items()})
     params.update({"dense." + k: v for k, v in dense.state_dict().items()})
-    save("model_lba_small", params=params, inputs=b, outputs=dict(h=h, chi=chi, pred=pred),
+    loss = torch.nn.functional.mse_loss(pred, b["label"])
+    loss.backward()
+    grads = {k: b[k].grad for k in ("chi", "e", "xi")}
+    for pre, mod in (("gcp_embedding.", emb), ("interaction_layers.", layers), ("invariant_node_projection.0.", proj_norm),
+                     ("invariant_node_projection.1.", proj), ("dense.", dense)):
+        grads.update({"w." + pre + k: p.grad for k, p in mod.named_parameters() if p.grad is not None})
+    save("model_lba_small", params=params, inputs=b, outputs=dict(h=h, chi=chi, pred=pred, loss=loss), grads=grads,
          meta=dict(num_layers=2, num_message_layers=4))
 
 

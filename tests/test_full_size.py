@@ -1,0 +1,166 @@
+"""GPU parity at the sizes and model shapes BASELINE.json names (configs[1..4]), against the CPU oracle:
+
+  * one GCPInteractions layer, fwd + bwd, on the FULL configs[1] graph (10 000 nodes / ~160 000 edges, (128,16));
+  * the same at configs[4] dims (256,32) on a 10 000-node / ~100 000-edge radius graph;
+  * `step()` (forward + MSE loss + backward to every parameter) of the LBA model at its shipped shape, (100,16) x 8 layers, on a
+    batch of 16 radius graphs (configs[2]);
+  * `step()` of the NMS model at the small_20body shape: 100 fully-connected 20-body graphs = 2 000 nodes / 38 000 edges,
+    (64,16) x 4 layers with position updates (configs[3], single device).
+
+Forward values: element-wise at 1e-5 of the output scale (ReLU is continuous: kinks do not matter there).  Gradients: smooth
+activation (silu) element-wise at 1e-4; the shipped ReLU configs through helpers.as_accurate (float64 oracle as the yardstick)."""
+import pytest
+import torch
+
+from oracle import gcp_oracle as O
+from tests.helpers import as_accurate, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gcpnet_amd
+
+    return gcpnet_amd
+
+
+def _layer_case(G, n_nodes, k, dims, act, seed):
+    from gcpnet_amd.synthetic import make_inputs
+
+    ins = make_inputs(n_nodes, k, node_dims=dims, seed=seed)
+    ei, x = ins.pop("edge_index"), ins.pop("x")
+    fr = O.localize(x, ei)
+    torch.manual_seed(seed + 1)
+    layer = G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(scalar_nonlinearity=act), layer_cfg=G.default_layer_cfg(),
+                              dropout=0.0).cuda().eval()
+    ocfg = O.default_module_cfg(scalar_nonlinearity=act, nonlinearities=(act, None))
+    g = torch.Generator().manual_seed(seed + 2)
+
+    def oracle(dtype):
+        P = {k_: t.detach().cpu().to(dtype).requires_grad_() for k_, t in layer.state_dict().items()}
+        ci = {k_: t.clone().to(dtype).requires_grad_() for k_, t in ins.items()}
+        wh, wc = O.gcp_interactions(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], ei, fr.to(dtype), ocfg, O.default_layer_cfg())
+        return P, ci, wh, wc
+
+    P, ci, wh, wc = oracle(torch.float32)
+    gi = {k_: t.cuda().requires_grad_() for k_, t in ins.items()}
+    gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
+    close(gh.detach().cpu(), wh.detach(), atol=1e-5 * max(1.0, float(wh.detach().abs().max())), rtol=1e-5)
+    close(gc.detach().cpu(), wc.detach(), atol=1e-5 * max(1.0, float(wc.detach().abs().max())), rtol=1e-5)
+    # a random linear functional of the outputs (a squared loss behind a LayerNorm has no gradient through the scalar path)
+    lh, lc = torch.randn(wh.shape, generator=g), torch.randn(wc.shape, generator=g)
+    ((wh * lh).sum() + (wc * lc).sum()).backward()
+    ((gh * lh.cuda()).sum() + (gc * lc.cuda()).sum()).backward()
+    if act == "silu":
+        for k_ in ins:
+            close(gi[k_].grad.cpu(), ci[k_].grad, atol=2e-5 * float(ci[k_].grad.abs().max()), rtol=1e-4)
+        for k_, p in layer.named_parameters():
+            close(p.grad.cpu(), P[k_].grad, atol=2e-5 * float(P[k_].grad.abs().max()), rtol=1e-4)
+    else:
+        P64, c64, wh64, wc64 = oracle(torch.float64)
+        ((wh64 * lh.double()).sum() + (wc64 * lc.double()).sum()).backward()
+        for k_ in ins:
+            as_accurate(gi[k_].grad.cpu(), ci[k_].grad, c64[k_].grad, k_)
+        for k_, p in layer.named_parameters():
+            as_accurate(p.grad.cpu(), P[k_].grad, P64[k_].grad, k_)
+
+
+@pytest.mark.parametrize("act", ["silu", "relu"])
+def test_layer_full_c2_graph(G, act):
+    """BASELINE configs[1] at full size: the graph bench.py times."""
+    _layer_case(G, 10000, 16, (128, 16), act, seed=0)
+
+
+def test_layer_c5_dims_100k_edges(G):
+    """BASELINE configs[4] dims (256,32) on a 10 000-node / 100 000-edge radius graph (K = 10 as in the full configuration)."""
+    _layer_case(G, 10000, 10, (256, 32), "silu", seed=3)
+
+
+def _radius_batch(n_graphs, atoms, k, seed, node_feats):
+    """Collated batch of `n_graphs` independent radius graphs (block-diagonal edge_index, PyG collation semantics)."""
+    from gcpnet_amd.synthetic import radius_graph
+
+    g = torch.Generator().manual_seed(seed)
+    xs, eis, bidx, off = [], [], [], 0
+    for i in range(n_graphs):
+        n = atoms + (i % 5) * 3  # ragged graph sizes
+        x, ei = radius_graph(n, k, seed=seed + i, expected_in_radius=25.0)
+        xs.append(x)
+        eis.append(ei + off)
+        bidx += [i] * n
+        off += n
+    x, ei = torch.cat(xs), torch.cat(eis, dim=1)
+    n, e = x.shape[0], ei.shape[1]
+    b = dict(x=x, edge_index=ei, batch=torch.tensor(bidx))
+    b.update(node_feats(n, g))
+    return b, n, e, g
+
+
+def _step_case(G, model, oracle_forward, batch, float_keys, pred_key):
+    P = {k: t.detach().cpu().clone().requires_grad_(t.is_floating_point()) for k, t in model.state_dict().items()}
+    P64 = {k: (t.detach().double() if t.is_floating_point() else t.detach().clone()).requires_grad_(t.is_floating_point())
+           for k, t in P.items()}
+    ci = dict(batch)
+    c64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    for k in float_keys:
+        ci[k] = ci[k].clone().requires_grad_()
+        c64[k] = c64[k].clone().requires_grad_()
+    out = oracle_forward(P, ci)
+    loss = torch.nn.functional.mse_loss(out[pred_key], ci["label"])
+    loss.backward()
+    out64 = oracle_forward(P64, c64)
+    torch.nn.functional.mse_loss(out64[pred_key], c64["label"]).backward()
+    b = G.Batch(**{k: v.cuda() for k, v in batch.items()})
+    for k in float_keys:
+        setattr(b, k, getattr(b, k).requires_grad_())
+    leaves = {k: getattr(b, k) for k in float_keys}
+    gl, preds, _ = model.step(b)
+    close(preds.detach().cpu(), out[pred_key].detach(), atol=1e-4 * max(1.0, float(out[pred_key].detach().abs().max())), rtol=1e-4)
+    close(gl.detach().cpu(), loss.detach(), atol=1e-6, rtol=1e-4)
+    gl.backward()
+    for k in float_keys:
+        as_accurate(leaves[k].grad.cpu(), ci[k].grad, c64[k].grad, k)
+    n = 0
+    top = max(float(t.grad.norm()) for t in P64.values() if t.grad is not None)  # parameters whose gradient (almost) vanishes
+    for k, p in model.named_parameters():                                        # are held to 1e-6 of the largest one
+        if P[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        as_accurate(p.grad.cpu(), P[k].grad, P64[k].grad, k, abs_floor=1e-6 * top)
+        n += 1
+    assert n > 100
+
+
+def test_lba_step_shipped_shape(G):
+    """configs[2]: gcpnet_lba.yaml's model -- (100,16) hidden, 8 GCPInteractions layers, atom-type embedding, invariant
+    projection + graph-mean readout + dense head -- on 16 radius graphs (r = 4.5, <= 32 neighbours), step() fwd + bwd."""
+    torch.manual_seed(31)
+    model_cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=100, chi_hidden_dim=16, e_hidden_dim=32,
+                     xi_hidden_dim=4, output_dim=1, output_scale_factor=2, num_encoder_layers=8, dropout=0.0, dense_dropout=0.1)
+    model = G.GCPNetLBA(model_cfg=model_cfg, module_cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg()).cuda().eval()
+
+    def feats(n, g):
+        return dict(h=torch.randint(0, 9, (n,), generator=g), chi=torch.randn(n, 2, 3, generator=g))
+
+    b, n, e, g = _radius_batch(16, 40, 32, 32, feats)
+    b["e"], b["xi"] = torch.randn(e, 16, generator=g), torch.randn(e, 1, 3, generator=g)
+    b["label"] = torch.randn(16, generator=g)
+    fwd = lambda P, i: O.lba_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(), 8)
+    _step_case(G, model, fwd, b, ("chi", "e", "xi"), "pred")
+
+
+def test_nms_step_20body_shape(G):
+    """configs[3] on one device: 100 fully-connected 20-body graphs (2 000 nodes / 38 000 edges), gcpnet_nms.yaml's model --
+    (64,16) hidden, 4 layers with position updates -- step() fwd + bwd."""
+    from tests.golden.gen_helpers import nms_like_batch
+
+    torch.manual_seed(41)
+    model_cfg = dict(h_input_dim=1, chi_input_dim=3, e_input_dim=17, xi_input_dim=1, h_hidden_dim=64, chi_hidden_dim=16,
+                     e_hidden_dim=32, xi_hidden_dim=4, num_encoder_layers=4, dropout=0.0)
+    model = G.GCPNetNMS(model_cfg=model_cfg, module_cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg()).cuda().eval()
+    b = nms_like_batch(100, 20, 42)
+    assert b["edge_index"].shape[1] == 38000 and b["h"].shape[0] == 2000
+    b["label"] = b["x"] + 0.3 * torch.randn(2000, 3, generator=torch.Generator().manual_seed(43))
+    fwd = lambda P, i: O.nms_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(), 4)
+    _step_case(G, model, fwd, b, ("h", "chi", "e", "xi"), "x")

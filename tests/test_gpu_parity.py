@@ -367,6 +367,18 @@ def test_interactions_prenorm_silu_golden(G):
     close(chi.cpu(), f.o["chi"], atol=2e-5, rtol=2e-5)
 
 
+def _check_step_grads(f, model, leaves):
+    """Gradients of step() against those the reference produced (fixture tag g): every parameter and float input."""
+    params = dict(model.named_parameters())
+    n = 0
+    for k, want in f.g.items():
+        got = params[k[2:]].grad if k.startswith("w.") else leaves[k].grad
+        assert got is not None, k
+        close(got.cpu(), want, atol=1e-6 + 2e-5 * float(want.abs().max()), rtol=1e-3)
+        n += 1
+    assert n > 50
+
+
 def test_model_nms_golden(G):
     f = Fixture("model_nms_small")
     model_cfg = dict(h_input_dim=1, chi_input_dim=3, e_input_dim=17, xi_input_dim=1, h_hidden_dim=32, chi_hidden_dim=8,
@@ -375,10 +387,15 @@ def test_model_nms_golden(G):
                         layer_cfg=G.default_layer_cfg(num_message_layers=4)).cuda().eval()
     model.load_state_dict(f.p)
     b = G.Batch(**{k: v.cuda() for k, v in f.i.items()})
-    with torch.no_grad():
-        b, x = model(b)
+    for k in ("h", "chi", "e", "xi"):
+        setattr(b, k, getattr(b, k).requires_grad_())
+    leaves = {k: getattr(b, k) for k in ("h", "chi", "e", "xi")}
+    loss, _, _ = model.step(b)  # gcpnet_nms_module.py:153-158: forward + MSELoss(x_pred, label)
     for k in ("h", "chi", "e", "xi", "x", "f_ij"):
-        close(getattr(b, k).cpu(), f.o[k], atol=1e-4, rtol=1e-4)  # model-level tolerance of the reference's tests
+        close(getattr(b, k).detach().cpu(), f.o[k], atol=1e-4, rtol=1e-4)  # model-level tolerance of the reference's tests
+    close(loss.detach().cpu(), f.o["loss"], atol=1e-6, rtol=1e-4)
+    loss.backward()
+    _check_step_grads(f, model, leaves)
 
 
 def test_model_lba_golden(G):
@@ -390,11 +407,16 @@ def test_model_lba_golden(G):
                         layer_cfg=G.default_layer_cfg(num_message_layers=4)).cuda().eval()
     model.load_state_dict(f.p)
     b = G.Batch(**{k: v.cuda() for k, v in f.i.items()})
-    with torch.no_grad():
-        b, pred = model(b)
-    close(b.h.cpu(), f.o["h"], atol=1e-4, rtol=1e-4)
-    close(b.chi.cpu(), f.o["chi"], atol=1e-4, rtol=1e-4)
-    close(pred.cpu(), f.o["pred"], atol=1e-4, rtol=1e-4)
+    for k in ("chi", "e", "xi"):
+        setattr(b, k, getattr(b, k).requires_grad_())
+    leaves = {k: getattr(b, k) for k in ("chi", "e", "xi")}
+    loss, pred, _ = model.step(b)  # gcpnet_lba_module.py:188-193
+    close(b.h.detach().cpu(), f.o["h"], atol=1e-4, rtol=1e-4)
+    close(b.chi.detach().cpu(), f.o["chi"], atol=1e-4, rtol=1e-4)
+    close(pred.detach().cpu(), f.o["pred"], atol=1e-4, rtol=1e-4)
+    close(loss.detach().cpu(), f.o["loss"], atol=1e-6, rtol=1e-4)
+    loss.backward()
+    _check_step_grads(f, model, leaves)
 
 
 @pytest.mark.parametrize("act", ["silu", "relu"])

@@ -169,18 +169,41 @@ def test_interactions_prenorm_silu():
     close(chi, f.o["chi"], atol=5e-6, rtol=5e-5)
 
 
+def _step_grads(f, forward, pred_key, float_inputs):
+    """step() of the LitModules (gcpnet_nms_module.py:153-158, gcpnet_lba_module.py:188-193): MSELoss(pred, label), backward to
+    the float inputs and every parameter; compared with the gradients the reference produced (fixture tag g)."""
+    P = {k: t.clone().requires_grad_(t.is_floating_point()) for k, t in f.p.items()}
+    ins = dict(f.i)
+    for k in float_inputs:
+        ins[k] = ins[k].clone().requires_grad_()
+    out = forward(P, ins)
+    loss = torch.nn.functional.mse_loss(out[pred_key], ins["label"])
+    close(loss.detach(), f.o["loss"], atol=1e-6, rtol=1e-5)
+    loss.backward()
+    n = 0
+    for k, want in f.g.items():
+        got = P[k[2:]].grad if k.startswith("w.") else ins[k].grad
+        assert got is not None, k
+        close(got, want, atol=1e-6 + 1e-5 * float(want.abs().max()), rtol=1e-4)
+        n += 1
+    assert n > 50
+    return out
+
+
 def test_model_nms():
     f = Fixture("model_nms_small")
-    out = O.nms_forward(f.p, f.i, O.default_module_cfg(), O.default_layer_cfg(num_message_layers=4), 2)
+    out = _step_grads(f, lambda P, i: O.nms_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(num_message_layers=4), 2),
+                      "x", ("h", "chi", "e", "xi"))
     for k in ("h", "chi", "e", "xi", "x", "f_ij"):
-        close(out[k], f.o[k], atol=1e-5, rtol=1e-4)
+        close(out[k].detach(), f.o[k], atol=1e-5, rtol=1e-4)
 
 
 def test_model_lba():
     f = Fixture("model_lba_small")
-    out = O.lba_forward(f.p, f.i, O.default_module_cfg(), O.default_layer_cfg(num_message_layers=4), 2)
+    out = _step_grads(f, lambda P, i: O.lba_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(num_message_layers=4), 2),
+                      "pred", ("chi", "e", "xi"))
     for k in ("h", "chi", "pred"):
-        close(out[k], f.o[k], atol=1e-5, rtol=1e-4)
+        close(out[k].detach(), f.o[k], atol=1e-5, rtol=1e-4)
 
 
 def test_oracle_equivariance():
