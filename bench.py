@@ -1,21 +1,28 @@
 #!/usr/bin/env python
 """Benchmark of the GCP message-passing hot path on MI355X (contract: see the task statement / DESIGN.md).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py [--config c2] --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--shard graph]
 
-step      = one forward + scalar loss + backward (to inputs and weights) of a stack of `--layers` GCPInteractions
-            layers over one synthetic radius graph resident in HBM (BASELINE.json configs[1]: 10 000 nodes /
-            160 000 edges, (s, V) = (128, 16), edge dims (32, 4), GCP2, 8 message GCPs + 2 feed-forward GCPs, post-norm,
-            dropout 0); N > 1: every rank holds its own graph of that size (graphs shard by whole graphs, weak
-            scaling) and the weight gradients are all-reduced over RCCL each step.
-value     = edges processed per second by the whole job = n_gpus * E * layers * steps / max-over-ranks time.
-roofline  = the dominant kernel (forward / backward / weight-gradient GEMM of the 7-block ResGCP message chain on edge
-            rows, whichever is slowest), timed live with HIP events on the stream it is launched on: algorithmic FLOPs per
-            launch / average launch time vs the fp32 MFMA peak; its algorithmic HBM bytes / time is reported next to it.
+--config  the BASELINE.json configuration that is timed (named in config.workload):
+            c2 (default) configs[1]: synthetic radius graph, 10 000 nodes / ~160 000 edges, (s,V) = (128,16), 4 GCPInteractions layers
+            c5           configs[4]: 100 000 nodes / 1 000 000 edges, (256,32), 4 layers (fits one GPU: ~75 GB of saved activations)
+            c1 / c4      NMS model step() on 100 fully-connected 5-body / 20-body graphs ((64,16), 4 layers, position updates)
+            c3           LBA model step() on 16 radius graphs ((100,16), 8 layers, readout head)
+step      = one forward + scalar loss + backward (to inputs and weights): of the layer stack with a random linear functional of the
+            outputs as the loss (c2, c5), or the model's own step() = forward + MSELoss + backward (c1, c3, c4).  Inputs are
+            resident in HBM.  N > 1: every rank holds its own graph / batch of that size (graphs shard whole, weak scaling) and
+            the weight gradients are all-reduced over RCCL each step; `--shard graph` (c2, c5) instead splits ONE graph by
+            target-node ranges (strong scaling, gcpnet_amd.parallel.ShardedGraph).
+value     = edges processed per second by the whole job = total edges * layers * steps / max-over-ranks wall time of the K steps.
+roofline  = the dominant kernel of the step (forward / backward / weight-gradient GEMM of the 7-block ResGCP message chain on the
+            edge rows, whichever takes longest), timed live with HIP events on the stream it is launched on: algorithmic FLOPs per
+            launch / median launch time vs the fp32 MFMA peak; its algorithmic HBM bytes / time is reported next to it.
 aggregate_kernel = the scatter-mean (segmented reduction) kernel against the HBM roofline.
-cpu_baseline = the oracle (pure PyTorch on the host cores) on one step of the same stack and inputs.
+cpu_baseline = the oracle (pure PyTorch on the host cores) on the same stack, weights and inputs (full c2 workload: 1 warm-up + 3
+            timed steps; larger configurations: a bounded sample, stated), plus `parity_check`: the GPU outputs and input gradients
+            of that same step against the oracle's.
 """
 import argparse
 import json
@@ -37,15 +44,24 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--nodes", type=int, default=10000)
-    ap.add_argument("--neighbors", type=int, default=16)
-    ap.add_argument("--sdim", type=int, default=128)
-    ap.add_argument("--vdim", type=int, default=16)
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--shard", choices=["batch", "graph"], default="batch",
+                    help="N > 1: 'batch' = one graph per rank (weak scaling); 'graph' = one graph split by node ranges (strong scaling)")
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--nodes", type=int, default=None)
+    ap.add_argument("--neighbors", type=int, default=None)
+    ap.add_argument("--sdim", type=int, default=None)
+    ap.add_argument("--vdim", type=int, default=None)
+    ap.add_argument("--no-c5-block", action="store_true", help="skip the short configs[4]-size measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step-only", action="store_true", help="profiling runs: only the timed steps (no per-kernel timing, no CPU baseline)")
     ap.add_argument("--cpu-layers", type=int, default=1, help="layers of the stack the CPU baseline runs (bounded sample)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    preset = {"c2": (10000, 16, 128, 16, 4), "c5": (100000, 10, 256, 32, 4)}.get(args.config, (10000, 16, 128, 16, 4))
+    for name, val in zip(("nodes", "neighbors", "sdim", "vdim", "layers"), preset):
+        if getattr(args, name) is None:
+            setattr(args, name, val)
+    return args
 
 
 def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
@@ -86,20 +102,6 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
         keep["out"] = ops.gcp2_chain(specs, s, v, frames, ws)  # training mode: s_pre / gates / states are saved
 
     t_fwd = timeit(fwd)
-    s0, v0, ws_, packs, outs = keep["out"][0].grad_fn.state
-    ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
-    with torch.no_grad():
-        def bwd():
-            keep["bwd"] = ops.gcp2_chain_backward_data(specs, n_edges, ins, outs, frames, ws_, packs, ds, dv, [True] * n)
-
-        t_bwd = timeit(bwd)
-        assert keep["bwd"] is not None, "the chain backward kernel does not cover this shape"
-        scrs = keep["bwd"][2]
-
-        def tn():
-            ops.run_weight_grad_jobs([ops._WeightGradJob(specs[k], n_edges, [ins[k][0]], outs[k][2], scrs[k]) for k in range(n)])
-
-        t_tn = timeit(tn)
     flops = n * 2.0 * n_edges * gcp_macs(sdim, vdim, sdim, vdim)
     H = blocks[0].hidden_dim
     row_s, row_v = 4 * sdim, 12 * vdim
@@ -108,13 +110,53 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     bytes_fwd = n_edges * ((row_s + row_v + 36) + n * (row_s + row_v + row_s + gate))
     bytes_bwd = n_edges * (2 * (row_s + row_v) + 36 + n * ((row_s + row_v + gate) + (row_s + gate + ext)))
     bytes_tn = n_edges * n * ((row_s + row_s + ext) + (gate + row_s))
-    return dict(t_fwd=t_fwd, t_bwd=t_bwd, t_tn=t_tn, flops=flops, n_blocks=n,
-                bytes=dict(fwd=bytes_fwd, bwd=bytes_bwd, tn=bytes_tn))
+    fwd_name = "gcp_wg_fwd_kernel" if ops.WG_STATS["fwd_chain"] > 0 else "gcp2_chain_fwd_kernel"
+    times, kbytes, kflops = {fwd_name: t_fwd}, {fwd_name: bytes_fwd}, {fwd_name: flops}
+    s0, v0, ws_, packs, outs = keep["out"][0].grad_fn.state
+    ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
+    with torch.no_grad():
+        probe = ops.gcp2_chain_backward_data(specs, n_edges, ins, outs, frames, ws_, packs, ds, dv, [True] * n) \
+            if sdim <= 128 else None
+    if probe is not None:  # (s <= 128: one launch of the wave-per-tile chain kernel + the weight-gradient GEMMs)
+        with torch.no_grad():
+            def bwd():
+                keep["bwd"] = ops.gcp2_chain_backward_data(specs, n_edges, ins, outs, frames, ws_, packs, ds, dv, [True] * n)
+
+            times["gcp2_chain_bwd_kernel"] = timeit(bwd)
+            scrs = keep["bwd"][2]
+
+            def tn():
+                ops.run_weight_grad_jobs([ops._WeightGradJob(specs[k], n_edges, [ins[k][0]], outs[k][2], scrs[k]) for k in range(n)])
+
+            times["tn_gemm_dma_kernel(+reduce)"] = timeit(tn)
+        kbytes.update({"gcp2_chain_bwd_kernel": bytes_bwd, "tn_gemm_dma_kernel(+reduce)": bytes_tn})
+        kflops.update({"gcp2_chain_bwd_kernel": flops, "tn_gemm_dma_kernel(+reduce)": flops})
+    else:  # wider chains: block by block through the workgroup backward kernel, weight-gradient GEMMs included (2x the FLOPs)
+        del probe
+
+        def bwd_all():
+            fwd()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            torch.autograd.backward(list(keep["out"]), [ds, dv])
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) * 1e-3
+
+        ts = sorted(bwd_all() for _ in range(max(3, iters // 4)))
+        name = f"gcp_wg_bwd_kernel x{n} + weight-gradient GEMMs"
+        times[name], kbytes[name], kflops[name] = ts[len(ts) // 2], bytes_bwd + bytes_tn, 2.0 * flops
+    keep.clear()
+    return dict(times=times, bytes=kbytes, flops=kflops, n_blocks=n)
+
+
+PMC_FILE = "profiles/r02_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
 
 
 def _pmc_file():
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_e_traffic.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             return json.load(f)
     except OSError:
         return {}
@@ -154,6 +196,152 @@ def aggregate_roofline(G, ops, n_nodes, n_edges, width, label, iters=30):
             "bytes_per_launch": nbytes}
 
 
+def build_layer_workload(args, rank, world, G, ops):
+    """c2 / c5: a stack of GCPInteractions layers on one synthetic radius graph per rank (or, with --shard graph, on this rank's
+    target-node range of ONE graph).  Returns a dict with the step function and bookkeeping."""
+    from gcpnet_amd.parallel import GradAllReducer, ShardedGraph, sharded_interactions_forward
+    from gcpnet_amd.synthetic import make_inputs
+
+    node_dims, edge_dims = (args.sdim, args.vdim), (32, 4)
+    sharded = world > 1 and args.shard == "graph"
+    host = make_inputs(args.nodes, args.neighbors, node_dims, edge_dims, seed=0 if sharded else rank)
+    n_edges_global = host["edge_index"].shape[1]
+    torch.manual_seed(0)  # identical replicated weights on every rank
+    cfg, lcfg = G.default_module_cfg(), G.default_layer_cfg()
+    layers = torch.nn.ModuleList(
+        G.GCPInteractions(node_dims, edge_dims, cfg=cfg, layer_cfg=lcfg, dropout=0.0) for _ in range(args.layers)).cuda()
+    layers.train()
+    params = [p for p in layers.parameters()]
+    reducer = GradAllReducer(params) if world > 1 else None
+    g = torch.Generator().manual_seed(1)  # the loss: a random linear functional of the outputs (a squared loss behind the
+    lw = dict(h=torch.randn(args.nodes, node_dims[0], generator=g),  # final GCPLayerNorm has a vanishing gradient)
+              chi=torch.randn(args.nodes, node_dims[1], 3, generator=g))
+    if sharded:
+        sg = ShardedGraph(host["edge_index"], args.nodes, rank, world)
+        x = host["x"].cuda()
+        sg.edge_index, sg.col_local = sg.edge_index.cuda(), sg.col_local.cuda()
+        frames = G.localize(x, sg.edge_index)
+        fr_out = G.localize(x, sg.out_edge_index_global.cuda())
+        node_frames = ops.segment_reduce(fr_out.reshape(-1, 9), ops.GatherPlan(sg.out_row_local.cuda(), sg.n_local),
+                                         mean=True).reshape(sg.n_local, 3, 3)
+        ins = {"h": sg.local_nodes(host["h"]), "chi": sg.local_nodes(host["chi"]), "e": sg.local_edges(host["e"]),
+               "xi": sg.local_edges(host["xi"])}
+        ins = {k: v.cuda().clone().requires_grad_() for k, v in ins.items()}
+        lw = {k: sg.local_nodes(v).cuda() for k, v in lw.items()}
+        n_edges_rank = sg.e1 - sg.e0
+    else:
+        dev = {k: v.cuda() for k, v in host.items()}
+        frames = G.localize(dev["x"], dev["edge_index"])
+        ins = {k: dev[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
+        lw = {k: v.cuda() for k, v in lw.items()}
+        n_edges_rank = n_edges_global
+
+    def forward():
+        h, chi = ins["h"], ins["chi"]
+        for layer in layers:
+            if sharded:
+                h, chi = sharded_interactions_forward(layer, (h, chi), (ins["e"], ins["xi"]), sg, frames, node_frames)
+            else:
+                h, chi = layer((h, chi), (ins["e"], ins["xi"]), dev["edge_index"], frames)
+        return h, chi
+
+    def step():
+        for p in params:
+            p.grad = None
+        for t in ins.values():
+            t.grad = None
+        h, chi = forward()
+        loss = (h * lw["h"]).sum() + (chi * lw["chi"]).sum()
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce_sum() if sharded else reducer.all_reduce_mean()
+        return loss
+
+    total_edges = n_edges_global if sharded else world * n_edges_global
+    label = (f"synthetic radius graph r=4.5 K={args.neighbors}: {args.nodes} nodes / {n_edges_global} edges "
+             f"{'in total, split by target-node ranges over the GPUs' if sharded else 'per GPU'}, (s,V)=({args.sdim},{args.vdim}), "
+             f"edge dims (32,4), {args.layers} GCPInteractions layers (GCP2, 8 message GCPs, 2 FF GCPs, post-norm, dropout 0), "
+             f"fwd + linear-functional loss + bwd to inputs and weights")
+    return dict(step=step, forward=forward, layers=layers, ins=ins, host=host, frames=frames, lw=lw, n_edges=n_edges_global,
+                total_edges=total_edges, n_layers=args.layers, label=label, sharded=sharded, n_edges_rank=n_edges_rank,
+                scaling="strong" if sharded else "weak")
+
+
+def build_model_workload(args, rank, world, G, ops):
+    """c1 / c4: NMS model step() on 100 fully-connected n-body graphs; c3: LBA model step() on 16 radius graphs."""
+    from gcpnet_amd.parallel import GradAllReducer
+    from gcpnet_amd.synthetic import model_batch
+
+    torch.manual_seed(0)
+    batch, model_cfg, kind, label = model_batch(args.config, seed=rank)
+    Model = G.GCPNetNMS if kind == "nms" else G.GCPNetLBA
+    model = Model(model_cfg=model_cfg, module_cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg()).cuda().train()
+    params = [p for p in model.parameters()]
+    reducer = GradAllReducer(params) if world > 1 else None
+    dev = {k: v.cuda() for k, v in batch.items()}
+    n_edges = batch["edge_index"].shape[1]
+
+    def step():
+        for p in params:
+            p.grad = None
+        b = G.Batch(**dev)
+        loss, _, _ = model.step(b)
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce_mean()
+        return loss
+
+    return dict(step=step, n_edges=n_edges, total_edges=world * n_edges, n_layers=model_cfg["num_encoder_layers"], label=label,
+                sharded=False, scaling="weak", model=model)
+
+
+def timed_steps(step, steps, warmup, world, dist):
+    """W warm-up steps, then K steps between barrier + synchronize on both sides (wall clock, MAX over ranks) -- plus one HIP
+    event pair per step on the compute stream, whose median is reported next to the mean."""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        loss = step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per = sorted(a.elapsed_time(b) for a, b in ev)
+    assert torch.isfinite(loss).item(), "non-finite loss"
+    return elapsed, per[len(per) // 2]
+
+
+def c5_block(G, ops, args):
+    """A short measurement at BASELINE configs[4] size on this one GPU (100 000 nodes / 1 000 000 edges, (256,32), 4 layers),
+    reported inside the default line: the configuration north_star's target sentence is written on."""
+    import copy
+    from gcpnet_amd.synthetic import layer_flops
+
+    a = copy.copy(args)
+    a.config, a.nodes, a.neighbors, a.sdim, a.vdim, a.layers, a.shard = "c5", 100000, 10, 256, 32, 4, "batch"
+    wl = build_layer_workload(a, 0, 1, G, ops)
+    elapsed, med = timed_steps(wl["step"], 3, 1, 1, None)
+    fl = layer_flops(a.nodes, wl["n_edges"], (256, 32), (32, 4))["fwd_bwd"] * a.layers
+    out = {"workload": wl["label"], "n_edges": wl["n_edges"], "steps": 3, "warmup": 1, "ms_per_step": elapsed / 3 * 1e3,
+           "ms_per_step_median": med, "edges_per_s": wl["n_edges"] * a.layers * 3 / elapsed,
+           "algorithmic_tflops_per_s": fl * 3 / elapsed / 1e12,
+           "frac_of_fp32_mfma_peak": fl * 3 / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -176,102 +364,67 @@ def main():
 
     import gcpnet_amd as G
     from gcpnet_amd import ops
-    from gcpnet_amd.parallel import GradAllReducer
-    from gcpnet_amd.synthetic import layer_flops, make_inputs
+    from gcpnet_amd.synthetic import layer_flops
 
-    node_dims, edge_dims = (args.sdim, args.vdim), (32, 4)
-    host = make_inputs(args.nodes, args.neighbors, node_dims, edge_dims, seed=rank)  # each rank: its own graph
-    n_edges = host["edge_index"].shape[1]
-    dev = {k: v.cuda() for k, v in host.items()}
-    torch.manual_seed(0)  # identical replicated weights on every rank
-    cfg, lcfg = G.default_module_cfg(), G.default_layer_cfg()
-    layers = torch.nn.ModuleList(
-        G.GCPInteractions(node_dims, edge_dims, cfg=cfg, layer_cfg=lcfg, dropout=0.0) for _ in range(args.layers)).cuda()
-    layers.train()
-    params = [p for p in layers.parameters()]
-    reducer = GradAllReducer(params) if world > 1 else None
-    frames = G.localize(dev["x"], dev["edge_index"])
-    ins = {k: dev[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
-
-    def step():
-        for p in params:
-            p.grad = None
-        for t in ins.values():
-            t.grad = None
-        h, chi = ins["h"], ins["chi"]
-        for layer in layers:
-            h, chi = layer((h, chi), (ins["e"], ins["xi"]), dev["edge_index"], frames)
-        loss = h.square().mean() + chi.square().mean()
-        loss.backward()
-        if reducer is not None:
-            reducer.all_reduce_mean()
-        return loss
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(loss).item(), "non-finite loss"
+    is_stack = args.config in ("c2", "c5")
+    wl = (build_layer_workload if is_stack else build_model_workload)(args, rank, world, G, ops)
+    elapsed, median_ms = timed_steps(wl["step"], args.steps, args.warmup, world, dist)
 
     if rank == 0 and args.step_only:
-        print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup}))
+        print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms, "steps": args.steps,
+                          "warmup": args.warmup, "config": args.config}))
     elif rank == 0:
-        value = world * n_edges * args.layers * args.steps / elapsed
-        fl = layer_flops(args.nodes, n_edges, node_dims, edge_dims)
-        kr = kernel_roofline(G, ops, layers[0], frames, n_edges, args.sdim, args.vdim)
-        times = {"gcp2_chain_fwd_kernel": kr["t_fwd"], "gcp2_chain_bwd_kernel": kr["t_bwd"],
-                 "tn_gemm_dma_kernel(+reduce)": kr["t_tn"]}
-        kbytes = {"gcp2_chain_fwd_kernel": kr["bytes"]["fwd"], "gcp2_chain_bwd_kernel": kr["bytes"]["bwd"],
-                  "tn_gemm_dma_kernel(+reduce)": kr["bytes"]["tn"]}
-        dom = max(times, key=times.get)  # each of the three does the same algorithmic work: n_blocks * 2 * E * gcp_macs FLOP
-        achieved = kr["flops"] / times[dom] / 1e12
+        value = wl["total_edges"] * wl["n_layers"] * args.steps / elapsed
         out = {
             "metric": "processed edges/sec (GCP fwd+bwd)", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_median": median_ms,
+            "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"synthetic radius graph r=4.5 K={args.neighbors}: {args.nodes} nodes / {n_edges} edges per GPU, "
-                            f"(s,V)=({args.sdim},{args.vdim}), edge dims (32,4), {args.layers} GCPInteractions layers "
-                            f"(GCP2, 8 message GCPs, 2 FF GCPs, post-norm, dropout 0), fwd+loss+bwd to inputs and weights",
-                "n_nodes": args.nodes, "n_edges": n_edges, "layers": args.layers,
-                "parallelism": f"graphs sharded 1 per GPU x{world}, RCCL all-reduce of weight grads" if world > 1 else "single GPU",
+                "workload": f"{args.config}: {wl['label']}", "n_edges": wl["n_edges"], "layers": wl["n_layers"],
+                "parallelism": ("single GPU" if world == 1 else
+                                (f"one graph split by target-node ranges over {world} GPUs: per layer all-gather of node features / "
+                                 f"reduce-scatter of their gradients + all-reduce (sum) of weight grads, RCCL" if wl["sharded"] else
+                                 f"one graph (batch) per GPU x{world}, RCCL all-reduce (mean) of weight grads")),
             },
-            "whole_step": {
-                "algorithmic_tflops_per_s": fl["fwd_bwd"] * args.layers * args.steps / elapsed / 1e12,
-                "frac_of_fp32_mfma_peak": fl["fwd_bwd"] * args.layers * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            },
-            "roofline": {
+        }
+        if is_stack:
+            node_dims = (args.sdim, args.vdim)
+            fl = layer_flops(args.nodes, wl["n_edges"], node_dims, (32, 4))["fwd_bwd"] * args.layers
+            per_job = fl * (1 if wl["sharded"] else world)
+            out["whole_step"] = {"algorithmic_tflops_per_s": per_job * args.steps / elapsed / 1e12,
+                                 "frac_of_fp32_mfma_peak": per_job * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS / world}
+        if is_stack and not wl["sharded"]:
+            kr = kernel_roofline(G, ops, wl["layers"][0], wl["frames"], wl["n_edges"], args.sdim, args.vdim)
+            times, kbytes = kr["times"], kr["bytes"]
+            dom = min(times, key=lambda k: kr["flops"][k] / times[k])  # the kernel furthest below its roofline
+            achieved = kr["flops"][dom] / times[dom] / 1e12
+            out["roofline"] = {
                 "kernel": f"{dom} on the {kr['n_blocks']}-block residual message chain (s,V)->(s,V) of one layer, E rows",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom), "mfma_busy_frac_pmc": pmc_mfma_busy(dom),
-                "avg_launch_ms": times[dom] * 1e3, "flop_per_launch": kr["flops"],
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
+                "traffic_source": PMC_FILE if pmc_traffic(dom) is not None else None,
+                "mfma_busy_frac_pmc": pmc_mfma_busy(dom),
+                "median_launch_ms": times[dom] * 1e3, "flop_per_launch": kr["flops"][dom],
                 "algorithmic_hbm_gbs": kbytes[dom] / times[dom] / 1e9,
                 "algorithmic_hbm_frac": kbytes[dom] / times[dom] / 1e9 / PEAK_HBM_GBS,
                 "all_kernels_ms": {k: v * 1e3 for k, v in times.items()},
-                "all_kernels_tflops": {k: kr["flops"] / v / 1e12 for k, v in times.items()},
+                "all_kernels_tflops": {k: kr["flops"][k] / v / 1e12 for k, v in times.items()},
                 "all_kernels_algorithmic_hbm_gbs": {k: kbytes[k] / v / 1e9 for k, v in times.items()},
-            },
+            }
+            width = args.sdim + 3 * args.vdim
             # the gather / aggregate kernel against the HBM roofline, at this run's size and at BASELINE configs[4]'s
             # (100k nodes / 1M edges, (256,32): 1.5 GB per launch, far beyond the 256 MB Infinity Cache)
-            "aggregate_kernel": aggregate_roofline(G, ops, args.nodes, n_edges, args.sdim + 3 * args.vdim,
-                                                   f"{args.nodes} nodes / {n_edges} edges, width s+3V = {args.sdim + 3 * args.vdim}"),
-            "aggregate_kernel_c5": aggregate_roofline(G, ops, 100000, 1000000, 256 + 96,
-                                                      "100000 nodes / 1000000 edges, width s+3V = 352", iters=10),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(layers, host, args)
+            out["aggregate_kernel"] = aggregate_roofline(G, ops, args.nodes, wl["n_edges"], width,
+                                                         f"{args.nodes} nodes / {wl['n_edges']} edges, width s+3V = {width}")
+            out["aggregate_kernel_c5"] = aggregate_roofline(G, ops, 100000, 1000000, 256 + 96,
+                                                            "100000 nodes / 1000000 edges, width s+3V = 352", iters=10)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"], out["parity_check"] = cpu_baseline(wl, args)
+            if world == 1 and args.config == "c2" and not args.no_c5_block:
+                wl.clear()
+                torch.cuda.empty_cache()
+                out["c5_single_gpu"] = c5_block(G, ops, args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -284,16 +437,24 @@ def main():
     sys.stdout.flush()
 
 
-def cpu_baseline(layers, host, args):
-    """The oracle on the host cores, on a bounded sample of the workload: one fwd+bwd step of ONE layer of the stack
-    (same weights) on a graph built by the same recipe with 1/4 of the nodes (same degree, same feature widths), so
-    that the default run stays within a few minutes.  Throughput per edge and layer is what is compared."""
+def cpu_baseline(wl, args):
+    """The oracle on the host cores: the SAME stack, weights, graph, inputs and loss as the timed GPU step (configs[1]: the full
+    workload, 1 warm-up + 3 timed steps; configs[4]: one layer on a 1/10-size graph of the same recipe, 1 timed step, stated in
+    `sample`), and the parity check that goes with it: GPU outputs and input gradients of that step against the oracle's."""
     from gcpnet_amd.synthetic import make_inputs
     from oracle import gcp_oracle as O
 
     cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds contention on these small ops
     torch.set_num_threads(cores)
-    sample = make_inputs(max(args.nodes // 4, 64), args.neighbors, (args.sdim, args.vdim), (32, 4), seed=1234)
+    layers, n_layers = wl["layers"], wl["n_layers"]
+    full = args.config == "c2"
+    if full:
+        sample, lw, reps, what = wl["host"], {k: v.cpu() for k, v in wl["lw"].items()}, 3, "the full timed workload"
+    else:
+        sample = make_inputs(max(args.nodes // 10, 64), args.neighbors, (args.sdim, args.vdim), (32, 4), seed=1234)
+        g = torch.Generator().manual_seed(1)
+        lw = dict(h=torch.randn(sample["h"].shape, generator=g), chi=torch.randn(sample["chi"].shape, generator=g))
+        n_layers, reps, what = 1, 1, "ONE layer of the stack on a 1/10-size graph of the same recipe"
     P = {k: v.detach().cpu().clone().requires_grad_() for k, v in layers.state_dict().items()}
     ins = {k: sample[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
     ei = sample["edge_index"]
@@ -301,19 +462,42 @@ def cpu_baseline(layers, host, args):
     cfg, lcfg = O.default_module_cfg(), O.default_layer_cfg()
 
     def one():
-        h, chi = O.gcp_interactions(P, "0.", ins["h"], ins["chi"], ins["e"], ins["xi"], ei, fr, cfg, lcfg)
-        (h.square().mean() + chi.square().mean()).backward()
+        for t in ins.values():
+            t.grad = None
+        h, chi = ins["h"], ins["chi"]
+        for i in range(n_layers):
+            h, chi = O.gcp_interactions(P, f"{i}.", h, chi, ins["e"], ins["xi"], ei, fr, cfg, lcfg)
+        ((h * lw["h"]).sum() + (chi * lw["chi"]).sum()).backward()
+        return h.detach(), chi.detach()
 
     one()  # warm-up (allocator, thread pool)
     t0 = time.perf_counter()
-    reps = 2
     for _ in range(reps):
-        one()
+        ch, cchi = one()
     dt = (time.perf_counter() - t0) / reps
-    return {"value": ei.shape[1] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"fwd+bwd of 1 GCPInteractions layer (same weights) on a {sample['h'].shape[0]}-node / "
-                      f"{ei.shape[1]}-edge graph of the same recipe, torch CPU {cores} threads, {dt:.2f} s per step, "
+    base = {"value": ei.shape[1] * n_layers / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{what}: fwd+bwd of {n_layers} GCPInteractions layer(s) (same weights, inputs and loss) on "
+                      f"{sample['h'].shape[0]} nodes / {ei.shape[1]} edges, torch CPU {cores} threads, {dt:.2f} s per step, "
                       f"mean of {reps} after 1 warm-up"}
+    # ---- parity of the timed GPU path against this very CPU run: outputs element-wise at 1e-5 of their
+    #      scale; input gradients in the relative L2 sense (the shipped config is ReLU: isolated sign flips of pre-activations
+    #      within round-off of zero move single rows, see tests/helpers.as_accurate)
+    import gcpnet_amd as G
+    gi = {k: sample[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    gfr = G.localize(sample["x"].cuda(), ei.cuda())
+    h, chi = gi["h"], gi["chi"]
+    for i in range(n_layers):
+        h, chi = layers[i]((h, chi), (gi["e"], gi["xi"]), ei.cuda(), gfr)
+    ((h * lw["h"].cuda()).sum() + (chi * lw["chi"].cuda()).sum()).backward()
+    fwd_err = max(float((h.detach().cpu() - ch).abs().max() / ch.abs().max().clamp(min=1.0)),
+                  float((chi.detach().cpu() - cchi).abs().max() / cchi.abs().max().clamp(min=1.0)))
+    grad_err = {k: float((gi[k].grad.cpu().double() - ins[k].grad.double()).norm() / ins[k].grad.double().norm().clamp(min=1e-30))
+                for k in gi}
+    parity = {"against": "the cpu_baseline run above (oracle, fp32)", "forward_max_abs_err_over_scale": fwd_err,
+              "forward_tol": 1e-5, "input_grad_rel_l2_err": grad_err, "input_grad_tol": 1e-3,
+              "ok": bool(fwd_err <= 1e-5 and max(grad_err.values()) <= 1e-3)}
+    assert parity["ok"], f"GPU path disagrees with the CPU oracle: {parity}"
+    return base, parity
 
 
 if __name__ == "__main__":

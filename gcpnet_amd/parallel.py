@@ -32,7 +32,13 @@ class GradAllReducer:
             off += p.numel()
 
     @torch.no_grad()
-    def all_reduce_mean(self):
+    def all_reduce_sum(self):
+        """As all_reduce_mean, with a SUM: for ranks that hold disjoint shares of ONE graph's rows (ShardedGraph), where the
+        weight gradient of the whole graph is the sum of the ranks' gradients."""
+        self.all_reduce_mean(_mean=False)
+
+    @torch.no_grad()
+    def all_reduce_mean(self, _mean: bool = True):
         """Gradients -> flat bucket (one multi-tensor copy), ONE all-reduce (averaging inside RCCL), and the parameters'
         .grad become views of the bucket (no copy back): three launches per step instead of two per parameter tensor."""
         world = dist.get_world_size(self.group)
@@ -45,7 +51,9 @@ class GradAllReducer:
                 src.append(p.grad)
         if dst:
             torch._foreach_copy_(dst, src)
-        if dist.get_backend(self.group) == "nccl":
+        if not _mean:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        elif dist.get_backend(self.group) == "nccl":
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
         else:  # gloo has no AVG
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -91,3 +99,163 @@ def shard_graph_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> 
         else:
             out[k] = v
     return out
+
+
+# ==============================================================================================================
+# ONE large graph across ranks: strong scaling of BASELINE configs[1] / configs[4]
+# ==============================================================================================================
+class ShardedGraph:
+    """Partition of one graph by TARGET-node ranges for message passing over several GPUs.
+
+    Edges are taken in col-sorted order and cut into `world` pieces of (almost) equal EDGE count, snapped to node boundaries:
+    rank r owns the nodes [n0, n1) and all their in-edges (col in range) -- the rows of the message kernels and of the
+    aggregation -- so compute per rank is proportional to its edges.  Messages need the features of the SOURCE nodes
+    (h[row], chi[row]), which may live anywhere: per layer one all-gather of the node features forward and the matching
+    reduce-scatter of their gradients backward (`all_gather_rows`, an autograd Function); at configs[4] size that is 100 000 x
+    352 floats = 141 MB per layer, ~17.6 MB per peer over 7 xGMI links in parallel.  Everything else is local: per-edge features and
+    frames, aggregation (scatter over the rank's own col range), node-level GCPs (their `scalarize(node_inputs=True)` needs the
+    mean frame over each local node's OUT-edges, built once from the replicated positions and index arrays).  Weights are
+    replicated; their gradients go through GradAllReducer with a SUM (each rank holds a disjoint share of the rows).
+
+    This class is index bookkeeping + collectives only (device-agnostic; the CPU tests drive it with the oracle)."""
+
+    def __init__(self, edge_index: torch.Tensor, n_nodes: int, rank: int, world: int, group=None):
+        self.rank, self.world, self.group, self.n_nodes = rank, world, group, int(n_nodes)
+        row, col = edge_index[0].long(), edge_index[1].long()
+        n_edges = int(col.shape[0])
+        if n_edges > 1 and not bool((col[1:] >= col[:-1]).all()):
+            self.edge_perm = torch.argsort(col, stable=True)
+            row, col = row[self.edge_perm], col[self.edge_perm]
+        else:
+            self.edge_perm = None
+        counts = torch.bincount(col, minlength=self.n_nodes)
+        ptr = torch.zeros(self.n_nodes + 1, dtype=torch.long, device=col.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        targets = torch.tensor([(k * n_edges) // world for k in range(world + 1)], dtype=torch.long, device=col.device)
+        bounds = torch.searchsorted(ptr, targets, right=False).clamp(max=self.n_nodes)  # first node whose edges start at/after the cut
+        bounds[0], bounds[-1] = 0, self.n_nodes
+        self.bounds = [int(b) for b in torch.cummax(bounds, 0).values.tolist()]
+        self.n0, self.n1 = self.bounds[rank], self.bounds[rank + 1]
+        self.e0, self.e1 = int(ptr[self.n0]), int(ptr[self.n1])
+        self.node_counts = [self.bounds[k + 1] - self.bounds[k] for k in range(world)]
+        self.max_nodes = max(self.node_counts)
+        self.edge_counts = [int(ptr[self.bounds[k + 1]] - ptr[self.bounds[k]]) for k in range(world)]
+        # local in-edges with GLOBAL node ids (gathers read the all-gathered tables) and with local target ids (aggregation)
+        self.edge_index = torch.stack((row[self.e0:self.e1], col[self.e0:self.e1]))
+        self.col_local = col[self.e0:self.e1] - self.n0
+        # out-edges of the local nodes (row in range), for the node-level mean frames: [2, E_out] with LOCAL row ids
+        out_mask = (row >= self.n0) & (row < self.n1)
+        self.out_edge_index_global = torch.stack((row[out_mask], col[out_mask]))
+        self.out_row_local = row[out_mask] - self.n0
+
+    @property
+    def n_local(self) -> int:
+        return self.n1 - self.n0
+
+    def local_nodes(self, t: torch.Tensor) -> torch.Tensor:
+        return t[self.n0:self.n1]
+
+    def local_edges(self, t: torch.Tensor) -> torch.Tensor:
+        """Rows of a per-edge tensor (given in the caller's edge order) that belong to this rank, in col-sorted order."""
+        if self.edge_perm is not None:
+            t = t[self.edge_perm]
+        return t[self.e0:self.e1]
+
+    # ---- collectives -----------------------------------------------------------------------------------------------
+    def _gather(self, local: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return local
+        D = local.shape[1]
+        pad = local.new_zeros((self.max_nodes, D))
+        pad[: self.n_local] = local
+        if dist.get_backend(self.group) == "nccl":
+            buf = local.new_empty((self.world * self.max_nodes, D))
+            dist.all_gather_into_tensor(buf, pad, group=self.group)
+            parts = [buf[k * self.max_nodes: k * self.max_nodes + c] for k, c in enumerate(self.node_counts)]
+        else:
+            bufs = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(bufs, pad, group=self.group)
+            parts = [b[:c] for b, c in zip(bufs, self.node_counts)]
+        return torch.cat(parts, dim=0)
+
+    def _scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
+        """Sum over ranks of `full` [N, D], rows of this rank's node range returned."""
+        if self.world == 1:
+            return full
+        D = full.shape[1]
+        if dist.get_backend(self.group) == "nccl":
+            inp = full.new_zeros((self.world * self.max_nodes, D))
+            for k, c in enumerate(self.node_counts):
+                inp[k * self.max_nodes: k * self.max_nodes + c] = full[self.bounds[k]: self.bounds[k + 1]]
+            out = full.new_empty((self.max_nodes, D))
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+            return out[: self.n_local].contiguous()
+        total = full.clone()  # gloo has no reduce-scatter
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return total[self.n0: self.n1].contiguous()
+
+    def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        """[n_local, D] -> [N, D] over all ranks; backward = reduce-scatter (sum) of the gradient rows to their owners."""
+        return _AllGatherRows.apply(local, self)
+
+
+class _AllGatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, local, sg: ShardedGraph):
+        ctx.sg = sg
+        return sg._gather(local.contiguous())
+
+    @staticmethod
+    def backward(ctx, g_full):
+        return ctx.sg._scatter_sum(g_full.contiguous()), None
+
+
+def sharded_interactions_forward(layer, node_rep, edge_rep, sg: ShardedGraph, frames, node_frames, node_pos=None):
+    """`GCPInteractions.forward` (components/gcpnet.py:1161-1262, unmasked) on one rank's share of a ShardedGraph.
+
+    node_rep = (h, chi) of the LOCAL nodes, edge_rep = (e, xi) and `frames` of the LOCAL in-edges (sg.local_edges order),
+    `node_frames` [n_local, 3, 3] the local nodes' mean out-edge frames.  Returns the updated local (h, chi) [and positions]."""
+    from . import ops
+    from .components import ScalarVector
+    from .gcpnet import _sv_add
+
+    h, chi = node_rep
+    n_loc, s, v = h.shape[0], h.shape[1], chi.shape[1]
+    node_rep = ScalarVector(h, chi)
+    if layer.pre_norm:
+        node_rep = layer.gcp_norm[0](node_rep)
+    # ---- the one exchange of the layer: every rank's node features, flattened [s | V x 3] (ScalarVector.flatten) ----------
+    flat = torch.cat((node_rep[0], node_rep[1].reshape(n_loc, 3 * v)), dim=1)
+    full = sg.all_gather_rows(flat)
+    h_full, chi_full = full[:, :s], full[:, s:].reshape(-1, v, 3)
+    mp = layer.interaction
+    m = mp._messages(ScalarVector(h_full.contiguous(), chi_full.contiguous()), ScalarVector(*edge_rep), sg.edge_index, frames)
+    plan = ops.GatherPlan(sg.col_local, n_loc) if not hasattr(sg, "_col_plan") else sg._col_plan
+    sg._col_plan = plan
+    mean = mp.reduce_function == "mean"
+    agg_s = ops.segment_reduce(m[0], plan, mean)
+    agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], -1), plan, mean).reshape(n_loc, v, 3)
+    hidden = ScalarVector(agg_s, agg_v)
+    if layer.gcp_dropout[0].active:
+        hidden = layer.gcp_dropout[0](hidden)
+    node_rep = (layer.gcp_norm[1] if layer.pre_norm else layer.gcp_norm[0])(node_rep, residual=hidden)
+
+    def node_gcp(module, rep):  # GCP2.forward(node_inputs=True) on local rows with the precomputed mean frames
+        out = module.apply_rows([rep[0]], [None], [rep[1]], [None], node_frames)
+        return ScalarVector(*out) if isinstance(out, tuple) else out
+
+    hidden = node_rep
+    for module in layer.feedforward_network:
+        hidden = node_gcp(module, hidden)
+    if layer.gcp_dropout[1].active:
+        hidden = layer.gcp_dropout[1](hidden)
+    node_rep = _sv_add(node_rep, hidden) if layer.pre_norm else layer.gcp_norm[1](node_rep, residual=hidden)
+    if not layer.updating_node_positions:
+        return node_rep
+    if not layer.ablate_x_force_update:
+        raise NotImplementedError("sharded position update with the inter-node force term")
+    rep = node_rep
+    for gcp in layer.node_position_update_network:
+        rep = node_gcp(gcp, rep)
+    upd = rep[1].reshape(n_loc, 3)
+    return node_rep, ops.axpy_clamp(node_pos, upd, float(layer.node_positions_weight), -100.0, 100.0)

@@ -57,3 +57,59 @@ def layer_flops(n_nodes: int, n_edges: int, node_dims=(128, 16), edge_dims=(32, 
     m_n = gcp_macs(s, v, 4 * s, 2 * v) + gcp_macs(4 * s, 2 * v, s, v)
     fwd = 2.0 * (n_edges * m_e + n_nodes * m_n)
     return dict(mac_per_edge=m_e, mac_per_node=m_n, fwd=fwd, fwd_bwd=3.0 * fwd)
+
+
+def nbody_batch(n_graphs: int, n_body: int, seed: int, h_dim: int = 1, chi_dim: int = 3, e_dim: int = 17, xi_dim: int = 1):
+    """Collated batch of fully-connected n-body graphs with random stand-in features of the NMS shapes
+    (src/datamodules/components/nms_dataset.py:23-61: h [N,1], chi [N,3,3], e [E,17], xi [E,1,3]; block-diagonal edge_index as
+    torch_geometric's Batch.from_data_list builds it) and a next-frame position label."""
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.arange(n_body)
+    r, c = torch.meshgrid(idx, idx, indexing="ij")
+    keep = r != c
+    offs = (torch.arange(n_graphs) * n_body).repeat_interleave(int(keep.sum()))
+    ei = torch.stack((r[keep].repeat(n_graphs) + offs, c[keep].repeat(n_graphs) + offs))
+    n, e = n_graphs * n_body, ei.shape[1]
+    x = torch.randn(n, 3, generator=g) * 2 + 1.5
+    return dict(h=torch.randn(n, h_dim, generator=g), chi=torch.randn(n, chi_dim, 3, generator=g), e=torch.randn(e, e_dim, generator=g),
+                xi=torch.randn(e, xi_dim, 3, generator=g), x=x, edge_index=ei, batch=torch.arange(n_graphs).repeat_interleave(n_body),
+                label=x + 0.3 * torch.randn(n, 3, generator=g))
+
+
+def radius_batch(n_graphs: int, atoms: int, max_neighbors: int, seed: int):
+    """Collated batch of independent radius graphs (r = 4.5, <= max_neighbors; atom3d_dataset.py:110-129 recipe) with the LBA
+    feature shapes: integer atom types h [N], chi [N,2,3], e [E,16], xi [E,1,3], one label per graph."""
+    g = torch.Generator().manual_seed(seed)
+    xs, eis, bidx, off = [], [], [], 0
+    for i in range(n_graphs):
+        n = atoms + (i % 5) * (atoms // 10)
+        x, ei = radius_graph(n, max_neighbors, seed=seed * 1000 + i, expected_in_radius=40.0)
+        xs.append(x)
+        eis.append(ei + off)
+        bidx.append(torch.full((n,), i, dtype=torch.long))
+        off += n
+    x, ei = torch.cat(xs), torch.cat(eis, dim=1)
+    n, e = x.shape[0], ei.shape[1]
+    return dict(h=torch.randint(0, 9, (n,), generator=g), chi=torch.randn(n, 2, 3, generator=g), e=torch.randn(e, 16, generator=g),
+                xi=torch.randn(e, 1, 3, generator=g), x=x, edge_index=ei, batch=torch.cat(bidx), label=torch.randn(n_graphs, generator=g))
+
+
+def model_batch(config: str, seed: int = 0):
+    """(batch, model_cfg, kind, label) of the model-level BASELINE configurations: c1 / c4 = NMS small (5-body) / small_20body,
+    100 graphs per batch, gcp_model_nms.yaml dims; c3 = ATOM3D-LBA, 16 pocket-sized radius graphs, gcp_model_lba.yaml dims."""
+    if config in ("c1", "c4"):
+        n_body = 5 if config == "c1" else 20
+        b = nbody_batch(100, n_body, seed)
+        cfg = dict(h_input_dim=1, chi_input_dim=3, e_input_dim=17, xi_input_dim=1, h_hidden_dim=64, chi_hidden_dim=16,
+                   e_hidden_dim=32, xi_hidden_dim=4, num_encoder_layers=4, dropout=0.0)
+        label = (f"NMS model step(): 100 fully-connected {n_body}-body graphs = {b['h'].shape[0]} nodes / {b['edge_index'].shape[1]} "
+                 f"edges per GPU, (64,16) hidden, 4 GCPInteractions layers with position updates, MSE loss, fwd+bwd")
+        return b, cfg, "nms", label
+    if config == "c3":
+        b = radius_batch(16, 400, 32, seed)
+        cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=100, chi_hidden_dim=16, e_hidden_dim=32,
+                   xi_hidden_dim=4, output_dim=1, output_scale_factor=2, num_encoder_layers=8, dropout=0.0, dense_dropout=0.0)
+        label = (f"LBA model step(): 16 radius graphs (r=4.5, K<=32) = {b['h'].shape[0]} nodes / {b['edge_index'].shape[1]} edges per "
+                 f"GPU, (100,16) hidden, 8 GCPInteractions layers + invariant projection + graph-mean readout + dense head, MSE loss")
+        return b, cfg, "lba", label
+    raise ValueError(config)

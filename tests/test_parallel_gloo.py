@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gcpnet_amd.parallel import GradAllReducer, shard_graph_batch
+from gcpnet_amd.parallel import GradAllReducer, ShardedGraph, shard_graph_batch
 from tests.helpers import Fixture
 
 
@@ -98,3 +98,99 @@ def test_shard_graph_batch_single_process():
     for p in parts:
         assert int(p["edge_index"].max()) < p["h"].shape[0] and int(p["edge_index"].min()) >= 0
         assert torch.equal(torch.unique(p["batch"]), torch.arange(int(p["batch"].max()) + 1))
+
+
+# ---- ONE graph split by target-node ranges: per-layer all-gather of node features forward,
+#      reduce-scatter of their gradients backward; the oracle plays the per-rank kernels -----------------------------------
+def _sharded_case():
+    """Seeded graph (not col-sorted: the sharding sorts), two GCPInteractions layers' parameters, inputs, loss weights."""
+    import gcpnet_amd as G
+    from oracle import gcp_oracle as O
+    from tests.helpers import rand_graph
+
+    n, e, dims = 90, 700, (24, 8)
+    torch.manual_seed(5)
+    layers = torch.nn.ModuleList(G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(scalar_nonlinearity="silu"),
+                                                   layer_cfg=G.default_layer_cfg(num_message_layers=3), dropout=0.0) for _ in range(2))
+    P = {k: v.detach().clone() for k, v in layers.state_dict().items()}
+    ei, x = rand_graph(n, e, 6)
+    g = torch.Generator().manual_seed(7)
+    ins = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g),
+               e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
+    lw = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g))
+    cfg = O.default_module_cfg(scalar_nonlinearity="silu", nonlinearities=("silu", None))
+    lcfg = O.default_layer_cfg(num_message_layers=3)
+    return P, ei, x, ins, lw, cfg, lcfg, n
+
+
+def _oracle_sharded_layer(O, P, pre, h, chi, e_loc, xi_loc, sg, frames_loc, out_ei_local, out_frames, cfg, lcfg):
+    """One post-norm GCPInteractions layer on a rank's share, mirroring gcpnet_amd.parallel.sharded_interactions_forward."""
+    n_loc, s, v = h.shape[0], h.shape[1], chi.shape[1]
+    full = sg.all_gather_rows(torch.cat((h, chi.reshape(n_loc, 3 * v)), dim=1))
+    h_full, chi_full = full[:, :s], full[:, s:].reshape(-1, v, 3)
+    (rs, rv), _ = O.message_passing(P, pre + "interaction.", h_full, chi_full, e_loc, xi_loc, sg.edge_index, frames_loc, cfg,
+                                    lcfg["mp_cfg"], return_messages=True)
+    h, chi = h + rs[sg.n0:sg.n1], chi + rv[sg.n0:sg.n1]  # (all in-edges of the local nodes are local: their mean is complete)
+    h, chi = O.gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
+    no_res = dict(cfg, vector_residual=False)
+    kws = [O._gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])), O._gcp_kwargs(no_res, nonlinearities=(None, None))]
+    fs, fv = h, chi
+    for k, kw in enumerate(kws):  # node-level GCPs: scalarize(node_inputs=True) over the local nodes' OUT-edges
+        fs, fv = O.gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, out_ei_local, out_frames, node_inputs=True, **kw)
+    return O.gcp_layer_norm(P, pre + "gcp_norm.1.", h + fs, chi + fv)
+
+
+def _sharded_job(rank, world):
+    from oracle import gcp_oracle as O
+
+    P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
+    P = {k: v.clone().requires_grad_() for k, v in P.items()}
+    sg = ShardedGraph(ei, n, rank, world)
+    frames_loc = O.localize(x, sg.edge_index)
+    out_frames = O.localize(x, sg.out_edge_index_global)
+    out_ei_local = torch.stack((sg.out_row_local, sg.out_edge_index_global[1]))
+    h = sg.local_nodes(ins["h"]).clone().requires_grad_()
+    chi = sg.local_nodes(ins["chi"]).clone().requires_grad_()
+    e_loc = sg.local_edges(ins["e"]).clone().requires_grad_()
+    xi_loc = sg.local_edges(ins["xi"]).clone().requires_grad_()
+    hh, cc = h, chi
+    for i in range(2):
+        hh, cc = _oracle_sharded_layer(O, P, f"{i}.", hh, cc, e_loc, xi_loc, sg, frames_loc, out_ei_local, out_frames, cfg, lcfg)
+    loss = (hh * sg.local_nodes(lw["h"])).sum() + (cc * sg.local_nodes(lw["chi"])).sum()
+    loss.backward()
+    params = [p for p in P.values()]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    GradAllReducer(params).all_reduce_sum()
+    return dict(n0=sg.n0, n1=sg.n1, e0=sg.e0, e1=sg.e1, edges=sg.edge_counts, perm=sg.edge_perm,
+                h=hh.detach(), chi=cc.detach(), dh=h.grad, dchi=chi.grad, de=e_loc.grad, dxi=xi_loc.grad,
+                w={k: v.grad.clone() for k, v in P.items()})
+
+
+def test_sharded_graph_matches_unsharded():
+    from oracle import gcp_oracle as O
+
+    P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
+    P = {k: v.clone().requires_grad_() for k, v in P.items()}
+    ci = {k: v.clone().requires_grad_() for k, v in ins.items()}
+    fr = O.localize(x, ei)
+    hh, cc = ci["h"], ci["chi"]
+    for i in range(2):
+        hh, cc = O.gcp_interactions(P, f"{i}.", hh, cc, ci["e"], ci["xi"], ei, fr, cfg, lcfg)
+    ((hh * lw["h"]).sum() + (cc * lw["chi"]).sum()).backward()
+    out = _run(_sharded_job)
+    assert out[0]["n0"] == 0 and out[0]["n1"] == out[1]["n0"] and out[1]["n1"] == n
+    assert sum(out[0]["edges"]) == ei.shape[1] and abs(out[0]["edges"][0] - out[0]["edges"][1]) <= 40  # equal-edge cut
+    perm = out[0]["perm"]
+    de, dxi = ci["e"].grad[perm], ci["xi"].grad[perm]  # (the shards hold their edges in col-sorted order)
+    tol = dict(atol=2e-6, rtol=1e-5)
+    for r in (0, 1):
+        o = out[r]
+        sl, es = slice(o["n0"], o["n1"]), slice(o["e0"], o["e1"])
+        assert torch.allclose(o["h"], hh.detach()[sl], **tol) and torch.allclose(o["chi"], cc.detach()[sl], **tol)
+        assert torch.allclose(o["dh"], ci["h"].grad[sl], **tol) and torch.allclose(o["dchi"], ci["chi"].grad[sl], **tol)
+        assert torch.allclose(o["de"], de[es], **tol) and torch.allclose(o["dxi"], dxi[es], **tol)
+        for k, v in P.items():
+            want = v.grad if v.grad is not None else torch.zeros_like(v)
+            assert torch.allclose(o["w"][k], want, atol=2e-6 * max(1.0, float(want.abs().max())), rtol=1e-5), k

@@ -1,0 +1,88 @@
+"""The product's sharded-graph path on the GPU (gcpnet_amd.parallel.ShardedGraph + sharded_interactions_forward): two ranks
+share cuda:0 and talk over gloo (RCCL refuses two ranks on one device; the collective calls are the same); the result --
+outputs, input gradients, summed weight gradients -- must equal the unsharded GCPInteractions stack on the same GPU."""
+import os
+
+import pytest
+import torch
+
+from tests.test_parallel_gloo import _run
+
+pytestmark = pytest.mark.gpu
+
+
+def _case():
+    import gcpnet_amd as G
+    from tests.helpers import rand_graph
+
+    n, e, dims = 500, 6000, (128, 16)
+    torch.manual_seed(5)
+    layers = torch.nn.ModuleList(G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(scalar_nonlinearity="silu"),
+                                                   layer_cfg=G.default_layer_cfg(), dropout=0.0) for _ in range(2))
+    ei, x = rand_graph(n, e, 6)
+    g = torch.Generator().manual_seed(7)
+    ins = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g),
+               e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
+    lw = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g))
+    return layers, ei, x, ins, lw, n
+
+
+def _sharded_gpu_job(rank, world):
+    import gcpnet_amd as G
+    from gcpnet_amd import ops
+    from gcpnet_amd.parallel import GradAllReducer, ShardedGraph, sharded_interactions_forward
+
+    torch.cuda.set_device(0)
+    layers, ei, x, ins, lw, n = _case()
+    layers = layers.cuda().eval()
+    sg = ShardedGraph(ei, n, rank, world)
+    xg = x.cuda()
+    sg.edge_index, sg.col_local = sg.edge_index.cuda(), sg.col_local.cuda()
+    frames = G.localize(xg, sg.edge_index)
+    fr_out = G.localize(xg, sg.out_edge_index_global.cuda())
+    node_frames = ops.segment_reduce(fr_out.reshape(-1, 9), ops.GatherPlan(sg.out_row_local.cuda(), sg.n_local),
+                                     mean=True).reshape(sg.n_local, 3, 3)
+    loc = dict(h=sg.local_nodes(ins["h"]), chi=sg.local_nodes(ins["chi"]), e=sg.local_edges(ins["e"]), xi=sg.local_edges(ins["xi"]))
+    loc = {k: v.cuda().clone().requires_grad_() for k, v in loc.items()}
+    h, chi = loc["h"], loc["chi"]
+    for layer in layers:
+        h, chi = sharded_interactions_forward(layer, (h, chi), (loc["e"], loc["xi"]), sg, frames, node_frames)
+    ((h * sg.local_nodes(lw["h"]).cuda()).sum() + (chi * sg.local_nodes(lw["chi"]).cuda()).sum()).backward()
+    params = [p for p in layers.parameters()]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    GradAllReducer(params).all_reduce_sum()
+    torch.cuda.synchronize()
+    return dict(n0=sg.n0, n1=sg.n1, e0=sg.e0, e1=sg.e1, perm=sg.edge_perm, h=h.detach().cpu(), chi=chi.detach().cpu(),
+                d={k: v.grad.cpu() for k, v in loc.items()}, w={k: p.grad.cpu() for k, p in layers.named_parameters()})
+
+
+def test_sharded_gpu_forward_backward_matches_unsharded():
+    layers, ei, x, ins, lw, n = _case()
+    layers = layers.cuda().eval()
+    import gcpnet_amd as G
+
+    gi = {k: v.cuda().requires_grad_() for k, v in ins.items()}
+    fr = G.localize(x.cuda(), ei.cuda())
+    h, chi = gi["h"], gi["chi"]
+    for layer in layers:
+        h, chi = layer((h, chi), (gi["e"], gi["xi"]), ei.cuda(), fr)
+    ((h * lw["h"].cuda()).sum() + (chi * lw["chi"].cuda()).sum()).backward()
+    ref = dict(h=h.detach().cpu(), chi=chi.detach().cpu(), d={k: v.grad.cpu() for k, v in gi.items()},
+               w={k: p.grad.cpu() for k, p in layers.named_parameters()})
+    out = _run(_sharded_gpu_job)
+    perm = out[0]["perm"]
+
+    def ok(a, b, name):
+        tol = 2e-5 * max(1.0, float(b.abs().max()))
+        assert torch.allclose(a, b, atol=tol, rtol=1e-4), f"{name}: max diff {(a - b).abs().max():.3e} (scale {b.abs().max():.3e})"
+
+    for r in (0, 1):
+        o = out[r]
+        sl, es = slice(o["n0"], o["n1"]), slice(o["e0"], o["e1"])
+        ok(o["h"], ref["h"][sl], "h"); ok(o["chi"], ref["chi"][sl], "chi")
+        ok(o["d"]["h"], ref["d"]["h"][sl], "dh"); ok(o["d"]["chi"], ref["d"]["chi"][sl], "dchi")
+        ok(o["d"]["e"], ref["d"]["e"][perm][es], "de"); ok(o["d"]["xi"], ref["d"]["xi"][perm][es], "dxi")
+        for k, want in ref["w"].items():
+            ok(o["w"][k], want, k)
