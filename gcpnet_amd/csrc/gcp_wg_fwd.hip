@@ -43,7 +43,7 @@ struct WgFwdParams {
     int NT, NG;
     int n;
     int KS, VS, HS, GS;
-    int o_x, o_v, o_vh, o_fr, o_gp, o_ws, o_st, ws_floats;
+    int o_x, o_v, o_vh, o_fr, o_ws, o_st, ws_floats, st_floats;
     unsigned long long* stamps;  // profiling hook (gcpnet_debug_set_phase_timing): s_memtime stamps of wave 0, last block
     long long stamp_cap;
     WgBlk blk[GCP_WG_MAX_BLOCKS];
@@ -55,31 +55,33 @@ template <int NW, int MT, bool PWL>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32, U = 4 / MT;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, e = lane & 31, hi = lane >> 5;
+    int lane = tid & 63, e = lane & 31, hi = lane >> 5;
+    // per-lane addresses are invariant over the block loop: hipcc hoists them out of it and spills them; laundering the lane
+    // indices at the phase boundaries makes every phase recompute the few it needs
+#define WG_LAUNDER() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub))
     const int r0 = blockIdx.x * 32;
     const int rows = p.rows;
     const int nvalid = min(32, rows - r0);
-    const int prow = tid / TPR, psub = tid - prow * TPR;  // (row, sub-index) of the VALU phases
+    int prow = tid / TPR, psub = tid - prow * TPR;  // (row, sub-index) of the VALU phases
     float* X = lds + p.o_x;
     float* V = lds + p.o_v;
     float* VH = lds + p.o_vh;
     float* FR = lds + p.o_fr;
-    float* GP = lds + p.o_gp;
-    float* ST = lds + p.o_st + w * (32 * 20);
+    float* ST = lds + p.o_st + w * p.st_floats;  // wave-private staging tile; waves 0..3: also their gate-partial slot (later)
     const int KS = p.KS, VS = p.VS, HS = p.HS, GS = p.GS;
     const int so = p.so, vo = p.vo, nf = p.nf, NT = p.NT;
     const bool scalar_gate = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;
     const float slope = p.slope;
 
-    // small weights of block b -> LDS buffer b & 1: [vector_down ; vector_down_frames] rows (stride vi | 1), vector_up rows
-    // (stride H | 1), gate bias, scalar_out bias.  Split in a request (global loads into registers, issued before a block's GEMM) and a commit
+    // small weights of block b -> LDS buffer b & 1: [vector_down ; vector_down_frames] rows (stride wg_stride(vi)), vector_up rows
+    // (stride wg_stride(H): 16-byte reads), gate bias, scalar_out bias.  Split in a request (global loads into registers, issued before a block's GEMM) and a commit
     // (LDS writes, after it): the round trip to L2 stays under the MFMAs.
     constexpr int WSR = 4;
     float wsr[WSR];
     auto ws_src = [&](const WgBlk& B, int i, int& dst) -> const float* {  // flat index over [down ; frames | up | gate bias]
-        const int H = B.H, vi = B.vi, HF = H + (nf ? 3 : 0), WSV = vi | 1, WSU = H | 1;
+        const int H = B.H, vi = B.vi, HF = H + (nf ? 3 : 0), WSV = wg_stride(vi), WSU = wg_stride(H);
         const int n1 = HF * vi, n2 = n1 + vo * H;
         if (i < n1) {
             const int x = i / vi, c = i - x * vi;
@@ -164,21 +166,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
             }
         }
-        const float* vsrc = p.v_in + (int64_t)r0 * vw;
-        const int nv = nvalid * vw;
-        for (int i0 = 0; i0 < 32 * vw; i0 += 4 * NTH) {
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = vsrc[min(i0 + tid + k * NTH, nv - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + tid + k * NTH;
-                if (i < 32 * vw) {
-                    const int r = i / vw, c = i - r * vw;
-                    V[r * VS + c] = i < nv ? v[k] : 0.f;
-                }
-            }
-        }
+        wg_tile_load<NTH>(V, VS, p.v_in + (int64_t)r0 * vw, vw, nvalid, tid, (vw & 3) == 0 && wg_aligned16(p.v_in));
         if (nf) {
             const float* fsrc = p.frames + (int64_t)r0 * 9;
             for (int i = tid; i < 32 * 9; i += NTH) FR[i] = fsrc[min(i, nvalid * 9 - 1)];
@@ -196,18 +184,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         };
         stamp(0);
         const float* ws = lds + p.o_ws + (b & 1) * p.ws_floats;
-        const int H = B.H, vi = B.vi, si = B.si, HF = H + (nf ? 3 : 0), WSV = vi | 1, WSU = H | 1;
+        const int H = B.H, vi = B.vi, si = B.si, HF = H + (nf ? 3 : 0), WSV = wg_stride(vi), WSU = wg_stride(H);
         const float* wu = ws + HF * WSV;
         const float* bg = wu + vo * WSU;
         const float* bs = ws + gcp_round_up(HF * WSV + vo * WSU + vo, 4);
         const int KG = B.KG, K = B.K, KP = 8 * KG;
         const float ns_s = gcp_neg_slope(B.act_s, slope), ns_v = gcp_neg_slope(B.act_v, slope);
 
+        WG_LAUNDER();
         // ---- prologue ----------------------------------------------------------------------------------------------------
         {
             const float* vrow = V + prow * VS;
             const int grow = min(r0 + prow, rows - 1);
             const int HFP = gcp_round_up(HF, 4);
+#pragma unroll 1
             for (int x = psub; x < HF; x += TPR) {
                 float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                 if constexpr (FIRST) {  // shares of the pre-projected (gathered) vector sources
@@ -219,11 +209,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
                 const float* wr = ws + x * WSV;
                 float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-                for (int c = 0; c < vi; ++c) {
-                    const float wv = wr[c];
-                    u0 = fmaf(wv, vrow[3 * c + 0], u0);
-                    u1 = fmaf(wv, vrow[3 * c + 1], u1);
-                    u2 = fmaf(wv, vrow[3 * c + 2], u2);
+                if ((vi & 3) == 0) {  // four channels per step: one 16-byte read of the weights, three of the vectors
+#pragma unroll 2
+                    for (int c = 0; c < vi; c += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(vrow + 3 * c);
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(vrow + 3 * c + 4);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(vrow + 3 * c + 8);
+                        u0 = fmaf(wv[0], a[0], u0); u1 = fmaf(wv[0], a[1], u1); u2 = fmaf(wv[0], a[2], u2);
+                        u0 = fmaf(wv[1], a[3], u0); u1 = fmaf(wv[1], bq[0], u1); u2 = fmaf(wv[1], bq[1], u2);
+                        u0 = fmaf(wv[2], bq[2], u0); u1 = fmaf(wv[2], bq[3], u1); u2 = fmaf(wv[2], d[0], u2);
+                        u0 = fmaf(wv[3], d[1], u0); u1 = fmaf(wv[3], d[2], u1); u2 = fmaf(wv[3], d[3], u2);
+                    }
+                } else {
+                    for (int c = 0; c < vi; ++c) {
+                        const float wv = wr[c];
+                        u0 = fmaf(wv, vrow[3 * c + 0], u0);
+                        u1 = fmaf(wv, vrow[3 * c + 1], u1);
+                        u2 = fmaf(wv, vrow[3 * c + 2], u2);
+                    }
                 }
                 u0 += q0; u1 += q1; u2 += q2;
                 if (x < H) {
@@ -251,11 +255,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         stamp(2);
         if (b + 1 < p.n) ws_request(b + 1);
 
+        WG_LAUNDER();
         // ---- scalar_out (+ gate partial) per output group ---------------------------------------------------------------
         f32x16 ynew[MT];  // the wave's slice of the block output (accumulator layout); the chain state when NG == 1
         f32x16 gacc;      // this wave's partial gate pre-activations (its columns of the reduction over so)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+        float zero = 0.f;  // (laundered: hipcc otherwise hoists the zero-initialised accumulators above the VALU phases in
+        asm volatile("" : "+v"(zero));  //  front of them and spills sixteen registers of zeros across each)
+        bool gacc_set = false;
         for (int og = 0; og < p.NG; ++og) {
             const int ot0 = og * NW * MT + w;
             if (ot0 >= NT) continue;  // (wave-uniform) nothing for this wave in this group
@@ -267,27 +273,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 otc[t] = min(ot0 + NW * t, NT - 1);
             }
             f32x16 acc[MT];
+            asm volatile("" : "+v"(zero));
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[t][r] = zero;
+            // K loop in batches of U groups of 8 columns, fragments requested two batches ahead.  With one tile per wave the
+            // batch BEHIND the last one carries the four weight fragments of the gate Linear for this wave's columns: they
+            // arrive under the reduction's MFMAs instead of costing a round trip to L2 afterwards.
+            f32x4 a0[U][MT], a1[U][MT], b0[U], b1[U];
+            int nb_;
             {
                 const float* pkA = B.pk + (int64_t)lane * 4;
+                const float* pkG = B.pk + B.offG1 + (int64_t)lane * 4;
                 const float* xb = X + e * KS + 4 * hi;
-                auto ldA = [&](f32x4(&a)[U][MT], f32x4(&bb)[U], int g0) {
+                const int nb = gcp_cdiv(KG, U);
+                const bool gate_pf = MT == 1 && scalar_gate;
+                auto ldA = [&](f32x4(&a)[U][MT], f32x4(&bb)[U], int bi) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const int g = min(g0 + u, KG - 1);
+                        const int g = min(U * bi + u, KG - 1);
                         bb[u] = *reinterpret_cast<const f32x4*>(xb + 8 * g);
 #pragma unroll
-                        for (int t = 0; t < MT; ++t)
-                            a[u][t] = *reinterpret_cast<const f32x4*>(pkA + ((int64_t)otc[t] * KG + g) * 256);
+                        for (int t = 0; t < MT; ++t) {
+                            const float* src = pkA + ((int64_t)otc[t] * KG + g) * 256;
+                            if (MT == 1 && U == 4) src = (gate_pf && bi == nb) ? pkG + (int64_t)(4 * otc[0] + u) * 256 : src;
+                            a[u][t] = *reinterpret_cast<const f32x4*>(src);
+                        }
                     }
                 };
-                auto mm = [&](f32x4(&a)[U][MT], f32x4(&bb)[U], int g0) {
+                auto mm = [&](f32x4(&a)[U][MT], f32x4(&bb)[U], int bi) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        if (g0 + u < KG) {
+                        if (U * bi + u < KG) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -295,18 +313,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t][i], bb[u][i], acc[t], 0, 0, 0);
                         }
                 };
-                f32x4 a0[U][MT], a1[U][MT], b0[U], b1[U];
+                nb_ = nb;
                 ldA(a0, b0, 0);
-                for (int g0 = 0; g0 < KG; g0 += 2 * U) {
-                    ldA(a1, b1, g0 + U);
+                for (int bi = 0; bi < nb; bi += 2) {
+                    ldA(a1, b1, bi + 1);
                     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE (hipcc otherwise sinks loads to their use)
-                    mm(a0, b0, g0);
-                    ldA(a0, b0, g0 + 2 * U);
+                    mm(a0, b0, bi);
+                    ldA(a0, b0, bi + 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    mm(a1, b1, g0 + U);
+                    mm(a1, b1, bi + 1);
                 }
             }
             stamp(3);
+            WG_LAUNDER();
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -341,46 +360,43 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
             }
 
+            __builtin_amdgcn_sched_barrier(0);  // (phases kept apart: interleaving them only raises register pressure)
             // gate partial over this wave's columns: B fragments = act_v(s_pre) straight from the accumulators
             if (scalar_gate) {
+                if (!gacc_set) {  // (initialised here, not in front of the reduction: sixteen live registers less in its loop)
+                    asm volatile("" : "+v"(zero));
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    if (tv[t]) {
-                        f32x4 ag[4];
+                    for (int r = 0; r < 16; ++r) gacc[r] = zero;
+                    gacc_set = true;
+                }
+                auto gate_mm = [&](const f32x16& av, auto frag) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            ag[q] = *reinterpret_cast<const f32x4*>(B.pk + B.offG1 + ((int64_t)(4 * otc[t] + q) * 64 + lane) * 4);
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 ag = frag(q);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                    ag[q][i], gcp_actf<PWL>(B.act_v, ns_v, slope, acc[t][4 * q + i]), gacc, 0, 0, 0);
+                        for (int i = 0; i < 4; ++i)
+                            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[i], gcp_actf<PWL>(B.act_v, ns_v, slope, av[4 * q + i]), gacc, 0, 0, 0);
                     }
+                };
+                if constexpr (MT == 1 && U == 4) {  // the prefetched batch nb sits in a0 when nb is even, in a1 when it is odd
+                    if (nb_ & 1) gate_mm(acc[0], [&](int q) { return a1[q][0]; });
+                    else gate_mm(acc[0], [&](int q) { return a0[q][0]; });
+                } else {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        if (tv[t]) {
+                            f32x4 ag[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                ag[q] = *reinterpret_cast<const f32x4*>(B.pk + B.offG1 + ((int64_t)(4 * otc[t] + q) * 64 + lane) * 4);
+                            gate_mm(acc[t], [&](int q) { return ag[q]; });
+                        }
+                }
             }
 
-            // full-row-piece stores through the wave-private staging tile (32 x 20: half a tile at a time)
-            auto store_acc = [&](float* dst, const f32x16& a, int otile) {
-                const int sub = lane >> 2, c4 = 4 * (lane & 3);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    gcp_wave_lds_sync();
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        f32x4 v = {a[8 * h + 4 * q], a[8 * h + 4 * q + 1], a[8 * h + 4 * q + 2], a[8 * h + 4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(ST + e * 20 + 8 * q + 4 * hi) = v;
-                    }
-                    gcp_wave_lds_sync();
-                    f32x4 wv[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) wv[j] = *reinterpret_cast<const f32x4*>(ST + (16 * j + sub) * 20 + c4);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int r = 16 * j + sub, c = 32 * otile + 16 * h + c4;
-                        if (r < nvalid && c < so) *reinterpret_cast<f32x4*>(dst + (int64_t)(r0 + r) * so + c) = wv[j];
-                    }
-                }
-            };
+            __builtin_amdgcn_sched_barrier(0);
+            // full 128-byte row pieces through the wave-private staging tile (wg_store_acc)
+            auto store_acc = [&](float* dst, const f32x16& av, int otile) { wg_store_acc(dst, so, 32 * otile, so, r0, nvalid, av, ST, lane); };
             if (B.s_pre) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
@@ -395,6 +411,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ynew[t][4 * q + i] = old[i] + gcp_actf<PWL>(B.act_s, ns_s, slope, acc[t][4 * q + i]);
                 }
+            __builtin_amdgcn_sched_barrier(0);
             if (B.s_out) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
@@ -402,6 +419,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
             }
         }
         stamp(4);
+        WG_LAUNDER();
         if (scalar_gate) {
             // partial gate pre-activations -> GP[w & 3][32][vo]; with eight waves the upper four add theirs in a second step
             // (half the LDS: the partials of a (256+, 32+) block would not fit otherwise)
@@ -416,13 +434,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
                 return v;
             };
+            if (!gacc_set) {  // (a wave without output tiles contributes zeros)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+            }
+            gcp_wave_lds_sync();  // (the slot doubles as this wave's staging tile: its reads are done)
             if (w < 4)
-                for (int q = 0; 8 * q < vo; ++q) *reinterpret_cast<f32x4*>(GP + (w * 32 + e) * GS + 8 * q + 4 * hi) = gp_quad(q);
+                for (int q = 0; 8 * q < vo; ++q) *reinterpret_cast<f32x4*>(ST + e * GS + 8 * q + 4 * hi) = gp_quad(q);
             if constexpr (NW == 8) {
                 wg_barrier();
                 if (w >= 4)
                     for (int q = 0; 8 * q < vo; ++q) {
-                        float* gp = GP + ((w - 4) * 32 + e) * GS + 8 * q + 4 * hi;
+                        float* gp = lds + p.o_st + (w - 4) * p.st_floats + e * GS + 8 * q + 4 * hi;
                         const f32x4 v = gp_quad(q);
                         f32x4 o = *reinterpret_cast<const f32x4*>(gp);
                         o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
@@ -450,22 +473,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
             }
         }
+        WG_LAUNDER();
         // ---- epilogue -----------------------------------------------------------------------------------------------------
         if (vo > 0) {
+#pragma unroll 1
             for (int o = psub; o < vo; o += TPR) {
                 float g = 1.f;
                 if (scalar_gate) {
                     float s = bg[o];
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) s += GP[(ww * 32 + prow) * GS + o];
+                    for (int ww = 0; ww < 4; ++ww) s += lds[p.o_st + ww * p.st_floats + prow * GS + o];
                     g = gcp_sigmoid(s);
                 }
                 float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-                for (int h = 0; h < H; ++h) {
-                    const float wv = wu[o * WSU + h];
-                    u0 = fmaf(wv, VH[prow * HS + 3 * h + 0], u0);
-                    u1 = fmaf(wv, VH[prow * HS + 3 * h + 1], u1);
-                    u2 = fmaf(wv, VH[prow * HS + 3 * h + 2], u2);
+                if ((H & 3) == 0) {
+                    const float* vh = VH + prow * HS;
+                    for (int h = 0; h < H; h += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wu + o * WSU + h);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(vh + 3 * h);
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(vh + 3 * h + 4);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(vh + 3 * h + 8);
+                        u0 = fmaf(wv[0], a[0], u0); u1 = fmaf(wv[0], a[1], u1); u2 = fmaf(wv[0], a[2], u2);
+                        u0 = fmaf(wv[1], a[3], u0); u1 = fmaf(wv[1], bq[0], u1); u2 = fmaf(wv[1], bq[1], u2);
+                        u0 = fmaf(wv[2], bq[2], u0); u1 = fmaf(wv[2], bq[3], u1); u2 = fmaf(wv[2], d[0], u2);
+                        u0 = fmaf(wv[3], d[1], u0); u1 = fmaf(wv[3], d[2], u1); u2 = fmaf(wv[3], d[3], u2);
+                    }
+                } else {
+                    for (int h = 0; h < H; ++h) {
+                        const float wv = wu[o * WSU + h];
+                        u0 = fmaf(wv, VH[prow * HS + 3 * h + 0], u0);
+                        u1 = fmaf(wv, VH[prow * HS + 3 * h + 1], u1);
+                        u2 = fmaf(wv, VH[prow * HS + 3 * h + 2], u2);
+                    }
                 }
                 float* vp = V + prow * VS + 3 * o;
                 float x0 = 0.f, x1 = 0.f, x2 = 0.f;
@@ -481,14 +520,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         }
         stamp(6);
         wg_barrier();  // B3: the vector tile is updated
-        if (vo > 0 && B.v_out) {
-            const int vw = 3 * vo, nv = nvalid * vw;
-            float* dst = B.v_out + (int64_t)r0 * vw;
-            for (int i = tid; i < nv; i += NTH) {
-                const int r = i / vw, c = i - r * vw;
-                dst[i] = V[r * VS + c];
-            }
-        }
+        if (vo > 0 && B.v_out)
+            wg_tile_store<NTH>(B.v_out + (int64_t)r0 * 3 * vo, V, VS, 3 * vo, nvalid, tid, ((3 * vo) & 3) == 0 && wg_aligned16(B.v_out));
         stamp(7);
     };
 
@@ -617,7 +650,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
         vmax = max(vmax, w.vi);
         hmax = max(hmax, S.H);
         const int HF = S.H + (p.nf ? 3 : 0);
-        wsmax = max(wsmax, gcp_round_up(HF * (w.vi | 1) + vo * (S.H | 1) + vo, 4) + gcp_round_up(so, 4));
+        wsmax = max(wsmax, gcp_round_up(HF * wg_stride(w.vi) + vo * wg_stride(max(S.H, 1)) + vo, 4) + gcp_round_up(so, 4));
     }
     if ((n > 1 || blocks[0].residual) && p.NG != 1) return GCPNET_E_UNSUPPORTED;
     if (n > 1) kmax = max(kmax, gcp_round_up(so, 4));
@@ -631,14 +664,14 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     }
     if (rows == 0) return 0;
     p.KS = wg_stride(kmax);
-    p.VS = gcp_odd(3 * vmax);
-    p.HS = gcp_odd(3 * hmax);
+    p.VS = wg_stride(3 * vmax);
+    p.HS = wg_stride(3 * hmax);
     p.GS = wg_stride(gcp_round_up(max(vo, 1), 8));
     p.ws_floats = gcp_round_up(wsmax, 4);
     int off = 0;
     p.o_x = off; off += 32 * p.KS;
-    p.o_st = off; off += NW * 32 * 20;
-    p.o_gp = off; off += gated ? 4 * 32 * p.GS : 0;
+    p.st_floats = max(WG_STAGE_FLOATS, gated ? 32 * p.GS : 0);
+    p.o_st = off; off += NW * p.st_floats;
     p.o_ws = off; off += (n > 1 ? 2 : 1) * p.ws_floats;
     p.o_v = off; off += gcp_round_up(32 * p.VS, 4);
     p.o_vh = off; off += gcp_round_up(32 * p.HS, 4);
