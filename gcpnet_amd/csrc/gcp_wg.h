@@ -107,6 +107,40 @@ __device__ __forceinline__ void wg_tile_load(float* tile, int stride, const floa
     }
 }
 
+// Split form of wg_tile_load for tiles of up to B * NTH 16-byte pieces: `request` puts every load of the tile in flight (no
+// branches around them: clamped addresses), `commit` writes them to LDS.  Several tiles requested back to back share ONE
+// memory round trip instead of paying one each.
+template <int B>
+struct WgTileReq {
+    f32x4 v[B];
+    bool ok;  // the tile fits this form (16-byte pieces, B per thread); otherwise commit() falls back to wg_tile_load
+};
+template <int NTH, int B>
+__device__ __forceinline__ void wg_tile_request(WgTileReq<B>& rq, const float* __restrict__ src, int width, int nvalid, int tid, bool vec) {
+    const int q = width >> 2, n4 = nvalid * q;
+    rq.ok = vec && q > 0 && 32 * q <= B * NTH;
+#pragma unroll
+    for (int k = 0; k < B; ++k) rq.v[k] = *reinterpret_cast<const f32x4*>(src + 4 * (int64_t)max(min(tid + k * NTH, n4 - 1), 0));
+}
+template <int NTH, int B>
+__device__ __forceinline__ void wg_tile_commit(const WgTileReq<B>& rq, float* tile, int stride, const float* __restrict__ src, int width,
+                                               int nvalid, int tid, bool vec) {
+    if (!rq.ok) {
+        wg_tile_load<NTH>(tile, stride, src, width, nvalid, tid, vec);
+        return;
+    }
+    const int q = width >> 2, n4 = nvalid * q, tot = 32 * q;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const int i = tid + k * NTH;
+        if (i < tot) {
+            const int r = i / q, c4 = i - r * q;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(tile + r * stride + 4 * c4) = i < n4 ? rq.v[k] : z;
+        }
+    }
+}
+
 // dst[r * width + c] = tile[r * stride + c] for r < nvalid (flat, coalesced).
 template <int NTH>
 __device__ __forceinline__ void wg_tile_store(float* __restrict__ dst, const float* tile, int stride, int width, int nvalid, int tid,

@@ -154,23 +154,45 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + c);
             }
         }
-        // ---- tile loads ---------------------------------------------------------------------------------------------------
-        wg_tile_load<NTH>(V, VS, p.v_in + (int64_t)r0 * 3 * vi, 3 * vi, nvalid, tid, ((3 * vi) & 3) == 0 && wg_aligned16(p.v_in));
-        if (vo > 0) {
-            wg_tile_load<NTH>(DVO, US, p.d_v_out + (int64_t)r0 * 3 * vo, 3 * vo, nvalid, tid,
-                              ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out));
-            if (gated) wg_tile_load<NTH>(DG, DGS, p.gate + (int64_t)r0 * vo, vo, nvalid, tid, vec_o && wg_aligned16(p.gate));
-        }
-        if (nf) {
-            const float* fsrc = p.frames + (int64_t)r0 * 9;
-            for (int i = tid; i < 32 * 9; i += NTH) FR[i] = fsrc[min(i, nvalid * 9 - 1)];
-        }
-        if constexpr (FUSED) {
-            wg_tile_load<NTH>(X, KS, p.s_in + (int64_t)r0 * si, si, nvalid, tid, (si & 3) == 0 && wg_aligned16(p.s_in));
-            const int npad = 8 * gcp_cdiv(p.KW, 8) - K;  // ones column (bias gradient) + zero padding
-            for (int i = tid; i < 32 * npad; i += NTH) {
-                const int r = i / npad, c = i - r * npad;
-                X[r * KS + K + c] = (c == 0 && r < nvalid) ? 1.f : 0.f;
+        // ---- tile loads: every global load of the tile is requested before the first LDS write (one memory round trip) ------
+        {
+            const float* vsrc = p.v_in + (int64_t)r0 * 3 * vi;
+            const bool v_vec = ((3 * vi) & 3) == 0 && wg_aligned16(p.v_in);
+            const float* osrc = vo > 0 ? p.d_v_out + (int64_t)r0 * 3 * vo : vsrc;
+            const bool o_vec = vo > 0 && ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out);
+            const float* gsrc = gated ? p.gate + (int64_t)r0 * vo : vsrc;
+            const bool g_vec = gated && vec_o && wg_aligned16(p.gate);
+            const float* xsrc = FUSED ? p.s_in + (int64_t)r0 * si : vsrc;
+            const bool x_vec = FUSED && (si & 3) == 0 && wg_aligned16(p.s_in);
+            WgTileReq<2> rv, ro;
+            WgTileReq<1> rg;
+            WgTileReq<4> rx;
+            wg_tile_request<NTH, 2>(rv, vsrc, 3 * vi, nvalid, tid, v_vec);
+            wg_tile_request<NTH, 2>(ro, osrc, 3 * max(vo, 1), nvalid, tid, o_vec);
+            wg_tile_request<NTH, 1>(rg, gsrc, max(vo, 1), nvalid, tid, g_vec);
+            if constexpr (FUSED) wg_tile_request<NTH, 4>(rx, xsrc, si, nvalid, tid, x_vec);
+            float frv[2];
+            const float* fsrc = nf ? p.frames + (int64_t)r0 * 9 : vsrc;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) frv[k] = fsrc[min(tid + k * NTH, nvalid * 9 - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+            wg_tile_commit<NTH, 2>(rv, V, VS, vsrc, 3 * vi, nvalid, tid, v_vec);
+            if (vo > 0) {
+                wg_tile_commit<NTH, 2>(ro, DVO, US, osrc, 3 * vo, nvalid, tid, o_vec);
+                if (gated) wg_tile_commit<NTH, 1>(rg, DG, DGS, gsrc, vo, nvalid, tid, g_vec);
+            }
+            if (nf) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (tid + k * NTH < 32 * 9) FR[tid + k * NTH] = frv[k];
+            }
+            if constexpr (FUSED) {
+                wg_tile_commit<NTH, 4>(rx, X, KS, xsrc, si, nvalid, tid, x_vec);
+                const int npad = 8 * gcp_cdiv(p.KW, 8) - K;  // ones column (bias gradient) + zero padding
+                for (int i = tid; i < 32 * npad; i += NTH) {
+                    const int r = i / npad, c = i - r * npad;
+                    X[r * KS + K + c] = (c == 0 && r < nvalid) ? 1.f : 0.f;
+                }
             }
         }
         wg_barrier();

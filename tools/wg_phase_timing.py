@@ -64,13 +64,14 @@ for it in range(3):
         lib.gcpnet_debug_set_phase_timing(C.c_void_p(buf.data_ptr()), ntiles)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
+    ops.FORCE_WG_CHAIN_BACKWARD = True
     torch.autograd.backward([out_s, out_v], [ds, dv])
     b.record()
     torch.cuda.synchronize()
 lib.gcpnet_debug_set_phase_timing(None, 0)
 print(f"one-block backward (incl. reduces) {a.elapsed_time(b) * 1e3:.0f} us; wg launches: {ops.WG_STATS}")
 t = buf.view(ntiles, 8).cpu().double()
-t = t[t[:, 7] > 0]
+t = t[(t[:, 7] > 0) & (t[:, 0] > 0)][:512]
 d = t[:, 1:8] - t[:, :7]
 print(f"workgroups with stamps: {t.shape[0]}, tile total median {(t[:, 7] - t[:, 0]).median().item():.0f} cycles")
 for i, lab in enumerate(BL):
