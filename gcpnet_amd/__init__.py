@@ -5,11 +5,12 @@ from .components import (GCPDropout, GCPLayerNorm, ScalarVector, VectorDropout, 
 from .config import AttrDict, default_layer_cfg, default_module_cfg, instantiate, load_model_config
 from .gcpnet import GCP2, GCP3, GCPEmbedding, GCPInteractions, GCPInteractions2, GCPMessagePassing, get_GCP_with_custom_cfg
 from .models import Batch, GCPNetLBA, GCPNetNMS
-from .ops import set_weight_grad_stream
+from .ops import invalidate_packs, set_weight_grad_stream
+from .optim import FusedAdam
 
 __all__ = [
     "GCP2", "GCP3", "GCPEmbedding", "GCPInteractions", "GCPInteractions2", "GCPMessagePassing", "get_GCP_with_custom_cfg", "ScalarVector",
     "GCPLayerNorm", "GCPDropout", "VectorDropout", "centralize", "decentralize", "localize", "get_nonlinearity",
     "is_identity", "AttrDict", "default_module_cfg", "default_layer_cfg", "instantiate", "load_model_config", "Batch",
-    "GCPNetNMS", "GCPNetLBA", "set_weight_grad_stream",
+    "GCPNetNMS", "GCPNetLBA", "set_weight_grad_stream", "invalidate_packs", "FusedAdam",
 ]

@@ -23,7 +23,7 @@ EXPORTS = [
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
-    "gcpnet_wg_reduce",
+    "gcpnet_wg_reduce", "gcpnet_dropout", "gcpnet_adam_step",
 ]
 
 
@@ -60,6 +60,10 @@ class WgBlock(C.Structure):
 
 
 WG_MAX_BLOCKS = 9
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64)]
 
 
 class WgBwdPlan(C.Structure):
@@ -162,6 +166,8 @@ def load():
     lib.gcpnet_wg_backward_plan.argtypes = [i32, P(Gcp2Weights), P(Gcp2Opts), i32, P(WgBwdPlan)]
     lib.gcpnet_wg_backward.argtypes = [i32, P(WgBwdArgs), vp]
     lib.gcpnet_wg_reduce.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.gcpnet_dropout.argtypes = [i64, i32, vp, f32, C.c_uint64, vp, vp]
+    lib.gcpnet_adam_step.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",

@@ -105,7 +105,8 @@ def canonical_act(name: Optional[str]) -> Optional[str]:
 
 
 class VectorDropout(nn.Module):
-    """Drops whole 3-vectors (:97-115).  The Bernoulli mask comes from torch's device RNG (plumbing)."""
+    """Drops whole 3-vectors (:97-115): one Bernoulli draw per vector, survivors scaled by 1 / (1 - p); HIP kernel
+    (ops.dropout, group = 3)."""
 
     def __init__(self, drop_rate):
         super().__init__()
@@ -114,9 +115,20 @@ class VectorDropout(nn.Module):
     def forward(self, x):
         if not self.training or self.drop_rate == 0:
             return x
-        keep = 1 - self.drop_rate
-        mask = torch.bernoulli(torch.full(x.shape[:-1], keep, device=x.device)).unsqueeze(-1)
-        return mask * x / keep
+        from . import ops
+
+        return ops.dropout(x, self.drop_rate, group=3)
+
+
+class ScalarDropout(nn.Dropout):
+    """nn.Dropout with the mask / scale applied by the HIP kernel (ops.dropout); same attribute (`p`) and eval behaviour."""
+
+    def forward(self, x):
+        if not self.training or self.p == 0:
+            return x
+        from . import ops
+
+        return ops.dropout(x, self.p, group=1)
 
 
 class GCPDropout(nn.Module):
@@ -124,7 +136,7 @@ class GCPDropout(nn.Module):
 
     def __init__(self, drop_rate: float):
         super().__init__()
-        self.scalar_dropout = nn.Dropout(drop_rate)
+        self.scalar_dropout = ScalarDropout(drop_rate)
         self.vector_dropout = VectorDropout(drop_rate)
 
     @property

@@ -268,6 +268,43 @@ def axpy(a: Tensor, b: Tensor, alpha: float) -> Tensor:
 
 
 # ==============================================================================================================
+# dropout (components/__init__.py:97-135)
+# ==============================================================================================================
+class _Dropout(torch.autograd.Function):
+    """y = x * mask / keep with one Bernoulli(keep) draw per `group` consecutive floats (1: nn.Dropout, 3: VectorDropout); the mask
+    is a counter-based hash of (seed, index), recomputed -- not stored -- in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, keep: float, group: int, seed: int):
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        check(lib.gcpnet_dropout(x.numel() // group, group, _p(x), float(keep), C.c_uint64(seed), _p(y), _stream()), "dropout")
+        ctx.cfg = (float(keep), int(group), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        keep, group, seed = ctx.cfg
+        g = _req(g, "grad")
+        dx = torch.empty_like(g)
+        check(lib.gcpnet_dropout(g.numel() // group, group, _p(g), keep, C.c_uint64(seed), _p(dx), _stream()), "dropout")
+        return dx, None, None, None
+
+
+def dropout(x: Tensor, drop_rate: float, group: int = 1, seed: Optional[int] = None) -> Tensor:
+    """Train-mode dropout of `x` (scaled by 1 / (1 - drop_rate)); group = 3 drops whole 3-vectors of a [..., 3] tensor.  The seed
+    defaults to a draw from torch's CPU generator (reproducible under torch.manual_seed, no device synchronisation)."""
+    x = _req(x, "x")
+    if x.numel() == 0:
+        return x
+    assert x.numel() % group == 0
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    return _Dropout.apply(x, 1.0 - float(drop_rate), int(group), int(seed))
+
+
+# ==============================================================================================================
 # GCP2
 # ==============================================================================================================
 @dataclass

@@ -359,6 +359,24 @@ int gcpnet_row_gate_bwd_blocks(int64_t rows);
 int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,
                              int64_t ld_out, void* stream);
 
+/* ---- dropout (components/__init__.py:97-135: nn.Dropout on the scalars, VectorDropout on whole 3-vectors), train mode:
+ * y[g * group + j] = keep(g) ? x[g * group + j] / keep_prob : 0 with keep(g) = uniform(seed, g) < keep_prob, a counter-based
+ * hash: the backward is the same call on the gradient with the same seed (no mask is stored).  group = 1 or 3. */
+int gcpnet_dropout(int64_t n_groups, int group, const float* x, float keep_prob, uint64_t seed, float* y, void* stream);
+
+/* ---- fused Adam over many small parameter tensors (the reference's optimizer: torch.optim.Adam, configs/model/gcpnet_*.yaml;
+ * amsgrad = False): one launch per GCP_ADAM_MAX_TENSORS tensors instead of ~10 launches per tensor.  `step` counts from 1. */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+} gcp_adam_tensor_t;
+#define GCP_ADAM_MAX_TENSORS 96
+int gcpnet_adam_step(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, void* stream);
+
 /* ---- profiling hook: when `buf` (device memory, n_tiles * 8 uint64) is non-NULL, each 32-row wave-tile of the GCP2
  * forward / backward kernels writes s_memtime stamps at its phase boundaries; NULL switches it off. */
 int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);

@@ -1,0 +1,94 @@
+"""GPU tests of the trainer-side pieces: HIP dropout (train-mode statistics, whole-vector masks, mask-consistent backward), a
+train-mode layer with the shipped dropout 0.1, fused Adam against torch.optim.Adam."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gcpnet_amd
+
+    return gcpnet_amd
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_statistics_and_backward(G, p):
+    from gcpnet_amd import ops
+
+    torch.manual_seed(3)
+    n = 200000
+    s = torch.ones(n, 8, device="cuda", requires_grad=True)
+    v = torch.ones(n, 4, 3, device="cuda", requires_grad=True)
+    ys, yv = ops.dropout(s, p, group=1), ops.dropout(v, p, group=3)
+    keep = 1.0 - p
+    # survivors are scaled by 1 / keep, everything else is exactly zero
+    u = torch.unique(ys.detach()).tolist()
+    assert len(u) == 2 and u[0] == 0.0 and abs(u[1] - 1.0 / keep) < 1e-6, u
+    rate_s, rate_v = float((ys != 0).float().mean()), float((yv != 0).float().mean())
+    tol = 5.0 * (keep * p / (n * 4)) ** 0.5  # five sigma of a Bernoulli mean over the fewer draws
+    assert abs(rate_s - keep) < tol and abs(rate_v - keep) < tol, (rate_s, rate_v)
+    assert abs(float(ys.mean()) - 1.0) < 5 * tol  # unbiased
+    # whole 3-vectors are dropped together (components/__init__.py:113-114)
+    alive = (yv != 0)
+    assert bool((alive.all(-1) | (~alive).all(-1)).all())
+    # rows are not dropped as a whole (independent draws per element / per vector)
+    assert 0.0 < float(alive[:, 0, 0].float().mean()) < 1.0 and float((alive[:, 0, 0] ^ alive[:, 1, 0]).float().mean()) > 0.05
+    # backward applies the very same mask and scale
+    gs, gv = torch.autograd.grad([ys.sum(), yv.sum()], [s, v])
+    assert torch.equal(gs, ys.detach()) and torch.equal(gv, yv.detach())
+    # a different draw next time; the same draw for the same seed
+    assert not torch.equal(ops.dropout(s, p, 1), ys)
+    assert torch.equal(ops.dropout(s.detach(), p, 1, seed=11), ops.dropout(s.detach(), p, 1, seed=11))
+
+
+def test_gcp_dropout_module_and_layer_in_train_mode(G):
+    """GCPDropout is the identity in eval mode and active in train mode; a GCPInteractions layer with the shipped dropout 0.1
+    runs fwd + bwd in train mode with finite results that differ from the eval-mode ones by O(p)."""
+    from oracle import gcp_oracle as O
+    from tests.helpers import rand_graph
+
+    torch.manual_seed(4)
+    d = G.GCPDropout(0.1).cuda()
+    s, v = torch.randn(50, 16, device="cuda"), torch.randn(50, 4, 3, device="cuda")
+    d.eval()
+    out = d(G.ScalarVector(s, v))
+    assert out[0] is s and out[1] is v
+    d.train()
+    out = d(G.ScalarVector(s, v))
+    assert not torch.equal(out[0], s) and float((out[0] == 0).float().mean()) > 0.02
+    n, e = 400, 5000
+    layer = G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.1).cuda()
+    ei, x = rand_graph(n, e, 5, sort_by_col=True)
+    fr = O.localize(x, ei).cuda()
+    g = torch.Generator().manual_seed(6)
+    ins = [torch.randn(n, 64, generator=g).cuda().requires_grad_(), torch.randn(n, 16, 3, generator=g).cuda().requires_grad_(),
+           torch.randn(e, 32, generator=g).cuda(), torch.randn(e, 4, 3, generator=g).cuda()]
+    layer.eval()
+    he, _ = layer((ins[0], ins[1]), (ins[2], ins[3]), ei.cuda(), fr)
+    layer.train()
+    ht, ct = layer((ins[0], ins[1]), (ins[2], ins[3]), ei.cuda(), fr)
+    (ht.sum() + ct.sum()).backward()
+    assert torch.isfinite(ht).all() and torch.isfinite(ins[0].grad).all() and torch.isfinite(ins[1].grad).all()
+    rel = float((ht - he).norm() / he.norm())
+    assert 1e-3 < rel < 1.0, rel
+
+
+def test_fused_adam_matches_torch_adam(G):
+    torch.manual_seed(7)
+    shapes = [(64, 141), (64,), (4, 16), (3, 16), (16, 4), (16, 64), (16,), (1, 1), (300, 7)]
+    ref = [torch.randn(s, device="cuda").requires_grad_() for s in shapes]
+    mine = [t.detach().clone().requires_grad_() for t in ref]
+    o1 = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    o2 = G.FusedAdam(mine, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for it in range(5):
+        gs = [torch.randn_like(t) for t in ref]
+        for a, b, g in zip(ref, mine, gs):
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+        for a, b in zip(ref, mine):
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), (it, a.shape, float((a - b).abs().max()))
+    sd = o2.state_dict()
+    assert sd["state"][0]["step"] == 5 and sd["state"][0]["exp_avg"].shape == shapes[0]
