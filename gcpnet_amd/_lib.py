@@ -22,7 +22,7 @@ EXPORTS = [
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing",
-    "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
+    "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
     "gcpnet_wg_reduce", "gcpnet_dropout", "gcpnet_adam_step",
 ]
 
@@ -162,6 +162,7 @@ def load():
     lib.gcpnet_wg_pack_floats.restype = i64
     lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
     lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]
+    lib.gcpnet_wg_pack_view.argtypes = [P(Gcp2Weights), i32, vp, i32, i32, i32, P(i32), P(i32), vp, vp]
     lib.gcpnet_wg_forward.argtypes = [i32, vp, vp, vp, P(Concat), P(Concat), i32, P(WgBlock), vp]
     lib.gcpnet_wg_backward_plan.argtypes = [i32, P(Gcp2Weights), P(Gcp2Opts), i32, P(WgBwdPlan)]
     lib.gcpnet_wg_backward.argtypes = [i32, P(WgBwdArgs), vp]

@@ -529,7 +529,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     for (int b = 1; b < p.n; ++b) run_block(std::false_type{}, b);
 }
 
-__global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, const float* __restrict__ W, const float* __restrict__ Wg,
+// The scalar_out weight as the pack kernel reads it: logical W'[r][c], r < so, c < K, is W[r * ld + col(c)] (or, transposed,
+// W[col(c) * ld + r]) with col(c) running through up to three column ranges of the stored matrix -- so that column slices of a
+// Linear (project-then-gather keeps [e | norms | frame scalars] of scalar_out's columns; a projection uses one source's
+// columns) and transposed weights (the input gradient of a Linear is a Linear with W^T) are packed without copies.
+struct WgPackView {
+    const float* W;
+    int ld, trans, nseg;
+    int start[3], len[3];
+};
+__device__ __forceinline__ float wg_view_at(const WgPackView& v, int r, int c) {
+    int pc = -1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < v.nseg && pc < 0) {
+            if (c < v.len[k]) pc = v.start[k] + c;
+            else c -= v.len[k];
+        }
+    }
+    return v.trans ? v.W[(int64_t)pc * v.ld + r] : v.W[(int64_t)r * v.ld + pc];
+}
+
+__global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view, const float* __restrict__ Wg,
                                                       float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= S.total) return;
@@ -541,7 +562,7 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, const float* __
         const int64_t blk = idx >> 8;
         const int ot = (int)(blk / S.KG), g = (int)(blk - (int64_t)ot * S.KG);
         const int r = 32 * ot + m, c = 8 * g + 4 * hi + i;
-        if (r < S.so && c < S.K) v = W[(int64_t)r * S.K + c];
+        if (r < S.so && c < S.K) v = wg_view_at(view, r, c);
     } else if (idx < S.offA2) {
         const int g = (int)((idx - S.offG1) >> 8);
         const int c = 8 * g + 4 * hi + i;
@@ -550,7 +571,7 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, const float* __
         const int64_t blk = (idx - S.offA2) >> 8;
         const int kt = (int)(blk / G4), g = (int)(blk - (int64_t)kt * G4);
         const int r = 8 * g + 4 * hi + i, c = 32 * kt + m;
-        if (r < S.so && c < S.K) v = W[(int64_t)r * S.K + c];
+        if (r < S.so && c < S.K) v = wg_view_at(view, r, c);
     } else {
         const int64_t blk = (idx - S.offG2) >> 8;
         const int ot = (int)(blk / S.VG), g = (int)(blk - (int64_t)ot * S.VG);
@@ -580,14 +601,32 @@ extern "C" int64_t gcpnet_wg_pack_floats(int si, int vi, int so, int vo, int hid
     return wg_shape(si, vi, so, vo, hidden, use_frames, gated).total;
 }
 
-extern "C" int gcpnet_wg_pack(const gcp2_weights_t* w, int gated, float* out, void* stream) {
-    if (!w || !out || !w->w_scalar) return GCPNET_E_BADARG;
+extern "C" int gcpnet_wg_pack_view(const gcp2_weights_t* w, int gated, const float* W, int ld, int trans, int nseg,
+                                   const int* start, const int* len, float* out, void* stream) {
+    if (!w || !out || !W || nseg < 1 || nseg > 3 || !start || !len || ld < 1) return GCPNET_E_BADARG;
     const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
     if (S.gated && !w->w_gate) return GCPNET_E_BADARG;
-    hipLaunchKernelGGL(wg_pack_kernel, dim3((unsigned)gcp_cdiv((int)S.total, 256)), dim3(256), 0, (hipStream_t)stream, S, w->w_scalar,
-                       w->w_gate, out);
+    WgPackView v;
+    v.W = W; v.ld = ld; v.trans = trans; v.nseg = nseg;
+    int tot = 0;
+    for (int k = 0; k < 3; ++k) {
+        v.start[k] = k < nseg ? start[k] : 0;
+        v.len[k] = k < nseg ? len[k] : 0;
+        if (v.start[k] < 0 || v.len[k] < 0) return GCPNET_E_BADARG;
+        tot += v.len[k];
+    }
+    if (tot != S.K) return GCPNET_E_BADARG;
+    hipLaunchKernelGGL(wg_pack_kernel, dim3((unsigned)gcp_cdiv((int)S.total, 256)), dim3(256), 0, (hipStream_t)stream, S, v, w->w_gate,
+                       out);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gcpnet_wg_pack(const gcp2_weights_t* w, int gated, float* out, void* stream) {
+    if (!w || !w->w_scalar) return GCPNET_E_BADARG;
+    const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
+    const int start = 0, len = S.K;
+    return gcpnet_wg_pack_view(w, gated, w->w_scalar, S.K, 0, 1, &start, &len, out, stream);
 }
 
 // Waves per workgroup / output tiles per wave for an output width (shared with the Python side through gcpnet_wg_config).
@@ -602,7 +641,8 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     if (rows < 0 || n <= 0 || n > GCP_WG_MAX_BLOCKS || !blocks || !s_in) return GCPNET_E_BADARG;
     const gcp2_weights_t& w0 = blocks[0].w;
     const int so = w0.so, vo = w0.vo;
-    if (w0.vi <= 0 || !v_in) return GCPNET_E_UNSUPPORTED;
+    if (w0.vi < 0 || (w0.vi == 0 && (vo > 0 || n > 1))) return GCPNET_E_UNSUPPORTED;  // (vi == 0: one scalar-only Linear block)
+    if (w0.vi > 0 && !v_in) return GCPNET_E_BADARG;
     if ((so & 3) || so < 4) return GCPNET_E_UNSUPPORTED;
     if (vo > 32 && blocks[0].o.vmode == GCP_VMODE_SCALAR_GATE) return GCPNET_E_UNSUPPORTED;  // (one 32-row tile of gate outputs)
     WgFwdParams p;
@@ -612,7 +652,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     if (v_add) p.v_add = *v_add;
     if (p.s_add.n < 0 || p.s_add.n > GCP_MAX_SEG || p.v_add.n < 0 || p.v_add.n > GCP_MAX_SEG) return GCPNET_E_BADARG;
     const gcp2_opts_t& o0 = blocks[0].o;
-    p.so = so; p.vo = vo; p.nf = (w0.use_frames ? 9 : 0); p.e3 = o0.e3; p.vmode = vo > 0 ? o0.vmode : GCP_VMODE_NONE;
+    p.so = so; p.vo = vo; p.nf = (w0.use_frames && w0.vi > 0 ? 9 : 0); p.e3 = o0.e3; p.vmode = vo > 0 ? o0.vmode : GCP_VMODE_NONE;
     p.vres = o0.vector_residual; p.slope = o0.slope;
     if (p.nf && !frames) return GCPNET_E_BADARG;
     int NW, MT;
@@ -627,8 +667,8 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     for (int b = 0; b < n; ++b) {
         const gcp_wg_block_t& c = blocks[b];
         const gcp2_weights_t& w = c.w;
-        if (!w.pack || !w.b_scalar || !w.w_down || (w.vo > 0 && !w.w_up)) return GCPNET_E_BADARG;
-        if (w.so != so || w.vo != vo || w.vi <= 0 || (w.use_frames ? 9 : 0) != p.nf) return GCPNET_E_UNSUPPORTED;
+        if (!w.pack || !w.b_scalar || (w.vi > 0 && !w.w_down) || (w.vo > 0 && !w.w_up)) return GCPNET_E_BADARG;
+        if (w.so != so || w.vo != vo || (w.vi > 0) != (w0.vi > 0) || (w.use_frames && w.vi > 0 ? 9 : 0) != p.nf) return GCPNET_E_UNSUPPORTED;
         if (p.nf && !w.w_frames) return GCPNET_E_BADARG;
         if (c.o.vmode != o0.vmode || c.o.e3 != o0.e3 || c.o.vector_residual != o0.vector_residual || c.o.slope != o0.slope)
             return GCPNET_E_UNSUPPORTED;

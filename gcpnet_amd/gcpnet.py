@@ -476,10 +476,10 @@ class GCPInteractions(nn.Module):
         for gcp in self.node_position_update_network:
             h_v, chi_v = gcp((h_v, chi_v), edge_index, f_ij, node_inputs=True, node_mask=node_mask)
         upd = chi_v.reshape(chi_v.shape[0], 3)
-        if not self.ablate_x_force_update:  # :1143-1153: per-node Linears (library GEMMs), per-edge force, mean over in-edges
+        if not self.ablate_x_force_update:  # :1143-1153: per-node Linears (ops.linear: workgroup kernel), per-edge force, mean over in-edges
             plan = GraphPlan.get(edge_index, h_v.shape[0])
-            a = torch.nn.functional.linear(h_v, self.phi_force_i.weight, self.phi_force_i.bias)
-            b = torch.nn.functional.linear(h_v, self.phi_force_j.weight, self.phi_force_j.bias)
+            a = ops.linear(h_v, self.phi_force_i.weight, self.phi_force_i.bias)
+            b = ops.linear(h_v, self.phi_force_j.weight, self.phi_force_j.bias)
             force = ops.edge_force(a, b, self.phi_force_ij[1].weight, f_ij, plan, self.force_act, self.force_slope)
             upd = ops.axpy(upd, ops.segment_reduce(force, plan.col, mean=True), 1.0)
         return upd

@@ -334,6 +334,9 @@ class Gcp2Spec:
     # block as two launches sharing vector_down / vector_down_frames): autograd then sums two gradients inside the backward
     # pass, so this block's weight gradients must be complete on the caller's stream when its backward returns
     shared_weights: bool = False
+    # scalar_out's weight as a VIEW of a wider stored matrix: (W_full [so, ld], [(first column, columns), ...] up to 3 ranges
+    # adding up to K).  The workgroup kernels pack straight from it (gcpnet_wg_pack_view); weights[0] may then be None.
+    w_view: Optional[tuple] = None
 
     @property
     def K(self):
@@ -355,7 +358,7 @@ def _weights_struct(spec: Gcp2Spec, w, pack: Tensor) -> Gcp2Weights:
     ws = Gcp2Weights()
     ws.si, ws.vi, ws.so, ws.vo, ws.hidden, ws.use_frames = spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames)
     ws.w_down, ws.w_frames, ws.w_up = (t.data_ptr() if t is not None else None for t in (w_down, w_frames, w_up))
-    ws.w_scalar, ws.b_scalar = w_scalar.data_ptr(), b_scalar.data_ptr()
+    ws.w_scalar, ws.b_scalar = (w_scalar.data_ptr() if w_scalar is not None else None), b_scalar.data_ptr()
     ws.w_gate = w_gate.data_ptr() if w_gate is not None else None
     ws.b_gate = b_gate.data_ptr() if b_gate is not None else None
     ws.pack = pack.data_ptr() if pack is not None else None
@@ -373,6 +376,15 @@ def _opts_struct(spec: Gcp2Spec, fused_residual: bool = False) -> Gcp2Opts:
 _PACK_EPOCH = 0
 
 
+def _dense_weights(spec: Gcp2Spec, w):
+    """`w` with scalar_out's weight materialised when the spec only carries a view of it (the wave-per-tile kernels and the
+    TN-GEMM helpers want a contiguous matrix)."""
+    if w[0] is not None:
+        return w
+    W, segs = spec.w_view
+    return (torch.cat([W[:, a:a + n] for a, n in segs], dim=1),) + tuple(w[1:])
+
+
 def invalidate_packs() -> None:
     """Forces every packed-weight image to be rebuilt at its next use.  The caches are keyed on (data_ptr, _version) of the
     weights, which in-place updates through `p.data` (legacy optimizers, EMA / SWA weight swaps, `p.data.copy_`) do not
@@ -383,6 +395,7 @@ def invalidate_packs() -> None:
 
 def _pack(spec: Gcp2Spec, w) -> Tensor:
     lib = _lib.load()
+    w = _dense_weights(spec, w)
     w_scalar, w_gate = w[0], w[5]
     key = (_PACK_EPOCH,) + tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate, w[2], w[3], w[4]))
     cache = spec.pack_cache
@@ -409,10 +422,12 @@ def _gated(spec: Gcp2Spec) -> bool:
 
 
 def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
-    """Packed image of scalar_out / vector_out_scale for the workgroup kernels (gcpnet_wg_pack), cached per weight version."""
+    """Packed image of scalar_out / vector_out_scale for the workgroup kernels (gcpnet_wg_pack[_view]), cached per weight version."""
     lib = _lib.load()
-    w_scalar, w_gate = w[0], w[5]
-    key = (_PACK_EPOCH,) + tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
+    view = spec.w_view
+    w_scalar, w_gate = (view[0] if view is not None else w[0]), w[5]
+    key = (_PACK_EPOCH, None if view is None else tuple(view[1])) + tuple(
+        None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
     cache = spec.pack_cache
     if cache is not None and cache.get("wg_key") == key:
         return cache["wg_pack"]
@@ -420,10 +435,55 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
     n = lib.gcpnet_wg_pack_floats(spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames), gated)
     pack = torch.empty(int(n), dtype=torch.float32, device=w_scalar.device)
     ws = _weights_struct(spec, w, pack)
-    check(lib.gcpnet_wg_pack(C.byref(ws), gated, _p(pack), _stream()), "wg_pack")
+    if view is None:
+        check(lib.gcpnet_wg_pack(C.byref(ws), gated, _p(pack), _stream()), "wg_pack")
+    else:
+        segs = view[1]
+        starts, lens = (C.c_int * len(segs))(*[a for a, _ in segs]), (C.c_int * len(segs))(*[m for _, m in segs])
+        check(lib.gcpnet_wg_pack_view(C.byref(ws), gated, _p(w_scalar), w_scalar.stride(0), 0, len(segs), starts, lens, _p(pack),
+                                      _stream()), "wg_pack_view")
     if cache is not None:
         cache["wg_key"], cache["wg_pack"] = key, pack
     return pack
+
+
+_ZERO_BIAS: dict = {}
+
+
+def wg_linear(x: Tensor, W: Tensor, out_dim: int, in_dim: int, col0: int = 0, trans: bool = False,
+              bias: Optional[Tensor] = None) -> Optional[Tensor]:
+    """x [n, in_dim] @ W'^T -> [n, out_dim] through the workgroup forward kernel (a block without vectors is a plain Linear), with
+    W' a view of the stored matrix W [*, ld]: W'[r, c] = W[r, col0 + c], or with `trans` W'[r, c] = W[c, col0 + r] (the input
+    gradient of the former).  Returns None for shapes outside the kernel (the caller then uses a library GEMM)."""
+    lib = _lib.load()
+    n = x.shape[0]
+    if out_dim % 4 or out_dim < 4 or n == 0 or not x.is_contiguous() or x.shape[1] != in_dim:
+        return None
+    spec = Gcp2Spec(si=in_dim, vi=0, so=out_dim, vo=0, hidden=0, use_frames=False, act_s=None, act_v=None, slope=0.0,
+                    vmode=VMODE_NONE, vector_residual=False, e3=False, s_plans=[None], v_plans=[])
+    dev = x.device
+    zb = bias
+    if zb is None:
+        zb = _ZERO_BIAS.get((dev, out_dim))
+        if zb is None:
+            zb = _ZERO_BIAS[(dev, out_dim)] = torch.zeros(out_dim, dtype=torch.float32, device=dev)
+    w = (None, zb, None, None, None, None, None)
+    npk = lib.gcpnet_wg_pack_floats(in_dim, 0, out_dim, 0, 0, 0, 0)
+    pack = torch.empty(int(npk), dtype=torch.float32, device=dev)
+    ws = _weights_struct(spec, w, pack)
+    start, length = (C.c_int * 1)(0), (C.c_int * 1)(in_dim)
+    base = C.c_void_p(W.data_ptr() + 4 * col0)
+    check(lib.gcpnet_wg_pack_view(C.byref(ws), 0, base, W.stride(0), int(trans), 1, start, length, _p(pack), _stream()), "wg_pack_view")
+    out = torch.empty((n, out_dim), dtype=torch.float32, device=dev)
+    blk = WgBlock()
+    blk.w, blk.o = ws, _opts_struct(spec)
+    blk.s_out, blk.residual = _p(out), 0
+    rc = lib.gcpnet_wg_forward(n, _p(x), None, None, None, None, 1, C.byref(blk), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "wg_forward(linear)")
+    WG_STATS["linear"] = WG_STATS.get("linear", 0) + 1
+    return out
 
 
 def _wg_block(spec: Gcp2Spec, w, s_out, v_out, s_pre, gate, residual: bool, keep: list) -> WgBlock:
@@ -533,8 +593,7 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
     n_v = len(v_src)
     rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_src[0].shape[0]
     dev = s_src[0].device
-    pack = _pack(spec, w)
-    ws = _weights_struct(spec, w, pack)
+    pack = None  # (image for the wave-per-tile kernels: built only when one of them runs)
     opts = _opts_struct(spec)
     sc = _concat(s_src, spec.s_plans, False)
     vc = _concat(v_src, spec.v_plans, True) if n_v else Concat()
@@ -558,6 +617,9 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
             check(rc, "wg_forward")
             WG_STATS["fwd"] += 1
             return rows, s_out, v_out, pack, s_pre, gate
+    w = _dense_weights(spec, w)
+    pack = _pack(spec, w)
+    ws = _weights_struct(spec, w, pack)
     if ((adds or vadds) and len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
             and not spec.residual and res_s is None and res_v is None and spec.vo > 0 and USE_HEAD_KERNEL):
         # the first message GCP after project-then-gather: plain (e, xi) inputs + gathered addend tables -> the register-
@@ -608,6 +670,9 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     d_s_in = torch.empty((rows, si), **f32)
     d_v_in = torch.empty((rows, vi, 3), **f32) if vi > 0 else None
     scr, t = _alloc_bwd_scratch(spec, rows, need_w, s_pre.device)
+    w = _dense_weights(spec, w)
+    if pack is None:
+        pack = _pack(spec, w)
     ws = _weights_struct(spec, w, pack)
     opts = _opts_struct(spec, fused_residual=spec.residual)
     sc = _concat(s_src, spec.s_plans, False)
@@ -1174,9 +1239,15 @@ class _Gcp2Projected(torch.autograd.Function):
         dims = [t.shape[1] for t in s_src]
         offs = [sum(dims[:k]) for k in range(n_s)]
         rest = [k for k in range(n_s) if k not in sg]
-        wsegs = [w_scalar[:, offs[k]:offs[k] + dims[k]].contiguous() for k in sg]
-        adds = [torch.matmul(s_src[k], wk.t()) for k, wk in zip(sg, wsegs)]
-        w_rest = torch.cat([w_scalar[:, offs[k]:offs[k] + dims[k]] for k in rest] + [w_scalar[:, spec.si:]], dim=1)
+        # node-level projections h W_k^T through the workgroup kernel, packed straight from W's column range (no slice copies,
+        # no library GEMM); the columns the edge kernel keeps -- [un-gathered sources | norms | frame scalars] -- as a view too
+        adds = []
+        for k in sg:
+            a = wg_linear(s_src[k], w_scalar, spec.so, dims[k], col0=offs[k]) if USE_WG_KERNELS else None
+            adds.append(a if a is not None else torch.matmul(s_src[k], w_scalar[:, offs[k]:offs[k] + dims[k]].t()))
+        segs = [(offs[k], dims[k]) for k in rest] + ([(spec.si, spec.K - spec.si)] if spec.K > spec.si else [])
+        use_view = USE_WG_KERNELS and len(segs) <= 3 and w_scalar.stride(1) == 1
+        w_rest = None if use_view else torch.cat([w_scalar[:, a:a + m] for a, m in segs], dim=1)
         chans = [t.shape[1] for t in v_src]
         voffs = [sum(chans[:k]) for k in range(n_v)]
         vr = [k for k in range(n_v) if k not in vg]
@@ -1195,7 +1266,8 @@ class _Gcp2Projected(torch.autograd.Function):
             wf_rest = torch.cat([w_frames[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
         spec2 = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=None,
                         add_plans=[spec.s_plans[k] for k in sg], vi=sum(chans[k] for k in vr),
-                        v_plans=[spec.v_plans[k] for k in vr], vadd_plans=[spec.v_plans[k] for k in vg])
+                        v_plans=[spec.v_plans[k] for k in vr], vadd_plans=[spec.v_plans[k] for k in vg],
+                        w_view=(w_scalar, segs) if use_view else None)
         w2 = (w_rest, b_scalar, wd_rest, wf_rest, w_up, w_gate, b_gate)
         need_grad = any(ctx.needs_input_grad)
         rows, s_out, v_out, pack, s_pre, gate = _gcp2_forward_launch(spec2, frames, [s_src[k] for k in rest],
@@ -1207,7 +1279,7 @@ class _Gcp2Projected(torch.autograd.Function):
             ctx.w_leaf = not spec.shared_weights
             ctx.weights = w
             ctx.n_w2 = [t is not None for t in w2]
-            ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre, gate, *wsegs, *wvs, *vts, *vadds)
+            ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre, gate, *wvs, *vts, *vadds)
         if spec.vo:
             return s_out, v_out
         return s_out
@@ -1226,7 +1298,6 @@ class _Gcp2Projected(torch.autograd.Function):
         w2 = tuple(w2)
         pack, s_pre, gate = saved[pos:pos + 3]
         pos += 3
-        wsegs = saved[pos:pos + len(sg)]; pos += len(sg)
         wvs = saved[pos:pos + len(vg)]; pos += len(vg)
         vts = saved[pos:pos + len(vg)]; pos += len(vg)
         vadds = saved[pos:pos + len(vg)]
@@ -1257,12 +1328,14 @@ class _Gcp2Projected(torch.autograd.Function):
                 grads_s[k] = d_s_in if len(rest) == 1 else d_s_in[:, off2:off2 + dims[k]]
             off2 += dims[k]
         dP = []
-        for k, wk in zip(sg, wsegs):  # projected sources: d(table) = ds_pre summed over the gathering rows, then the GEMM's adjoint
+        w_scalar = ctx.weights[0]
+        for k in sg:  # projected sources: d(table) = ds_pre summed over the gathering rows, then the Linear's adjoint (W_k^T view)
             pl = spec.s_plans[k]
             g = ds_pre if pl is None else _segment_reduce_raw(ds_pre, 0, spec.so, spec.so, pl, False)
             dP.append(g)
             if ctx.needs_input_grad[base + k]:
-                grads_s[k] = torch.matmul(g, wk)
+                dx = wg_linear(g, w_scalar, dims[k], spec.so, col0=offs[k], trans=True) if USE_WG_KERNELS else None
+                grads_s[k] = dx if dx is not None else torch.matmul(g, w_scalar[:, offs[k]:offs[k] + dims[k]])
         grads_v: List[Optional[Tensor]] = [None] * n_v
         off2 = 0
         for k in vr:
@@ -1323,6 +1396,54 @@ class _Gcp2Projected(torch.autograd.Function):
         g_res_s = d_s_out if ctx.has_res[0] else None
         g_res_v = d_v_out if ctx.has_res[1] else None
         return (None, None, None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
+
+
+class _Linear(torch.autograd.Function):
+    """nn.Linear on node rows (phi_force_i / phi_force_j of the position update, gcpnet.py:1052-1056): forward and input gradient
+    through the workgroup kernel (wg_linear), weight / bias gradient through the row-split TN GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        out = wg_linear(x, weight, weight.shape[0], weight.shape[1], bias=bias)
+        if out is None:
+            out = torch.addmm(bias, x, weight.t())
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        g = _req(g, "grad")
+        so, dim = weight.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = wg_linear(g, weight, dim, so, trans=True)
+            if dx is None:
+                dx = torch.matmul(g, weight)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            n = x.shape[0]
+            a, b = Operand(), Operand()
+            a.n, b.n = 1, 1
+            a.ptr[0], a.dim[0], a.ld[0] = g.data_ptr(), so, so
+            b.ptr[0], b.dim[0], b.ld[0] = x.data_ptr(), dim, x.stride(0)
+            b.ones = 1
+            dw = torch.empty((so, dim), dtype=torch.float32, device=g.device)
+            db = torch.empty((so,), dtype=torch.float32, device=g.device)
+            pr = TnProblem()
+            pr.rows, pr.a, pr.b = n, a, b
+            pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = dw.data_ptr(), dim, 1, so, dim
+            pr.out2, pr.out2_n = db.data_ptr(), dim
+            pr.splits = lib.gcpnet_tn_splits(n, so, dim + 1)
+            part = torch.empty((pr.splits, so, dim + 1), dtype=torch.float32, device=g.device)
+            pr.partial = part.data_ptr()
+            check(lib.gcpnet_tn_gemm(1, C.byref(pr), _stream()), "tn_gemm")
+        return dx, dw, db
+
+
+def linear(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    return _Linear.apply(_req(x, "x"), _req(weight, "weight"), _req(bias, "bias"))
 
 
 class _EdgeForce(torch.autograd.Function):

@@ -146,6 +146,13 @@ int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, const float
  * vector_out_scale Linear). */
 int64_t gcpnet_wg_pack_floats(int si, int vi, int so, int vo, int hidden, int use_frames, int gated);
 int gcpnet_wg_pack(const gcp2_weights_t* w, int gated, float* pack_out, void* stream);
+/* The same from a VIEW of the stored scalar_out weight: logical W'[r][c] (r < so, c < K = si + H + 9) is W[r * ld + col(c)], or
+ * W[col(c) * ld + r] when `trans`, col(c) running through `nseg` <= 3 column ranges (start[k], len[k]) whose lengths add up to
+ * K.  Packs column slices (project-then-gather: the kernel keeps [e | norms | frame scalars] of scalar_out's columns; a node-level
+ * projection uses one source's columns) and transposed weights (input gradient of a Linear) without materialising them.
+ * With vi == 0, vo == 0 a block is a plain Linear + activation: gcpnet_wg_forward then replaces nn.Linear on [rows, si]. */
+int gcpnet_wg_pack_view(const gcp2_weights_t* w, int gated, const float* W, int ld, int trans, int nseg, const int* start,
+                        const int* len, float* pack_out, void* stream);
 
 typedef struct {
     gcp2_weights_t w;   /* dims of THIS block, reference-layout weights, w.pack = image of gcpnet_wg_pack */

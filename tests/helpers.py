@@ -42,7 +42,7 @@ def rand_graph(n, e, seed, sort_by_col=False):
     return torch.stack((row, col)), x
 
 
-def as_accurate(got, cpu32, cpu64, name="", factor=4.0, floor=1e-3, abs_floor=0.0):
+def as_accurate(got, cpu32, cpu64, name="", factor=4.0, floor=2e-3, abs_floor=0.0):
     """`got` (the HIP path, fp32) is as close to the float64 result as the reference's own fp32 CPU arithmetic is, up to
     `factor` (L2 over the tensor), with a floor of `floor` x the tensor's norm (a handful of flips more or fewer on one side
     moves a small weight gradient by a few 1e-4 of its norm; the smooth-activation variants of the same tests, which run the
