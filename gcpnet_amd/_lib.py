@@ -23,7 +23,7 @@ EXPORTS = [
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
-    "gcpnet_wg_reduce", "gcpnet_dropout", "gcpnet_adam_step",
+    "gcpnet_wg_reduce", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph",
 ]
 
 
@@ -169,6 +169,9 @@ def load():
     lib.gcpnet_wg_reduce.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     lib.gcpnet_dropout.argtypes = [i64, i32, vp, f32, C.c_uint64, vp, vp]
     lib.gcpnet_adam_step.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, i32, vp]
+    lib.gcpnet_nms_edge_features.argtypes = [i64, vp, vp, vp, vp, i32, f32, i32, vp, vp, vp]
+    lib.gcpnet_nms_node_features.argtypes = [i64, vp, vp, vp, vp, vp, vp]
+    lib.gcpnet_radius_graph.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",

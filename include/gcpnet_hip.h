@@ -384,6 +384,24 @@ typedef struct {
 int gcpnet_adam_step(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, void* stream);
 
+/* ---- input side ---------------------------------------------------------------------------------
+ * NMS featuriser, src/datamodules/components/nms_dataset.py:23-61 + helper.py:16-59:
+ *   e_out [E, n_attr + n_rbf] = [edge_attr | RBF(|x_row - x_col|; mu = linspace(0, d_max, n_rbf), sigma = d_max / n_rbf)],
+ *   xi_out [E, 1, 3] = unit(x_row - x_col) (0 for coincident points: nan_to_num);
+ *   h_out [N, 1] = |vel|, chi_out [N, 3, 3] = [vel, unit(x[i+1] - x[i]), unit(x[i-1] - x[i])] with the orientations taken along
+ *   the node order inside each graph (`batch` = graph id per node, NULL = one graph; zero at a graph's ends). */
+int gcpnet_nms_edge_features(int64_t E, const float* x, const int32_t* row, const int32_t* col, const float* edge_attr, int n_attr,
+                             float d_max, int n_rbf, float* e_out, float* xi_out, void* stream);
+int gcpnet_nms_node_features(int64_t N, const float* vel, const float* x, const int32_t* batch, float* h_out, float* chi_out,
+                             void* stream);
+/* Radius graph (atom3d_dataset.py:110-112 recipe): for every node the `max_neighbors` (<= 64) nearest other nodes of its graph
+ * within `radius`, ascending by distance (ties: lower node id), nbr [N, max_neighbors] (-1 padded) and count [N], indexed by node
+ * id.  The caller provides the cell list: nodes sorted by global cell = graph * (nx*ny*nz) + (cz*ny + cy)*nx + cx with cell edge
+ * >= radius (x_sorted [N,3], order = node id per sorted position, cell_of, cell_start [n_graphs*nx*ny*nz + 1]).  Edge (row =
+ * neighbour, col = node) lists built from it are col-sorted by construction. */
+int gcpnet_radius_graph(int N, const float* x_sorted, const int32_t* order, const int32_t* cell_of, const int32_t* cell_start, int nx,
+                        int ny, int nz, float radius, int max_neighbors, int32_t* nbr, int32_t* count, void* stream);
+
 /* ---- profiling hook: when `buf` (device memory, n_tiles * 8 uint64) is non-NULL, each 32-row wave-tile of the GCP2
  * forward / backward kernels writes s_memtime stamps at its phase boundaries; NULL switches it off. */
 int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);

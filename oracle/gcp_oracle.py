@@ -516,3 +516,42 @@ def random_rotation(seed: int = 0) -> Tensor:
 
 
 __all__ = [n for n in dir() if not n.startswith("_") and n not in ("math", "torch", "F", "annotations")]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# input side: NMS featuriser, src/datamodules/components/nms_dataset.py:23-61 with
+# helper.py:16-59 (_normalize, _rbf, _orientations); pinned by tests/golden/nms_features.npz (generated with the
+# reference's real helper functions) and, for the radius graph, tests/golden/radius_graph.npz (scipy cKDTree)
+# ----------------------------------------------------------------------------------------------------------
+def nms_features(x: Tensor, vel: Tensor, edge_attr: Tensor, edge_index: Tensor, batch: Tensor, d_max: float = 4.5,
+                 num_rbf: int = 16) -> Dict[str, Tensor]:
+    row, col = edge_index[0], edge_index[1]
+    ev = x[row] - x[col]  # nms_dataset.py:33
+    d = ev.norm(dim=-1)
+    mu = torch.linspace(0.0, d_max, num_rbf).view(1, -1)  # helper.py:40-45
+    rbf = torch.exp(-(((d.unsqueeze(-1) - mu) / (d_max / num_rbf)) ** 2))
+    e = torch.nan_to_num(torch.cat((edge_attr, rbf), dim=-1))
+    xi = torch.nan_to_num(torch.nan_to_num(ev / d.unsqueeze(-1)).unsqueeze(-2))  # helper.py:23-25, nms_dataset.py:41-43
+    h = torch.sqrt((vel ** 2).sum(-1)).unsqueeze(-1)  # nms_dataset.py:58
+    fwd, bwd = torch.zeros_like(x), torch.zeros_like(x)  # helper.py:52-59, per graph
+    same_next = batch[1:] == batch[:-1]
+    f = torch.nan_to_num((x[1:] - x[:-1]) / (x[1:] - x[:-1]).norm(dim=-1, keepdim=True))
+    fwd[:-1][same_next] = f[same_next]
+    bwd[1:][same_next] = -f[same_next]
+    chi = torch.stack((vel, fwd, bwd), dim=1)
+    return dict(h=h, chi=chi, e=e, xi=xi)
+
+
+def radius_graph(x: Tensor, batch: Tensor, radius: float = 4.5, max_neighbors: int = 32) -> Tensor:
+    """K nearest other nodes of the same graph within `radius`, ascending by distance; edges (row = neighbour, col = node),
+    col-sorted.  Brute force in float64 (small inputs only)."""
+    xd = x.double()
+    d2 = ((xd.unsqueeze(1) - xd.unsqueeze(0)) ** 2).sum(-1)
+    ok = (batch.unsqueeze(1) == batch.unsqueeze(0)) & (d2 <= radius * radius)
+    ok.fill_diagonal_(False)
+    d2 = torch.where(ok, d2, torch.full_like(d2, float("inf")))
+    k = min(max_neighbors, x.shape[0])
+    val, idx = torch.topk(d2, k, dim=1, largest=False, sorted=True)
+    keep = torch.isfinite(val)
+    col = torch.arange(x.shape[0]).unsqueeze(1).expand_as(idx)[keep]
+    return torch.stack((idx[keep], col))

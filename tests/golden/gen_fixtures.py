@@ -344,6 +344,58 @@ def fx_interactions2():
              inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames, x=x), outputs=outs, grads=grads)
 
 
+def fx_input_side():
+    """Input side.  (1) NMS featuriser: the reference's real helper functions (`_rbf`, `_normalize`,
+    `_orientations`, src/datamodules/components/helper.py) driven exactly as nms_dataset.py:23-61,180-206 drives them (that file
+    itself needs PyG / atom3d to import), per graph, then collated.  (2) radius graph: the scipy cKDTree path of
+    gcpnet_amd.synthetic (K nearest within r, per graph) -- the GPU builder must reproduce its edge list bit for bit."""
+    from src.datamodules.components import helper as H
+    from scipy.spatial import cKDTree
+
+    g = torch.Generator().manual_seed(90)
+    n_graphs, n_body = 3, 5
+    xs, vels, attrs, eis, outs = [], [], [], [], dict(h=[], chi=[], e=[], xi=[])
+    for k in range(n_graphs):
+        loc, vel = torch.randn(n_body, 3, generator=g) * 2, torch.randn(n_body, 3, generator=g)
+        if k == 1:
+            loc[3] = loc[2]  # coincident bodies: 0 / 0 in _normalize -> nan_to_num -> 0
+        charges = torch.randint(0, 2, (n_body,), generator=g).float() * 2 - 1
+        idx = torch.arange(n_body)
+        r, c = torch.meshgrid(idx, idx, indexing="ij")
+        keep = r != c
+        ei = torch.stack((r[keep], c[keep]))
+        edge_attr = (charges[ei[0]] * charges[ei[1]]).unsqueeze(-1)
+        # nms_dataset.py:33-45
+        E_vectors = loc[ei[0]] - loc[ei[1]]
+        rbf = H._rbf(E_vectors.norm(dim=-1), D_max=4.5, D_count=16)
+        edge_s = torch.cat((edge_attr, rbf), dim=-1)
+        edge_v = H._normalize(E_vectors).unsqueeze(-2)
+        edge_s, edge_v = map(torch.nan_to_num, (edge_s, edge_v))
+        # nms_dataset.py:56-59
+        node_s = torch.sqrt(torch.sum(vel ** 2, dim=-1)).unsqueeze(-1)
+        node_v = torch.cat((vel.unsqueeze(1), H._orientations(loc)), dim=1)
+        xs.append(loc); vels.append(vel); attrs.append(edge_attr); eis.append(ei + k * n_body)
+        for key, val in (("h", node_s), ("chi", node_v), ("e", edge_s), ("xi", edge_v)):
+            outs[key].append(val)
+    save("nms_features", inputs=dict(x=torch.cat(xs), vel=torch.cat(vels), edge_attr=torch.cat(attrs), edge_index=torch.cat(eis, 1),
+                                     batch=torch.arange(n_graphs).repeat_interleave(n_body)),
+         outputs={k: torch.cat(v) for k, v in outs.items()})
+
+    rng = np.random.default_rng(91)
+    pts, eis, bidx, off = [], [], [], 0
+    for k, (n, side) in enumerate(((700, 22.0), (500, 30.0), (40, 3.0))):  # dense, sparse (some nodes below K), tiny (n - 1 < K)
+        x = rng.uniform(0.0, side, size=(n, 3)).astype(np.float32)
+        K = 16
+        dist, nbr = cKDTree(x).query(x, k=min(K + 1, n), distance_upper_bound=4.5)
+        dist, nbr = dist[:, 1:], nbr[:, 1:]
+        ok = np.isfinite(dist)
+        col = np.repeat(np.arange(n), dist.shape[1]).reshape(n, dist.shape[1])[ok]
+        eis.append(np.stack((nbr[ok], col)).astype(np.int64) + off)
+        pts.append(x); bidx.append(np.full(n, k)); off += n
+    save("radius_graph", inputs=dict(x=torch.from_numpy(np.concatenate(pts)), batch=torch.from_numpy(np.concatenate(bidx))),
+         outputs=dict(edge_index=torch.from_numpy(np.concatenate(eis, 1))), meta=dict(radius=4.5, max_neighbors=16))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     fx_geometry()
@@ -353,3 +405,4 @@ if __name__ == "__main__":
     fx_interactions()
     fx_interactions2()
     fx_models()
+    fx_input_side()

@@ -1,7 +1,6 @@
 """Stub modules that let the reference's hot-path files import in the authoring container.
 
-Only used by ``tests/golden/gen_fixtures.py`` (authoring-time fixture generation) and by
-``tests/test_oracle_vs_reference.py`` (skipped when ``/root/reference`` is absent).  Nothing here ships
+Only used by ``tests/golden/gen_fixtures.py`` (authoring-time fixture generation; the GPU box never sees the reference).  Nothing here ships
 arithmetic of its own except ``torch_scatter.scatter``, which restates the documented semantics of
 pytorch-scatter 2.0.9 (``environment.yaml:209`` of the reference): sum by ``index`` into ``dim_size`` rows,
 ``mean`` = sum / clamp(count, 1).

@@ -178,3 +178,20 @@ def test_config_loader_accepts_reference_layout(tmp_path):
     assert isinstance(model, G.GCPNetNMS)
     assert len(model.interaction_layers) == 2 and model.interaction_layers[0].updating_node_positions
     assert "interaction_layers.1.interaction.message_fusion.2.scalar_out.weight" in model.state_dict()
+
+
+def test_compat_aliases_resolve_reference_dotted_names():
+    """gcpnet_amd.compat.install_aliases(): the reference's `_target_` strings and LitModule imports resolve to this package."""
+    import importlib
+    import subprocess
+    import sys
+
+    code = (
+        "import gcpnet_amd, gcpnet_amd.compat as c; c.install_aliases();"
+        "from src.models.components.gcpnet import GCPInteractions, GCP2, GCPEmbedding;"
+        "from src.models.components import ScalarVector, GCPLayerNorm, centralize, decentralize, localize;"
+        "import importlib; m = importlib.import_module('src.models.components.gcpnet');"
+        "assert getattr(m, 'GCPInteractions') is gcpnet_amd.GCPInteractions and GCP2 is gcpnet_amd.GCP2;"
+        "assert ScalarVector is gcpnet_amd.ScalarVector and localize is gcpnet_amd.localize; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]

@@ -221,3 +221,18 @@ def test_oracle_equivariance():
     close(h1, h0, atol=1e-5, rtol=1e-4)
     close(c1, c0 @ Q.t(), atol=1e-5, rtol=1e-4)
     close(x1, x0 @ Q.t(), atol=1e-5, rtol=1e-4)
+
+
+def test_nms_features_golden():
+    """Oracle restatement of the NMS featuriser against the fixture built with the reference's real helper functions."""
+    f = Fixture("nms_features")
+    out = O.nms_features(f.i["x"], f.i["vel"], f.i["edge_attr"], f.i["edge_index"], f.i["batch"])
+    for k in ("h", "chi", "e", "xi"):
+        close(out[k], f.o[k], atol=1e-6, rtol=1e-6)
+
+
+def test_radius_graph_golden():
+    """Brute-force oracle against the scipy cKDTree edge list (the fixture): identical index arrays."""
+    f = Fixture("radius_graph")
+    ei = O.radius_graph(f.i["x"], f.i["batch"], float(f.m["radius"]), int(f.m["max_neighbors"]))
+    assert torch.equal(ei, f.o["edge_index"])

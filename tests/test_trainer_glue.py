@@ -92,3 +92,29 @@ def test_fused_adam_matches_torch_adam(G):
             assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), (it, a.shape, float((a - b).abs().max()))
     sd = o2.state_dict()
     assert sd["state"][0]["step"] == 5 and sd["state"][0]["exp_avg"].shape == shapes[0]
+
+
+def test_nms_featurize_golden(G):
+    """GPU featuriser against the fixture built with the reference's helper functions (incl. coincident bodies -> zeros)."""
+    from tests.helpers import Fixture, close
+
+    f = Fixture("nms_features")
+    out = G.nms_featurize(f.i["x"].cuda(), f.i["vel"].cuda(), f.i["edge_attr"].cuda(), f.i["edge_index"].cuda(), f.i["batch"].cuda())
+    for k in ("h", "chi", "e", "xi"):
+        close(out[k].cpu(), f.o[k], atol=2e-6, rtol=1e-5)
+
+
+def test_radius_graph_matches_scipy_bit_for_bit(G):
+    """GPU cell-list radius graph: the committed scipy fixture (3 graphs: dense, sparse, fewer nodes than K) and a fresh 20 000-node
+    cloud against gcpnet_amd.synthetic.radius_graph -- identical edge_index arrays, col-sorted."""
+    from tests.helpers import Fixture
+
+    f = Fixture("radius_graph")
+    ei = G.radius_graph(f.i["x"].cuda(), r=float(f.m["radius"]), max_num_neighbors=int(f.m["max_neighbors"]), batch=f.i["batch"].cuda())
+    assert torch.equal(ei.cpu(), f.o["edge_index"])
+    from gcpnet_amd.synthetic import radius_graph as scipy_graph
+
+    x, want = scipy_graph(20000, 16, seed=5)
+    got = G.radius_graph(x.cuda(), r=4.5, max_num_neighbors=16)
+    assert torch.equal(got.cpu(), want)
+    assert bool((got[1, 1:] >= got[1, :-1]).all())
