@@ -48,7 +48,136 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 }
 
+// y = act(x) / dx = g * act'(x), element-wise (models/__init__.py:42-57); used where an activation sits between separately launched
+// pieces (the frame-gate path of GCP2, components/gcpnet.py:369-384).
+__global__ __launch_bounds__(256) void act_kernel(int64_t n, const float* __restrict__ x, const float* __restrict__ g, int act, float slope,
+                                                  float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = g ? g[i] * gcp_act_grad(act, x[i], slope) : gcp_act(act, x[i], slope);
+}
+
+// Frame gate of GCP2 (components/gcpnet.py:369-384 with vectorize, components/__init__.py:329-378, which is linear in the frame:
+// for node rows the mean out-edge frame does what gather / vectorize / scatter-mean do).  Per row, with g the 9 gate scalars,
+// F the row's frame, Wf = vector_up_frames.weight [vo, 3]:
+//   gv[c, :] = sum_a g[3 c + a] F[a, :];  gvr[o, :] = sum_c Wf[o, c] gv[c, :];  n[o] = sqrt(|gvr[o]|^2 + 1e-8) + 1e-8;
+//   out[o, :] = vu[o, :] * act_v(n[o]).
+__device__ __forceinline__ void fg_gv(const float* g, const float* F, float (&gv)[3][3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gv[c][d] = g[3 * c] * F[d] + g[3 * c + 1] * F[3 + d] + g[3 * c + 2] * F[6 + d];
+}
+
+__global__ __launch_bounds__(256) void frame_gate_fwd_kernel(int64_t rows, int vo, const float* __restrict__ g, int ldg,
+                                                             const float* __restrict__ frames, const float* __restrict__ wf,
+                                                             const float* __restrict__ vu, int act, float slope, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * vo; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vo;
+        const int o = (int)(i - r * vo);
+        float gv[3][3];
+        fg_gv(g + r * ldg, frames + r * 9, gv);
+        float q[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = wf[3 * o] * gv[0][d] + wf[3 * o + 1] * gv[1][d] + wf[3 * o + 2] * gv[2][d];
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + 1e-8f) + 1e-8f;
+        const float a = gcp_act(act, n, slope);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) out[3 * i + d] = vu[3 * i + d] * a;
+    }
+}
+
+// One thread per row: d vu, d g (row-local sums over the output channels), and this wave's share of d Wf [vo, 3] in
+// part[wave, vo * 3] (wave-level butterfly; summed over waves by gcpnet_reduce_partials).
+__global__ __launch_bounds__(256) void frame_gate_bwd_kernel(int64_t rows, int vo, const float* __restrict__ g, int ldg,
+                                                             const float* __restrict__ frames, const float* __restrict__ wf,
+                                                             const float* __restrict__ vu, int act, float slope,
+                                                             const float* __restrict__ d_out, float* __restrict__ d_vu,
+                                                             float* __restrict__ d_g, float* __restrict__ part) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = r < rows;
+    const int64_t rc = ok ? r : 0;
+    float gv[3][3], dgv[3][3];
+    fg_gv(g + rc * ldg, frames + rc * 9, gv);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dgv[c][d] = 0.f;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    for (int o = 0; o < vo; ++o) {
+        const float w0 = wf[3 * o], w1 = wf[3 * o + 1], w2 = wf[3 * o + 2];
+        float q[3], dq[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = w0 * gv[0][d] + w1 * gv[1][d] + w2 * gv[2][d];
+        const float rs = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + 1e-8f), n = rs + 1e-8f;
+        const float a = gcp_act(act, n, slope), da_dn = gcp_act_grad(act, n, slope);
+        const int64_t j = (rc * vo + o) * 3;
+        float da = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float go = ok ? d_out[j + d] : 0.f;
+            if (ok) d_vu[j + d] = go * a;
+            da += go * vu[j + d];
+        }
+        const float coef = da * da_dn / rs;
+        float dw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            dq[d] = coef * q[d];
+            dgv[0][d] += w0 * dq[d]; dgv[1][d] += w1 * dq[d]; dgv[2][d] += w2 * dq[d];
+            dw[0] += dq[d] * gv[0][d]; dw[1] += dq[d] * gv[1][d]; dw[2] += dq[d] * gv[2][d];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = dw[c];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if ((threadIdx.x & 63) == 0) part[wave * vo * 3 + 3 * o + c] = v;
+        }
+    }
+    if (ok) {
+        const float* F = frames + r * 9;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d_g[r * ldg + 3 * c + a] = dgv[c][0] * F[3 * a] + dgv[c][1] * F[3 * a + 1] + dgv[c][2] * F[3 * a + 2];
+        for (int k = 9; k < ldg; ++k) d_g[r * ldg + k] = 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int gcpnet_activation(int64_t n, const float* x, const float* grad, int act, float slope, float* y, void* stream) {
+    if (n < 0 || !x || !y || act < 0 || act > GCP_ACT_SIGMOID) return GCPNET_E_BADARG;
+    if (n == 0) return 0;
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, n, x, grad, act, slope, y);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_frame_gate_bwd_parts(int64_t rows) { return (int)((((rows + 255) / 256) * 256) / 64); }
+
+extern "C" int gcpnet_frame_gate_forward(int64_t rows, int vo, const float* g, int ldg, const float* frames, const float* w_up_frames,
+                                         const float* vu, int act, float slope, float* out, void* stream) {
+    if (rows < 0 || vo < 1 || ldg < 9 || !g || !frames || !w_up_frames || !vu || !out) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    const int64_t nb = (rows * vo + 255) / 256;
+    hipLaunchKernelGGL(frame_gate_fwd_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, rows, vo, g, ldg,
+                       frames, w_up_frames, vu, act, slope, out);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_frame_gate_backward(int64_t rows, int vo, const float* g, int ldg, const float* frames, const float* w_up_frames,
+                                          const float* vu, int act, float slope, const float* d_out, float* d_vu, float* d_g, float* part,
+                                          void* stream) {
+    if (rows < 0 || vo < 1 || ldg < 9 || !g || !frames || !w_up_frames || !vu || !d_out || !d_vu || !d_g || !part) return GCPNET_E_BADARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(frame_gate_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, vo, g, ldg,
+                       frames, w_up_frames, vu, act, slope, d_out, d_vu, d_g, part);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gcpnet_dropout(int64_t n_groups, int group, const float* x, float keep_prob, uint64_t seed, float* y, void* stream) {
     if (n_groups < 0 || group < 1 || !x || !y || !(keep_prob > 0.f) || keep_prob > 1.f) return GCPNET_E_BADARG;

@@ -104,7 +104,7 @@ class GCP2(nn.Module):
         if not (self.vector_input_dim and self.vector_output_dim):
             return VMODE_NONE
         if self.frame_gate and not self.ablate_frame_updates:
-            _unsupported("GCP2(frame_gate=True) (vectorize path)")
+            return VMODE_NONE  # (the frame gate runs as its own kernel behind the block: _apply_rows)
         if self.vector_gate:
             return VMODE_SCALAR_GATE
         return VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
@@ -145,8 +145,28 @@ class GCP2(nn.Module):
         return out
 
     def _apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool):
+        if (self.frame_gate and not self.ablate_frame_updates and self.vector_input_dim and self.vector_output_dim
+                and hasattr(self, "vector_up_frames")):
+            return self._apply_rows_frame_gate(s_sources, s_plans, v_sources, v_plans, row_frames, residual)
         spec = self.make_spec(s_plans, v_plans, residual)
         return ops.gcp2(spec, s_sources, v_sources, row_frames if spec.use_frames else None, self._weights())
+
+    def _apply_rows_frame_gate(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool):
+        """`frame_gate: true` (:369-384; no shipped config sets it): the block runs un-gated and without scalar activation -- its
+        outputs are then s_pre and vector_up(vh) (+ v) --, the two activations, the Linear(so -> 9) and the frame gate itself
+        (vectorize -> vector_up_frames -> norm -> act_v -> scale) follow as their own HIP launches."""
+        spec = replace(self.make_spec(s_plans, v_plans, False), act_s=None, act_v=None, vmode=VMODE_NONE)
+        w = self._weights()
+        s_pre, vu = ops.gcp2(spec, s_sources, v_sources, row_frames, (w[0], w[1], w[2], w[3], w[4], None, None))
+        lin = self.vector_out_scale_frames
+        w12 = torch.nn.functional.pad(lin.weight, (0, 0, 0, 3))  # 9 -> 12 output rows (16-byte rows of the gate scalars)
+        b12 = torch.nn.functional.pad(lin.bias, (0, 3))
+        g = ops.linear(ops.activation(s_pre, self.act_v, self.slope), w12, b12)
+        v_out = ops.frame_gate(g, row_frames, self.vector_up_frames.weight, vu, self.act_v, self.slope)
+        s_out = ops.activation(s_pre, self.act_s, self.slope)
+        if residual:
+            return ops.axpy(s_sources[0], s_out, 1.0), ops.axpy(v_sources[0], v_out, 1.0)
+        return s_out, v_out
 
     def _ablate_outputs(self, out):
         """:443-446, :466-467 -- ablated outputs are zeros (of the right shape)."""

@@ -1446,6 +1446,71 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return _Linear.apply(_req(x, "x"), _req(weight, "weight"), _req(bias, "bias"))
 
 
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        check(lib.gcpnet_activation(x.numel(), _p(x), None, ACT[act], float(slope), _p(y), _stream()), "activation")
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, float(slope))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        g = _req(g, "grad")
+        dx = torch.empty_like(x)
+        check(lib.gcpnet_activation(x.numel(), _p(x), _p(g), ACT[ctx.cfg[0]], ctx.cfg[1], _p(dx), _stream()), "activation")
+        return dx, None, None
+
+
+def activation(x: Tensor, act: Optional[str], slope: float = 1e-2) -> Tensor:
+    """get_nonlinearity(act)(x) (models/__init__.py:42-57); identity for None."""
+    return x if act is None else _Activation.apply(_req(x, "x"), act, slope)
+
+
+class _FrameGate(torch.autograd.Function):
+    """v_out = vu * act_v(safe_norm(vector_up_frames(vectorize(g)))) per row (components/gcpnet.py:369-384), see gcpnet_frame_gate_*."""
+
+    @staticmethod
+    def forward(ctx, g, frames, w_up_frames, vu, act, slope):
+        lib = _lib.load()
+        rows, vo = vu.shape[0], vu.shape[1]
+        out = torch.empty_like(vu)
+        check(lib.gcpnet_frame_gate_forward(rows, vo, _p(g), g.shape[1], _p(frames), _p(w_up_frames), _p(vu), ACT[act], float(slope),
+                                            _p(out), _stream()), "frame_gate_forward")
+        ctx.save_for_backward(g, frames, w_up_frames, vu)
+        ctx.cfg = (act, float(slope))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        g, frames, wf, vu = ctx.saved_tensors
+        rows, vo = vu.shape[0], vu.shape[1]
+        f32 = dict(dtype=torch.float32, device=vu.device)
+        d_out = _req(d_out, "grad")
+        d_vu, d_g = torch.empty_like(vu), torch.empty_like(g)
+        n_parts = max(int(lib.gcpnet_frame_gate_bwd_parts(rows)), 1)
+        part = torch.zeros((n_parts, vo * 3), **f32)
+        check(lib.gcpnet_frame_gate_backward(rows, vo, _p(g), g.shape[1], _p(frames), _p(wf), _p(vu), ACT[ctx.cfg[0]], ctx.cfg[1],
+                                             _p(d_out), _p(d_vu), _p(d_g), _p(part), _stream()), "frame_gate_backward")
+        d_w = torch.zeros((vo * 3,), **f32)
+        if rows:
+            tmp = torch.empty((lib.gcpnet_reduce_partials_groups(n_parts), vo * 3), **f32)
+            job = ReduceJob()
+            job.parts, job.n_parts, job.width, job.tmp, job.out = part.data_ptr(), n_parts, vo * 3, tmp.data_ptr(), d_w.data_ptr()
+            check(lib.gcpnet_reduce_partials(1, C.byref(job), _stream()), "reduce_partials")
+        return d_g, None, d_w.view(vo, 3), d_vu, None, None
+
+
+def frame_gate(g: Tensor, frames: Tensor, w_up_frames: Tensor, vu: Tensor, act: Optional[str], slope: float = 1e-2) -> Tensor:
+    return _FrameGate.apply(_req(g, "gate scalars"), _req(frames.detach(), "frames"), _req(w_up_frames, "vector_up_frames.weight"),
+                            _req(vu, "vector_up output"), act, slope)
+
+
 class _EdgeForce(torch.autograd.Function):
     """force[e] = sum_k coef[e, k] f_ij[e, k, :] with coef = W3 act(A[row] + B[col]) (reference gcpnet.py:1143-1150).
     A, B: per-node tables [N, s]; W3 [3, s]; frames [E, 3, 3] (constants of the step)."""

@@ -366,6 +366,23 @@ int gcpnet_row_gate_bwd_blocks(int64_t rows);
 int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,
                              int64_t ld_out, void* stream);
 
+/* ---- activation between separately launched pieces: y = act(x), or with `grad` != NULL y = grad * act'(x)
+ * (models/__init__.py:42-57) */
+int gcpnet_activation(int64_t n, const float* x, const float* grad, int act, float slope, float* y, void* stream);
+
+/* ---- frame gate of GCP2 (`frame_gate: true`, components/gcpnet.py:369-384; vectorize, components/__init__.py:329-378):
+ * g [rows, ldg >= 9] = vector_out_scale_frames(act_v(s_pre)), frames [rows, 3, 3] (edge frames, or the mean out-edge frames for node
+ * rows: vectorize is linear in the frame), w_up_frames = vector_up_frames.weight [vo, 3], vu [rows, vo, 3] = vector_up output:
+ *   out[r, o, :] = vu[r, o, :] * act_v(safe_norm(sum_c w_up_frames[o, c] * sum_a g[r, 3c + a] frames[r, a, :])).
+ * Backward: d_vu, d_g [rows, ldg] and per-wave shares of d w_up_frames in part [gcpnet_frame_gate_bwd_parts(rows), vo * 3]
+ * (gcpnet_reduce_partials). */
+int gcpnet_frame_gate_forward(int64_t rows, int vo, const float* g, int ldg, const float* frames, const float* w_up_frames,
+                              const float* vu, int act, float slope, float* out, void* stream);
+int gcpnet_frame_gate_backward(int64_t rows, int vo, const float* g, int ldg, const float* frames, const float* w_up_frames,
+                               const float* vu, int act, float slope, const float* d_out, float* d_vu, float* d_g, float* part,
+                               void* stream);
+int gcpnet_frame_gate_bwd_parts(int64_t rows);
+
 /* ---- dropout (components/__init__.py:97-135: nn.Dropout on the scalars, VectorDropout on whole 3-vectors), train mode:
  * y[g * group + j] = keep(g) ? x[g * group + j] / keep_prob : 0 with keep(g) = uniform(seed, g) < keep_prob, a counter-based
  * hash: the backward is the same call on the gradient with the same seed (no mask is stored).  group = 1 or 3. */

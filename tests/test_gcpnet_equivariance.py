@@ -88,7 +88,8 @@ def _frames(G, d):
     dict(nonlinearities=("relu", None), vector_gate=True, bottleneck=4),
     dict(nonlinearities=("silu", "sigmoid"), vector_gate=False, bottleneck=4),
     dict(nonlinearities=("relu", None), vector_gate=True, ablate_frame_updates=True),
-], ids=["vector_gate_silu", "vector_gate_relu", "self_gate", "baseline_no_frames"])
+    dict(nonlinearities=("silu", "silu"), frame_gate=True, bottleneck=4),
+], ids=["vector_gate_silu", "vector_gate_relu", "self_gate", "baseline_no_frames", "frame_gate"])
 @pytest.mark.parametrize("node_inputs", [True, False], ids=["node", "edge"])
 def test_gcp2(G, data, kw, node_inputs):
     """GCP2EquivarianceTest.test_gcp2_* (:726-860): a single block on node rows or on edge rows."""

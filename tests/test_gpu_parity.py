@@ -108,6 +108,8 @@ GCP2_CASES = {
     "gcp2_silu_sigmoid": dict(nonlinearities=("silu", "sigmoid"), bottleneck=2),
     "gcp2_selfgate": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False),
     "gcp2_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
+    "gcp2_frame_gate": dict(nonlinearities=("silu", "silu"), bottleneck=2, frame_gate=True),        # node rows (mean frames)
+    "gcp2_frame_gate_edge": dict(nonlinearities=("relu", "sigmoid"), frame_gate=True),              # edge rows
     "gcp3_edge_default": dict(bottleneck=4, cls="GCP3"),
     "gcp3_node_default": dict(bottleneck=2, cls="GCP3"),
     "gcp3_feedforward": dict(bottleneck=4, cls="GCP3", feedforward_out=True),
