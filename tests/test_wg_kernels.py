@@ -119,6 +119,18 @@ def test_message_chain_vs_oracle(G, n, e, dims, blocks, act, wg_bwd):
     ls, lv = torch.randn(ws_.shape, generator=g), torch.randn(wv_.shape, generator=g)
     ((ws_ * ls).sum() + (wv_ * lv).sum()).backward()
     ((ws64 * ls.double()).sum() + (wv64 * lv.double()).sum()).backward()
+    # conditioning of THIS problem instance: the float64 gradients after perturbing inputs and weights by fp32-round-off-sized
+    # relative noise (1e-6).  Where a ReLU pre-activation sits that close to zero the exact gradient itself jumps; no fp32
+    # evaluation can be asked to be closer to the unperturbed one than that.
+    sens = {}
+    if act == "relu":
+        gp = torch.Generator().manual_seed(99)
+        nz = lambda t: (t.detach() * (1 + 1e-6 * torch.randn(t.shape, generator=gp, dtype=torch.float64))).requires_grad_()
+        Pp, cp = {k: nz(t) for k, t in P64.items()}, {k: nz(t) for k, t in c64.items()}
+        wsp, wvp = O.message_passing(Pp, "", cp["h"], cp["chi"], cp["e"], cp["xi"], ei, fr.double(), ocfg, olcfg["mp_cfg"])
+        ((wsp * ls.double()).sum() + (wvp * lv.double()).sum()).backward()
+        sens = {k: float((cp[k].grad - c64[k].grad).norm()) for k in cp}
+        sens.update({k: float((Pp[k].grad - P64[k].grad).norm()) for k in Pp if Pp[k].grad is not None})
     try:
         ((out[0] * ls.cuda()).sum() + (out[1] * lv.cuda()).sum()).backward()
     finally:
@@ -130,7 +142,7 @@ def test_message_chain_vs_oracle(G, n, e, dims, blocks, act, wg_bwd):
         if act == "silu":  # smooth: element-wise
             close(a, b, atol=2e-5 * float(b.abs().max()), rtol=1e-4)
         else:  # relu: as accurate as the CPU fp32 path, measured against float64 (helpers.as_accurate)
-            as_accurate(a, b, b64, name)
+            as_accurate(a, b, b64, name, abs_floor=4.0 * sens.get(name, 0.0))
 
     for k in ins:
         grads_close(gi[k].grad.cpu(), ci[k].grad, c64[k].grad, k)
