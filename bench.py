@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--sdim", type=int, default=None)
     ap.add_argument("--vdim", type=int, default=None)
     ap.add_argument("--no-c5-block", action="store_true", help="skip the short configs[4]-size measurement of the default run")
+    ap.add_argument("--hip-graph", action="store_true", help="capture the step in a hipGraph and time replays (launch-bound configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step-only", action="store_true", help="profiling runs: only the timed steps (no per-kernel timing, no CPU baseline)")
     ap.add_argument("--cpu-layers", type=int, default=1, help="layers of the stack the CPU baseline runs (bounded sample)")
@@ -368,7 +369,13 @@ def main():
 
     is_stack = args.config in ("c2", "c5")
     wl = (build_layer_workload if is_stack else build_model_workload)(args, rank, world, G, ops)
-    elapsed, median_ms = timed_steps(wl["step"], args.steps, args.warmup, world, dist)
+    step_fn = wl["step"]
+    if args.hip_graph:
+        from gcpnet_amd.graphs import GraphedStep
+
+        assert world == 1, "--hip-graph: single-GPU runs (collectives are not captured here)"
+        step_fn = GraphedStep(wl["step"], warmup=max(args.warmup, 3))
+    elapsed, median_ms = timed_steps(step_fn, args.steps, args.warmup, world, dist)
 
     if rank == 0 and args.step_only:
         print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms, "steps": args.steps,
@@ -382,6 +389,7 @@ def main():
             "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: {wl['label']}", "n_edges": wl["n_edges"], "layers": wl["n_layers"],
+                "launch": "hipGraph replay of the captured step" if args.hip_graph else "eager launches",
                 "parallelism": ("single GPU" if world == 1 else
                                 (f"one graph split by target-node ranges over {world} GPUs: per layer all-gather of node features / "
                                  f"reduce-scatter of their gradients + all-reduce (sum) of weight grads, RCCL" if wl["sharded"] else

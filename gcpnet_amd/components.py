@@ -179,8 +179,7 @@ class GCPLayerNorm(nn.Module):
 
 
 def _plan_for_batch(batch_index: torch.Tensor) -> GatherPlan:
-    n = int(batch_index.max()) + 1 if batch_index.numel() else 0
-    return GatherPlan(batch_index, n)
+    return GatherPlan.get(batch_index)
 
 
 def centralize(batch, key: str, batch_index: torch.Tensor, node_mask: Optional[torch.Tensor] = None):
@@ -199,7 +198,7 @@ def decentralize(batch, key: str, batch_index: torch.Tensor, entities_centroid: 
     """:204-217 (unmasked branch)."""
     if node_mask is not None:
         raise NotImplementedError("decentralize(node_mask=...) is not on the accelerated path yet (SURVEY.md 8 f3)")
-    plan = GatherPlan(batch_index, entities_centroid.shape[0])
+    plan = GatherPlan.get(batch_index, entities_centroid.shape[0])
     return ops.axpy(batch[key], ops.gather_rows(entities_centroid, plan), 1.0)
 
 

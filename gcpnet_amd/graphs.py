@@ -1,0 +1,41 @@
+"""hipGraph capture of a whole training step (forward + loss + backward [+ optimizer]) for launch-bound configurations.
+
+A GCPNet step on the n-body batches of the NMS task is ~700 kernel launches for 2 000 - 38 000 edges: the GPU idles between launches
+while Python and the HIP runtime enqueue them.  Captured once into a hipGraph (torch.cuda.CUDAGraph; the ctypes launches of this
+package go to torch's current stream, so they are recorded like any other kernel) the step replays from a single call.
+
+Requirements (the usual ones of CUDA/HIP graphs): static shapes and static input tensors (copy new data INTO them), no host
+synchronisation inside the step (index plans are cached on their tensors: GraphPlan.get / GatherPlan.get; run a few eager warm-up
+steps first, which `GraphedStep` does), dropout masks would be frozen (capture with dropout 0 / eval dropout)."""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+from . import ops
+
+
+class GraphedStep:
+    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3):
+        self._saved_side = ops.WEIGHT_GRADS_ON_SIDE_STREAM
+        ops.WEIGHT_GRADS_ON_SIDE_STREAM = False  # (one stream inside the capture; the end-of-backward join is a host callback)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    step_fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ops.invalidate_packs()  # every packed-weight image is rebuilt INSIDE the graph, i.e. at every replay
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = step_fn()
+        finally:
+            ops.WEIGHT_GRADS_ON_SIDE_STREAM = self._saved_side
+        ops.invalidate_packs()  # (eager calls after this must not trust images that live in the graph's private pool)
+
+    def __call__(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.loss

@@ -115,8 +115,7 @@ class GCPNetLBA(nn.Module):
         batch.h, batch.chi, batch.e, batch.xi = h, chi, e, xi
         out = self.invariant_node_projection[0]((h, chi))
         out = self.invariant_node_projection[1](out, batch.edge_index, batch.f_ij, node_inputs=True)
-        n_graphs = int(batch.batch.max()) + 1
-        out = ops.segment_reduce(out, GatherPlan(batch.batch, n_graphs), mean=True)  # scatter(..., reduce="mean")
+        out = ops.segment_reduce(out, GatherPlan.get(batch.batch), mean=True)  # scatter(..., reduce="mean"), dim_size = max + 1
         out = self.dense(out).squeeze()
         return batch, out
 

@@ -56,6 +56,27 @@ class GatherPlan:
         self.seg_ptr = ptr.to(torch.int32).contiguous()
         self.inv_count = (1.0 / counts.clamp(min=1).to(torch.float32)).contiguous()
 
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, idx: Tensor, n_src: Optional[int] = None) -> "GatherPlan":
+        """Plan for an index tensor that is reused from step to step (the `batch` vector of a collated batch), cached on the
+        tensor object: building one costs a sort, a bincount and two host synchronisations (`max`, the sortedness test) -- per
+        call that is most of a small model's step, and it cannot happen inside a captured hipGraph.  n_src = idx.max() + 1 when
+        not given (torch_scatter's dim_size default)."""
+        import weakref
+
+        key = (idx.data_ptr(), tuple(idx.shape), idx._version, n_src, str(idx.device))
+        hit = cls._cache.get(key)
+        if hit is not None and hit[0]() is idx:
+            return hit[1]
+        n = n_src if n_src is not None else (int(idx.max()) + 1 if idx.numel() else 0)
+        plan = cls(idx, n)
+        if len(cls._cache) > 64:
+            cls._cache.clear()
+        cls._cache[key] = (weakref.ref(idx), plan)
+        return plan
+
 
 class GraphPlan:
     """Per-batch preprocessing of `edge_index` ([2, E], row = source, col = target), cached on the caller's
