@@ -15,6 +15,8 @@
 //   P7/P8  (VALU) adjoint of the vector prologue: d vh, d vf, d(v_in)
 //   P9     (VALU) per-thread partial sums of the small vector weight gradients
 // Without the fusion (node rows: few tiles, wide blocks) ds_pre / norms / dgate go to HBM for gcpnet_tn_gemm instead.
+#include <cstdlib>
+
 #include "gcp_wg.h"
 
 namespace {
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
     const bool vec_v = (vi & 3) == 0, vec_o = (vo & 3) == 0, vec_h = (H & 3) == 0;
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         WG_LAUNDER();
-        auto stamp = [&](int k) {
-            if (w == 0) gcp_stamp(p.stamps, p.stamp_cap, k, lane);
+        auto stamp = [&](int k) {  // (a tile from the middle of the workgroup's range: steady state, not the drained tail)
+            if (w == 0 && (tile - (int)blockIdx.x) / (int)gridDim.x == p.ntiles / (int)gridDim.x / 2) gcp_stamp(p.stamps, p.stamp_cap, k, lane);
         };
         stamp(0);
         const int r0 = tile * 32;
@@ -773,7 +775,11 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     const bool gated = o->vmode == GCP_VMODE_SCALAR_GATE && w->vo > 0;
     if (gated && w->vo > 32) return GCPNET_E_UNSUPPORTED;  // (one 32-row tile of gate outputs)
     const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
-    const int NW = (w->so > 160 || S.K > 160) ? 8 : 4;
+    int NW = (w->so > 160 || S.K > 160) ? 8 : 4;
+    if (const char* ev = getenv("GCPNET_WG_BWD_NW")) {  // (tuning knob: 4 or 8 waves per workgroup)
+        if (ev[0] == '4') NW = 4;
+        if (ev[0] == '8') NW = 8;
+    }
     if (gcp_cdiv(S.NT, NW) > 4) return GCPNET_E_UNSUPPORTED;
     const int rem = S.NKT % NW;
     const int split = (rem == 1 && S.NKT > 1) ? 1 : 0;
@@ -784,7 +790,7 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     const int n_sm = w->vo * S.H + HF * w->vi;
     if (n_sm > NSW * 64 * NW) return GCPNET_E_UNSUPPORTED;
     const int KW = S.K + 1, NNT = gcp_cdiv(KW, 32);
-    const int fused = want_fused && S.NT <= NW && KTn == 1 && NNT <= 5;
+    const int fused = want_fused && S.NT <= NW && KTn == 1 && NNT <= 5 && !getenv("GCPNET_WG_BWD_NOFUSE");
     if (!g_wg_cus) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)

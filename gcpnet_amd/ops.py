@@ -1036,7 +1036,10 @@ class _Gcp2Chain(torch.autograd.Function):
             check(lib.gcpnet_gcp2_chain_forward(rows, _p(s0), _p(v0), _p(frames), n, items, _stream()), "gcp2_chain_forward")
         if need_grad:
             ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
-            ctx.state = (s0, v0, ws, packs, outs)
+            # (the chain's own outputs must not hang off ctx: output -> grad_fn -> ctx -> output is a cycle through C++ that the
+            # garbage collector cannot see, i.e. every forward whose backward never runs would leak its saved activations)
+            saved = outs[:-1] + [(None, None, outs[-1][2], outs[-1][3])]
+            ctx.state = (s0, v0, ws, packs, saved)
             ctx.w_leaf = not any(sp.shared_weights for sp in specs)
             ctx.weights = weights
         return outs[-1][0], outs[-1][1]

@@ -157,3 +157,33 @@ def test_hip_graph_replay_matches_eager_step(G):
     assert torch.equal(loss2, ref_loss) and not torch.equal(loss2, eager_loss)
     for p, g in zip(params, g2):
         assert torch.equal(p.grad, g)
+
+
+def test_forward_without_backward_frees_saved_activations(G):
+    """A training-mode forward whose backward never runs (validation without no_grad, an aborted step) must give its saved
+    activations back once the outputs are dropped: nothing may hang off the autograd context in a cycle."""
+    import gc
+
+    from gcpnet_amd.synthetic import make_inputs
+
+    ins = make_inputs(600, 10, node_dims=(128, 16), seed=5)
+    ei, x = ins.pop("edge_index").cuda(), ins.pop("x").cuda()
+    torch.manual_seed(0)
+    layer = G.GCPInteractions((128, 16), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0).cuda()
+    fr = G.localize(x, ei)
+    gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
+
+    def fwd():
+        return layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei, fr)
+
+    out = fwd()
+    del out
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for _ in range(3):
+        out = fwd()
+        del out
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= base + (1 << 20), (torch.cuda.memory_allocated() - base)
