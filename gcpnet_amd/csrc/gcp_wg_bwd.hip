@@ -54,52 +54,63 @@ struct WgBwdParams {
     int KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, WSV, WSU, WTV, WTU;
     int o_x, o_ds, o_v, o_dvo, o_dvu, o_vh, o_dvhf, o_fr, o_dg, o_rn, o_sgn, o_dext, o_epart, o_ws;
     int n_up, n_sm;  // small weight gradients: vector_up entries, all entries
+    int sm_tiles, sm_up_tiles, sm_nu, sm_nd;  // their 16 x 16 tiles: all, those of vector_up, tiles along N (up / down)
     unsigned long long* stamps;  // profiling hook: s_memtime stamps of wave 0 at the phase boundaries (last tile of the workgroup)
     long long stamp_cap;
 };
 
-constexpr int NSW = 4;  // small-weight-gradient accumulators per thread
+constexpr int NSW = 2;  // 16 x 16 tiles of the small vector weight gradients per wave
 
 // NW waves; KT = full K tiles per wave in P4; FN = 32-wide tiles of the fused weight gradient's K + 1 columns (0 = not fused)
 template <int NW, int KT, int FN, bool PWL>
-__global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParams p) {
+__global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32;
     constexpr bool FUSED = FN > 0;
     constexpr int FNR = FUSED ? FN : 1;
+    // The parameters are read through the kernarg segment pointer, and that pointer is laundered at every phase boundary: the
+    // ~80 uniform values (and everything uniform derived from them) are then re-loaded (s_load, scalar cache) by the phase
+    // that needs them instead of staying live in SGPRs across the whole persistent tile loop -- where they do not fit:
+    // hipcc spilled ~360 of them into VGPR lanes, ~1 100 v_readlane_b32 per tile and wave.
+    typedef const __attribute__((address_space(4))) WgBwdParams* Karg;
+    Karg kp = (Karg)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*kp)
     int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63, e = lane & 31, hi = lane >> 5;
     int prow = tid / TPR, psub = tid - prow * TPR;
-    // Per-lane addresses are loop-invariant in the persistent tile loop: hipcc hoists them all out of it and spills them.
-    // Laundering the lane indices at every phase boundary makes each phase recompute the few it needs.
-#define WG_LAUNDER() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub))
-    const int rows = p.rows;
-    float* X = lds + p.o_x;
-    float* DS = lds + p.o_ds;
-    float* V = lds + p.o_v;
-    float* DVO = lds + p.o_dvo;
-    float* DVU = lds + p.o_dvu;
-    float* VH = lds + p.o_vh;
-    float* DVHF = lds + p.o_dvhf;
-    float* FR = lds + p.o_fr;
-    float* DG = lds + p.o_dg;
-    float* RN = lds + p.o_rn;
-    float* SGN = lds + p.o_sgn;
-    float* DEXT = lds + p.o_dext;
-    float* EPART = lds + p.o_epart;
-    float* ST = EPART + w * 32 * p.EPS;  // wave-private staging (half tiles, 32 x 20) shares the wave's split-K partial slot
-    const float* WD = lds + p.o_ws;                 // [HF][WSV]   [vector_down ; vector_down_frames]
-    const float* WDT = WD + p.HF * p.WSV;           // [vi][WTV]   transposed
-    const float* WU = WDT + p.vi * p.WTV;           // [vo][WSU]   vector_up
-    const float* WUT = WU + p.vo * p.WSU;           // [H][WTU]    transposed
-    const int KS = p.KS, DSS = p.DSS, VS = p.VS, US = p.US, HS = p.HS, FS = p.FS, DGS = p.DGS, EXS = p.EXS, EPS = p.EPS;
-    const int si = p.si, vi = p.vi, so = p.so, vo = p.vo, H = p.H, nf = p.nf, K = p.K, HF = p.HF, NT = p.NT, SG = p.SG;
+    int rows, KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, si, vi, so, vo, H, nf, K, HF, NT, SG, exs;
+    float *X, *DS, *V, *DVO, *DVU, *VH, *DVHF, *FR, *DG, *RN, *SGN, *DEXT, *EPART, *ST, *extp;
+    const float *WD, *WDT, *WU, *WUT;
+#define WG_RELOAD()                                                                                                        \
+    do {                                                                                                                   \
+        rows = p.rows;                                                                                                     \
+        KS = p.KS; DSS = p.DSS; VS = p.VS; US = p.US; HS = p.HS; FS = p.FS; DGS = p.DGS; EXS = p.EXS; EPS = p.EPS;         \
+        si = p.si; vi = p.vi; so = p.so; vo = p.vo; H = p.H; nf = p.nf; K = p.K; HF = p.HF; NT = p.NT; SG = p.SG;          \
+        X = lds + p.o_x; DS = lds + p.o_ds; V = lds + p.o_v; DVO = lds + p.o_dvo; DVU = lds + p.o_dvu; VH = lds + p.o_vh;  \
+        DVHF = lds + p.o_dvhf; FR = lds + p.o_fr; DG = lds + p.o_dg; RN = lds + p.o_rn; SGN = lds + p.o_sgn;               \
+        DEXT = lds + p.o_dext; EPART = lds + p.o_epart;                                                                    \
+        ST = EPART + w * 32 * EPS; /* wave-private staging (half tiles, 32 x 20) shares the wave's split-K partial slot */ \
+        WD = lds + p.o_ws;         /* [HF][WSV]   [vector_down ; vector_down_frames] */                                    \
+        WDT = WD + HF * p.WSV;     /* [vi][WTV]   transposed */                                                            \
+        WU = WDT + vi * p.WTV;     /* [vo][WSU]   vector_up */                                                             \
+        WUT = WU + vo * p.WSU;     /* [H][WTU]    transposed */                                                            \
+        /* where P1 leaves [norms | frame scalars]: X's extras columns, or (not fused) a tile of its own that goes to HBM  \
+           (it doubles as the d(extras) tile later) */                                                                     \
+        extp = FUSED ? X + si : DEXT;                                                                                      \
+        exs = FUSED ? KS : EXS;                                                                                            \
+    } while (0)
+    // Per-lane addresses are loop-invariant in the persistent tile loop too: hipcc hoists them all out of it and spills
+    // them.  Laundering the lane indices at every phase boundary makes each phase recompute the few it needs.
+#define WG_LAUNDER()                                                                                                       \
+    do {                                                                                                                   \
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub), "+s"(kp));                      \
+        WG_RELOAD();                                                                                                       \
+    } while (0)
+    WG_RELOAD();
     const bool gated = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;
     const float slope = p.slope;
     const float ns_s = gcp_neg_slope(p.act_s, slope), ns_v = gcp_neg_slope(p.act_v, slope);
-    float* extp = FUSED ? X + si : DEXT;  // where P1 leaves [norms | frame scalars]: X's extras columns, or (not fused) a tile
-    const int exs = FUSED ? KS : EXS;     //   of its own that goes to HBM (it doubles as the d(extras) tile later)
 
     // ---- once per workgroup: small weights (both orientations) -> LDS, zero the never-written paddings ------------------
     {
@@ -130,7 +141,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         for (int r = 0; r < 16; ++r) dW[n][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dWg[r] = 0.f;
-    float wsm[NSW] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wsm[NSW];
+#pragma unroll
+    for (int sl = 0; sl < NSW; ++sl) wsm[sl] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbg = 0.f;
     wg_barrier();
 
@@ -546,9 +559,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                         dWg = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dWg, 0, 0, 0);
                     }
                 }
-                if (tid < vo) {  // gate bias gradient: column sums of dgate
+                if (tid < 8 * vo) {  // gate bias gradient: column sums of dgate, 8 threads (4 rows each) per channel
+                    const int o = tid >> 3, part = tid & 7;
                     float sacc = 0.f;
-                    for (int r = 0; r < 32; ++r) sacc += DG[r * DGS + tid];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sacc += DG[(4 * part + k) * DGS + o];
+                    sacc += __shfl_xor(sacc, 1);
+                    sacc += __shfl_xor(sacc, 2);
+                    sacc += __shfl_xor(sacc, 4);
                     dbg += sacc;
                 }
             }
@@ -556,6 +574,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 
         stamp(6);
         WG_LAUNDER();
+        // ResGCP pass-through of d(v_out) for P8 (the LDS copy has been recycled; L2 still has the tile): requested here, one
+        // phase ahead, for the thread's first two channels
+        float gpre[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (p.residual && vo > 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* g = p.d_v_out + ((int64_t)min(r0 + prow, rows - 1) * vo + min(psub + j * TPR, vo - 1)) * 3;
+                gpre[j][0] = g[0]; gpre[j][1] = g[1]; gpre[j][2] = g[2];
+            }
+        }
         // ---- P7: adjoint of the vector prologue: d vh, d vf ---------------------------------------------------------------
         {
             auto dext = [&](int x) -> float {  // d(extras column x) of this thread's row
@@ -623,7 +651,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 
         WG_LAUNDER();
         // ---- P8: d(v_in) = [vector_down ; vector_down_frames]^T d[vh | vf] (+ pass-through terms) ----------------------------
-        for (int c = psub; c < vi; c += TPR) {
+        auto p8 = [&](int c, bool pre, float h0, float h1, float h2) {
             const float* wt = WDT + c * p.WTV;
             const float* dq = DVHF + prow * FS;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -633,14 +661,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             }
             if (p.vres && vo > 0) { a0 += DVU[prow * US + 3 * c + 0]; a1 += DVU[prow * US + 3 * c + 1]; a2 += DVU[prow * US + 3 * c + 2]; }
             if (prow < nvalid) {
-                if (p.residual) {  // ResGCP pass-through (the LDS copy of d(v_out) has been recycled: L2 still has the tile)
-                    const float* g = p.d_v_out + ((int64_t)(r0 + prow) * vo + c) * 3;
-                    a0 += g[0]; a1 += g[1]; a2 += g[2];
+                if (p.residual) {
+                    if (pre) {
+                        a0 += h0; a1 += h1; a2 += h2;
+                    } else {
+                        const float* g = p.d_v_out + ((int64_t)(r0 + prow) * vo + c) * 3;
+                        a0 += g[0]; a1 += g[1]; a2 += g[2];
+                    }
                 }
                 float* dp = p.d_v_in + ((int64_t)(r0 + prow) * vi + c) * 3;
                 dp[0] = a0; dp[1] = a1; dp[2] = a2;
             }
-        }
+        };
+        if (psub < vi) p8(psub, true, gpre[0][0], gpre[0][1], gpre[0][2]);
+        if (psub + TPR < vi) p8(psub + TPR, true, gpre[1][0], gpre[1][1], gpre[1][2]);
+        for (int c = psub + 2 * TPR; c < vi; c += TPR) p8(c, false, 0.f, 0.f, 0.f);
         if (p.dvhf) {  // d[vh | vf] per row, [3, HF'] xyz-major: the gradient of the pre-projected vector tables' gathered rows
             const int wdt = 3 * p.HFP;
             for (int i = tid; i < nvalid * wdt; i += NTH) {
@@ -649,26 +684,42 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             }
         }
         WG_LAUNDER();
-        // ---- P9: small vector weight gradients, per-thread partial sums over the tile's rows ------------------------------
+        // ---- P9: small vector weight gradients on the matrix cores (v_mfma_f32_16x16x4_f32): 16 x 16 output tiles of
+        //          d vector_up[o, h] = sum dvu[row, o, :] . vh[row, h, :] and
+        //          d [vector_down ; vector_down_frames][x, c] = sum d[vh | vf][row, x, :] . v[row, c, :],
+        //          reduction over the tile's 96 (row, xyz) pairs (slot (st, kq) = row 4 (st & 7) + kq, component st >> 3);
+        //          tiles round-robin over the waves, accumulators persistent across the workgroup's tiles -----------------
+        {
+            const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-        for (int j = 0; j < NSW; ++j) {
-            const int idx = tid + j * NTH;
-            if (idx < p.n_sm) {
-                const float* pa;
-                const float* pb;
-                int sa, sb;
-                if (idx < p.n_up) {  // d vector_up[o, h] = sum dvu[row, o, :] . vh[row, h, :]
-                    const int o = idx / H, h = idx - o * H;
-                    pa = DVU + 3 * o; sa = US; pb = VH + 3 * h; sb = HS;
-                } else {             // d [vector_down ; vector_down_frames][x, c] = sum d[vh | vf][row, x, :] . v[row, c, :]
-                    const int i2 = idx - p.n_up, x = i2 / vi, c = i2 - x * vi;
-                    pa = DVHF + 3 * x; sa = FS; pb = V + 3 * c; sb = VS;
+            for (int sl = 0; sl < NSW; ++sl) {
+                const int t = w + NW * sl;
+                if (t < p.sm_tiles) {
+                    const bool up = t < p.sm_up_tiles;
+                    const int tt = up ? t : t - p.sm_up_tiles;
+                    const int nn = up ? p.sm_nu : p.sm_nd;  // tiles along N
+                    const int mt = tt / nn, nt = tt - mt * nn;
+                    const int M = up ? vo : HF, N = up ? H : vi;
+                    const int m = 16 * mt + l16, n = 16 * nt + l16;
+                    const int sa = up ? US : FS, sb = up ? HS : VS;
+                    const float* pa = (up ? DVU : DVHF) + 3 * min(m, M - 1) + kq * sa;
+                    const float* pb = (up ? VH : V) + 3 * min(n, N - 1) + kq * sb;
+                    const bool mok = m < M, nok = n < N;
+                    f32x4 acc = wsm[sl];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            av[k] = pa[4 * k * sa + d];
+                            bv[k] = pb[4 * k * sb + d];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? av[k] : 0.f, nok ? bv[k] : 0.f, acc, 0, 0, 0);
+                    }
+                    wsm[sl] = acc;
                 }
-                float sacc = 0.f;
-#pragma unroll 4
-                for (int r = 0; r < 32; ++r)
-                    sacc += pa[r * sa] * pb[r * sb] + pa[r * sa + 1] * pb[r * sb + 1] + pa[r * sa + 2] * pb[r * sb + 2];
-                wsm[j] += sacc;
             }
         }
         wg_barrier();  // the tiles are free for the next iteration's loads
@@ -698,16 +749,35 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 }
             }
         }
-        if (gated && tid < vo) p.dwg_part[(int64_t)blockIdx.x * vo * (so + 1) + (int64_t)tid * (so + 1) + so] = dbg;
+        if (gated && tid < 8 * vo && (tid & 7) == 0)
+            p.dwg_part[(int64_t)blockIdx.x * vo * (so + 1) + (int64_t)(tid >> 3) * (so + 1) + so] = dbg;
     }
     if (p.wsm_part) {
+        const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-        for (int j = 0; j < NSW; ++j) {
-            const int idx = tid + j * NTH;
-            if (idx < p.n_sm) p.wsm_part[(int64_t)blockIdx.x * p.n_sm + idx] = wsm[j];
+        for (int sl = 0; sl < NSW; ++sl) {
+            const int t = w + NW * sl;
+            if (t < p.sm_tiles) {
+                const bool up = t < p.sm_up_tiles;
+                const int tt = up ? t : t - p.sm_up_tiles;
+                const int nn = up ? p.sm_nu : p.sm_nd;
+                const int mt = tt / nn, nt = tt - mt * nn;
+                const int M = up ? vo : HF, N = up ? H : vi;
+                const int n = 16 * nt + l16;
+                float* out = p.wsm_part + (int64_t)blockIdx.x * p.n_sm + (up ? 0 : p.n_up);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * mt + 4 * kq + r;
+                    if (i < M && n < N) out[i * N + n] = wsm[sl][r];
+                }
+            }
         }
     }
 }
+
+#undef p
+#undef WG_RELOAD
+#undef WG_LAUNDER
 
 // out[...] = sum over parts, fixed order.  parts[g][r * C + c] for r < R, c < C; columns c < CW of row r go to
 // out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].  A block sums 64 consecutive entries: its 256 threads are four
@@ -788,7 +858,8 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     if (KTn > 4) return GCPNET_E_UNSUPPORTED;
     const int HF = S.H + (S.nf ? 3 : 0);
     const int n_sm = w->vo * S.H + HF * w->vi;
-    if (n_sm > NSW * 64 * NW) return GCPNET_E_UNSUPPORTED;
+    const int sm_tiles = (w->vo > 0 ? gcp_cdiv(w->vo, 16) * gcp_cdiv(S.H, 16) : 0) + gcp_cdiv(HF, 16) * gcp_cdiv(w->vi, 16);
+    if (sm_tiles > NSW * NW) return GCPNET_E_UNSUPPORTED;
     const int KW = S.K + 1, NNT = gcp_cdiv(KW, 32);
     const int fused = want_fused && S.NT <= NW && KTn == 1 && NNT <= 5 && !getenv("GCPNET_WG_BWD_NOFUSE");
     if (!g_wg_cus) {
@@ -854,6 +925,9 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     for (int k = 0; k < p.v_add.n; ++k)
         if (!p.v_add.ptr[k] || p.v_add.dim[k] != p.HFP) return GCPNET_E_BADARG;
     p.n_up = w.vo * S.H; p.n_sm = pl.n_small;
+    p.sm_nu = max(gcp_cdiv(S.H, 16), 1); p.sm_nd = gcp_cdiv(w.vi, 16);
+    p.sm_up_tiles = w.vo > 0 ? gcp_cdiv(w.vo, 16) * p.sm_nu : 0;
+    p.sm_tiles = p.sm_up_tiles + gcp_cdiv(p.HF, 16) * p.sm_nd;
     const int NW = pl.nw;
     const int xw = pl.fused ? 8 * gcp_cdiv(pl.kw, 8) : 0;
     p.KS = wg_stride(max(xw, 4));

@@ -1,5 +1,5 @@
 """Times the backward launches of one GCPMessagePassing layer at configs[4] size, split into the first message GCP (head) and the
-chain blocks, for the tuning knobs GCPNET_WG_BWD_NW / GCPNET_WG_BWD_NOFUSE.  usage: python tools/c5_head_bwd.py [nodes] [K]"""
+chain blocks, for the tuning knobs GCPNET_WG_BWD_NW / GCPNET_WG_BWD_NOFUSE.  usage: python tools/c5_head_bwd.py [nodes] [K] [sdim vdim]"""
 import os
 import sys
 import time
@@ -13,7 +13,8 @@ from gcpnet_amd.synthetic import make_inputs  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-dims = (256, 32)
+dims = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (256, 32)
+ops.FORCE_WG_CHAIN_BACKWARD = True  # (so <= 128 would otherwise take the wave-per-tile chain kernel)
 host = make_inputs(N, K, dims, (32, 4), seed=0)
 dev = {k: v.cuda() for k, v in host.items()}
 torch.manual_seed(0)
