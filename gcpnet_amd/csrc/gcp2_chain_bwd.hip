@@ -133,41 +133,68 @@ __device__ __forceinline__ void gcp_load_gate(const float* __restrict__ gate, in
 }
 
 template <int NTG, int VQ, bool PWL, int HC>
-__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p) {
+__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 4 * VQ;  // registers per xyz component of a vector-channel quantity
     constexpr int NX = HC ? 4 * ((HC + 3 + 7) / 8) : 8;  // registers per xyz component of a [vh | vf] quantity (H + 3 <= 16)
-    const GcpShape& S = p.sh;
-    const CbLds L = cb_lds(S);
+    // The parameters are read through the kernarg segment pointer, laundered at every section boundary: uniform values are then
+    // re-loaded (s_load) by the section that uses them instead of staying live in SGPRs across the whole block loop, where
+    // they did not fit (~250 SGPRs spilled into VGPR lanes, a v_readlane_b32 per use).
+    typedef const __attribute__((address_space(4))) ChainBwdParams* Karg;
+    Karg kp = (Karg)__builtin_amdgcn_kernarg_segment_ptr();
+// (generic view of the laundered constant-address-space pointer: the address space is inferred back, loads stay s_load)
+#define p (*(const ChainBwdParams*)kp)
     int lane = threadIdx.x;
     int e = lane & 31, hi = lane >> 5;
     const int r0 = blockIdx.x * GCP_TILE_ROWS;
-    const int rows = p.rows;
     int row = r0 + e;
-    bool row_ok = row < rows;
-    float* vt = lds + L.o_vt;      // the block's input vectors, [row][channel][xyz]
-    float* xt = lds + L.o_x;       // row-major copy of d(vector_up output), later of [d vh | d vf] (weight-gradient partials)
-    float* vht = lds + L.o_vht;    // row-major copy of vector_down(v)
-    float* fr = lds + L.o_fr;
-    float* dext = lds + L.o_dext;  // d(norms | frame scalars): from the lanes of the scalar_out adjoint to the vh / vf channels' lanes
-    float* e3t = lds + L.o_e3;     // signs of the x_cross projections (e3 variant only)
-    float* stage = lds + L.o_stage;  // transposition tile of the row-wise stores (tile_io.h, gcp_store_acc_rows)
-    const int so = S.so, vi = S.vi;  // si == so, vo == vi
-    const int H = HC ? HC : S.H, HF = HC ? HC + 3 : S.HF;  // (frames are in use whenever HC is given)
-    const int SVB = HC ? 4 * ((HC + 7) / 8) : S.SVB, SVD = HC ? 4 * ((HC + 3 + 7) / 8) : S.SVD;
-    const int EP = gcp_round_up(S.H + S.nf, 4), VOP = gcp_round_up(vi, 4);
-    const float slope = p.o.slope;
-    const bool scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;
-    const int NUG = S.NUG;
-    const int xg = NTG / NUG, xs = NTG - xg * NUG;  // group / slot of the 32-wide tile holding the norms and frame scalars
-    const bool vec_vo = (vi & 3) == 0;
+    GcpShape S;
+    CbLds L;
+    ChainItemB it;
+    int kcur = 0;
+    int rows, so, vi, H, HF, SVB, SVD, EP, VOP, NUG, xg, xs;
+    float slope, ns_s, ns_v;
+    bool scalar_gate, vec_vo, row_ok;
+    float *vt, *xt, *vht, *fr, *dext, *e3t, *stage;
+    // vt: the block's input vectors, [row][channel][xyz]; xt: row-major copy of d(vector_up output), later of [d vh | d vf]
+    // (weight-gradient partials); vht: row-major copy of vector_down(v); dext: d(norms | frame scalars), from the lanes of the
+    // scalar_out adjoint to the vh / vf channels' lanes; e3t: signs of the x_cross projections (e3 variant only); stage:
+    // transposition tile of the row-wise stores (tile_io.h, gcp_store_acc_rows)
+#define CB_RELOAD()                                                                                                       \
+    do {                                                                                                                  \
+        S = p.sh;                                                                                                         \
+        it = p.it[kcur];                                                                                                  \
+        L = cb_lds(S);                                                                                                    \
+        rows = p.rows;                                                                                                    \
+        row_ok = row < rows;                                                                                              \
+        vt = lds + L.o_vt; xt = lds + L.o_x; vht = lds + L.o_vht; fr = lds + L.o_fr; dext = lds + L.o_dext;                \
+        e3t = lds + L.o_e3; stage = lds + L.o_stage;                                                                      \
+        so = S.so; vi = S.vi; /* si == so, vo == vi */                                                                    \
+        H = HC ? HC : S.H; HF = HC ? HC + 3 : S.HF; /* (frames are in use whenever HC is given) */                         \
+        SVB = HC ? 4 * ((HC + 7) / 8) : S.SVB; SVD = HC ? 4 * ((HC + 3 + 7) / 8) : S.SVD;                                  \
+        EP = gcp_round_up(S.H + S.nf, 4); VOP = gcp_round_up(vi, 4);                                                      \
+        slope = p.o.slope;                                                                                                \
+        scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;                                                                 \
+        NUG = S.NUG;                                                                                                      \
+        xg = NTG / NUG; xs = NTG - xg * NUG; /* group / slot of the 32-wide tile holding the norms and frame scalars */   \
+        vec_vo = (vi & 3) == 0;                                                                                           \
+        ns_s = gcp_neg_slope(it.act_s, slope); ns_v = gcp_neg_slope(it.act_v, slope);                                     \
+    } while (0)
+    // (the per-lane addresses of the loop body would be hoisted out of the loop and spilled, too: lane indices laundered with it)
+#define CB_LAUNDER()                                                                                                      \
+    do {                                                                                                                  \
+        asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi), "+s"(kp));                                                       \
+        row = r0 + e;                                                                                                     \
+        CB_RELOAD();                                                                                                      \
+    } while (0)
+    kcur = p.n - 1;
+    CB_RELOAD();
 
     gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
     f32x16 dyr[NTG];
     float sg[NV];  // sigmoid(gate) of the current block: channel crow(r, hi) of row e
     // ---- prologue: everything the LAST block needs, plus the incoming gradients, in one memory round trip ----------
     {
-        const ChainItemB& it = p.it[p.n - 1];
         GcpSegBuf<8> vb;
         gcp_seg_issue(vb, it.v_in, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
@@ -185,12 +212,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
     for (int k = p.n - 1; k >= 0; --k) {
-        // Opaque to the optimiser: otherwise the per-lane addresses of the loop body are hoisted out of the loop and spilled.
-        asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
-        row = r0 + e;
-        row_ok = row < rows;
-        const ChainItemB& it = p.it[k];
-        const float ns_s = gcp_neg_slope(it.act_s, slope), ns_v = gcp_neg_slope(it.act_v, slope);
+        kcur = k;
+        CB_LAUNDER();
         const bool stamp_here = k == 0;
         // d(V) chain state: channel crow(r, hi) of row e, 12 consecutive floats per register quad.  It travels through the
         // output buffer d_v_in between blocks (each lane re-reads exactly the 48 bytes it wrote itself a whole block earlier,
@@ -336,9 +359,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         float* part = it.w_part ? it.w_part + (int64_t)blockIdx.x * (vi * H + vi * HF) : nullptr;
         if (part) small_tn(xt, L.VS, 3, 1, vi, vht, L.HS, 3, 1, H, part, false);  // d vector_up[o, h] = sum dvu[row, o, d] vh[row, h, d]
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
-        asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));
-        row = r0 + e;
-        row_ok = row < rows;
+        CB_LAUNDER();
 
         // ---- D. ds_pre = d(s_out) * act_s'(s_pre) + act_v'(s_pre) * (Wg^T dgate), in the s_pre registers; the gate adjoint's
         //         B fragments are the d(gate) registers (section D is packed for that pairing) ----------------------------
@@ -375,6 +396,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             }
         }
         gcp_store_acc_rows_half<NTG>(it.ds_pre, so, 0, so, r0, rows, spr, stage, lane);
+        CB_LAUNDER();
 
         // ---- E. d(s) += W^T ds_pre: 16 * NTG k-pair steps whose B operands are the ds_pre registers; the weight
         //         fragments rotate through three batches of 4 steps, requested two batches ahead and pinned there ------
@@ -416,6 +438,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             }
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
+        CB_LAUNDER();
 
         if (k == 0) gcp_store_acc_rows_half<NTG>(p.d_s_in, so, 0, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
@@ -484,12 +507,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             }
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
+        CB_LAUNDER();
         // ---- G. requests for the next block (k-1) -- gates, vectors -- and, while they are in flight, the second
         //         partial-sum pass -------------------------------------------------------------------------------------------
-        if (k > 0) {
-            const ChainItemB& nx = p.it[k - 1];
-            gcp_load_gate<VQ>(scalar_gate ? nx.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
-        }
+        if (k > 0) gcp_load_gate<VQ>(scalar_gate ? p.it[k - 1].gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
         GcpSegBuf<8> vb;
         if (k > 0) {
             gcp_seg_issue(vb, p.it[k - 1].v_in, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
@@ -506,6 +527,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     }
     gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
 }
+
+#undef p
+#undef CB_RELOAD
+#undef CB_LAUNDER
 
 template <int NTG, int VQ, bool PWL>
 int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {

@@ -67,6 +67,11 @@ __device__ __forceinline__ void wg_barrier() {
 
 __device__ __forceinline__ bool wg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// i / d for 0 <= i < 2^16, 1 < d < 2^16 without the ~35-instruction run-time division: magic = ceil(2^32 / d) from the host
+// (wg_magic); magic == 0 (d == 1, or "not given") falls back to the division.
+__host__ __device__ inline unsigned wg_magic(int d) { return d > 1 ? (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d) : 0u; }
+__device__ __forceinline__ int wg_div(int i, int d, unsigned magic) { return magic ? (int)__umulhi((unsigned)i, magic) : i / d; }
+
 // tile[r * stride + c] = src[r * width + c] for r < 32, c < width (rows of a 32-row tile are contiguous in memory: a flat,
 // coalesced copy); rows >= nvalid read as zero.  Loads are unconditional (clamped) and batched four deep per thread.
 // `vec`: width % 4 == 0, stride % 4 == 0 and src 16-byte aligned -> 16-byte accesses.
@@ -124,7 +129,7 @@ __device__ __forceinline__ void wg_tile_request(WgTileReq<B>& rq, const float* _
 }
 template <int NTH, int B>
 __device__ __forceinline__ void wg_tile_commit(const WgTileReq<B>& rq, float* tile, int stride, const float* __restrict__ src, int width,
-                                               int nvalid, int tid, bool vec) {
+                                               int nvalid, int tid, bool vec, unsigned mq = 0) {
     if (!rq.ok) {
         wg_tile_load<NTH>(tile, stride, src, width, nvalid, tid, vec);
         return;
@@ -134,7 +139,7 @@ __device__ __forceinline__ void wg_tile_commit(const WgTileReq<B>& rq, float* ti
     for (int k = 0; k < B; ++k) {
         const int i = tid + k * NTH;
         if (i < tot) {
-            const int r = i / q, c4 = i - r * q;
+            const int r = wg_div(i, q, mq), c4 = i - r * q;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(tile + r * stride + 4 * c4) = i < n4 ? rq.v[k] : z;
         }
@@ -144,11 +149,11 @@ __device__ __forceinline__ void wg_tile_commit(const WgTileReq<B>& rq, float* ti
 // dst[r * width + c] = tile[r * stride + c] for r < nvalid (flat, coalesced).
 template <int NTH>
 __device__ __forceinline__ void wg_tile_store(float* __restrict__ dst, const float* tile, int stride, int width, int nvalid, int tid,
-                                              bool vec) {
+                                              bool vec, unsigned mq = 0) {
     if (vec) {
         const int q = width >> 2, n4 = nvalid * q;
         for (int i = tid; i < n4; i += NTH) {
-            const int r = i / q, c4 = i - r * q;
+            const int r = wg_div(i, q, mq), c4 = i - r * q;
             *reinterpret_cast<f32x4*>(dst + 4 * (int64_t)i) = *reinterpret_cast<const f32x4*>(tile + r * stride + 4 * c4);
         }
     } else {

@@ -54,6 +54,7 @@ struct WgBwdParams {
     int KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, WSV, WSU, WTV, WTU;
     int o_x, o_ds, o_v, o_dvo, o_dvu, o_vh, o_dvhf, o_fr, o_dg, o_rn, o_sgn, o_dext, o_epart, o_ws;
     int n_up, n_sm;  // small weight gradients: vector_up entries, all entries
+    unsigned mg_v, mg_o, mg_g, mg_x, mg_xpad, mg_epad, mg_ns, mg_wdt, mg_hfp, mg_ep, mg_vop;  // wg_magic of the tile-copy divisors
     int sm_tiles, sm_up_tiles, sm_nu, sm_nd;  // their 16 x 16 tiles: all, those of vector_up, tiles along N (up / down)
     unsigned long long* stamps;  // profiling hook: s_memtime stamps of wave 0 at the phase boundaries (last tile of the workgroup)
     long long stamp_cap;
@@ -148,6 +149,41 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
     wg_barrier();
 
     const bool vec_v = (vi & 3) == 0, vec_o = (vo & 3) == 0, vec_h = (H & 3) == 0;
+    // Tile loads, one tile ahead: every global load of a tile is requested (clamped addresses, no branches) before P7 of the
+    // previous tile and written to LDS at the top of its own iteration -- the memory round trip runs under P7-P9.
+    WgTileReq<2> rv, ro;
+    WgTileReq<1> rg;
+    WgTileReq<4> rx;
+    float frv[2];
+    f32x4 spq[4], dyq[4];  // s_pre / d(s_out) slices of this wave's first tile of so (used in P3)
+    auto request = [&](int t) {
+        const int tr0 = t * 32, tnv = min(32, rows - tr0);
+        const int64_t trow = min(tr0 + e, rows - 1);
+        const int ot = min(w, NT - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = min(32 * ot + 8 * q + 4 * hi, so - 4);
+            spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + trow * so + c);
+            dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + trow * so + c);
+        }
+        const float* vsrc = p.v_in + (int64_t)tr0 * 3 * vi;
+        const bool v_vec = ((3 * vi) & 3) == 0 && wg_aligned16(p.v_in);
+        const float* osrc = vo > 0 ? p.d_v_out + (int64_t)tr0 * 3 * vo : vsrc;
+        const bool o_vec = vo > 0 && ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out);
+        const float* gsrc = gated ? p.gate + (int64_t)tr0 * vo : vsrc;
+        const bool g_vec = gated && vec_o && wg_aligned16(p.gate);
+        wg_tile_request<NTH, 2>(rv, vsrc, 3 * vi, tnv, tid, v_vec);
+        wg_tile_request<NTH, 2>(ro, osrc, 3 * max(vo, 1), tnv, tid, o_vec);
+        wg_tile_request<NTH, 1>(rg, gsrc, max(vo, 1), tnv, tid, g_vec);
+        if constexpr (FUSED) {
+            const float* xsrc = p.s_in + (int64_t)tr0 * si;
+            wg_tile_request<NTH, 4>(rx, xsrc, si, tnv, tid, (si & 3) == 0 && wg_aligned16(p.s_in));
+        }
+        const float* fsrc = nf ? p.frames + (int64_t)tr0 * 9 : vsrc;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) frv[k] = fsrc[min(tid + k * NTH, tnv * 9 - 1)];
+    };
+    request(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         WG_LAUNDER();
         auto stamp = [&](int k) {  // (a tile from the middle of the workgroup's range: steady state, not the drained tail)
@@ -158,18 +194,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         const int nvalid = min(32, rows - r0);
         const bool row_ok = e < nvalid;
         const int64_t rowc = min(r0 + e, rows - 1);
-        // ---- s_pre / d(s_out) slices of this wave's first tile: requested now, used in P3 -------------------------------
-        f32x4 spq[4], dyq[4];
-        {
-            const int ot = min(w, NT - 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = min(32 * ot + 8 * q + 4 * hi, so - 4);
-                spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + rowc * so + c);
-                dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + c);
-            }
-        }
-        // ---- tile loads: every global load of the tile is requested before the first LDS write (one memory round trip) ------
         {
             const float* vsrc = p.v_in + (int64_t)r0 * 3 * vi;
             const bool v_vec = ((3 * vi) & 3) == 0 && wg_aligned16(p.v_in);
@@ -177,24 +201,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             const bool o_vec = vo > 0 && ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out);
             const float* gsrc = gated ? p.gate + (int64_t)r0 * vo : vsrc;
             const bool g_vec = gated && vec_o && wg_aligned16(p.gate);
-            const float* xsrc = FUSED ? p.s_in + (int64_t)r0 * si : vsrc;
-            const bool x_vec = FUSED && (si & 3) == 0 && wg_aligned16(p.s_in);
-            WgTileReq<2> rv, ro;
-            WgTileReq<1> rg;
-            WgTileReq<4> rx;
-            wg_tile_request<NTH, 2>(rv, vsrc, 3 * vi, nvalid, tid, v_vec);
-            wg_tile_request<NTH, 2>(ro, osrc, 3 * max(vo, 1), nvalid, tid, o_vec);
-            wg_tile_request<NTH, 1>(rg, gsrc, max(vo, 1), nvalid, tid, g_vec);
-            if constexpr (FUSED) wg_tile_request<NTH, 4>(rx, xsrc, si, nvalid, tid, x_vec);
-            float frv[2];
-            const float* fsrc = nf ? p.frames + (int64_t)r0 * 9 : vsrc;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) frv[k] = fsrc[min(tid + k * NTH, nvalid * 9 - 1)];
-            __builtin_amdgcn_sched_barrier(0);
-            wg_tile_commit<NTH, 2>(rv, V, VS, vsrc, 3 * vi, nvalid, tid, v_vec);
+            wg_tile_commit<NTH, 2>(rv, V, VS, vsrc, 3 * vi, nvalid, tid, v_vec, p.mg_v);
             if (vo > 0) {
-                wg_tile_commit<NTH, 2>(ro, DVO, US, osrc, 3 * vo, nvalid, tid, o_vec);
-                if (gated) wg_tile_commit<NTH, 1>(rg, DG, DGS, gsrc, vo, nvalid, tid, g_vec);
+                wg_tile_commit<NTH, 2>(ro, DVO, US, osrc, 3 * vo, nvalid, tid, o_vec, p.mg_o);
+                if (gated) wg_tile_commit<NTH, 1>(rg, DG, DGS, gsrc, vo, nvalid, tid, g_vec, p.mg_g);
             }
             if (nf) {
 #pragma unroll
@@ -202,10 +212,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                     if (tid + k * NTH < 32 * 9) FR[tid + k * NTH] = frv[k];
             }
             if constexpr (FUSED) {
-                wg_tile_commit<NTH, 4>(rx, X, KS, xsrc, si, nvalid, tid, x_vec);
+                const float* xsrc = p.s_in + (int64_t)r0 * si;
+                wg_tile_commit<NTH, 4>(rx, X, KS, xsrc, si, nvalid, tid, (si & 3) == 0 && wg_aligned16(p.s_in), p.mg_x);
                 const int npad = 8 * gcp_cdiv(p.KW, 8) - K;  // ones column (bias gradient) + zero padding
                 for (int i = tid; i < 32 * npad; i += NTH) {
-                    const int r = i / npad, c = i - r * npad;
+                    const int r = wg_div(i, npad, p.mg_xpad), c = i - r * npad;
                     X[r * KS + K + c] = (c == 0 && r < nvalid) ? 1.f : 0.f;
                 }
             }
@@ -267,14 +278,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             if constexpr (!FUSED) {
                 const int npad = p.EP - (H + nf);  // stride padding of the ext rows that go to HBM
                 for (int i = tid; i < 32 * npad; i += NTH) {
-                    const int r = i / npad, c = i - r * npad;
+                    const int r = wg_div(i, npad, p.mg_epad), c = i - r * npad;
                     DEXT[r * EXS + H + nf + c] = 0.f;
                 }
             }
         }
         wg_barrier();
         if constexpr (!FUSED) {
-            if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * p.EP, DEXT, EXS, p.EP, nvalid, tid, wg_aligned16(p.ext));
+            if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * p.EP, DEXT, EXS, p.EP, nvalid, tid, wg_aligned16(p.ext), p.mg_ep);
         }
 
         stamp(2);
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         }
         wg_barrier();
         if constexpr (!FUSED) {
-            if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * p.VOP, DG, DGS, p.VOP, nvalid, tid, wg_aligned16(p.dgate));
+            if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * p.VOP, DG, DGS, p.VOP, nvalid, tid, wg_aligned16(p.dgate), p.mg_vop);
         }
 
         stamp(3);
@@ -574,6 +585,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 
         stamp(6);
         WG_LAUNDER();
+        request(min(tile + (int)gridDim.x, p.ntiles - 1));  // the next tile's loads (this tile's if it is the last: harmless)
         // ResGCP pass-through of d(v_out) for P8 (the LDS copy has been recycled; L2 still has the tile): requested here, one
         // phase ahead, for the thread's first two channels
         float gpre[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -638,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             if (p.split) {  // scalar-input columns inside the split tile: summed over the waves' partials and stored
                 const int c0 = 32 * (p.NKT - 1), ns = min(si, K) - c0;  // (> 0 only when the last tile holds scalar columns)
                 for (int i = tid; i < 32 * max(ns, 0); i += NTH) {
-                    const int r = i / ns, c = i - r * ns;
+                    const int r = wg_div(i, ns, p.mg_ns), c = i - r * ns;
                     float sacc = 0.f;
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) sacc += EPART[(ww * 32 + r) * EPS + c];
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         if (p.dvhf) {  // d[vh | vf] per row, [3, HF'] xyz-major: the gradient of the pre-projected vector tables' gathered rows
             const int wdt = 3 * p.HFP;
             for (int i = tid; i < nvalid * wdt; i += NTH) {
-                const int r = i / wdt, j = i - r * wdt, d = j / p.HFP, x = j - d * p.HFP;
+                const int r = wg_div(i, wdt, p.mg_wdt), j = i - r * wdt, d = wg_div(j, p.HFP, p.mg_hfp), x = j - d * p.HFP;
                 p.dvhf[(int64_t)r0 * wdt + i] = x < HF ? DVHF[r * FS + 3 * x + d] : 0.f;
             }
         }
@@ -925,6 +937,10 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     for (int k = 0; k < p.v_add.n; ++k)
         if (!p.v_add.ptr[k] || p.v_add.dim[k] != p.HFP) return GCPNET_E_BADARG;
     p.n_up = w.vo * S.H; p.n_sm = pl.n_small;
+    p.mg_v = wg_magic(3 * w.vi / 4); p.mg_o = wg_magic(3 * w.vo / 4); p.mg_g = wg_magic(w.vo / 4); p.mg_x = wg_magic(w.si / 4);
+    p.mg_xpad = wg_magic(8 * gcp_cdiv(pl.kw, 8) - S.K); p.mg_epad = wg_magic(p.EP - (S.H + S.nf));
+    p.mg_ns = wg_magic(min(w.si, S.K) - 32 * (S.NKT - 1)); p.mg_wdt = wg_magic(3 * p.HFP); p.mg_hfp = wg_magic(p.HFP);
+    p.mg_ep = wg_magic(p.EP / 4); p.mg_vop = wg_magic(p.VOP / 4);
     p.sm_nu = max(gcp_cdiv(S.H, 16), 1); p.sm_nd = gcp_cdiv(w.vi, 16);
     p.sm_up_tiles = w.vo > 0 ? gcp_cdiv(w.vo, 16) * p.sm_nu : 0;
     p.sm_tiles = p.sm_up_tiles + gcp_cdiv(p.HF, 16) * p.sm_nd;
