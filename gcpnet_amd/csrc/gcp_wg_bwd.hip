@@ -21,6 +21,105 @@
 
 namespace {
 
+// Everything about a block's shape that the kernel needs as integers: dimensions, tile counts, LDS strides and offsets.  One
+// constexpr function computes it for the host (which fills WgBwdParams from it) and for the compile-time-shape instantiations
+// of the kernel (SHP below), where all of it folds into immediates, loops unroll and the uniform branches disappear.
+#define WG_BWD_DIMS(X)                                                                                                      \
+    X(si) X(vi) X(so) X(vo) X(H) X(nf) X(K) X(NT) X(NKT) X(SG) X(VG) X(HF) X(split) X(LW) X(KW) X(NNT) X(EP) X(VOP) X(HFP)  \
+    X(KS) X(DSS) X(VS) X(US) X(HS) X(FS) X(DGS) X(EXS) X(EPS) X(WSV) X(WSU) X(WTV) X(WTU)                                   \
+    X(o_x) X(o_ds) X(o_v) X(o_dvo) X(o_dvu) X(o_vh) X(o_dvhf) X(o_fr) X(o_dg) X(o_rn) X(o_sgn) X(o_dext) X(o_epart) X(o_ws) \
+    X(n_up) X(n_sm) X(sm_tiles) X(sm_up_tiles) X(sm_nu) X(sm_nd)
+#define WG_BWD_MAGICS(X) X(mg_v) X(mg_o) X(mg_g) X(mg_x) X(mg_xpad) X(mg_epad) X(mg_ns) X(mg_wdt) X(mg_hfp) X(mg_ep) X(mg_vop)
+
+struct WgBwdDims {
+#define X(f) int f;
+    WG_BWD_DIMS(X)
+#undef X
+#define X(f) unsigned f;
+    WG_BWD_MAGICS(X)
+#undef X
+    int KTn, fused, lds_floats;
+};
+
+constexpr int c_cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int c_rup(int x, int m) { return (x + m - 1) / m * m; }
+constexpr int c_max(int a, int b) { return a > b ? a : b; }
+constexpr int c_min(int a, int b) { return a < b ? a : b; }
+constexpr int c_stride(int width) { return 4 * (c_cdiv(width, 4) | 1); }  // == wg_stride
+constexpr unsigned c_magic(int d) { return d > 1 ? (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d) : 0u; }  // == wg_magic
+
+// (si, vi, so, vo, hidden: as in gcp2_weights_t; gated: scalar gate in use; want_fused: the caller asked for fused weight
+// gradients; NW: waves per workgroup)
+constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int use_frames, int gated, int want_fused, int NW) {
+    WgBwdDims d{};
+    d.si = si; d.vi = vi; d.so = so; d.vo = vo;
+    d.H = vi > 0 ? hidden : 0;
+    d.nf = (vi > 0 && use_frames) ? 9 : 0;
+    d.K = si + d.H + d.nf;
+    d.NT = c_cdiv(so, 32);
+    d.NKT = c_cdiv(d.K, 32);
+    d.SG = 4 * d.NT;
+    d.VG = c_cdiv(vo, 8);
+    d.HF = d.H + (d.nf ? 3 : 0);
+    const int rem = d.NKT % NW;
+    d.split = (rem == 1 && d.NKT > 1) ? 1 : 0;
+    const int NFT = d.split ? d.NKT - 1 : d.NKT;
+    d.KTn = c_cdiv(NFT, NW);
+    d.LW = d.K - 32 * (d.NKT - 1);
+    d.KW = d.K + 1;
+    d.NNT = c_cdiv(d.KW, 32);
+    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5) ? 1 : 0;
+    d.EP = c_rup(d.H + d.nf, 4);
+    d.VOP = c_rup(vo, 4);
+    d.HFP = c_rup(d.HF, 4);
+    d.n_up = vo * d.H;
+    d.n_sm = vo * d.H + d.HF * vi;
+    d.sm_nu = c_max(c_cdiv(d.H, 16), 1);
+    d.sm_nd = c_cdiv(vi, 16);
+    d.sm_up_tiles = vo > 0 ? c_cdiv(vo, 16) * d.sm_nu : 0;
+    d.sm_tiles = d.sm_up_tiles + c_cdiv(d.HF, 16) * d.sm_nd;
+    const int xw = d.fused ? 8 * c_cdiv(d.KW, 8) : 0;
+    d.KS = c_stride(c_max(xw, 4));
+    d.DSS = c_stride(32 * d.NT);
+    d.VS = c_stride(3 * vi); d.US = c_stride(3 * c_max(vo, 1)); d.HS = c_stride(3 * c_max(d.H, 1)); d.FS = c_stride(3 * d.HF);
+    d.DGS = c_stride(c_rup(c_max(vo, 1), 8));
+    d.EXS = c_stride(c_max(d.EP, d.K - si));
+    d.EPS = c_max(20, c_stride(c_rup(d.LW, 8)));
+    d.WSV = c_stride(vi); d.WTV = c_stride(d.HF); d.WSU = c_stride(c_max(d.H, 1)); d.WTU = c_stride(c_max(vo, 1));
+    int off = 0;
+    d.o_x = off; off += d.fused ? 32 * d.KS : 0;
+    d.o_ds = off; off += 32 * d.DSS;
+    d.o_epart = off; off += NW * 32 * d.EPS;
+    d.o_v = off; off += 32 * d.VS;
+    d.o_dvu = off; off += 32 * d.US;
+    d.o_vh = off; off += 32 * d.HS;
+    d.o_fr = off; off += 32 * 9;
+    d.o_dg = off; off += 32 * d.DGS;
+    d.o_rn = off; off += c_rup(32 * (d.H | 1), 4);
+    d.o_sgn = off; off += 32 * 3 + 32;
+    d.o_ws = off; off += d.HF * d.WSV + vi * d.WTV + vo * d.WSU + d.H * d.WTU;
+    off = c_rup(off, 4);
+    // d(v_out) is dead after P2; its space then holds d[vh | vf] and (not fused: from P1 on) the extras tile.  The extras tile
+    // must not overlap d(v_out) when it is written in P1, so it sits behind it in that case.
+    d.o_dvo = off;
+    const int dvo = 32 * d.US, dq = 32 * d.FS, dx = 32 * d.EXS;
+    d.o_dvhf = off;
+    if (d.fused) { d.o_dext = off + dq; off += c_max(dvo, dq + dx); }
+    else { d.o_dext = off + c_max(dvo, dq); off += c_max(dvo, dq) + dx; }
+    d.lds_floats = off;
+    d.mg_v = c_magic(3 * vi / 4); d.mg_o = c_magic(3 * vo / 4); d.mg_g = c_magic(vo / 4); d.mg_x = c_magic(si / 4);
+    d.mg_xpad = c_magic(8 * c_cdiv(d.KW, 8) - d.K); d.mg_epad = c_magic(d.EP - (d.H + d.nf));
+    d.mg_ns = c_magic(c_min(si, d.K) - 32 * (d.NKT - 1)); d.mg_wdt = c_magic(3 * d.HFP); d.mg_hfp = c_magic(d.HFP);
+    d.mg_ep = c_magic(d.EP / 4); d.mg_vop = c_magic(d.VOP / 4);
+    return d;
+}
+
+// Compile-time shapes (template parameter SHP of the kernel): the residual message GCPs of the shipped configurations,
+// (s, V) -> (s, V) with frames and a scalar gate.  0 = run-time shape.
+template <int SHP> struct WgBwdShape { static constexpr int S = 0, V = 0, HID = 0; };
+template <> struct WgBwdShape<1> { static constexpr int S = 128, V = 16, HID = 4; };  // BASELINE configs[1]: (128, 16), bottleneck 4
+template <> struct WgBwdShape<2> { static constexpr int S = 256, V = 32, HID = 8; };  // BASELINE configs[4]: (256, 32)
+
 struct WgBwdParams {
     int rows, ntiles;
     const float* s_in;
@@ -62,8 +161,9 @@ struct WgBwdParams {
 
 constexpr int NSW = 2;  // 16 x 16 tiles of the small vector weight gradients per wave
 
-// NW waves; KT = full K tiles per wave in P4; FN = 32-wide tiles of the fused weight gradient's K + 1 columns (0 = not fused)
-template <int NW, int KT, int FN, bool PWL>
+// NW waves; KT = full K tiles per wave in P4; FN = 32-wide tiles of the fused weight gradient's K + 1 columns (0 = not fused);
+// SHP: compile-time shape (WgBwdShape), 0 = every dimension from the parameters
+template <int NW, int KT, int FN, bool PWL, int SHP>
 __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32;
@@ -80,22 +180,30 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63, e = lane & 31, hi = lane >> 5;
     int prow = tid / TPR, psub = tid - prow * TPR;
+    constexpr WgBwdDims CD = wg_bwd_dims(WgBwdShape<SHP>::S, WgBwdShape<SHP>::V, WgBwdShape<SHP>::S, WgBwdShape<SHP>::V,
+                                         WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW);
+#define DM(f) (SHP ? CD.f : p.f)  // a shape value: immediate for the compile-time shapes
     int rows, KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, si, vi, so, vo, H, nf, K, HF, NT, SG, exs;
+    int NKT, VG, split, LW, KW, NNT, EP, VOP, HFP, WSV, WSU, WTV, WTU, n_up, n_sm, sm_tiles, sm_up_tiles, sm_nu, sm_nd;
     float *X, *DS, *V, *DVO, *DVU, *VH, *DVHF, *FR, *DG, *RN, *SGN, *DEXT, *EPART, *ST, *extp;
     const float *WD, *WDT, *WU, *WUT;
 #define WG_RELOAD()                                                                                                        \
     do {                                                                                                                   \
         rows = p.rows;                                                                                                     \
-        KS = p.KS; DSS = p.DSS; VS = p.VS; US = p.US; HS = p.HS; FS = p.FS; DGS = p.DGS; EXS = p.EXS; EPS = p.EPS;         \
-        si = p.si; vi = p.vi; so = p.so; vo = p.vo; H = p.H; nf = p.nf; K = p.K; HF = p.HF; NT = p.NT; SG = p.SG;          \
-        X = lds + p.o_x; DS = lds + p.o_ds; V = lds + p.o_v; DVO = lds + p.o_dvo; DVU = lds + p.o_dvu; VH = lds + p.o_vh;  \
-        DVHF = lds + p.o_dvhf; FR = lds + p.o_fr; DG = lds + p.o_dg; RN = lds + p.o_rn; SGN = lds + p.o_sgn;               \
-        DEXT = lds + p.o_dext; EPART = lds + p.o_epart;                                                                    \
+        KS = DM(KS); DSS = DM(DSS); VS = DM(VS); US = DM(US); HS = DM(HS); FS = DM(FS); DGS = DM(DGS); EXS = DM(EXS);      \
+        EPS = DM(EPS); si = DM(si); vi = DM(vi); so = DM(so); vo = DM(vo); H = DM(H); nf = DM(nf); K = DM(K); HF = DM(HF); \
+        NT = DM(NT); SG = DM(SG); NKT = DM(NKT); VG = DM(VG); split = DM(split); LW = DM(LW); KW = DM(KW); NNT = DM(NNT);  \
+        EP = DM(EP); VOP = DM(VOP); HFP = DM(HFP); WSV = DM(WSV); WSU = DM(WSU); WTV = DM(WTV); WTU = DM(WTU);             \
+        n_up = DM(n_up); n_sm = DM(n_sm); sm_tiles = DM(sm_tiles); sm_up_tiles = DM(sm_up_tiles); sm_nu = DM(sm_nu);       \
+        sm_nd = DM(sm_nd);                                                                                                 \
+        X = lds + DM(o_x); DS = lds + DM(o_ds); V = lds + DM(o_v); DVO = lds + DM(o_dvo); DVU = lds + DM(o_dvu);           \
+        VH = lds + DM(o_vh); DVHF = lds + DM(o_dvhf); FR = lds + DM(o_fr); DG = lds + DM(o_dg); RN = lds + DM(o_rn);       \
+        SGN = lds + DM(o_sgn); DEXT = lds + DM(o_dext); EPART = lds + DM(o_epart);                                         \
         ST = EPART + w * 32 * EPS; /* wave-private staging (half tiles, 32 x 20) shares the wave's split-K partial slot */ \
-        WD = lds + p.o_ws;         /* [HF][WSV]   [vector_down ; vector_down_frames] */                                    \
-        WDT = WD + HF * p.WSV;     /* [vi][WTV]   transposed */                                                            \
-        WU = WDT + vi * p.WTV;     /* [vo][WSU]   vector_up */                                                             \
-        WUT = WU + vo * p.WSU;     /* [H][WTU]    transposed */                                                            \
+        WD = lds + DM(o_ws);       /* [HF][WSV]   [vector_down ; vector_down_frames] */                                    \
+        WDT = WD + HF * WSV;       /* [vi][WTV]   transposed */                                                            \
+        WU = WDT + vi * WTV;       /* [vo][WSU]   vector_up */                                                             \
+        WUT = WU + vo * WSU;       /* [H][WTU]    transposed */                                                            \
         /* where P1 leaves [norms | frame scalars]: X's extras columns, or (not fused) a tile of its own that goes to HBM  \
            (it doubles as the d(extras) tile later) */                                                                     \
         extp = FUSED ? X + si : DEXT;                                                                                      \
@@ -115,21 +223,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 
     // ---- once per workgroup: small weights (both orientations) -> LDS, zero the never-written paddings ------------------
     {
-        float* wd = lds + p.o_ws;
-        float* wdt = wd + HF * p.WSV;
-        float* wu = wdt + vi * p.WTV;
-        float* wut = wu + vo * p.WSU;
+        float* wd = lds + DM(o_ws);
+        float* wdt = wd + HF * WSV;
+        float* wu = wdt + vi * WTV;
+        float* wut = wu + vo * WSU;
         for (int i = tid; i < HF * vi; i += NTH) {
             const int x = i / vi, c = i - x * vi;
             const float v = x < H ? p.w_down[i] : p.w_frames[i - H * vi];
-            wd[x * p.WSV + c] = v;
-            wdt[c * p.WTV + x] = v;
+            wd[x * WSV + c] = v;
+            wdt[c * WTV + x] = v;
         }
         for (int i = tid; i < vo * H; i += NTH) {
             const int o = i / H, h = i - o * H;
             const float v = p.w_up[i];
-            wu[o * p.WSU + h] = v;
-            wut[h * p.WTU + o] = v;
+            wu[o * WSU + h] = v;
+            wut[h * WTU + o] = v;
         }
         for (int i = tid; i < 32 * DGS; i += NTH) DG[i] = 0.f;
         for (int i = tid; i < 32 * DSS; i += NTH) DS[i] = 0.f;
@@ -201,10 +309,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             const bool o_vec = vo > 0 && ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out);
             const float* gsrc = gated ? p.gate + (int64_t)r0 * vo : vsrc;
             const bool g_vec = gated && vec_o && wg_aligned16(p.gate);
-            wg_tile_commit<NTH, 2>(rv, V, VS, vsrc, 3 * vi, nvalid, tid, v_vec, p.mg_v);
+            wg_tile_commit<NTH, 2>(rv, V, VS, vsrc, 3 * vi, nvalid, tid, v_vec, DM(mg_v));
             if (vo > 0) {
-                wg_tile_commit<NTH, 2>(ro, DVO, US, osrc, 3 * vo, nvalid, tid, o_vec, p.mg_o);
-                if (gated) wg_tile_commit<NTH, 1>(rg, DG, DGS, gsrc, vo, nvalid, tid, g_vec, p.mg_g);
+                wg_tile_commit<NTH, 2>(ro, DVO, US, osrc, 3 * vo, nvalid, tid, o_vec, DM(mg_o));
+                if (gated) wg_tile_commit<NTH, 1>(rg, DG, DGS, gsrc, vo, nvalid, tid, g_vec, DM(mg_g));
             }
             if (nf) {
 #pragma unroll
@@ -213,10 +321,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             }
             if constexpr (FUSED) {
                 const float* xsrc = p.s_in + (int64_t)r0 * si;
-                wg_tile_commit<NTH, 4>(rx, X, KS, xsrc, si, nvalid, tid, (si & 3) == 0 && wg_aligned16(p.s_in), p.mg_x);
-                const int npad = 8 * gcp_cdiv(p.KW, 8) - K;  // ones column (bias gradient) + zero padding
+                wg_tile_commit<NTH, 4>(rx, X, KS, xsrc, si, nvalid, tid, (si & 3) == 0 && wg_aligned16(p.s_in), DM(mg_x));
+                const int npad = 8 * gcp_cdiv(KW, 8) - K;  // ones column (bias gradient) + zero padding
                 for (int i = tid; i < 32 * npad; i += NTH) {
-                    const int r = wg_div(i, npad, p.mg_xpad), c = i - r * npad;
+                    const int r = wg_div(i, npad, DM(mg_xpad)), c = i - r * npad;
                     X[r * KS + K + c] = (c == 0 && r < nvalid) ? 1.f : 0.f;
                 }
             }
@@ -233,10 +341,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                 for (int k = 0; k < p.v_add.n; ++k) {  // shares of the pre-projected (gathered) vector sources
                     const int32_t* ix = p.v_add.idx[k];
-                    const float* t = p.v_add.ptr[k] + (int64_t)(ix ? ix[grow] : grow) * 3 * p.HFP;
-                    q0 += t[x]; q1 += t[p.HFP + x]; q2 += t[2 * p.HFP + x];
+                    const float* t = p.v_add.ptr[k] + (int64_t)(ix ? ix[grow] : grow) * 3 * HFP;
+                    q0 += t[x]; q1 += t[HFP + x]; q2 += t[2 * HFP + x];
                 }
-                const float* wr = WD + x * p.WSV;
+                const float* wr = WD + x * WSV;
                 float u0 = 0.f, u1 = 0.f, u2 = 0.f;
                 if (vec_v) {
                     for (int c = 0; c < vi; c += 4) {
@@ -276,16 +384,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 }
             }
             if constexpr (!FUSED) {
-                const int npad = p.EP - (H + nf);  // stride padding of the ext rows that go to HBM
+                const int npad = EP - (H + nf);  // stride padding of the ext rows that go to HBM
                 for (int i = tid; i < 32 * npad; i += NTH) {
-                    const int r = wg_div(i, npad, p.mg_epad), c = i - r * npad;
+                    const int r = wg_div(i, npad, DM(mg_epad)), c = i - r * npad;
                     DEXT[r * EXS + H + nf + c] = 0.f;
                 }
             }
         }
         wg_barrier();
         if constexpr (!FUSED) {
-            if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * p.EP, DEXT, EXS, p.EP, nvalid, tid, wg_aligned16(p.ext), p.mg_ep);
+            if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * EP, DEXT, EXS, EP, nvalid, tid, wg_aligned16(p.ext), DM(mg_ep));
         }
 
         stamp(2);
@@ -293,7 +401,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         // ---- P2: adjoint of the vector epilogue (gcpnet.py:364-391) --------------------------------------------------------
         if (vo > 0) {
             for (int o = psub; o < vo; o += TPR) {
-                const float* wu = WU + o * p.WSU;
+                const float* wu = WU + o * WSU;
                 const float* vh = VH + prow * HS;
                 float u0 = 0.f, u1 = 0.f, u2 = 0.f;
                 if (vec_h) {
@@ -333,7 +441,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         }
         wg_barrier();
         if constexpr (!FUSED) {
-            if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * p.VOP, DG, DGS, p.VOP, nvalid, tid, wg_aligned16(p.dgate), p.mg_vop);
+            if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * VOP, DG, DGS, VOP, nvalid, tid, wg_aligned16(p.dgate), DM(mg_vop));
         }
 
         stamp(3);
@@ -354,8 +462,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
             if (gated) {
-                const float* pg = p.pk + p.offG2 + ((int64_t)ot * p.VG * 64 + lane) * 4;
-                for (int g = 0; g < p.VG; ++g) {
+                const float* pg = p.pk + p.offG2 + ((int64_t)ot * VG * 64 + lane) * 4;
+                for (int g = 0; g < VG; ++g) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(pg + (int64_t)g * 256);
                     const f32x4 b = *reinterpret_cast<const f32x4*>(DG + e * DGS + 8 * g + 4 * hi);
 #pragma unroll
@@ -405,7 +513,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         WG_LAUNDER();
         // ---- P4: d[s | norms | frame scalars]^T = W^T ds_pre^T ------------------------------------------------------------
         {
-            const int NFT = p.split ? p.NKT - 1 : p.NKT;  // tiles handed out whole, round-robin
+            const int NFT = split ? NKT - 1 : NKT;  // tiles handed out whole, round-robin
             if (w < NFT) {
                 int ktc[KT];
 #pragma unroll
@@ -483,8 +591,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 }
             }
             WG_LAUNDER();
-            if (p.split) {  // the last tile of K: every wave reduces over its share of so, partial sums -> EPART[w]
-                const int kt = p.NKT - 1;
+            if (split) {  // the last tile of K: every wave reduces over its share of so, partial sums -> EPART[w]
+                const int kt = NKT - 1;
                 const int gs = gcp_cdiv(SG, NW), g_lo = w * gs, g_hi = min(SG, g_lo + gs);
                 f32x16 acc3;
 #pragma unroll
@@ -507,7 +615,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                         }
                 }
                 gcp_wave_lds_sync();  // (ST shares this slot: its reads are done)
-                for (int q = 0; 8 * q < p.LW; ++q) {
+                for (int q = 0; 8 * q < LW; ++q) {
                     f32x4 v;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -532,7 +640,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 float a_n = da[0];
                 float b_n[FN];
 #pragma unroll
-                for (int n = 0; n < FN; ++n) b_n[n] = xb[32 * min(n, p.NNT - 1)];
+                for (int n = 0; n < FN; ++n) b_n[n] = xb[32 * min(n, NNT - 1)];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const float a_c = a_n;
@@ -542,11 +650,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                     if (j + 1 < 16) {
                         a_n = da[2 * (j + 1) * DSS];
 #pragma unroll
-                        for (int n = 0; n < FN; ++n) b_n[n] = xb[2 * (j + 1) * KS + 32 * min(n, p.NNT - 1)];
+                        for (int n = 0; n < FN; ++n) b_n[n] = xb[2 * (j + 1) * KS + 32 * min(n, NNT - 1)];
                     }
 #pragma unroll
                     for (int n = 0; n < FN; ++n)
-                        if (n < p.NNT) dW[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[n], dW[n], 0, 0, 0);
+                        if (n < NNT) dW[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[n], dW[n], 0, 0, 0);
                 }
             }
             // ---- P6: dWg[vo][own 32 columns of so] += dgate^T act_v(s_pre) -------------------------------------------------
@@ -585,7 +693,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 
         stamp(6);
         WG_LAUNDER();
-        request(min(tile + (int)gridDim.x, p.ntiles - 1));  // the next tile's loads (this tile's if it is the last: harmless)
+        // the next tile's loads (this tile's again if it is the last: harmless).  Fused: requested after P8 instead -- next to
+        // the 100+ persistent accumulator registers the 70 request registers do not fit alongside P7 / P8
+        if constexpr (!FUSED) request(min(tile + (int)gridDim.x, p.ntiles - 1));
         // ResGCP pass-through of d(v_out) for P8 (the LDS copy has been recycled; L2 still has the tile): requested here, one
         // phase ahead, for the thread's first two channels
         float gpre[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -600,8 +710,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         {
             auto dext = [&](int x) -> float {  // d(extras column x) of this thread's row
                 const int c = si + x;
-                if (p.split && c >= 32 * (p.NKT - 1)) {
-                    const int cc = c - 32 * (p.NKT - 1);
+                if (split && c >= 32 * (NKT - 1)) {
+                    const int cc = c - 32 * (NKT - 1);
                     float sacc = 0.f;
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) sacc += EPART[(ww * 32 + prow) * EPS + cc];
@@ -613,7 +723,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                 if (x < H) {
                     if (vo > 0) {
-                        const float* wt = WUT + x * p.WTU;
+                        const float* wt = WUT + x * WTU;
                         const float* du = DVU + prow * US;
                         if (vec_o) {
                             for (int o = 0; o < vo; o += 4) {
@@ -647,10 +757,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 }
                 DVHF[prow * FS + 3 * x + 0] = a0; DVHF[prow * FS + 3 * x + 1] = a1; DVHF[prow * FS + 3 * x + 2] = a2;
             }
-            if (p.split) {  // scalar-input columns inside the split tile: summed over the waves' partials and stored
-                const int c0 = 32 * (p.NKT - 1), ns = min(si, K) - c0;  // (> 0 only when the last tile holds scalar columns)
+            if (split) {  // scalar-input columns inside the split tile: summed over the waves' partials and stored
+                const int c0 = 32 * (NKT - 1), ns = min(si, K) - c0;  // (> 0 only when the last tile holds scalar columns)
                 for (int i = tid; i < 32 * max(ns, 0); i += NTH) {
-                    const int r = wg_div(i, ns, p.mg_ns), c = i - r * ns;
+                    const int r = wg_div(i, ns, DM(mg_ns)), c = i - r * ns;
                     float sacc = 0.f;
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) sacc += EPART[(ww * 32 + r) * EPS + c];
@@ -664,7 +774,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         WG_LAUNDER();
         // ---- P8: d(v_in) = [vector_down ; vector_down_frames]^T d[vh | vf] (+ pass-through terms) ----------------------------
         auto p8 = [&](int c, bool pre, float h0, float h1, float h2) {
-            const float* wt = WDT + c * p.WTV;
+            const float* wt = WDT + c * WTV;
             const float* dq = DVHF + prow * FS;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int x = 0; x < HF; ++x) {
@@ -689,13 +799,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
         if (psub + TPR < vi) p8(psub + TPR, true, gpre[1][0], gpre[1][1], gpre[1][2]);
         for (int c = psub + 2 * TPR; c < vi; c += TPR) p8(c, false, 0.f, 0.f, 0.f);
         if (p.dvhf) {  // d[vh | vf] per row, [3, HF'] xyz-major: the gradient of the pre-projected vector tables' gathered rows
-            const int wdt = 3 * p.HFP;
+            const int wdt = 3 * HFP;
             for (int i = tid; i < nvalid * wdt; i += NTH) {
-                const int r = wg_div(i, wdt, p.mg_wdt), j = i - r * wdt, d = wg_div(j, p.HFP, p.mg_hfp), x = j - d * p.HFP;
+                const int r = wg_div(i, wdt, DM(mg_wdt)), j = i - r * wdt, d = wg_div(j, HFP, DM(mg_hfp)), x = j - d * HFP;
                 p.dvhf[(int64_t)r0 * wdt + i] = x < HF ? DVHF[r * FS + 3 * x + d] : 0.f;
             }
         }
         WG_LAUNDER();
+        if constexpr (FUSED) request(min(tile + (int)gridDim.x, p.ntiles - 1));
         // ---- P9: small vector weight gradients on the matrix cores (v_mfma_f32_16x16x4_f32): 16 x 16 output tiles of
         //          d vector_up[o, h] = sum dvu[row, o, :] . vh[row, h, :] and
         //          d [vector_down ; vector_down_frames][x, c] = sum d[vh | vf][row, x, :] . v[row, c, :],
@@ -706,10 +817,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 #pragma unroll
             for (int sl = 0; sl < NSW; ++sl) {
                 const int t = w + NW * sl;
-                if (t < p.sm_tiles) {
-                    const bool up = t < p.sm_up_tiles;
-                    const int tt = up ? t : t - p.sm_up_tiles;
-                    const int nn = up ? p.sm_nu : p.sm_nd;  // tiles along N
+                if (t < sm_tiles) {
+                    const bool up = t < sm_up_tiles;
+                    const int tt = up ? t : t - sm_up_tiles;
+                    const int nn = up ? sm_nu : sm_nd;  // tiles along N
                     const int mt = tt / nn, nt = tt - mt * nn;
                     const int M = up ? vo : HF, N = up ? H : vi;
                     const int m = 16 * mt + l16, n = 16 * nt + l16;
@@ -742,14 +853,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
     // ---- partial weight gradients of this workgroup ---------------------------------------------------------------------------
     if constexpr (FUSED) {
         if (w < NT) {
-            float* out = p.dw_part + (int64_t)blockIdx.x * so * p.KW;
+            float* out = p.dw_part + (int64_t)blockIdx.x * so * KW;
 #pragma unroll
             for (int n = 0; n < FN; ++n)
-                if (n < p.NNT) {
+                if (n < NNT) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = 32 * w + gcp_crow(r, hi), c = 32 * n + e;
-                        if (m < so && c < p.KW) out[(int64_t)m * p.KW + c] = dW[n][r];
+                        if (m < so && c < KW) out[(int64_t)m * KW + c] = dW[n][r];
                     }
                 }
             if (gated) {
@@ -769,14 +880,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 #pragma unroll
         for (int sl = 0; sl < NSW; ++sl) {
             const int t = w + NW * sl;
-            if (t < p.sm_tiles) {
-                const bool up = t < p.sm_up_tiles;
-                const int tt = up ? t : t - p.sm_up_tiles;
-                const int nn = up ? p.sm_nu : p.sm_nd;
+            if (t < sm_tiles) {
+                const bool up = t < sm_up_tiles;
+                const int tt = up ? t : t - sm_up_tiles;
+                const int nn = up ? sm_nu : sm_nd;
                 const int mt = tt / nn, nt = tt - mt * nn;
                 const int M = up ? vo : HF, N = up ? H : vi;
                 const int n = 16 * nt + l16;
-                float* out = p.wsm_part + (int64_t)blockIdx.x * p.n_sm + (up ? 0 : p.n_up);
+                float* out = p.wsm_part + (int64_t)blockIdx.x * n_sm + (up ? 0 : n_up);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * mt + 4 * kq + r;
@@ -788,6 +899,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
 }
 
 #undef p
+#undef DM
 #undef WG_RELOAD
 #undef WG_LAUNDER
 
@@ -826,7 +938,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
 
 int g_wg_cus = 0;
 
-template <int NW, int KT, int FN>
+template <int NW, int KT, int FN, int SHP = 0>
 int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipStream_t st) {
     auto go = [&](auto kern) -> int {
         if (lds_bytes > 64 * 1024) {
@@ -837,7 +949,24 @@ int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipSt
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     };
-    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false>);
+    if constexpr (SHP != 0) return go(gcp_wg_bwd_kernel<NW, KT, FN, true, SHP>);  // (the compile-time shapes exist for PWL only)
+    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true, 0>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false, 0>);
+}
+
+// True if the launch's shape is exactly the compile-time shape SHP (every integer the kernel would otherwise read).
+template <int SHP, int NW, int FN>
+bool wg_bwd_is_shape(const WgBwdParams& p, const gcp2_weights_t& w, bool gated) {
+    if (!(w.si == WgBwdShape<SHP>::S && w.so == WgBwdShape<SHP>::S && w.vi == WgBwdShape<SHP>::V && w.vo == WgBwdShape<SHP>::V &&
+          w.hidden == WgBwdShape<SHP>::HID && w.use_frames && gated))
+        return false;
+    constexpr WgBwdDims CD = wg_bwd_dims(WgBwdShape<SHP>::S, WgBwdShape<SHP>::V, WgBwdShape<SHP>::S, WgBwdShape<SHP>::V,
+                                         WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW);
+    bool same = true;
+#define X(f) same = same && p.f == CD.f;
+    WG_BWD_DIMS(X)
+    WG_BWD_MAGICS(X)
+#undef X
+    return same;
 }
 
 }  // namespace
@@ -863,17 +992,11 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
         if (ev[0] == '8') NW = 8;
     }
     if (gcp_cdiv(S.NT, NW) > 4) return GCPNET_E_UNSUPPORTED;
-    const int rem = S.NKT % NW;
-    const int split = (rem == 1 && S.NKT > 1) ? 1 : 0;
-    const int NFT = split ? S.NKT - 1 : S.NKT;
-    const int KTn = gcp_cdiv(NFT, NW);
-    if (KTn > 4) return GCPNET_E_UNSUPPORTED;
-    const int HF = S.H + (S.nf ? 3 : 0);
-    const int n_sm = w->vo * S.H + HF * w->vi;
-    const int sm_tiles = (w->vo > 0 ? gcp_cdiv(w->vo, 16) * gcp_cdiv(S.H, 16) : 0) + gcp_cdiv(HF, 16) * gcp_cdiv(w->vi, 16);
-    if (sm_tiles > NSW * NW) return GCPNET_E_UNSUPPORTED;
-    const int KW = S.K + 1, NNT = gcp_cdiv(KW, 32);
-    const int fused = want_fused && S.NT <= NW && KTn == 1 && NNT <= 5 && !getenv("GCPNET_WG_BWD_NOFUSE");
+    const WgBwdDims D = wg_bwd_dims(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated,
+                                    want_fused && !getenv("GCPNET_WG_BWD_NOFUSE"), NW);
+    if (D.KTn > 4) return GCPNET_E_UNSUPPORTED;
+    if (D.sm_tiles > NSW * NW) return GCPNET_E_UNSUPPORTED;
+    const int KTn = D.KTn, fused = D.fused, KW = D.KW, n_sm = D.n_sm, split = D.split;
     if (!g_wg_cus) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -927,58 +1050,29 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     p.w_down = w.w_down; p.w_frames = w.w_frames; p.w_up = w.w_up;
     p.ds_pre = a->ds_pre; p.dvhf = a->dvhf; p.ext = a->ext; p.dgate = a->dgate;
     p.dw_part = a->dw_part; p.dwg_part = a->dwg_part; p.wsm_part = a->wsm_part;
-    p.si = w.si; p.vi = w.vi; p.so = w.so; p.vo = w.vo; p.H = S.H; p.nf = S.nf; p.K = S.K; p.NT = S.NT; p.NKT = S.NKT;
-    p.SG = 4 * S.NT; p.VG = S.VG; p.HF = S.H + (S.nf ? 3 : 0);
+    const int NW = pl.nw;
+    const WgBwdDims D = wg_bwd_dims(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated, pl.fused, NW);
+    if (D.fused != pl.fused || D.split != pl.split || D.KW != pl.kw) return GCPNET_E_BADARG;  // (same function: cannot differ)
+#define X(f) p.f = D.f;
+    WG_BWD_DIMS(X)
+    WG_BWD_MAGICS(X)
+#undef X
     p.act_s = o.act_s; p.act_v = o.act_v; p.vmode = w.vo > 0 ? o.vmode : GCP_VMODE_NONE; p.vres = o.vector_residual; p.e3 = o.e3;
     p.residual = a->residual; p.slope = o.slope;
-    p.split = pl.split; p.LW = S.K - 32 * (S.NKT - 1);
-    p.KW = pl.kw; p.NNT = gcp_cdiv(pl.kw, 32);
-    p.EP = pl.ext_w; p.VOP = pl.dgate_w; p.HFP = gcp_round_up(p.HF, 4);
     for (int k = 0; k < p.v_add.n; ++k)
         if (!p.v_add.ptr[k] || p.v_add.dim[k] != p.HFP) return GCPNET_E_BADARG;
-    p.n_up = w.vo * S.H; p.n_sm = pl.n_small;
-    p.mg_v = wg_magic(3 * w.vi / 4); p.mg_o = wg_magic(3 * w.vo / 4); p.mg_g = wg_magic(w.vo / 4); p.mg_x = wg_magic(w.si / 4);
-    p.mg_xpad = wg_magic(8 * gcp_cdiv(pl.kw, 8) - S.K); p.mg_epad = wg_magic(p.EP - (S.H + S.nf));
-    p.mg_ns = wg_magic(min(w.si, S.K) - 32 * (S.NKT - 1)); p.mg_wdt = wg_magic(3 * p.HFP); p.mg_hfp = wg_magic(p.HFP);
-    p.mg_ep = wg_magic(p.EP / 4); p.mg_vop = wg_magic(p.VOP / 4);
-    p.sm_nu = max(gcp_cdiv(S.H, 16), 1); p.sm_nd = gcp_cdiv(w.vi, 16);
-    p.sm_up_tiles = w.vo > 0 ? gcp_cdiv(w.vo, 16) * p.sm_nu : 0;
-    p.sm_tiles = p.sm_up_tiles + gcp_cdiv(p.HF, 16) * p.sm_nd;
-    const int NW = pl.nw;
-    const int xw = pl.fused ? 8 * gcp_cdiv(pl.kw, 8) : 0;
-    p.KS = wg_stride(max(xw, 4));
-    p.DSS = wg_stride(32 * S.NT);
-    p.VS = wg_stride(3 * w.vi); p.US = wg_stride(3 * max(w.vo, 1)); p.HS = wg_stride(3 * max(S.H, 1)); p.FS = wg_stride(3 * p.HF);
-    p.DGS = wg_stride(gcp_round_up(max(w.vo, 1), 8));
-    p.EXS = wg_stride(max(p.EP, S.K - w.si));
-    p.EPS = max(20, wg_stride(gcp_round_up(p.LW, 8)));
-    p.WSV = wg_stride(w.vi); p.WTV = wg_stride(p.HF); p.WSU = wg_stride(max(S.H, 1)); p.WTU = wg_stride(max(w.vo, 1));
-    int off = 0;
-    p.o_x = off; off += pl.fused ? 32 * p.KS : 0;
-    p.o_ds = off; off += 32 * p.DSS;
-    p.o_epart = off; off += NW * 32 * p.EPS;
-    p.o_v = off; off += 32 * p.VS;
-    p.o_dvu = off; off += 32 * p.US;
-    p.o_vh = off; off += 32 * p.HS;
-    p.o_fr = off; off += 32 * 9;
-    p.o_dg = off; off += 32 * p.DGS;
-    p.o_rn = off; off += gcp_round_up(32 * (S.H | 1), 4);
-    p.o_sgn = off; off += 32 * 3 + 32;
-    p.o_ws = off; off += p.HF * p.WSV + w.vi * p.WTV + w.vo * p.WSU + S.H * p.WTU;
-    off = gcp_round_up(off, 4);
-    // d(v_out) is dead after P2; its space then holds d[vh | vf] and (not fused: from P1 on) the extras tile.  The extras tile
-    // must not overlap d(v_out) when it is written in P1, so it sits behind it in that case.
-    p.o_dvo = off;
-    const int dvo = 32 * p.US, dq = 32 * p.FS, dx = 32 * p.EXS;
-    p.o_dvhf = off;
-    if (pl.fused) { p.o_dext = off + dq; off += max(dvo, dq + dx); }
-    else { p.o_dext = off + max(dvo, dq); off += max(dvo, dq) + dx; }
-    const size_t lds_bytes = (size_t)off * sizeof(float);
+    const size_t lds_bytes = (size_t)D.lds_floats * sizeof(float);
     if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
     const bool pwl = gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
     const int grid = pl.grid;
+    // compile-time shapes: the residual message GCPs of BASELINE configs[1] (fused, 4 waves) and configs[4] (8 waves)
+    if (pwl && !getenv("GCPNET_WG_BWD_NOSHAPE")) {
+        if (pl.fused && NW == 4 && wg_bwd_is_shape<1, 4, 5>(p, w, gated)) return launch_bwd<4, 1, 5, 1>(p, pwl, grid, lds_bytes, st);
+        if (!pl.fused && NW == 8 && pl.kt == 1 && wg_bwd_is_shape<2, 8, 0>(p, w, gated))
+            return launch_bwd<8, 1, 0, 2>(p, pwl, grid, lds_bytes, st);
+    }
     if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);
     if (NW == 4) return pl.kt == 1 ? launch_bwd<4, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<4, 4, 0>(p, pwl, grid, lds_bytes, st);
     return pl.kt == 1 ? launch_bwd<8, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 4, 0>(p, pwl, grid, lds_bytes, st);
