@@ -52,28 +52,43 @@ struct WgFwdParams {
 
 
 template <int NW, int MT, bool PWL>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32, U = 4 / MT;
+    // Parameters are read through the kernarg segment pointer, laundered at the phase boundaries: the uniform values are
+    // re-loaded (s_load) by the phase that uses them instead of living in SGPRs across the whole block loop (where ~90 of them
+    // were spilled into VGPR lanes).  The generic view of the pointer is inferred back to the constant address space.
+    typedef const __attribute__((address_space(4))) WgFwdParams* Karg;
+    Karg kp = (Karg)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*(const WgFwdParams*)kp)
     int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63, e = lane & 31, hi = lane >> 5;
-    // per-lane addresses are invariant over the block loop: hipcc hoists them out of it and spills them; laundering the lane
-    // indices at the phase boundaries makes every phase recompute the few it needs
-#define WG_LAUNDER() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub))
     const int r0 = blockIdx.x * 32;
-    const int rows = p.rows;
-    const int nvalid = min(32, rows - r0);
     int prow = tid / TPR, psub = tid - prow * TPR;  // (row, sub-index) of the VALU phases
-    float* X = lds + p.o_x;
-    float* V = lds + p.o_v;
-    float* VH = lds + p.o_vh;
-    float* FR = lds + p.o_fr;
-    float* ST = lds + p.o_st + w * p.st_floats;  // wave-private staging tile; waves 0..3: also their gate-partial slot (later)
-    const int KS = p.KS, VS = p.VS, HS = p.HS, GS = p.GS;
-    const int so = p.so, vo = p.vo, nf = p.nf, NT = p.NT;
-    const bool scalar_gate = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;
-    const float slope = p.slope;
+    int rows, nvalid, KS, VS, HS, GS, so, vo, nf, NT;
+    float *X, *V, *VH, *FR, *ST;
+    bool scalar_gate;
+    float slope;
+#define WG_RELOAD()                                                                                                      \
+    do {                                                                                                                 \
+        rows = p.rows;                                                                                                   \
+        nvalid = min(32, rows - r0);                                                                                     \
+        X = lds + p.o_x; V = lds + p.o_v; VH = lds + p.o_vh; FR = lds + p.o_fr;                                          \
+        ST = lds + p.o_st + w * p.st_floats; /* wave-private staging tile; waves 0..3: also their gate-partial slot */   \
+        KS = p.KS; VS = p.VS; HS = p.HS; GS = p.GS;                                                                      \
+        so = p.so; vo = p.vo; nf = p.nf; NT = p.NT;                                                                      \
+        scalar_gate = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;                                                        \
+        slope = p.slope;                                                                                                 \
+    } while (0)
+    // per-lane addresses are invariant over the block loop as well: hipcc hoists them out of it and spills them; laundering
+    // the lane indices at the phase boundaries makes every phase recompute the few it needs
+#define WG_LAUNDER()                                                                                                     \
+    do {                                                                                                                 \
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub), "+s"(kp));                    \
+        WG_RELOAD();                                                                                                     \
+    } while (0)
+    WG_RELOAD();
 
     // small weights of block b -> LDS buffer b & 1: [vector_down ; vector_down_frames] rows (stride wg_stride(vi)), vector_up rows
     // (stride wg_stride(H): 16-byte reads), gate bias, scalar_out bias.  Split in a request (global loads into registers, issued before a block's GEMM) and a commit
@@ -178,20 +193,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
 
     auto run_block = [&](auto first_tag, const int b) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        const WgBlk& B = p.blk[b];
+#define B (p.blk[b])
         auto stamp = [&](int k) {
             if (b == p.n - 1 && w == 0) gcp_stamp(p.stamps, p.stamp_cap, k, lane);
         };
         stamp(0);
-        const float* ws = lds + p.o_ws + (b & 1) * p.ws_floats;
-        const int H = B.H, vi = B.vi, si = B.si, HF = H + (nf ? 3 : 0), WSV = wg_stride(vi), WSU = wg_stride(H);
-        const float* wu = ws + HF * WSV;
-        const float* bg = wu + vo * WSU;
-        const float* bs = ws + gcp_round_up(HF * WSV + vo * WSU + vo, 4);
-        const int KG = B.KG, K = B.K, KP = 8 * KG;
-        const float ns_s = gcp_neg_slope(B.act_s, slope), ns_v = gcp_neg_slope(B.act_v, slope);
+        const float *ws, *wu, *bg, *bs;
+        int H, vi, si, HF, WSV, WSU, KG, K, KP;
+        float ns_s, ns_v;
+#define RB_LAUNDER()                                                                                                     \
+    do {                                                                                                                 \
+        WG_LAUNDER();                                                                                                    \
+        ws = lds + p.o_ws + (b & 1) * p.ws_floats;                                                                       \
+        H = B.H; vi = B.vi; si = B.si; HF = H + (nf ? 3 : 0); WSV = wg_stride(vi); WSU = wg_stride(H);                   \
+        wu = ws + HF * WSV;                                                                                              \
+        bg = wu + vo * WSU;                                                                                              \
+        bs = ws + gcp_round_up(HF * WSV + vo * WSU + vo, 4);                                                             \
+        KG = B.KG; K = B.K; KP = 8 * KG;                                                                                 \
+        ns_s = gcp_neg_slope(B.act_s, slope); ns_v = gcp_neg_slope(B.act_v, slope);                                      \
+    } while (0)
 
-        WG_LAUNDER();
+        RB_LAUNDER();
         // ---- prologue ----------------------------------------------------------------------------------------------------
         {
             const float* vrow = V + prow * VS;
@@ -255,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         stamp(2);
         if (b + 1 < p.n) ws_request(b + 1);
 
-        WG_LAUNDER();
+        RB_LAUNDER();
         // ---- scalar_out (+ gate partial) per output group ---------------------------------------------------------------
         f32x16 ynew[MT];  // the wave's slice of the block output (accumulator layout); the chain state when NG == 1
         f32x16 gacc;      // this wave's partial gate pre-activations (its columns of the reduction over so)
@@ -325,7 +347,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
             }
             stamp(3);
-            WG_LAUNDER();
+            // (lane indices only: inside the group loop the kernarg pointer must stay provably uniform)
+            asm volatile("" : "+v"(tid), "+v"(lane), "+v"(e), "+v"(hi), "+v"(prow), "+v"(psub));
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
             }
         }
         stamp(4);
-        WG_LAUNDER();
+        RB_LAUNDER();
         if (scalar_gate) {
             // partial gate pre-activations -> GP[w & 3][32][vo]; with eight waves the upper four add theirs in a second step
             // (half the LDS: the partials of a (256+, 32+) block would not fit otherwise)
@@ -473,7 +496,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 }
             }
         }
-        WG_LAUNDER();
+        RB_LAUNDER();
         // ---- epilogue -----------------------------------------------------------------------------------------------------
         if (vo > 0) {
 #pragma unroll 1
@@ -528,6 +551,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     run_block(std::true_type{}, 0);
     for (int b = 1; b < p.n; ++b) run_block(std::false_type{}, b);
 }
+#undef B
+#undef p
+#undef RB_LAUNDER
+#undef WG_RELOAD
+#undef WG_LAUNDER
 
 // The scalar_out weight as the pack kernel reads it: logical W'[r][c], r < so, c < K, is W[r * ld + col(c)] (or, transposed,
 // W[col(c) * ld + r]) with col(c) running through up to three column ranges of the stored matrix -- so that column slices of a
