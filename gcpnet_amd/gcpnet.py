@@ -265,6 +265,168 @@ class GCP3(GCP2):
         return out
 
 
+class GCP(nn.Module):
+    """The original geometry-complete perceptron (:30-249): a GVP-like stage -- `scalar_out` over [s | |vector_down v|], gated
+    `vector_up` (:204-224, process_vector :103-119) -- followed by the frame stage -- `vector_down_frames` of the NEW vectors,
+    scalarize, `scalar_out_frames`, process_vector_frames (:129-161, :226-249).  Both stages run on the GCP2 kernels:
+
+      * stage 1 is a GCP2 block without frame scalars (`use_frames=False`);
+      * stage 2 is a GCP2 block on (s1, v1) whose merged input is [s1 | one norm column | 9 frame scalars]: a single hidden channel
+        with zero `vector_down` / `vector_up` weights (its norm column gets a zero weight column), `vector_residual` on, so that
+        the "vector_up" result is v1 itself, which the kernel epilogue then gates (sigma gate = scalar-gate mode with
+        `vector_out_scale_sigma_frames`; self gate; none).  `frame_gate` uses the frame-gate kernels behind an un-gated stage 2.
+
+    Parameters are created in the reference's order (same state_dict keys, same seeded initial weights)."""
+
+    feedforward_out = False
+
+    def __init__(self, input_dims, output_dims, nonlinearities: Tuple[Optional[str]] = ("relu", "sigmoid"), scalar_gate: int = 0,
+                 vector_gate: bool = True, frame_gate: bool = False, sigma_frame_gate: bool = False, bottleneck: int = 1,
+                 vector_residual: bool = False, vector_frame_residual: bool = False, ablate_frame_updates: bool = False,
+                 ablate_scalars: bool = False, ablate_vectors: bool = False, enable_e3_equivariance: bool = False,
+                 scalarization_vectorization_output_dim: int = 3, **kwargs):
+        super().__init__()
+        if nonlinearities is None:
+            nonlinearities = (None, None)
+        self.scalar_input_dim, self.vector_input_dim = input_dims
+        self.scalar_output_dim, self.vector_output_dim = output_dims
+        self.act_s, self.act_v = canonical_act(nonlinearities[0]), canonical_act(nonlinearities[1])
+        self.scalar_gate, self.vector_gate, self.frame_gate, self.sigma_frame_gate = (
+            scalar_gate, vector_gate, frame_gate, sigma_frame_gate)
+        self.vector_residual, self.vector_frame_residual = vector_residual, vector_frame_residual
+        self.ablate_frame_updates = ablate_frame_updates
+        self.ablate_scalars, self.ablate_vectors = ablate_scalars, ablate_vectors
+        self.enable_e3_equivariance = enable_e3_equivariance
+        self.slope = 1e-2
+        if scalarization_vectorization_output_dim != 3:
+            _unsupported("scalarization_vectorization_output_dim != 3")
+        if self.scalar_gate > 0:  # created, never used by GCP.forward (:69-70)
+            self.norm = nn.LayerNorm(self.scalar_output_dim)
+        self.hidden_dim = 0
+        so, vi, vo = self.scalar_output_dim, self.vector_input_dim, self.vector_output_dim
+        if vi:
+            assert vi % bottleneck == 0, f"Input channel of vector ({vi}) must be divisible with bottleneck factor ({bottleneck})"
+            self.hidden_dim = vi // bottleneck if bottleneck > 1 else max(vi, vo)
+            self.vector_down = nn.Linear(vi, self.hidden_dim, bias=False)
+            self.scalar_out = nn.Linear(self.hidden_dim + self.scalar_input_dim, so)
+            if vo:
+                self.vector_up = nn.Linear(self.hidden_dim, vo, bias=False)
+                if self.vector_gate:
+                    self.vector_out_scale = nn.Linear(so, vo)
+            if not ablate_frame_updates:
+                self.vector_down_frames = nn.Linear(self.hidden_dim if not vo else vo, 3, bias=False)
+                self.scalar_out_frames = nn.Linear(so + 9, so)
+                if vo and self.sigma_frame_gate:
+                    self.vector_out_scale_sigma_frames = nn.Linear(so, vo)
+                elif vo and self.frame_gate:
+                    self.vector_out_scale_frames = nn.Linear(so, 9)
+                    self.vector_up_frames = nn.Linear(3, vo, bias=False)
+        else:
+            self.scalar_out = nn.Linear(self.scalar_input_dim, so)
+        self._pack_cache: dict = {}
+
+    def _vmode(self) -> int:  # (of stage 1)
+        if not (self.vector_input_dim and self.vector_output_dim):
+            return VMODE_NONE
+        if self.vector_gate:
+            return VMODE_SCALAR_GATE
+        return VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
+
+    def apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool = False):
+        """Same contract as GCP2.apply_rows."""
+        if not self.vector_input_dim:
+            if not self.ablate_frame_updates:  # (the reference's forward reads vector_down_frames, which does not exist then)
+                raise AttributeError("GCP without vector input has no vector_down_frames: only ablate_frame_updates=True runs "
+                                     "(reference gcpnet.py:93-94, 229)")
+            assert len(s_sources) == 1 and s_plans[0] is None
+            x = torch.zeros_like(s_sources[0]) if self.ablate_scalars else s_sources[0]
+            s_out = ops.activation(ops.linear(x, self.scalar_out.weight, self.scalar_out.bias), self.act_s, self.slope)
+            if not self.vector_output_dim:
+                return s_out
+            return s_out, s_out.new_zeros(s_out.shape[0], self.vector_output_dim, 3)
+        if self.ablate_scalars:
+            s_sources = [torch.zeros_like(t) for t in s_sources]
+        if self.ablate_vectors:
+            v_sources = [torch.zeros_like(t) for t in v_sources]
+        vo, so = self.vector_output_dim, self.scalar_output_dim
+        gate = getattr(self, "vector_out_scale", None)
+        spec1 = Gcp2Spec(si=self.scalar_input_dim, vi=self.vector_input_dim, so=so, vo=vo, hidden=self.hidden_dim,
+                         use_frames=False, act_s=self.act_s, act_v=self.act_v, slope=self.slope, vmode=self._vmode(),
+                         vector_residual=bool(self.vector_residual) and bool(vo), e3=False, s_plans=list(s_plans),
+                         v_plans=list(v_plans), residual=False, pack_cache=self._pack_cache)
+        out1 = ops.gcp2(spec1, s_sources, v_sources, None,
+                        (self.scalar_out.weight, self.scalar_out.bias, self.vector_down.weight, None,
+                         self.vector_up.weight if vo else None,
+                         None if gate is None or not vo else gate.weight, None if gate is None or not vo else gate.bias))
+        if self.ablate_frame_updates:
+            out = out1
+        else:
+            s1, v1 = (out1 if vo else (out1, None))
+            v_src, v_pl = ([v1], [None]) if vo else (list(v_sources), list(v_plans))
+            vi2 = vo if vo else self.vector_input_dim
+            wf = self.scalar_out_frames.weight
+            w2 = torch.cat((wf[:, :so], wf.new_zeros(so, 1), wf[:, so:]), dim=1)  # [s1 | the unused norm column | frame scalars]
+            w_down = wf.new_zeros(1, vi2)
+            sigma = vo and self.sigma_frame_gate
+            fgate = vo and self.frame_gate and not sigma
+            if not vo or fgate:
+                vmode2 = VMODE_NONE
+            elif sigma:
+                vmode2 = VMODE_SCALAR_GATE
+            else:
+                vmode2 = VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
+            spec2 = Gcp2Spec(si=so, vi=vi2, so=so, vo=vo, hidden=1, use_frames=True, act_s=None if fgate else self.act_s,
+                             act_v=self.act_v, slope=self.slope, vmode=vmode2, vector_residual=bool(vo),
+                             e3=bool(self.enable_e3_equivariance), s_plans=[None], v_plans=v_pl, residual=False,
+                             pack_cache=None, shared_weights=True)
+            sg = self.vector_out_scale_sigma_frames if sigma else None
+            out = ops.gcp2(spec2, [s1], v_src, row_frames,
+                           (w2, self.scalar_out_frames.bias, w_down, self.vector_down_frames.weight,
+                            wf.new_zeros(vo, 1) if vo else None, None if sg is None else sg.weight,
+                            None if sg is None else sg.bias))
+            if fgate:  # :139-155
+                s_pre2, v_pass = out
+                lin = self.vector_out_scale_frames
+                w12 = torch.nn.functional.pad(lin.weight, (0, 0, 0, 3))
+                b12 = torch.nn.functional.pad(lin.bias, (0, 3))
+                g = ops.linear(ops.activation(s_pre2, self.act_v, self.slope), w12, b12)
+                v_out = ops.frame_gate(g, row_frames, self.vector_up_frames.weight, v_pass, self.act_v, self.slope)
+                if self.vector_frame_residual:
+                    v_out = ops.axpy(v_pass, v_out, 1.0)
+                out = (ops.activation(s_pre2, self.act_s, self.slope), v_out)
+            if isinstance(out, tuple):  # :246-248 (the early exits above return un-ablated outputs, as the reference does)
+                s_o, v_o = out
+                out = (torch.zeros_like(s_o) if self.ablate_scalars else s_o, torch.zeros_like(v_o) if self.ablate_vectors else v_o)
+            elif self.ablate_scalars:  # :243-245: the nonlinearity of a zeroed pre-activation
+                out = torch.full_like(out, 0.5) if self.act_s == "sigmoid" else torch.zeros_like(out)
+        if residual:
+            if isinstance(out, tuple):
+                return ops.axpy(s_sources[0], out[0], 1.0), ops.axpy(v_sources[0], out[1], 1.0)
+            return ops.axpy(s_sources[0], out, 1.0)
+        return out
+
+    def forward(self, s_maybe_v, edge_index, frames, node_inputs: bool = False, node_mask=None):
+        """:163-249.  Returns ScalarVector, or a Tensor when the block has no vector output."""
+        if node_mask is not None:
+            _unsupported("GCP.forward(node_mask=...)")
+        if self.vector_input_dim:
+            s, v = s_maybe_v
+            row_frames = None
+            if not self.ablate_frame_updates:
+                if node_inputs:
+                    if self.enable_e3_equivariance:
+                        _unsupported("enable_e3_equivariance with node_inputs=True")
+                    row_frames = GraphPlan.get(edge_index, s.shape[0]).node_frames(frames)
+                else:
+                    row_frames = frames
+            out = self.apply_rows([s], [None], [v], [None], row_frames)
+        else:
+            out = self.apply_rows([s_maybe_v], [None], [], [], None)
+        if not self.vector_output_dim:
+            return out
+        return ScalarVector(*out)
+
+
 def get_GCP_with_custom_cfg(input_dims, output_dims, cfg, **kwargs):
     """:826-835 -- the whole module_cfg is forwarded; unknown keys are swallowed by GCP2's **kwargs."""
     cfg_dict = copy(to_container(cfg))
@@ -396,6 +558,8 @@ class GCPMessagePassing(nn.Module):
 
     def _chainable(self, mods) -> bool:
         if not self.use_residual_message_gcp or len(mods) > 8 or any(getattr(m, "feedforward_out", False) for m in mods):
+            return False
+        if any(isinstance(m, GCP) for m in mods):  # (the original two-stage block: two launches per block)
             return False
         a = mods[0]
         if a.scalar_output_dim > (512 if ops.USE_WG_KERNELS else 128) or not a.vector_input_dim or not a.vector_output_dim or a.vector_output_dim > 64:

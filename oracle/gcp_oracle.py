@@ -226,6 +226,89 @@ def gcp2(
     return s_out, v_out
 
 
+# ----------------------------------------------------------------------------------------------------------
+# GCP (the original block) -- components/gcpnet.py:30-249
+# ----------------------------------------------------------------------------------------------------------
+def gcp(
+    P: Params,
+    pre: str,
+    s: Tensor,
+    v: Optional[Tensor],
+    edge_index: Tensor,
+    frames: Tensor,
+    node_inputs: bool = False,
+    nonlinearities: Sequence[Optional[str]] = ("relu", "sigmoid"),
+    vector_gate: bool = True,
+    frame_gate: bool = False,
+    sigma_frame_gate: bool = False,
+    vector_residual: bool = False,
+    vector_frame_residual: bool = False,
+    ablate_frame_updates: bool = False,
+    ablate_scalars: bool = False,
+    ablate_vectors: bool = False,
+    enable_e3_equivariance: bool = False,
+    slope: float = 1e-2,
+):
+    """The original two-stage perceptron: a GVP-like stage (scalar_out over [s | |vector_down v|], gated vector_up,
+    gcpnet.py:204-224 + process_vector :103-119) followed by the frame stage (vector_down_frames -> scalarize -> scalar_out_frames,
+    process_vector_frames :129-161; gcpnet.py:226-249).  Only blocks with vector input (the reference's forward needs
+    `vector_down_frames`, which exists only then)."""
+    if nonlinearities is None:
+        nonlinearities = (None, None)
+    act_s, act_v = nonlinearities
+    has_vout = (pre + "vector_up.weight") in P
+    if ablate_scalars:
+        s = torch.zeros_like(s)
+    if ablate_vectors:
+        v = torch.zeros_like(v)
+    vh = torch.einsum("rcd,hc->rdh", v, P[pre + "vector_down.weight"])  # [rows, xyz, H]            :208-209
+    merged = torch.cat((s, safe_norm(vh, dim=-2)), dim=-1)
+    s_pre = merged @ P[pre + "scalar_out.weight"].t() + P[pre + "scalar_out.bias"]  # :215
+    v_cur = v
+    if has_vout:  # process_vector :103-119
+        vu = torch.einsum("rdh,oh->rdo", vh, P[pre + "vector_up.weight"])
+        if vector_residual:
+            vu = vu + v.transpose(-1, -2)
+        v_cur = vu.transpose(-1, -2)
+        if vector_gate:
+            g = nonlinearity(act_v, s_pre, slope) @ P[pre + "vector_out_scale.weight"].t() + P[pre + "vector_out_scale.bias"]
+            v_cur = v_cur * torch.sigmoid(g).unsqueeze(-1)
+        elif act_v is not None:
+            v_cur = v_cur * nonlinearity(act_v, safe_norm(v_cur, dim=-1, keepdim=True), slope)
+    s_cur = nonlinearity(act_s, s_pre, slope)  # :220
+    if ablate_frame_updates:  # :225-226 (no output ablation on this exit)
+        return (s_cur, v_cur) if has_vout else s_cur
+    # frame stage :228-249
+    vf = torch.einsum("rcd,kc->rkd", v_cur, P[pre + "vector_down_frames.weight"])  # [rows, 3 ch, xyz]
+    sh = scalarize(vf, edge_index, frames, node_inputs, enable_e3_equivariance, vf.shape[0])
+    s_pre2 = torch.cat((s_cur, sh), dim=-1) @ P[pre + "scalar_out_frames.weight"].t() + P[pre + "scalar_out_frames.bias"]
+    if not has_vout:  # :243-246
+        if ablate_scalars:
+            s_pre2 = torch.zeros_like(s_pre2)
+        return nonlinearity(act_s, s_pre2, slope)
+    v_out = v_cur  # process_vector_frames :129-161
+    if sigma_frame_gate:
+        g = nonlinearity(act_v, s_pre2, slope) @ P[pre + "vector_out_scale_sigma_frames.weight"].t() \
+            + P[pre + "vector_out_scale_sigma_frames.bias"]
+        v_out = v_out * torch.sigmoid(g).unsqueeze(-1)
+    elif frame_gate:
+        g = nonlinearity(act_v, s_pre2, slope) @ P[pre + "vector_out_scale_frames.weight"].t() \
+            + P[pre + "vector_out_scale_frames.bias"]
+        gv = vectorize(g, edge_index, frames, node_inputs, s_pre2.shape[0])
+        gvr = torch.einsum("rkd,ok->rod", gv, P[pre + "vector_up_frames.weight"])
+        v_out = v_out * nonlinearity(act_v, safe_norm(gvr, dim=-1, keepdim=True), slope)
+        if vector_frame_residual:
+            v_out = v_out + v_cur
+    elif act_v is not None:
+        v_out = v_out * nonlinearity(act_v, safe_norm(v_out, dim=-1, keepdim=True), slope)
+    s_out = nonlinearity(act_s, s_pre2, slope)
+    if ablate_scalars:
+        s_out = torch.zeros_like(s_out)
+    if ablate_vectors:
+        v_out = torch.zeros_like(v_out)
+    return s_out, v_out
+
+
 def _gcp_kwargs(cfg: Mapping, **over) -> Dict:
     """What get_GCP_with_custom_cfg (gcpnet.py:826-835) forwards that GCP2 actually reads."""
     kw = dict(

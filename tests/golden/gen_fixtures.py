@@ -134,6 +134,21 @@ def fx_gcp2():
              scalar_out_nonlinearity="relu")
 
 
+def fx_gcp_original():
+    """The original `GCP` block (gcpnet.py:30-249): GVP-like stage + frame stage."""
+    run_gcp2("gcp_edge_default", (40, 8), (24, 8), False, 60, cls="GCP", bottleneck=4)
+    run_gcp2("gcp_node_default", (24, 8), (40, 12), True, 61, cls="GCP", bottleneck=2, nonlinearities=("silu", "sigmoid"))
+    run_gcp2("gcp_sigma_gate", (24, 8), (16, 8), False, 62, cls="GCP", nonlinearities=("relu", "sigmoid"), sigma_frame_gate=True,
+             vector_residual=True)
+    run_gcp2("gcp_frame_gate", (24, 8), (16, 4), True, 63, cls="GCP", nonlinearities=("silu", "silu"), bottleneck=2,
+             frame_gate=True, vector_frame_residual=True)
+    run_gcp2("gcp_selfgate_e3", (24, 8), (20, 6), False, 64, cls="GCP", nonlinearities=("silu", "sigmoid"), vector_gate=False,
+             enable_e3_equivariance=True)
+    run_gcp2("gcp_scalar_out", (32, 8), (16, 0), True, 65, cls="GCP", nonlinearities=("relu", None))
+    run_gcp2("gcp_ablate_frames", (24, 8), (16, 4), False, 66, cls="GCP", nonlinearities=("relu", None), bottleneck=4,
+             ablate_frame_updates=True)
+
+
 def fx_layernorm():
     torch.manual_seed(30)
     ln = comp.GCPLayerNorm(SV(64, 16))
@@ -398,8 +413,13 @@ def fx_input_side():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:  # only the named groups, e.g. `gen_fixtures.py fx_gcp_original`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     fx_geometry()
     fx_gcp2()
+    fx_gcp_original()
     fx_layernorm()
     fx_embedding()
     fx_interactions()

@@ -147,6 +147,39 @@ def test_gcp2_golden(G, name):
             close(p.grad.cpu(), f.g["w." + k], **GRAD)
 
 
+GCP_CASES = {  # the original GCP block (reference gcpnet.py:30-249), fixtures from the reference
+    "gcp_edge_default": dict(bottleneck=4),
+    "gcp_node_default": dict(bottleneck=2, nonlinearities=("silu", "sigmoid")),
+    "gcp_sigma_gate": dict(nonlinearities=("relu", "sigmoid"), sigma_frame_gate=True, vector_residual=True),
+    "gcp_frame_gate": dict(nonlinearities=("silu", "silu"), bottleneck=2, frame_gate=True, vector_frame_residual=True),
+    "gcp_selfgate_e3": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False, enable_e3_equivariance=True),
+    "gcp_scalar_out": dict(nonlinearities=("relu", None)),
+    "gcp_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GCP_CASES))
+def test_gcp_original_golden(G, name):
+    f = Fixture(name)
+    mod = G.GCP(tuple(int(d) for d in f.m["in_dims"]), tuple(int(d) for d in f.m["out_dims"]), **GCP_CASES[name]).cuda()
+    mod.load_state_dict(f.p)
+    s, v = f.i["s"].cuda().requires_grad_(), f.i["v"].cuda().requires_grad_()
+    out = mod((s, v), f.i["edge_index"].cuda(), f.i["frames"].cuda(), node_inputs=bool(f.m["node_inputs"]))
+    outs = dict(s=out[0], v=out[1]) if isinstance(out, tuple) else dict(s=out)
+    for k, t in outs.items():
+        close(t.detach().cpu(), f.o[k], **FWD)
+    sq_loss(*outs.values()).backward()
+    close(s.grad.cpu(), f.g["s"], **GRAD)
+    close(v.grad.cpu(), f.g["v"], **GRAD)
+    n = 0
+    for k, p in mod.named_parameters():
+        if "w." + k in f.g:
+            assert p.grad is not None, k
+            close(p.grad.cpu(), f.g["w." + k], **GRAD)
+            n += 1
+    assert n >= 4
+
+
 def test_gcp2_e3_edge_vs_oracle(G):
     """enable_e3_equivariance on edge rows + vector_residual + leakyrelu, against the oracle."""
     torch.manual_seed(3)

@@ -64,6 +64,26 @@ def test_gcp3_feedforward_state_dict_names_match_reference():
     mod.load_state_dict(f.p)
 
 
+@pytest.mark.parametrize("name,seed,kw", [
+    ("gcp_edge_default", 60, dict(bottleneck=4)),
+    ("gcp_sigma_gate", 62, dict(nonlinearities=("relu", "sigmoid"), sigma_frame_gate=True, vector_residual=True)),
+    ("gcp_frame_gate", 63, dict(nonlinearities=("silu", "silu"), bottleneck=2, frame_gate=True, vector_frame_residual=True)),
+    ("gcp_scalar_out", 65, dict(nonlinearities=("relu", None))),
+    ("gcp_ablate_frames", 66, dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True)),
+])
+def test_original_gcp_state_dict_and_seeded_init_match_reference(name, seed, kw):
+    """The original GCP block (reference gcpnet.py:30-101): same keys in the same order, and -- parameters being created in
+    the reference's order -- the same seed gives the reference's initial weights bit for bit."""
+    import torch
+    f = Fixture(name)
+    torch.manual_seed(seed)
+    mod = G.GCP(tuple(int(d) for d in f.m["in_dims"]), tuple(int(d) for d in f.m["out_dims"]), **kw)
+    sd = mod.state_dict()
+    assert list(sd) == list(f.p)
+    for k in sd:
+        assert torch.equal(sd[k], f.p[k]), k
+
+
 def test_interactions2_state_dict_names_match_reference():
     import functools
     for name, kw, upd in (("interactions2_eq", dict(use_scalar_message_attention=True, aggregate_with_row=True,

@@ -80,6 +80,37 @@ def test_gcp2(name):
             assert g is None or float(g.abs().max()) == 0.0
 
 
+GCP_CASES = {  # the original GCP block (gcpnet.py:30-249)
+    "gcp_edge_default": dict(),
+    "gcp_node_default": dict(nonlinearities=("silu", "sigmoid")),
+    "gcp_sigma_gate": dict(nonlinearities=("relu", "sigmoid"), sigma_frame_gate=True, vector_residual=True),
+    "gcp_frame_gate": dict(nonlinearities=("silu", "silu"), frame_gate=True, vector_frame_residual=True),
+    "gcp_selfgate_e3": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False, enable_e3_equivariance=True),
+    "gcp_scalar_out": dict(nonlinearities=("relu", None)),
+    "gcp_ablate_frames": dict(nonlinearities=("relu", None), ablate_frame_updates=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GCP_CASES))
+def test_gcp_original(name):
+    f = Fixture(name)
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    s = f.i["s"].clone().requires_grad_()
+    v = f.i["v"].clone().requires_grad_()
+    out = O.gcp(P, "", s, v, f.i["edge_index"], f.i["frames"], node_inputs=bool(f.m["node_inputs"]), **GCP_CASES[name])
+    outs = dict(s=out[0], v=out[1]) if isinstance(out, tuple) else dict(s=out)
+    for k in outs:
+        close(outs[k], f.o[k], **TOL)
+    loss = sq_loss(*outs.values())
+    names = ["s", "v"] + ["w." + k for k in P]
+    tens = [s, v] + list(P.values())
+    for n, g in zip(names, _grads(loss, tens)):
+        if n in f.g:
+            close(g, f.g[n], atol=2e-6, rtol=1e-4)
+        else:
+            assert g is None or float(g.abs().max()) == 0.0
+
+
 def test_layernorm():
     f = Fixture("layernorm")
     so, vo = O.gcp_layer_norm(f.p, "", f.i["s"], f.i["v"])
