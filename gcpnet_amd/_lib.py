@@ -24,7 +24,7 @@ EXPORTS = [
     "gcpnet_debug_set_phase_timing",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
     "gcpnet_wg_reduce", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
-    "gcpnet_frame_gate_bwd_parts",
+    "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize",
 ]
 
 
@@ -176,6 +176,7 @@ def load():
     lib.gcpnet_frame_gate_forward.argtypes = [i64, i32, vp, i32, vp, vp, vp, i32, f32, vp, vp]
     lib.gcpnet_frame_gate_backward.argtypes = [i64, i32, vp, i32, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp]
     lib.gcpnet_frame_gate_bwd_parts.argtypes = [i64]
+    lib.gcpnet_node_scalarize.argtypes = [i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.gcpnet_radius_graph.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -253,6 +253,52 @@ __global__ void axpy_clamp_kernel(int64_t n, const float* __restrict__ a, const 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- scalarize on node rows with the E(3) variant (components/__init__.py:283-321 with node_inputs and enable_e3_equivariance):
+// out[n, 3 k + a] = mean over the out-edges e of node n of f(frames[e, a, :] . vf[n, :, k]), f = |.| for a == 1 (the x_cross axis).
+// The |.| makes this the one scalarize case that is not linear in the frame, i.e. not expressible through the mean out-edge frame
+// the GCP kernels use for node rows.  vf: [N, 3 (xyz), ldk] (channel k < 3 innermost).  One thread per (node, channel); the
+// backward (frames are constants of the step) recomputes the signs.
+__global__ __launch_bounds__(256) void node_scalarize_kernel(int n_nodes, const int32_t* __restrict__ seg_ptr,
+                                                             const int32_t* __restrict__ perm, const float* __restrict__ vf, int ldk,
+                                                             const float* __restrict__ frames, int e3, float* __restrict__ out,
+                                                             const float* __restrict__ d_out, float* __restrict__ d_vf) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int n = t / 3, k = t - 3 * n;
+    if (n >= n_nodes) return;
+    const int beg = seg_ptr[n], end = seg_ptr[n + 1];
+    const float inv = 1.0f / (float)max(end - beg, 1);
+    const float v0 = vf[((int64_t)n * 3 + 0) * ldk + k], v1 = vf[((int64_t)n * 3 + 1) * ldk + k], v2 = vf[((int64_t)n * 3 + 2) * ldk + k];
+    float acc[3] = {0.f, 0.f, 0.f};
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float dq[3] = {0.f, 0.f, 0.f};
+    if (d_out) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dq[a] = d_out[(int64_t)n * 9 + 3 * k + a] * inv;
+    }
+    for (int p = beg; p < end; ++p) {
+        const float* f = frames + (int64_t)(perm ? perm[p] : p) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float f0 = f[3 * a], f1 = f[3 * a + 1], f2 = f[3 * a + 2];
+            float pr = f0 * v0 + f1 * v1 + f2 * v2;
+            float sg = 1.f;
+            if (e3 && a == 1) {
+                sg = pr < 0.f ? -1.f : 1.f;
+                pr = fabsf(pr);
+            }
+            acc[a] += pr;
+            const float c = dq[a] * sg;
+            g0 = fmaf(c, f0, g0); g1 = fmaf(c, f1, g1); g2 = fmaf(c, f2, g2);
+        }
+    }
+    if (d_out) {
+        d_vf[((int64_t)n * 3 + 0) * ldk + k] = g0; d_vf[((int64_t)n * 3 + 1) * ldk + k] = g1; d_vf[((int64_t)n * 3 + 2) * ldk + k] = g2;
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) out[(int64_t)n * 9 + 3 * k + a] = acc[a] * inv;
+    }
+}
+
 }  // namespace
 
 extern "C" int gcpnet_segment_reduce(int n_seg, const int32_t* seg_ptr, const int32_t* perm, const float* x, int64_t ldx,
@@ -267,6 +313,17 @@ extern "C" int gcpnet_segment_reduce(int n_seg, const int32_t* seg_ptr, const in
     else
         hipLaunchKernelGGL(segment_reduce_kernel<false>, grid, block, 0, (hipStream_t)stream, n_seg, seg_ptr, perm, x,
                            ldx, D, mean, out, ldo, accumulate);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_node_scalarize(int n_nodes, const int32_t* seg_ptr, const int32_t* perm, const float* vf, int ldk,
+                                     const float* frames, int e3, float* out, const float* d_out, float* d_vf, void* stream) {
+    if (n_nodes < 0 || !seg_ptr || !vf || !frames || ldk < 3) return GCPNET_E_BADARG;
+    if ((d_out != nullptr) != (d_vf != nullptr) || (!d_out && !out)) return GCPNET_E_BADARG;
+    if (n_nodes == 0) return 0;
+    hipLaunchKernelGGL(node_scalarize_kernel, dim3((unsigned)gcp_cdiv(3 * n_nodes, 256)), dim3(256), 0, (hipStream_t)stream, n_nodes,
+                       seg_ptr, perm, vf, ldk, frames, e3, out, d_out, d_vf);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

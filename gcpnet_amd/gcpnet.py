@@ -32,6 +32,18 @@ def _unsupported(what: str):
     raise NotImplementedError(f"{what} is not on the MI355X path yet (SURVEY.md section 8, rows f2/f3)")
 
 
+def _node_e3_frame_scalars(v: torch.Tensor, w_frames: torch.Tensor, edge_index, frames) -> torch.Tensor:
+    """scalarize(vector_down_frames(v), node_inputs=True, enable_e3_equivariance=True) (components/__init__.py:283-321) -> [N, 9].
+    The |.| on the x_cross projections is taken per out-edge BEFORE the mean, so the mean out-edge frame of the node-row kernels
+    does not apply: the three frame channels per node come from the Linear kernel, the per-edge projections / |.| / mean from
+    gcpnet_node_scalarize."""
+    n, vi = v.shape[0], v.shape[1]
+    x2 = v.transpose(1, 2).reshape(n * 3, vi)
+    w4 = torch.nn.functional.pad(w_frames, (0, 0, 0, 1))  # 3 -> 4 output channels (16-byte rows)
+    vf = ops.linear(x2, w4, w_frames.new_zeros(4)).view(n, 3, 4)
+    return ops.node_scalarize(vf, frames, GraphPlan.get(edge_index, n).row, e3=True)
+
+
 class GCP2(nn.Module):
     """Geometry-complete perceptron, :252-468.  Parameters are created in the reference's order so that the same
     seed yields the same initial weights."""
@@ -193,7 +205,8 @@ class GCP2(nn.Module):
             if not self.ablate_frame_updates:
                 if node_inputs:
                     if self.enable_e3_equivariance:
-                        _unsupported("enable_e3_equivariance with node_inputs=True")
+                        out = self._forward_node_e3(s, v, edge_index, frames)
+                        return out if not self.vector_output_dim else ScalarVector(*out)
                     row_frames = GraphPlan.get(edge_index, s.shape[0]).node_frames(frames)
                 else:
                     row_frames = frames
@@ -203,6 +216,26 @@ class GCP2(nn.Module):
         if not self.vector_output_dim:
             return out
         return ScalarVector(*out)
+
+    def _forward_node_e3(self, s, v, edge_index, frames):
+        """Node rows with `enable_e3_equivariance` (:421-432 -> components/__init__.py:305-309): the nine frame scalars are
+        computed per out-edge (|.| before the mean) by `_node_e3_frame_scalars` and enter the block as a second scalar source; the
+        block itself then runs without frames, with scalar_out's columns reordered to [s | frame scalars | norms]."""
+        if getattr(self, "feedforward_out", False) or (self.frame_gate and self.vector_output_dim):
+            _unsupported("enable_e3_equivariance on node rows together with feedforward_out / frame_gate")
+        if self.ablate_scalars:
+            s = torch.zeros_like(s)
+        if self.ablate_vectors:
+            v = torch.zeros_like(v)
+        fs = _node_e3_frame_scalars(v, self.vector_down_frames.weight, edge_index, frames)
+        si, H = self.scalar_input_dim, self.hidden_dim
+        w = self.scalar_out.weight
+        w_re = torch.cat((w[:, :si], w[:, si + H:], w[:, si:si + H]), dim=1)
+        spec = replace(self.make_spec([None, None], [None]), si=si + 9, use_frames=False, e3=False, pack_cache=None,
+                       shared_weights=True)
+        ws = self._weights()
+        out = ops.gcp2(spec, [s, fs], [v], None, (w_re, ws[1], ws[2], None, ws[4], ws[5], ws[6]))
+        return self._ablate_outputs(out)
 
 
 class GCP3(GCP2):
@@ -332,8 +365,9 @@ class GCP(nn.Module):
             return VMODE_SCALAR_GATE
         return VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
 
-    def apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool = False):
-        """Same contract as GCP2.apply_rows."""
+    def apply_rows(self, s_sources, s_plans, v_sources, v_plans, row_frames, residual: bool = False, node_e3=None):
+        """Same contract as GCP2.apply_rows.  `node_e3` = (edge_index, frames): node rows with enable_e3_equivariance -- the frame
+        scalars of stage 2 then come from `_node_e3_frame_scalars` instead of a per-row frame."""
         if not self.vector_input_dim:
             if not self.ablate_frame_updates:  # (the reference's forward reads vector_down_frames, which does not exist then)
                 raise AttributeError("GCP without vector input has no vector_down_frames: only ablate_frame_updates=True runs "
@@ -375,15 +409,28 @@ class GCP(nn.Module):
                 vmode2 = VMODE_SCALAR_GATE
             else:
                 vmode2 = VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
-            spec2 = Gcp2Spec(si=so, vi=vi2, so=so, vo=vo, hidden=1, use_frames=True, act_s=None if fgate else self.act_s,
-                             act_v=self.act_v, slope=self.slope, vmode=vmode2, vector_residual=bool(vo),
-                             e3=bool(self.enable_e3_equivariance), s_plans=[None], v_plans=v_pl, residual=False,
-                             pack_cache=None, shared_weights=True)
             sg = self.vector_out_scale_sigma_frames if sigma else None
-            out = ops.gcp2(spec2, [s1], v_src, row_frames,
-                           (w2, self.scalar_out_frames.bias, w_down, self.vector_down_frames.weight,
-                            wf.new_zeros(vo, 1) if vo else None, None if sg is None else sg.weight,
-                            None if sg is None else sg.bias))
+            if node_e3 is not None:
+                if fgate:
+                    _unsupported("enable_e3_equivariance on node rows together with frame_gate")
+                assert len(v_src) == 1 and v_pl[0] is None
+                fs = _node_e3_frame_scalars(v_src[0], self.vector_down_frames.weight, *node_e3)
+                spec2 = Gcp2Spec(si=so + 9, vi=vi2, so=so, vo=vo, hidden=1, use_frames=False, act_s=self.act_s, act_v=self.act_v,
+                                 slope=self.slope, vmode=vmode2, vector_residual=bool(vo), e3=False, s_plans=[None, None],
+                                 v_plans=v_pl, residual=False, pack_cache=None, shared_weights=True)
+                out = ops.gcp2(spec2, [s1, fs], v_src, None,
+                               (torch.cat((wf, wf.new_zeros(so, 1)), dim=1), self.scalar_out_frames.bias, w_down, None,
+                                wf.new_zeros(vo, 1) if vo else None, None if sg is None else sg.weight,
+                                None if sg is None else sg.bias))
+            else:
+                spec2 = Gcp2Spec(si=so, vi=vi2, so=so, vo=vo, hidden=1, use_frames=True, act_s=None if fgate else self.act_s,
+                                 act_v=self.act_v, slope=self.slope, vmode=vmode2, vector_residual=bool(vo),
+                                 e3=bool(self.enable_e3_equivariance), s_plans=[None], v_plans=v_pl, residual=False,
+                                 pack_cache=None, shared_weights=True)
+                out = ops.gcp2(spec2, [s1], v_src, row_frames,
+                               (w2, self.scalar_out_frames.bias, w_down, self.vector_down_frames.weight,
+                                wf.new_zeros(vo, 1) if vo else None, None if sg is None else sg.weight,
+                                None if sg is None else sg.bias))
             if fgate:  # :139-155
                 s_pre2, v_pass = out
                 lin = self.vector_out_scale_frames
@@ -413,12 +460,10 @@ class GCP(nn.Module):
             s, v = s_maybe_v
             row_frames = None
             if not self.ablate_frame_updates:
-                if node_inputs:
-                    if self.enable_e3_equivariance:
-                        _unsupported("enable_e3_equivariance with node_inputs=True")
-                    row_frames = GraphPlan.get(edge_index, s.shape[0]).node_frames(frames)
-                else:
-                    row_frames = frames
+                if node_inputs and self.enable_e3_equivariance:
+                    out = self.apply_rows([s], [None], [v], [None], None, node_e3=(edge_index, frames))
+                    return out if not self.vector_output_dim else ScalarVector(*out)
+                row_frames = GraphPlan.get(edge_index, s.shape[0]).node_frames(frames) if node_inputs else frames
             out = self.apply_rows([s], [None], [v], [None], row_frames)
         else:
             out = self.apply_rows([s_maybe_v], [None], [], [], None)

@@ -1535,6 +1535,40 @@ def frame_gate(g: Tensor, frames: Tensor, w_up_frames: Tensor, vu: Tensor, act: 
                             _req(vu, "vector_up output"), act, slope)
 
 
+class _NodeScalarize(torch.autograd.Function):
+    """scalarize(vf, node_inputs=True, enable_e3_equivariance) (components/__init__.py:283-321): per out-edge projection of the
+    node's three frame channels, |.| on the x_cross axis, mean over the out-edges.  vf: [N, 3 (xyz), ldk >= 3]; frames [E, 3, 3]
+    are constants of the step."""
+
+    @staticmethod
+    def forward(ctx, vf, frames, plan: GatherPlan, e3: bool):
+        lib = _lib.load()
+        n, ldk = vf.shape[0], vf.shape[2]
+        out = torch.empty((n, 9), dtype=torch.float32, device=vf.device)
+        check(lib.gcpnet_node_scalarize(n, _p(plan.seg_ptr), _p(plan.perm), _p(vf), ldk, _p(frames), int(e3), _p(out), None, None,
+                                        _stream()), "node_scalarize")
+        ctx.save_for_backward(vf, frames)
+        ctx.plan, ctx.e3 = plan, bool(e3)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        vf, frames = ctx.saved_tensors
+        d_out = _req(d_out, "grad")
+        d_vf = torch.zeros_like(vf)
+        check(lib.gcpnet_node_scalarize(vf.shape[0], _p(ctx.plan.seg_ptr), _p(ctx.plan.perm), _p(vf), vf.shape[2], _p(frames),
+                                        int(ctx.e3), None, _p(d_out), _p(d_vf), _stream()), "node_scalarize backward")
+        return d_vf, None, None, None
+
+
+def node_scalarize(vf: Tensor, frames: Tensor, plan: GatherPlan, e3: bool = True) -> Tensor:
+    """[N, 9] frame scalars of node rows from per-node frame channels vf [N, 3 (xyz), >= 3 (channel)] and the edges' frames;
+    `plan` = the CSR of the edges by SOURCE node (GraphPlan.row)."""
+    assert vf.dim() == 3 and vf.shape[1] == 3 and vf.shape[2] >= 3 and plan.n_src == vf.shape[0]
+    return _NodeScalarize.apply(_req(vf, "frame channels"), _req(frames.detach(), "frames"), plan, e3)
+
+
 class _EdgeForce(torch.autograd.Function):
     """force[e] = sum_k coef[e, k] f_ij[e, k, :] with coef = W3 act(A[row] + B[col]) (reference gcpnet.py:1143-1150).
     A, B: per-node tables [N, s]; W3 [3, s]; frames [E, 3, 3] (constants of the step)."""

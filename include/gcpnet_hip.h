@@ -383,6 +383,14 @@ int gcpnet_frame_gate_backward(int64_t rows, int vo, const float* g, int ldg, co
                                void* stream);
 int gcpnet_frame_gate_bwd_parts(int64_t rows);
 
+/* ---- scalarize on node rows with enable_e3_equivariance (replaces components/__init__.py:283-321 for node_inputs=True with the
+ * E(3) |.|, the one case the mean out-edge frame cannot express): out[n, 3 k + a] = mean over the out-edges e of n (CSR by source
+ * node: seg_ptr [n_nodes + 1], perm = edge ids in segment order or NULL) of f(frames[e, a, :] . vf[n, :, k]), f = |.| for a == 1
+ * when e3.  vf: [n_nodes, 3 (xyz), ldk], channel k < 3 innermost.  Forward: d_out = d_vf = NULL, writes out [n_nodes, 9].
+ * Backward: d_out [n_nodes, 9] given, writes d_vf (same layout as vf; entries k >= 3 untouched); frames are constants. */
+int gcpnet_node_scalarize(int n_nodes, const int32_t* seg_ptr, const int32_t* perm, const float* vf, int ldk, const float* frames,
+                          int e3, float* out, const float* d_out, float* d_vf, void* stream);
+
 /* ---- dropout (components/__init__.py:97-135: nn.Dropout on the scalars, VectorDropout on whole 3-vectors), train mode:
  * y[g * group + j] = keep(g) ? x[g * group + j] / keep_prob : 0 with keep(g) = uniform(seed, g) < keep_prob, a counter-based
  * hash: the backward is the same call on the gradient with the same seed (no mask is stored).  group = 1 or 3. */

@@ -145,6 +145,8 @@ def fx_gcp_original():
     run_gcp2("gcp_selfgate_e3", (24, 8), (20, 6), False, 64, cls="GCP", nonlinearities=("silu", "sigmoid"), vector_gate=False,
              enable_e3_equivariance=True)
     run_gcp2("gcp_scalar_out", (32, 8), (16, 0), True, 65, cls="GCP", nonlinearities=("relu", None))
+    run_gcp2("gcp_node_e3", (24, 8), (24, 8), True, 67, cls="GCP", nonlinearities=("silu", "sigmoid"), bottleneck=2,
+             sigma_frame_gate=True, enable_e3_equivariance=True)
     run_gcp2("gcp_ablate_frames", (24, 8), (16, 4), False, 66, cls="GCP", nonlinearities=("relu", None), bottleneck=4,
              ablate_frame_updates=True)
 

@@ -108,6 +108,8 @@ GCP2_CASES = {
     "gcp2_silu_sigmoid": dict(nonlinearities=("silu", "sigmoid"), bottleneck=2),
     "gcp2_selfgate": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False),
     "gcp2_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
+    "gcp2_vres_e3": dict(nonlinearities=("leakyrelu", None), bottleneck=4, vector_residual=True,
+                         enable_e3_equivariance=True),                                               # node rows, E(3) |.| per edge
     "gcp2_frame_gate": dict(nonlinearities=("silu", "silu"), bottleneck=2, frame_gate=True),        # node rows (mean frames)
     "gcp2_frame_gate_edge": dict(nonlinearities=("relu", "sigmoid"), frame_gate=True),              # edge rows
     "gcp3_edge_default": dict(bottleneck=4, cls="GCP3"),
@@ -153,6 +155,7 @@ GCP_CASES = {  # the original GCP block (reference gcpnet.py:30-249), fixtures f
     "gcp_sigma_gate": dict(nonlinearities=("relu", "sigmoid"), sigma_frame_gate=True, vector_residual=True),
     "gcp_frame_gate": dict(nonlinearities=("silu", "silu"), bottleneck=2, frame_gate=True, vector_frame_residual=True),
     "gcp_selfgate_e3": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False, enable_e3_equivariance=True),
+    "gcp_node_e3": dict(nonlinearities=("silu", "sigmoid"), bottleneck=2, sigma_frame_gate=True, enable_e3_equivariance=True),
     "gcp_scalar_out": dict(nonlinearities=("relu", None)),
     "gcp_ablate_frames": dict(nonlinearities=("relu", None), bottleneck=4, ablate_frame_updates=True),
 }

@@ -86,6 +86,7 @@ GCP_CASES = {  # the original GCP block (gcpnet.py:30-249)
     "gcp_sigma_gate": dict(nonlinearities=("relu", "sigmoid"), sigma_frame_gate=True, vector_residual=True),
     "gcp_frame_gate": dict(nonlinearities=("silu", "silu"), frame_gate=True, vector_frame_residual=True),
     "gcp_selfgate_e3": dict(nonlinearities=("silu", "sigmoid"), vector_gate=False, enable_e3_equivariance=True),
+    "gcp_node_e3": dict(nonlinearities=("silu", "sigmoid"), sigma_frame_gate=True, enable_e3_equivariance=True),
     "gcp_scalar_out": dict(nonlinearities=("relu", None)),
     "gcp_ablate_frames": dict(nonlinearities=("relu", None), ablate_frame_updates=True),
 }
