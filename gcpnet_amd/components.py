@@ -182,11 +182,31 @@ def _plan_for_batch(batch_index: torch.Tensor) -> GatherPlan:
     return GatherPlan.get(batch_index)
 
 
+def edge_mask_of(edge_index: torch.Tensor, node_mask: torch.Tensor) -> torch.Tensor:
+    """:230, :296, :347 -- an edge takes part when both of its end points are unmasked."""
+    return node_mask[edge_index[0]] & node_mask[edge_index[1]]
+
+
+def mask_frames(frames: torch.Tensor, edge_index: torch.Tensor, node_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """What `node_mask` does inside scalarize (:295-302) and vectorize (:346-357): masked edges contribute zeros and still count
+    in the node-row means, i.e. their frames act as zero frames (whatever the caller stored there: the masked localize writes
+    +inf).  The GCP kernels then run unchanged on the result."""
+    if node_mask is None:
+        return frames
+    return torch.where(edge_mask_of(edge_index, node_mask)[:, None, None], frames, torch.zeros_like(frames))
+
+
 def centralize(batch, key: str, batch_index: torch.Tensor, node_mask: Optional[torch.Tensor] = None):
-    """:171-200 (unmasked branch): per-graph centroid by segmented mean, subtract the gathered centroid."""
-    if node_mask is not None:
-        raise NotImplementedError("centralize(node_mask=...) is not on the accelerated path yet (SURVEY.md 8 f3)")
+    """:171-200: per-graph centroid by segmented mean, subtract the gathered centroid.  Masked (:177-193): the centroid of the
+    unmasked nodes; masked rows of the centred copy are +inf."""
     x = batch[key]
+    if node_mask is not None:
+        idx = torch.nonzero(node_mask).squeeze(1)
+        xs, bs = x.index_select(0, idx).contiguous(), batch_index.index_select(0, idx)
+        plan = GatherPlan(bs, int(batch_index.max()) + 1 if batch_index.numel() else 0)
+        centroid = ops.segment_reduce(xs, plan, mean=True)
+        centered_sel = ops.axpy(xs, ops.gather_rows(centroid, plan), -1.0)
+        return centroid, torch.full_like(x, float("inf")).index_copy(0, idx, centered_sel)
     plan = _plan_for_batch(batch_index)
     centroid = ops.segment_reduce(x, plan, mean=True)
     centered = ops.axpy(x, ops.gather_rows(centroid, plan), -1.0)
@@ -195,19 +215,29 @@ def centralize(batch, key: str, batch_index: torch.Tensor, node_mask: Optional[t
 
 def decentralize(batch, key: str, batch_index: torch.Tensor, entities_centroid: torch.Tensor,
                  node_mask: Optional[torch.Tensor] = None):
-    """:204-217 (unmasked branch)."""
+    """:204-217.  Masked (:211-213, as written there): `batch_index` must list the graphs of the UNMASKED nodes (or no node be
+    masked); masked rows of the result are +inf."""
+    x = batch[key]
     if node_mask is not None:
-        raise NotImplementedError("decentralize(node_mask=...) is not on the accelerated path yet (SURVEY.md 8 f3)")
+        idx = torch.nonzero(node_mask).squeeze(1)
+        if batch_index.shape[0] != idx.shape[0]:
+            raise RuntimeError(f"decentralize(node_mask=...): {idx.shape[0]} unmasked nodes but {batch_index.shape[0]} graph "
+                               "indices (the reference adds entities_centroid[batch_index] to batch[key][node_mask], :212)")
+        plan = GatherPlan(batch_index, entities_centroid.shape[0])
+        moved = ops.axpy(x.index_select(0, idx).contiguous(), ops.gather_rows(entities_centroid, plan), 1.0)
+        return torch.full_like(x, float("inf")).index_copy(0, idx, moved)
     plan = GatherPlan.get(batch_index, entities_centroid.shape[0])
-    return ops.axpy(batch[key], ops.gather_rows(entities_centroid, plan), 1.0)
+    return ops.axpy(x, ops.gather_rows(entities_centroid, plan), 1.0)
 
 
 def localize(x: torch.Tensor, edge_index: torch.Tensor, norm_x_diff: bool = True,
              node_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """:221-269 (unmasked branch).  Frames are constants of the step (no gradient), as in the reference's use."""
+    """:221-269.  Frames are constants of the step (no gradient), as in the reference's use.  With a node mask the frames of the
+    masked edges are +inf (:232-236, :262-264)."""
+    frames = ops.localize(x, GraphPlan.get(edge_index, x.shape[0]), norm_x_diff)
     if node_mask is not None:
-        raise NotImplementedError("localize(node_mask=...) is not on the accelerated path yet (SURVEY.md 8 f3)")
-    return ops.localize(x, GraphPlan.get(edge_index, x.shape[0]), norm_x_diff)
+        frames = torch.where(edge_mask_of(edge_index, node_mask)[:, None, None], frames, torch.full_like(frames, float("inf")))
+    return frames
 
 
 def is_identity(nonlinearity: Optional[Union[Callable, nn.Module]] = None):

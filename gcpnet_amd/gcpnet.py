@@ -17,7 +17,7 @@ from torch import nn
 
 from . import ops
 from ._lib import VMODE_NONE, VMODE_SCALAR_GATE, VMODE_SELF_GATE
-from .components import GCPDropout, GCPLayerNorm, ScalarVector, canonical_act
+from .components import GCPDropout, GCPLayerNorm, ScalarVector, canonical_act, edge_mask_of, mask_frames
 from .config import to_container
 from .ops import GatherPlan, Gcp2Spec, GraphPlan
 
@@ -196,9 +196,9 @@ class GCP2(nn.Module):
         return s_out, v_out
 
     def forward(self, s_maybe_v, edge_index, frames, node_inputs: bool = False, node_mask=None):
-        """:394-468.  Returns ScalarVector, or a Tensor when the block has no vector output."""
-        if node_mask is not None:
-            _unsupported("GCP2.forward(node_mask=...)")
+        """:394-468.  Returns ScalarVector, or a Tensor when the block has no vector output.  `node_mask` (scalarize / vectorize,
+        components/__init__.py:295-302, 346-357): edges with a masked end point act through zero frames (components.mask_frames)."""
+        frames = mask_frames(frames, edge_index, node_mask)
         if self.vector_input_dim:
             s, v = s_maybe_v
             row_frames = None
@@ -453,9 +453,8 @@ class GCP(nn.Module):
         return out
 
     def forward(self, s_maybe_v, edge_index, frames, node_inputs: bool = False, node_mask=None):
-        """:163-249.  Returns ScalarVector, or a Tensor when the block has no vector output."""
-        if node_mask is not None:
-            _unsupported("GCP.forward(node_mask=...)")
+        """:163-249.  Returns ScalarVector, or a Tensor when the block has no vector output.  `node_mask`: as in GCP2.forward."""
+        frames = mask_frames(frames, edge_index, node_mask)
         if self.vector_input_dim:
             s, v = s_maybe_v
             row_frames = None
@@ -616,8 +615,7 @@ class GCPMessagePassing(nn.Module):
                 and not a.ablate_scalars and not a.ablate_vectors and all(key(m) == key(a) for m in mods))
 
     def message(self, node_rep, edge_rep, edge_index, frames, node_mask=None):
-        if node_mask is not None:
-            _unsupported("GCPMessagePassing(node_mask=...)")
+        frames = mask_frames(frames, edge_index, node_mask)  # (:920-929: the mask only reaches the blocks' scalarize / vectorize)
         return self._messages(ScalarVector(*node_rep), ScalarVector(*edge_rep), edge_index, frames).flatten()
 
     def aggregate(self, message, edge_index, dim_size: int):
@@ -626,8 +624,7 @@ class GCPMessagePassing(nn.Module):
         return ops.segment_reduce(message, side, mean=self.reduce_function == "mean")
 
     def forward(self, node_rep, edge_rep, edge_index, frames, node_mask=None) -> ScalarVector:
-        if node_mask is not None:
-            _unsupported("GCPMessagePassing(node_mask=...)")
+        frames = mask_frames(frames, edge_index, node_mask)
         node_rep, edge_rep = ScalarVector(*node_rep), ScalarVector(*edge_rep)
         m = self._messages(node_rep, edge_rep, edge_index, frames)
         n = node_rep[0].shape[0]
@@ -713,17 +710,66 @@ class GCPInteractions(nn.Module):
             upd = ops.axpy(upd, ops.segment_reduce(force, plan.col, mean=True), 1.0)
         return upd
 
-    def forward(self, node_rep, edge_rep, edge_index, frames, node_rep_regressive=None, node_mask=None, node_pos=None):
+    def autoregressive_forward(self, node_rep, edge_rep, edge_index, frames, autoregressive_node_rep, node_mask=None):
+        """:1066-1116 -- edges row < col carry messages of the current representation, the others of the autoregressive one; the
+        two sums (layers built with autoregressive=True aggregate with "add") are divided by the in-degree over ALL edges."""
+        fwd = edge_index[0] < edge_index[1]
+        i_f, i_b = torch.nonzero(fwd).squeeze(1), torch.nonzero(~fwd).squeeze(1)
+        pick = lambda sv, i: ScalarVector(sv[0].index_select(0, i), sv[1].index_select(0, i))
+        a = self.interaction(node_rep, pick(edge_rep, i_f), edge_index[:, i_f], frames.index_select(0, i_f), node_mask=node_mask)
+        b = self.interaction(ScalarVector(*autoregressive_node_rep), pick(edge_rep, i_b), edge_index[:, i_b],
+                             frames.index_select(0, i_b), node_mask=node_mask)
+        inv = GraphPlan.get(edge_index, node_rep[0].shape[0]).col.inv_count  # 1 / max(in-degree, 1)
+        m = _sv_add(a, b)
+        return ScalarVector(m[0] * inv[:, None], m[1] * inv[:, None, None])
+
+    def _forward_masked(self, node_rep, edge_rep, edge_index, frames, node_rep_regressive, node_mask, node_pos):
+        """:1186-1262 with `node_mask`: the message passing sees the mask through its frames; everything after it runs on the
+        unmasked rows only -- the feed-forward GCPs on the sub-graph those nodes induce (relabelled edge ids; the reference hands
+        them the FULL-size mask, indexed by the relabelled ids, :1238) -- and the result replaces the unmasked rows of the
+        (pre-normed) input."""
+        if self.pre_norm:
+            node_rep = self.gcp_norm[0](node_rep)
         if node_rep_regressive is not None:
-            _unsupported("GCPInteractions autoregressive forward")
-        if node_mask is not None:
-            _unsupported("GCPInteractions(node_mask=...)")
+            hidden = self.autoregressive_forward(node_rep, edge_rep, edge_index, frames, node_rep_regressive, node_mask=node_mask)
+        else:
+            hidden = self.interaction(node_rep, edge_rep, edge_index, frames, node_mask=node_mask)
+        full = node_rep
+        idx = torch.nonzero(node_mask).squeeze(1)
+        sel = lambda sv: ScalarVector(sv[0].index_select(0, idx), sv[1].index_select(0, idx))
+        node_rep, hidden = sel(node_rep), sel(hidden)
+        ff_index, ff_frames = edge_index, frames
+        if not bool(node_mask.all()) and edge_index.shape[1] > 0:  # torch_geometric.utils.subgraph(..., relabel_nodes=True)
+            keep = torch.nonzero(edge_mask_of(edge_index, node_mask)).squeeze(1)
+            relabel = torch.cumsum(node_mask.long(), 0) - 1
+            ff_index, ff_frames = relabel[edge_index[:, keep]], frames.index_select(0, keep)
+        if self.gcp_dropout[0].active:
+            hidden = self.gcp_dropout[0](hidden)
+        node_rep = self.gcp_norm[1 if self.pre_norm else 0](node_rep, residual=hidden)
+        hidden = node_rep
+        for module in self.feedforward_network:
+            hidden = module(hidden, ff_index, ff_frames, node_inputs=True, node_mask=node_mask)
+        if self.gcp_dropout[1].active:
+            hidden = self.gcp_dropout[1](hidden)
+        node_rep = _sv_add(node_rep, hidden) if self.pre_norm else self.gcp_norm[1](node_rep, residual=hidden)
+        node_rep = ScalarVector(full[0].index_copy(0, idx, node_rep[0]), full[1].index_copy(0, idx, node_rep[1]))  # :1248-1251
+        if not self.updating_node_positions:
+            return node_rep
+        upd = self.derive_x_update(node_rep, edge_index, frames, node_mask=node_mask)
+        return node_rep, ops.axpy_clamp(node_pos, upd, float(self.node_positions_weight), -100.0, 100.0)
+
+    def forward(self, node_rep, edge_rep, edge_index, frames, node_rep_regressive=None, node_mask=None, node_pos=None):
         node_rep = ScalarVector(node_rep[0], node_rep[1])
         edge_rep = ScalarVector(edge_rep[0], edge_rep[1])
+        if node_mask is not None:
+            return self._forward_masked(node_rep, edge_rep, edge_index, frames, node_rep_regressive, node_mask, node_pos)
 
         if self.pre_norm:
             node_rep = self.gcp_norm[0](node_rep)
-        hidden = self.interaction(node_rep, edge_rep, edge_index, frames)
+        if node_rep_regressive is not None:
+            hidden = self.autoregressive_forward(node_rep, edge_rep, edge_index, frames, node_rep_regressive)
+        else:
+            hidden = self.interaction(node_rep, edge_rep, edge_index, frames)
         if self.gcp_dropout[0].active:
             hidden = self.gcp_dropout[0](hidden)
         if self.pre_norm:  # :1220-1226
@@ -798,16 +844,15 @@ class GCPInteractions2(nn.Module):
 
     def derive_x_update(self, node_rep, edge_index, f_ij, node_mask=None):
         """:1356-1378.  Returns the un-weighted update."""
-        if node_mask is not None:
-            _unsupported("GCPInteractions2(node_mask=...)")
-        _, chi_v = self.node_position_update_gcp(node_rep, edge_index, f_ij, node_inputs=True)
+        _, chi_v = self.node_position_update_gcp(node_rep, edge_index, f_ij, node_inputs=True, node_mask=node_mask)
         return chi_v.reshape(chi_v.shape[0], 3)
 
     def forward(self, node_rep, edge_rep, edge_index, frames, node_mask=None, node_pos=None):
-        if node_mask is not None:
-            _unsupported("GCPInteractions2(node_mask=...)")
+        """:1380-1451.  `node_mask`: the blocks see it through their frames (components.mask_frames); the outputs of masked nodes
+        are zeroed (:1435-1436, :1448-1449)."""
         node_rep = ScalarVector(node_rep[0], node_rep[1])
         edge_rep = ScalarVector(edge_rep[0], edge_rep[1])
+        frames = mask_frames(frames, edge_index, node_mask)
         if self.pre_norm:
             node_rep = self.gcp_norm[0](node_rep)
         hidden = self.interaction(node_rep, edge_rep, edge_index, frames)
@@ -820,8 +865,48 @@ class GCPInteractions2(nn.Module):
             node_rep = _sv_add(node_rep, hidden)
         else:
             node_rep = self.gcp_norm[0](node_rep, residual=hidden)
+        if node_mask is not None:
+            node_rep = node_rep.mask(node_mask.float())
         if not self.updating_node_positions:
             return node_rep
         upd = self.derive_x_update(node_rep, edge_index, frames)
-        return node_rep, ops.axpy(node_pos, upd, float(self.node_positions_weight))  # :1442-1444
+        node_pos = ops.axpy(node_pos, upd, float(self.node_positions_weight))  # :1442-1444
+        if node_mask is not None:
+            node_pos = node_pos * node_mask.float().unsqueeze(-1)
+        return node_rep, node_pos
 
+
+class GCPMLPDecoder(nn.Module):
+    """:1454-1491 -- Linear readout stack over the node scalars (optionally with residual updates on all but the last layer),
+    returning (logits, log_softmax(logits)).  The Linears run on the workgroup GEMM kernel (ops.linear; output widths that are
+    not multiples of 4 -- the default vocabulary of 20 is -- are padded with zero rows for the launch)."""
+
+    def __init__(self, hidden_dim: int, vocab_size: int = 20, num_layers: int = 1, residual_updates: bool = False):
+        super().__init__()
+        self.residual_updates = residual_updates
+        layers = [nn.Linear(hidden_dim, hidden_dim) for _ in range(num_layers - 1)] + [nn.Linear(hidden_dim, vocab_size)]
+        self.readout = nn.ModuleList(layers) if residual_updates else nn.Sequential(*layers)
+
+    @staticmethod
+    def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+        out = layer.out_features
+        pad = (-out) % 4
+        if not pad:
+            return ops.linear(x, layer.weight, layer.bias)
+        w = torch.nn.functional.pad(layer.weight, (0, 0, 0, pad))
+        return ops.linear(x, w, torch.nn.functional.pad(layer.bias, (0, pad)))[:, :out]
+
+    def residual_forward(self, h: torch.Tensor) -> torch.Tensor:
+        x = h
+        for layer in list(self.readout)[:-1]:
+            x = ops.axpy(x, self._linear(layer, x), 1.0)
+        return self._linear(self.readout[-1], x)
+
+    def forward(self, h: torch.Tensor):
+        if self.residual_updates:
+            logits = self.residual_forward(h)
+        else:
+            logits = h
+            for layer in self.readout:
+                logits = self._linear(layer, logits)
+        return logits, torch.log_softmax(logits, dim=-1)

@@ -80,19 +80,34 @@ def recover_sv(x: Tensor, vdim: int) -> Tuple[Tensor, Tensor]:
     return x[..., : x.shape[-1] - 3 * vdim], x[..., x.shape[-1] - 3 * vdim:].reshape(x.shape[0], vdim, 3)
 
 
-def centralize(x: Tensor, batch_index: Tensor) -> Tuple[Tensor, Tensor]:
-    """components/__init__.py:195-200 (unmasked branch)."""
+def centralize(x: Tensor, batch_index: Tensor, node_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """components/__init__.py:170-200.  Masked: the centroid of the unmasked nodes; masked rows of the centred copy are +inf."""
+    if node_mask is not None:
+        c = scatter(x[node_mask], batch_index[node_mask], reduce="mean")
+        out = torch.full_like(x, float("inf"))
+        out[node_mask] = x[node_mask] - c[batch_index][node_mask]
+        return c, out
     c = scatter(x, batch_index, reduce="mean")
     return c, x - c[batch_index]
 
 
-def decentralize(x: Tensor, batch_index: Tensor, centroid: Tensor) -> Tensor:
-    """components/__init__.py:215-217 (unmasked branch)."""
+def decentralize(x: Tensor, batch_index: Tensor, centroid: Tensor, node_mask: Optional[Tensor] = None) -> Tensor:
+    """components/__init__.py:203-217."""
+    if node_mask is not None:
+        out = torch.full_like(x, float("inf"))
+        out[node_mask] = x[node_mask] + centroid[batch_index]  # (as written, :212: shapes agree when `batch_index` lists the
+        return out                                              #  unmasked nodes only, or no node is masked)
     return x + centroid[batch_index]
 
 
-def localize(x: Tensor, edge_index: Tensor, norm_x_diff: bool = True) -> Tensor:
-    """components/__init__.py:221-269 (unmasked branch): frame rows [x_diff; x_cross; x_vertical]."""
+def edge_mask_of(edge_index: Tensor, node_mask: Tensor) -> Tensor:
+    """components/__init__.py:230, 296, 347: an edge is kept when both end points are unmasked."""
+    return node_mask[edge_index[0]] & node_mask[edge_index[1]]
+
+
+def localize(x: Tensor, edge_index: Tensor, norm_x_diff: bool = True, node_mask: Optional[Tensor] = None) -> Tensor:
+    """components/__init__.py:221-269: frame rows [x_diff; x_cross; x_vertical]; with a node mask the frames of the masked edges
+    are +inf (:232-236, :262-264)."""
     xi, xj = x[edge_index[0]], x[edge_index[1]]
     d = xi - xj
     c = torch.cross(xi, xj, dim=-1)
@@ -100,27 +115,49 @@ def localize(x: Tensor, edge_index: Tensor, norm_x_diff: bool = True) -> Tensor:
         d = d / (d.pow(2).sum(1, keepdim=True).sqrt() + 1)
         c = c / (c.pow(2).sum(1, keepdim=True).sqrt() + 1)
     vert = torch.cross(d, c, dim=-1)
-    return torch.stack((d, c, vert), dim=1)
+    f = torch.stack((d, c, vert), dim=1)
+    if node_mask is not None:
+        f = torch.where(edge_mask_of(edge_index, node_mask)[:, None, None], f, torch.full_like(f, float("inf")))
+    return f
 
 
-def scalarize(vec: Tensor, edge_index: Tensor, frames: Tensor, node_inputs: bool, e3: bool, dim_size: int) -> Tensor:
-    """components/__init__.py:273-325 (unmasked).  ``vec`` is [rows, 3 channels, 3 xyz]; the result is
+def _masked_frames(frames: Tensor, edge_index: Tensor, node_mask: Optional[Tensor]) -> Tensor:
+    """What the masked branches of scalarize (:295-302) and vectorize (:346-357) amount to: masked edges contribute zeros (and
+    still count in the node-row means), i.e. their frames act as zero frames."""
+    if node_mask is None:
+        return frames
+    return torch.where(edge_mask_of(edge_index, node_mask)[:, None, None], frames, torch.zeros_like(frames))
+
+
+def scalarize(vec: Tensor, edge_index: Tensor, frames: Tensor, node_inputs: bool, e3: bool, dim_size: int,
+              node_mask: Optional[Tensor] = None) -> Tensor:
+    """components/__init__.py:273-325.  ``vec`` is [rows, 3 channels, 3 xyz]; the result is
     [rows, 9] with entry 3*channel + frame_row = <frame_row, channel vector>."""
     row = edge_index[0]
     src = vec[row] if node_inputs else vec
-    local = torch.einsum("ead,ekd->eka", frames, src)
+    local = torch.einsum("ead,ekd->eka", _masked_frames(frames, edge_index, node_mask), src)
     if e3:
         local = torch.cat((local[..., :1], local[..., 1:2].abs(), local[..., 2:]), dim=-1)
     flat = local.reshape(local.shape[0], 9)
     return scatter(flat, row, dim_size=dim_size, reduce="mean") if node_inputs else flat
 
 
-def vectorize(gate: Tensor, edge_index: Tensor, frames: Tensor, node_inputs: bool, dim_size: int) -> Tensor:
-    """components/__init__.py:329-378 (unmasked): 9 gate scalars -> 3 vectors sum_a g[3c+a] * frame_row_a."""
+def vectorize(gate: Tensor, edge_index: Tensor, frames: Tensor, node_inputs: bool, dim_size: int,
+              node_mask: Optional[Tensor] = None) -> Tensor:
+    """components/__init__.py:329-378: 9 gate scalars -> 3 vectors sum_a g[3c+a] * frame_row_a."""
     row = edge_index[0]
     g = gate[row] if node_inputs else gate
-    out = torch.einsum("eca,ead->ecd", g.reshape(-1, 3, 3), frames)
+    out = torch.einsum("eca,ead->ecd", g.reshape(-1, 3, 3), _masked_frames(frames, edge_index, node_mask))
     return scatter(out, row, dim_size=dim_size, reduce="mean") if node_inputs else out
+
+
+def subgraph(node_mask: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tuple[Tensor, Tensor]:
+    """torch_geometric.utils.subgraph(subset, edge_index, edge_attr, relabel_nodes=True) (PyG 2.x; call site
+    components/gcpnet.py:1212-1217), documented semantics restated: the edges with both end points in the subset, in their
+    original order, node ids relabelled to the position inside the (sorted) subset."""
+    keep = edge_mask_of(edge_index, node_mask)
+    relabel = torch.cumsum(node_mask.long(), 0) - 1
+    return relabel[edge_index[:, keep]], edge_attr[keep]
 
 
 def gcp_layer_norm(P: Params, pre: str, s: Tensor, v: Optional[Tensor], eps: float = 1e-8):
@@ -159,6 +196,7 @@ def gcp2(
     vector_output_dim: Optional[int] = None,
     slope: float = 1e-2,
     scalar_out_nonlinearity: Optional[str] = "silu",
+    node_mask: Optional[Tensor] = None,
 ):
     """One geometry-complete perceptron.  Returns (s_out, v_out) or just s_out when there is no vector output.
 
@@ -184,7 +222,7 @@ def gcp2(
         merged = torch.cat((s, safe_norm(vh, dim=-2)), dim=-1)
         if not ablate_frame_updates:
             vf = torch.einsum("rcd,kc->rkd", v, P[pre + "vector_down_frames.weight"])  # [rows, 3 ch, xyz]
-            sh = scalarize(vf, edge_index, frames, node_inputs, enable_e3_equivariance, vf.shape[0])
+            sh = scalarize(vf, edge_index, frames, node_inputs, enable_e3_equivariance, vf.shape[0], node_mask)
             merged = torch.cat((merged, sh), dim=-1)
     else:
         merged = s
@@ -208,7 +246,7 @@ def gcp2(
         if frame_gate and not ablate_frame_updates:
             g = nonlinearity(act_v, s_pre, slope) @ P[pre + "vector_out_scale_frames.weight"].t() \
                 + P[pre + "vector_out_scale_frames.bias"]
-            gv = vectorize(g, edge_index, frames, node_inputs, s_pre.shape[0])  # [rows, 3, xyz]
+            gv = vectorize(g, edge_index, frames, node_inputs, s_pre.shape[0], node_mask)  # [rows, 3, xyz]
             gvr = torch.einsum("rkd,ok->rod", gv, P[pre + "vector_up_frames.weight"])
             v_out = v_out * nonlinearity(act_v, safe_norm(gvr, dim=-1, keepdim=True), slope)
         elif vector_gate:
@@ -248,6 +286,7 @@ def gcp(
     ablate_vectors: bool = False,
     enable_e3_equivariance: bool = False,
     slope: float = 1e-2,
+    node_mask: Optional[Tensor] = None,
 ):
     """The original two-stage perceptron: a GVP-like stage (scalar_out over [s | |vector_down v|], gated vector_up,
     gcpnet.py:204-224 + process_vector :103-119) followed by the frame stage (vector_down_frames -> scalarize -> scalar_out_frames,
@@ -280,7 +319,7 @@ def gcp(
         return (s_cur, v_cur) if has_vout else s_cur
     # frame stage :228-249
     vf = torch.einsum("rcd,kc->rkd", v_cur, P[pre + "vector_down_frames.weight"])  # [rows, 3 ch, xyz]
-    sh = scalarize(vf, edge_index, frames, node_inputs, enable_e3_equivariance, vf.shape[0])
+    sh = scalarize(vf, edge_index, frames, node_inputs, enable_e3_equivariance, vf.shape[0], node_mask)
     s_pre2 = torch.cat((s_cur, sh), dim=-1) @ P[pre + "scalar_out_frames.weight"].t() + P[pre + "scalar_out_frames.bias"]
     if not has_vout:  # :243-246
         if ablate_scalars:
@@ -294,7 +333,7 @@ def gcp(
     elif frame_gate:
         g = nonlinearity(act_v, s_pre2, slope) @ P[pre + "vector_out_scale_frames.weight"].t() \
             + P[pre + "vector_out_scale_frames.bias"]
-        gv = vectorize(g, edge_index, frames, node_inputs, s_pre2.shape[0])
+        gv = vectorize(g, edge_index, frames, node_inputs, s_pre2.shape[0], node_mask)
         gvr = torch.einsum("rkd,ok->rod", gv, P[pre + "vector_up_frames.weight"])
         v_out = v_out * nonlinearity(act_v, safe_norm(gvr, dim=-1, keepdim=True), slope)
         if vector_frame_residual:
@@ -389,6 +428,7 @@ def message_passing(
     reduce_function: str = "mean",
     return_messages: bool = False,
     aggregate_with_row: bool = False,
+    node_mask: Optional[Tensor] = None,
 ):
     row, col = edge_index[0], edge_index[1]
     n_msg = mp_cfg["num_message_layers"]
@@ -402,13 +442,13 @@ def message_passing(
     kws = [first] + [mid] * (n_msg - 2) + ([last] if n_msg > 1 else [])
 
     if mp_cfg["use_residual_message_gcp"]:  # gcpnet.py:919-924
-        ms, mv = gcp2(P, f"{pre}message_fusion.0.", ms, mv, edge_index, frames, **kws[0])
+        ms, mv = gcp2(P, f"{pre}message_fusion.0.", ms, mv, edge_index, frames, node_mask=node_mask, **kws[0])
         for k in range(1, len(kws)):
-            ds, dv = gcp2(P, f"{pre}message_fusion.{k}.", ms, mv, edge_index, frames, **kws[k])
+            ds, dv = gcp2(P, f"{pre}message_fusion.{k}.", ms, mv, edge_index, frames, node_mask=node_mask, **kws[k])
             ms, mv = ms + ds, mv + dv
     else:
         for k in range(len(kws)):
-            ms, mv = gcp2(P, f"{pre}message_fusion.{k}.", ms, mv, edge_index, frames, **kws[k])
+            ms, mv = gcp2(P, f"{pre}message_fusion.{k}.", ms, mv, edge_index, frames, node_mask=node_mask, **kws[k])
 
     if (pre + "scalar_message_attention.0.weight") in P:  # gcpnet.py:932-934
         att = torch.sigmoid(ms @ P[pre + "scalar_message_attention.0.weight"].t()
@@ -436,8 +476,12 @@ def gcp_interactions(
     layer_cfg: Mapping,
     node_pos: Optional[Tensor] = None,
     nonlinearities: Optional[Sequence[Optional[str]]] = None,
+    node_mask: Optional[Tensor] = None,
+    regressive: Optional[Tuple[Tensor, Tensor]] = None,
 ):
-    """Eval-mode (dropout = identity) forward.  Returns (h, chi) or ((h, chi), node_pos)."""
+    """Eval-mode (dropout = identity) forward.  Returns (h, chi) or ((h, chi), node_pos).  `node_mask`: the masked call path
+    (:1201-1217, :1248-1251); `regressive` = (h, chi) of the autoregressive node representation (:1066-1116, layers built
+    with autoregressive=True aggregate with "add")."""
     if nonlinearities is None:
         nonlinearities = cfg["nonlinearities"]
     pre_norm = layer_cfg["pre_norm"]
@@ -446,7 +490,23 @@ def gcp_interactions(
 
     if pre_norm:  # gcpnet.py:1188-1189
         h, chi = gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
-    rs, rv = message_passing(P, pre + "interaction.", h, chi, e, xi, edge_index, frames, cfg, layer_cfg["mp_cfg"])
+    mp = layer_cfg["mp_cfg"]
+    if regressive is not None:  # autoregressive_forward, gcpnet.py:1066-1116
+        fwd = edge_index[0] < edge_index[1]
+        a = message_passing(P, pre + "interaction.", h, chi, e[fwd], xi[fwd], edge_index[:, fwd], frames[fwd], cfg, mp,
+                            reduce_function="add", node_mask=node_mask)
+        b = message_passing(P, pre + "interaction.", regressive[0], regressive[1], e[~fwd], xi[~fwd], edge_index[:, ~fwd],
+                            frames[~fwd], cfg, mp, reduce_function="add", node_mask=node_mask)
+        cnt = scatter(torch.ones(edge_index.shape[1], dtype=h.dtype), edge_index[1], dim_size=h.shape[0]).clamp(min=1)
+        rs, rv = (a[0] + b[0]) / cnt[:, None], (a[1] + b[1]) / cnt[:, None, None]
+    else:
+        rs, rv = message_passing(P, pre + "interaction.", h, chi, e, xi, edge_index, frames, cfg, mp, node_mask=node_mask)
+    ff_index, ff_frames = edge_index, frames
+    if node_mask is not None:  # :1201-1217: the rest of the layer runs on the unmasked nodes (and, if any node is masked, on
+        h_full, chi_full = h, chi  # the sub-graph they induce -- with the FULL-size mask indexed by the relabelled ids, :1238)
+        h, chi, rs, rv = h[node_mask], chi[node_mask], rs[node_mask], rv[node_mask]
+        if not bool(node_mask.all()) and edge_index.shape[1] > 0:
+            ff_index, ff_frames = subgraph(node_mask, edge_index, frames)
     h, chi = h + rs, chi + rv  # gcpnet.py:1220
     h, chi = gcp_layer_norm(P, pre + ("gcp_norm.1." if pre_norm else "gcp_norm.0."), h, chi)
 
@@ -460,15 +520,19 @@ def gcp_interactions(
         kws.append(_gcp_kwargs(no_res, nonlinearities=(None, None)))
     fs, fv = h, chi
     for k, kw in enumerate(kws):  # gcpnet.py:1229-1239
-        fs, fv = gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, edge_index, frames, node_inputs=True, **kw)
+        fs, fv = gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, ff_index, ff_frames, node_inputs=True, node_mask=node_mask, **kw)
     h, chi = h + fs, chi + fv  # gcpnet.py:1242
     if not pre_norm:
         h, chi = gcp_layer_norm(P, pre + "gcp_norm.1.", h, chi)
+    if node_mask is not None:  # :1248-1251: only the unmasked rows are replaced
+        h_full, chi_full = h_full.clone(), chi_full.clone()
+        h_full[node_mask], chi_full[node_mask] = h, chi
+        h, chi = h_full, chi_full
 
     if not updating:
         return h, chi
     # derive_x_update, gcpnet.py:1119-1158 (force term ablated in every shipped config)
-    hv, xv = gcp2(P, pre + "node_position_update_network.0.", h, chi, edge_index, frames, node_inputs=True,
+    hv, xv = gcp2(P, pre + "node_position_update_network.0.", h, chi, edge_index, frames, node_inputs=True, node_mask=node_mask,
                   **_gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])))
     upd = xv.squeeze(1)
     if (pre + "phi_force_i.weight") in P:  # force term (:1143-1153): uses the scalar OUTPUT of the position-update GCP
@@ -499,6 +563,7 @@ def gcp_interactions2(
     layer_cfg: Mapping,
     node_pos: Optional[Tensor] = None,
     nonlinearities: Optional[Sequence[Optional[str]]] = None,
+    node_mask: Optional[Tensor] = None,
 ):
     """Eval-mode forward.  Returns (h, chi) or ((h, chi), node_pos).  The two-layer `scalar_out` of the GCP3 blocks and the
     scalar message gate are picked up from the parameter names."""
@@ -509,7 +574,8 @@ def gcp_interactions2(
     if pre_norm:  # gcpnet.py:1402-1403
         h, chi = gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
     rs, rv = message_passing(P, pre + "interaction.", h, chi, e, xi, edge_index, frames, cfg, layer_cfg["mp_cfg"],
-                             reduce_function="sum", aggregate_with_row=layer_cfg.get("aggregate_with_row", False))
+                             reduce_function="sum", aggregate_with_row=layer_cfg.get("aggregate_with_row", False),
+                             node_mask=node_mask)
     fs, fv = torch.cat((rs, h), dim=-1), torch.cat((rv, chi), dim=1)  # gcpnet.py:1414
     no_res = dict(cfg)
     no_res["vector_residual"] = False
@@ -520,15 +586,35 @@ def gcp_interactions2(
     if n_ff > 1:
         kws.append(_gcp_kwargs(no_res, nonlinearities=(None, None)))
     for k, kw in enumerate(kws):  # gcpnet.py:1417-1424
-        fs, fv = gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, edge_index, frames, node_inputs=True, **kw)
+        fs, fv = gcp2(P, f"{pre}feedforward_network.{k}.", fs, fv, edge_index, frames, node_inputs=True, node_mask=node_mask, **kw)
     h, chi = h + fs, chi + fv  # gcpnet.py:1427
     if not pre_norm:
         h, chi = gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
+    if node_mask is not None:  # :1435-1436
+        h, chi = h * node_mask.to(h.dtype)[:, None], chi * node_mask.to(h.dtype)[:, None, None]
     if (pre + "node_position_update_gcp.scalar_out.weight") not in P:
         return h, chi
-    _, xv = gcp2(P, pre + "node_position_update_gcp.", h, chi, edge_index, frames, node_inputs=True,
+    _, xv = gcp2(P, pre + "node_position_update_gcp.", h, chi, edge_index, frames, node_inputs=True, node_mask=node_mask,
                  **_gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])))
-    return (h, chi), node_pos + xv.squeeze(1) * cfg.get("node_positions_weight", 1.0)  # gcpnet.py:1356-1378,1442
+    node_pos = node_pos + xv.squeeze(1) * cfg.get("node_positions_weight", 1.0)  # gcpnet.py:1356-1378,1442
+    if node_mask is not None:  # :1448-1449
+        node_pos = node_pos * node_mask.to(h.dtype)[:, None]
+    return (h, chi), node_pos
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GCPMLPDecoder -- components/gcpnet.py:1454-1491
+# ----------------------------------------------------------------------------------------------------------
+def mlp_decoder(P: Params, pre: str, h: Tensor, residual_updates: bool = False) -> Tuple[Tensor, Tensor]:
+    """Linear readout stack (`readout.k`), optionally with residual updates on all but the last layer; (logits, log_softmax)."""
+    n = 0
+    while f"{pre}readout.{n}.weight" in P:
+        n += 1
+    x = h
+    for k in range(n):
+        y = x @ P[f"{pre}readout.{k}.weight"].t() + P[f"{pre}readout.{k}.bias"]
+        x = x + y if (residual_updates and k < n - 1) else y
+    return x, F.log_softmax(x, dim=-1)
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -254,6 +254,98 @@ def fx_interactions():
          inputs=dict(h=h2, chi=chi2, e=e2, xi=xi2, edge_index=ei, frames=frames), outputs=dict(h=ho, chi=co))
 
 
+def fx_masked():
+    """Masked / autoregressive call paths: node_mask in centralize / localize / scalarize / vectorize
+    (components/__init__.py:177-193,229-264,294-300,346-357), GCP2 with a mask, GCPInteractions with a mask (sub-graph
+    feed-forward, gcpnet.py:1201-1251) and its autoregressive forward (:1066-1116), GCPMLPDecoder (:1454-1491)."""
+    ei, x = rand_graph(24, 96, 70)
+    g = torch.Generator().manual_seed(71)
+    mask = torch.rand(24, generator=g) > 0.3
+    mask[:3] = torch.tensor([True, False, True])
+    bidx = torch.tensor([0] * 9 + [1] * 8 + [2] * 7)
+    f = comp.localize(x, ei, norm_x_diff=True, node_mask=mask)
+    vec_e, vec_n = randn(96, 3, 3, seed=72), randn(24, 3, 3, seed=73)
+    gate_e, gate_n = randn(96, 9, seed=74), randn(24, 9, seed=75)
+    cen, xc = comp.centralize(ref_stubs.Bag(x=x), "x", bidx, node_mask=mask)
+    save("geometry_masked",
+         inputs=dict(x=x, edge_index=ei, mask=mask, batch=bidx, vec_e=vec_e, vec_n=vec_n, gate_e=gate_e, gate_n=gate_n),
+         outputs=dict(frames=f, centroid=cen, x_centered=xc,
+                      scalarize_edge=comp.scalarize(vec_e, ei, f, False, False, 96, node_mask=mask),
+                      scalarize_node=comp.scalarize(vec_n, ei, f, True, True, 24, node_mask=mask),
+                      vectorize_edge=comp.vectorize(gate_e, ei, f, False, 96, node_mask=mask),
+                      vectorize_node=comp.vectorize(gate_n, ei, f, True, 24, node_mask=mask)))
+
+    # one GCP2 on node rows with a mask (frames of the masked edges are +inf, as localize produces them)
+    torch.manual_seed(76)
+    mod = gn.GCP2(SV(24, 8), SV(16, 4), nonlinearities=("silu", "sigmoid"), bottleneck=2)
+    s, v = randn(24, 24, seed=77).requires_grad_(), randn(24, 8, 3, seed=78).requires_grad_()
+    out = mod((s, v), ei, f, node_inputs=True, node_mask=mask)
+    sq_loss(out[0], out[1]).backward()
+    grads = dict(s=s.grad, v=v.grad)
+    grads.update({"w." + k: p.grad for k, p in mod.named_parameters() if p.grad is not None})
+    save("gcp2_masked_node", params=mod.state_dict(), inputs=dict(s=s, v=v, edge_index=ei, frames=f, mask=mask),
+         outputs=dict(s=out[0], v=out[1]), grads=grads, meta=dict(node_inputs=1, in_dims=(24, 8), out_dims=(16, 4)))
+
+    # GCPInteractions with a mask: with and without position update; all-true mask (no sub-graph)
+    cfg, lc = ref_stubs.make_cfg(), ref_stubs.make_layer_cfg()
+    nd, ed = SV(32, 8), SV(16, 4)
+    h, chi = randn(24, 32, seed=79).requires_grad_(), randn(24, 8, 3, seed=80).requires_grad_()
+    e, xi = randn(96, 16, seed=81).requires_grad_(), randn(96, 4, 3, seed=82).requires_grad_()
+    all_true = torch.ones(24, dtype=torch.bool)
+    for name, upd, m, pre_norm in (("interactions_masked", False, mask, False), ("interactions_masked_posupd", True, mask, False),
+                                   ("interactions_masked_all", False, all_true, True)):
+        lcm = ref_stubs.make_layer_cfg(pre_norm=pre_norm)
+        fm = comp.localize(x, ei, node_mask=m)
+        torch.manual_seed(83)
+        layer = gn.GCPInteractions(nd, ed, cfg=cfg, layer_cfg=lcm, dropout=0.0, updating_node_positions=upd)
+        layer.eval()
+        for t in (h, chi, e, xi):
+            t.grad = None
+        # (the reference writes the new rows INTO its node input, :1250: a clone is fed so that the leaves survive)
+        if upd:
+            (ho, co), xo = layer((h.clone(), chi.clone()), (e, xi), ei, fm, node_mask=m, node_pos=x)
+            outs = dict(h=ho, chi=co, x=xo)
+            fin = torch.isfinite(xo).all(dim=1)  # (the un-masked force-free update only touches rows through finite frames)
+            loss = sq_loss(ho, co, xo[fin])
+        else:
+            ho, co = layer((h.clone(), chi.clone()), (e, xi), ei, fm, node_mask=m)
+            outs = dict(h=ho, chi=co)
+            loss = sq_loss(ho, co)
+        loss.backward()
+        grads = dict(h=h.grad, chi=chi.grad, e=e.grad, xi=xi.grad)
+        grads.update({"w." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+        save(name, params=layer.state_dict(), inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=fm, x=x, mask=m),
+             outputs=outs, grads=grads, meta=dict(pre_norm=int(pre_norm)))
+
+    # autoregressive forward (layers built with autoregressive=True sum their messages, :996)
+    fr = comp.localize(x, ei)
+    torch.manual_seed(84)
+    layer = gn.GCPInteractions(nd, ed, cfg=cfg, layer_cfg=lc, dropout=0.0, autoregressive=True)
+    layer.eval()
+    hr, chir = randn(24, 32, seed=85).requires_grad_(), randn(24, 8, 3, seed=86).requires_grad_()
+    for t in (h, chi, e, xi):
+        t.grad = None
+    ho, co = layer((h, chi), (e, xi), ei, fr, node_rep_regressive=(hr, chir))
+    sq_loss(ho, co).backward()
+    grads = dict(h=h.grad, chi=chi.grad, e=e.grad, xi=xi.grad, h_reg=hr.grad, chi_reg=chir.grad)
+    grads.update({"w." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+    save("interactions_autoregressive", params=layer.state_dict(),
+         inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=fr, h_reg=hr, chi_reg=chir), outputs=dict(h=ho, chi=co),
+         grads=grads)
+
+    # GCPMLPDecoder, both variants
+    for name, res in (("mlp_decoder", False), ("mlp_decoder_residual", True)):
+        torch.manual_seed(87)
+        dec = gn.GCPMLPDecoder(32, vocab_size=20, num_layers=3, residual_updates=res)
+        hh = randn(24, 32, seed=88).requires_grad_()
+        logits, logp = dec(hh)
+        (sq_loss(logits) + (logp * randn(24, 20, seed=89)).mean()).backward()
+        grads = dict(h=hh.grad)
+        grads.update({"w." + k: p.grad for k, p in dec.named_parameters()})
+        save(name, params=dec.state_dict(), inputs=dict(h=hh, lw=randn(24, 20, seed=89)), outputs=dict(logits=logits, log_probs=logp),
+             grads=grads)
+
+
 def fx_models():
     """The LitModules cannot be imported (no Lightning here); their forwards (gcpnet_nms_module.py:127-151,
     gcpnet_lba_module.py:155-186) are driven step by step with the real reference components."""
@@ -426,5 +518,6 @@ if __name__ == "__main__":
     fx_embedding()
     fx_interactions()
     fx_interactions2()
+    fx_masked()
     fx_models()
     fx_input_side()

@@ -83,6 +83,24 @@ class _TensorType(metaclass=_TensorTypeMeta):
     pass
 
 
+def _subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=None):
+    """torch_geometric.utils.subgraph (PyG 2.x), documented semantics restated for an index-tensor `subset`: keeps the edges whose
+    two end points are both in the subset (original order), optionally relabels node ids to their position in the subset."""
+    import torch
+
+    n = int(num_nodes) if num_nodes is not None else int(max(int(edge_index.max()) + 1 if edge_index.numel() else 0,
+                                                             int(subset.max()) + 1 if subset.numel() else 0))
+    node_mask = torch.zeros(n, dtype=torch.bool)
+    node_mask[subset] = True
+    keep = node_mask[edge_index[0]] & node_mask[edge_index[1]]
+    ei = edge_index[:, keep]
+    if relabel_nodes:
+        relabel = torch.zeros(n, dtype=torch.long)
+        relabel[subset] = torch.arange(subset.shape[0])
+        ei = relabel[ei]
+    return ei, (edge_attr[keep] if edge_attr is not None else None)
+
+
 def install():
     """Insert the stub modules into ``sys.modules`` and put the reference on ``sys.path``."""
     if "src.models.components.gcpnet" in sys.modules:
@@ -97,7 +115,7 @@ def install():
     mod("torch_scatter", scatter=_scatter)
     tg = mod("torch_geometric")
     tg.data = mod("torch_geometric.data", Batch=_Bag, Data=_Bag)
-    tg.utils = mod("torch_geometric.utils", subgraph=None)
+    tg.utils = mod("torch_geometric.utils", subgraph=_subgraph)
     tg.loader = mod("torch_geometric.loader", DataLoader=object)
     mod("torch_cluster")
     mod("omegaconf", OmegaConf=_OmegaConf, DictConfig=DictConfig)

@@ -297,6 +297,102 @@ def test_interactions_golden(G, name):
             close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=1e-3)
 
 
+# ---- masked / autoregressive call paths, fixtures from the reference -----------------------------------
+def test_geometry_masked_golden(G):
+    """centralize / localize with node_mask (components/__init__.py:177-193, 229-264): +inf on the masked rows / edges."""
+    f = Fixture("geometry_masked")
+    i = f.i
+    m, ei, x = i["mask"].bool().cuda(), i["edge_index"].cuda(), i["x"].cuda()
+    fr = G.localize(x, ei, node_mask=m).cpu()
+    assert torch.equal(torch.isinf(fr), torch.isinf(f.o["frames"]))
+    fin = torch.isfinite(f.o["frames"])
+    close(fr[fin], f.o["frames"][fin], **FWD)
+    cen, xc = G.centralize(G.Batch(x=x), "x", i["batch"].cuda(), node_mask=m)
+    close(cen.cpu(), f.o["centroid"], **FWD)
+    xc = xc.cpu()
+    assert torch.equal(torch.isinf(xc), torch.isinf(f.o["x_centered"]))
+    close(xc[i["mask"].bool()], f.o["x_centered"][i["mask"].bool()], **FWD)
+
+
+def test_gcp2_masked_node_golden(G):
+    f = Fixture("gcp2_masked_node")
+    mod = G.GCP2((24, 8), (16, 4), nonlinearities=("silu", "sigmoid"), bottleneck=2).cuda()
+    mod.load_state_dict(f.p)
+    s, v = f.i["s"].cuda().requires_grad_(), f.i["v"].cuda().requires_grad_()
+    out = mod((s, v), f.i["edge_index"].cuda(), f.i["frames"].cuda(), node_inputs=True, node_mask=f.i["mask"].bool().cuda())
+    close(out[0].detach().cpu(), f.o["s"], **FWD)
+    close(out[1].detach().cpu(), f.o["v"], **FWD)
+    sq_loss(*out).backward()
+    close(s.grad.cpu(), f.g["s"], **GRAD)
+    close(v.grad.cpu(), f.g["v"], **GRAD)
+    for k, p in mod.named_parameters():
+        if "w." + k in f.g:
+            close(p.grad.cpu(), f.g["w." + k], **GRAD)
+
+
+@pytest.mark.parametrize("name", ["interactions_masked", "interactions_masked_posupd", "interactions_masked_all",
+                                  "interactions_autoregressive"])
+def test_interactions_masked_and_autoregressive_golden(G, name):
+    """GCPInteractions with node_mask (sub-graph feed-forward, reference gcpnet.py:1201-1251) and autoregressive_forward
+    (:1066-1116): outputs and every gradient against the reference's."""
+    f = Fixture(name)
+    auto = name == "interactions_autoregressive"
+    upd = name == "interactions_masked_posupd"
+    pre_norm = bool(int(f.m["pre_norm"])) if "pre_norm" in f.m else False
+    layer = G.GCPInteractions((32, 8), (16, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(pre_norm=pre_norm),
+                              dropout=0.0, autoregressive=auto, updating_node_positions=upd).cuda().eval()
+    layer.load_state_dict(f.p)
+    keys = ("h", "chi", "e", "xi") + (("h_reg", "chi_reg") if auto else ())
+    ins = {k: f.i[k].cuda().requires_grad_() for k in keys}
+    ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
+    kw = {}
+    if "mask" in f.i:
+        kw["node_mask"] = f.i["mask"].bool().cuda()
+    if auto:
+        kw["node_rep_regressive"] = (ins["h_reg"], ins["chi_reg"])
+    if upd:
+        (h, chi), x = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, node_pos=f.i["x"].cuda(), **kw)
+        outs = dict(h=h, chi=chi, x=x)
+    else:
+        h, chi = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, **kw)
+        outs = dict(h=h, chi=chi)
+    for k, t in outs.items():
+        t = t.detach().cpu()
+        fin = torch.isfinite(f.o[k])
+        assert torch.equal(torch.isfinite(t), fin), k
+        close(t[fin], f.o[k][fin], atol=2e-5, rtol=2e-5)
+    if upd:
+        fin = torch.isfinite(outs["x"]).all(dim=1)
+        loss = sq_loss(outs["h"], outs["chi"], outs["x"][fin])
+    else:
+        loss = sq_loss(*outs.values())
+    loss.backward()
+    for k, t in ins.items():
+        close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=1e-3)
+    n = 0
+    for k, p in layer.named_parameters():
+        if "w." + k in f.g:
+            assert p.grad is not None, k
+            close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=1e-3)
+            n += 1
+    assert n > 50
+
+
+@pytest.mark.parametrize("name,res", [("mlp_decoder", False), ("mlp_decoder_residual", True)])
+def test_mlp_decoder_golden(G, name, res):
+    f = Fixture(name)
+    dec = G.GCPMLPDecoder(32, vocab_size=20, num_layers=3, residual_updates=res).cuda()
+    dec.load_state_dict(f.p)
+    h = f.i["h"].cuda().requires_grad_()
+    logits, logp = dec(h)
+    close(logits.detach().cpu(), f.o["logits"], **FWD)
+    close(logp.detach().cpu(), f.o["log_probs"], **FWD)
+    (sq_loss(logits) + (logp * f.i["lw"].cuda()).mean()).backward()
+    close(h.grad.cpu(), f.g["h"], **GRAD)
+    for k, p in dec.named_parameters():
+        close(p.grad.cpu(), f.g["w." + k], **GRAD)
+
+
 @pytest.mark.parametrize("rows,s", [(1, 4), (37, 128), (5000, 64), (9000, 260), (33, 1024)])
 def test_row_gate_vs_torch(G, rows, s):
     """Scalar message gate kernel (reference gcpnet.py:932-934) against the same formula in fp64 on the CPU."""

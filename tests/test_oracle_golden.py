@@ -165,6 +165,84 @@ def test_interactions(name):
             close(g, f.g[n], atol=5e-6, rtol=1e-3)
 
 
+def test_geometry_masked():
+    """node_mask branches of centralize / localize / scalarize / vectorize (components/__init__.py:177-193,229-264,294-300,346-357)."""
+    f = Fixture("geometry_masked")
+    i = f.i
+    m, ei = i["mask"].bool(), i["edge_index"]
+    fr = O.localize(i["x"], ei, node_mask=m)
+    assert torch.equal(torch.isinf(fr), torch.isinf(f.o["frames"]))
+    fin = torch.isfinite(f.o["frames"])
+    close(fr[fin], f.o["frames"][fin], **TOL)
+    cen, xc = O.centralize(i["x"], i["batch"], node_mask=m)
+    close(cen, f.o["centroid"], **TOL)
+    assert torch.equal(torch.isinf(xc), torch.isinf(f.o["x_centered"]))
+    close(xc[m], f.o["x_centered"][m], **TOL)
+    close(O.scalarize(i["vec_e"], ei, f.o["frames"], False, False, 96, node_mask=m), f.o["scalarize_edge"], **TOL)
+    close(O.scalarize(i["vec_n"], ei, f.o["frames"], True, True, 24, node_mask=m), f.o["scalarize_node"], **TOL)
+    close(O.vectorize(i["gate_e"], ei, f.o["frames"], False, 96, node_mask=m), f.o["vectorize_edge"], **TOL)
+    close(O.vectorize(i["gate_n"], ei, f.o["frames"], True, 24, node_mask=m), f.o["vectorize_node"], **TOL)
+
+
+def test_gcp2_masked_node():
+    f = Fixture("gcp2_masked_node")
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    s, v = f.i["s"].clone().requires_grad_(), f.i["v"].clone().requires_grad_()
+    out = O.gcp2(P, "", s, v, f.i["edge_index"], f.i["frames"], node_inputs=True, nonlinearities=("silu", "sigmoid"),
+                 node_mask=f.i["mask"].bool())
+    close(out[0], f.o["s"], **TOL)
+    close(out[1], f.o["v"], **TOL)
+    names = ["s", "v"] + ["w." + k for k in P]
+    for n, g in zip(names, _grads(sq_loss(*out), [s, v] + list(P.values()))):
+        if n in f.g:
+            close(g, f.g[n], atol=2e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["interactions_masked", "interactions_masked_posupd", "interactions_masked_all",
+                                  "interactions_autoregressive"])
+def test_interactions_masked_and_autoregressive(name):
+    """GCPInteractions with node_mask (sub-graph feed-forward, gcpnet.py:1201-1251) and autoregressive_forward (:1066-1116)."""
+    f = Fixture(name)
+    i = f.i
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    keys = ("h", "chi", "e", "xi") + (("h_reg", "chi_reg") if name == "interactions_autoregressive" else ())
+    ins = {k: i[k].clone().requires_grad_() for k in keys}
+    cfg = O.default_module_cfg()
+    lc = O.default_layer_cfg(pre_norm=bool(int(f.m["pre_norm"]))) if "pre_norm" in f.m else O.default_layer_cfg()
+    upd = name == "interactions_masked_posupd"
+    mask = i["mask"].bool() if "mask" in i else None
+    reg = (ins["h_reg"], ins["chi_reg"]) if name == "interactions_autoregressive" else None
+    out = O.gcp_interactions(P, "", ins["h"], ins["chi"], ins["e"], ins["xi"], i["edge_index"], i["frames"], cfg, lc,
+                             node_pos=i["x"] if upd else None, node_mask=mask, regressive=reg)
+    outs = dict(h=out[0][0], chi=out[0][1], x=out[1]) if upd else dict(h=out[0], chi=out[1])
+    for k, t in outs.items():
+        fin = torch.isfinite(f.o[k])
+        assert torch.equal(torch.isfinite(t), fin), k
+        close(t[fin], f.o[k][fin], atol=5e-6, rtol=5e-5)
+    if upd:
+        fin = torch.isfinite(outs["x"]).all(dim=1)
+        loss = sq_loss(outs["h"], outs["chi"], outs["x"][fin])
+    else:
+        loss = sq_loss(*outs.values())
+    names = list(ins) + ["w." + k for k in P]
+    for n, g in zip(names, _grads(loss, list(ins.values()) + list(P.values()))):
+        if n in f.g:
+            close(g, f.g[n], atol=5e-6, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name,res", [("mlp_decoder", False), ("mlp_decoder_residual", True)])
+def test_mlp_decoder(name, res):
+    f = Fixture(name)
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    h = f.i["h"].clone().requires_grad_()
+    logits, logp = O.mlp_decoder(P, "", h, residual_updates=res)
+    close(logits, f.o["logits"], **TOL)
+    close(logp, f.o["log_probs"], **TOL)
+    loss = sq_loss(logits) + (logp * f.i["lw"]).mean()
+    for n, g in zip(["h"] + ["w." + k for k in P], _grads(loss, [h] + list(P.values()))):
+        close(g, f.g[n], atol=2e-6, rtol=1e-4)
+
+
 INTERACTIONS2 = {  # GCPInteractions2 as gcpnet_eq.yaml builds it (GCP3, gate, sum over row, 1 FF GCP); 2-FF variant + positions
     "interactions2_eq": dict(use_scalar_message_attention=True, aggregate_with_row=True, num_feedforward_layers=1),
     "interactions2_posupd": dict(use_scalar_message_attention=True, num_message_layers=4, num_feedforward_layers=2),
