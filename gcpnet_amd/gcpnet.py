@@ -889,12 +889,7 @@ class GCPMLPDecoder(nn.Module):
 
     @staticmethod
     def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
-        out = layer.out_features
-        pad = (-out) % 4
-        if not pad:
-            return ops.linear(x, layer.weight, layer.bias)
-        w = torch.nn.functional.pad(layer.weight, (0, 0, 0, pad))
-        return ops.linear(x, w, torch.nn.functional.pad(layer.bias, (0, pad)))[:, :out]
+        return ops.linear_padded(x, layer.weight, layer.bias)
 
     def residual_forward(self, h: torch.Tensor) -> torch.Tensor:
         x = h

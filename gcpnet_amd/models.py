@@ -99,7 +99,8 @@ class GCPNetLBA(nn.Module):
                 sigma_frame_gate=module_cfg.sigma_frame_gate, vector_frame_residual=module_cfg.vector_frame_residual,
                 ablate_frame_updates=module_cfg.ablate_frame_updates,
                 enable_e3_equivariance=module_cfg.enable_e3_equivariance, node_inputs=True)])
-        # readout head: a [num_graphs, s] -> [num_graphs, 1] MLP, host glue
+        # readout head, [num_graphs, s] -> [num_graphs, output_dim] (gcpnet_lba_module.py:104-109): the modules hold the
+        # parameters (reference state_dict keys dense.0.* / dense.3.*); `_readout_head` runs them on the HIP kernels
         self.dense = nn.Sequential(
             nn.Linear(self.node_dims.scalar, self.node_dims.scalar * model_cfg.output_scale_factor), nn.ReLU(inplace=True),
             nn.Dropout(model_cfg.dense_dropout),
@@ -116,8 +117,18 @@ class GCPNetLBA(nn.Module):
         out = self.invariant_node_projection[0]((h, chi))
         out = self.invariant_node_projection[1](out, batch.edge_index, batch.f_ij, node_inputs=True)
         out = ops.segment_reduce(out, GatherPlan.get(batch.batch), mean=True)  # scatter(..., reduce="mean"), dim_size = max + 1
-        out = self.dense(out).squeeze()
+        out = self._readout_head(out).squeeze()
         return batch, out
+
+    def _readout_head(self, x: torch.Tensor) -> torch.Tensor:
+        """dense = Linear -> ReLU -> Dropout -> Linear (gcpnet_lba_module.py:104-109, applied at :184) behind the graph mean
+        (segment_reduce above): both Linears on the workgroup GEMM kernel, ReLU and (train mode) dropout as HIP launches -- no
+        vendor-library GEMM or ATen kernel in the readout."""
+        l0, drop, l1 = self.dense[0], self.dense[2], self.dense[3]
+        y = ops.activation(ops.linear_padded(x, l0.weight, l0.bias), "relu", 0.0)
+        if self.training and drop.p > 0:
+            y = ops.dropout(y, drop.p, group=1)
+        return ops.linear_padded(y, l1.weight, l1.bias)
 
     def step(self, batch: Any):
         labels = batch.label

@@ -1470,6 +1470,17 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return _Linear.apply(_req(x, "x"), _req(weight, "weight"), _req(bias, "bias"))
 
 
+def linear_padded(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    """`linear` for any output width: widths that are not multiples of 4 (a 1-wide regression head, a 20-wide vocabulary is
+    fine) are padded with zero rows for the launch and sliced back."""
+    out = weight.shape[0]
+    pad = (-out) % 4
+    if not pad:
+        return linear(x, weight, bias)
+    w = torch.nn.functional.pad(weight, (0, 0, 0, pad))
+    return linear(x, w, torch.nn.functional.pad(bias, (0, pad)))[:, :out]
+
+
 class _Activation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act, slope):
