@@ -1,5 +1,5 @@
 """Zero-edit switch for the reference tree: `install_aliases()` makes the reference's own dotted names --
-`src.models.components.gcpnet.{GCP2, GCP3, GCPEmbedding, GCPMessagePassing, GCPInteractions, GCPInteractions2,
+`src.models.components.gcpnet.{GCP, GCP2, GCP3, GCPMLPDecoder, GCPEmbedding, GCPMessagePassing, GCPInteractions, GCPInteractions2,
 get_GCP_with_custom_cfg}` and `src.models.components.{ScalarVector, GCPLayerNorm, GCPDropout, VectorDropout, centralize,
 decentralize, localize}` -- resolve to this package, so that neither the Hydra `_target_` strings
 (configs/model/gcpnet_nms.yaml:3-6, module_cfg/gcp_module_nms.yaml:1-4) nor the LitModules' import lines
@@ -15,7 +15,7 @@ import importlib
 import sys
 import types
 
-GCPNET_NAMES = ("GCP2", "GCP3", "GCPEmbedding", "GCPMessagePassing", "GCPInteractions", "GCPInteractions2", "get_GCP_with_custom_cfg")
+GCPNET_NAMES = ("GCP", "GCP2", "GCP3", "GCPMLPDecoder", "GCPEmbedding", "GCPMessagePassing", "GCPInteractions", "GCPInteractions2", "get_GCP_with_custom_cfg")
 COMPONENT_NAMES = ("ScalarVector", "GCPLayerNorm", "GCPDropout", "VectorDropout", "centralize", "decentralize", "localize")
 
 

@@ -11,6 +11,8 @@
 //             staging tile as full 64-byte row pieces                                                           -> barrier B2
 //   epilogue (VALU, thread = (row, output channel)): vector_up, gate = sigmoid(sum of partials), gating, residual; the
 //             wave's slice of the new scalar state goes back to X                                              -> barrier B3
+#include <cstdlib>
+
 #include "gcp_wg.h"
 
 namespace {
@@ -51,7 +53,48 @@ struct WgFwdParams {
 
 
 
-template <int NW, int MT, bool PWL>
+// Compile-time shapes (template parameter SHP; 0 = run-time shape): a launch of n > 1 IDENTICAL residual message GCPs
+// (s, V) -> (s, V) with frames and a scalar gate -- the ResGCP chain of BASELINE configs[1] (128, 16, hidden 4) and configs[4]
+// (256, 32, hidden 8).  One constexpr function gives every integer of such a launch; the host takes the instantiation only when the
+// parameters it computed the general way are exactly these (wg_fwd_is_shape), and in the kernel they fold into immediates.
+#define WG_FWD_DIMS(X) X(so) X(vo) X(nf) X(NT) X(NG) X(KS) X(VS) X(HS) X(GS) X(o_x) X(o_v) X(o_vh) X(o_fr) X(o_ws) X(o_st) X(ws_floats) X(st_floats)
+#define WG_FWD_BLK_DIMS(X) X(si) X(vi) X(H) X(K) X(KG)
+struct WgFwdDims {
+#define X(f) int f;
+    WG_FWD_DIMS(X)
+    WG_FWD_BLK_DIMS(X)
+#undef X
+    int lds_floats;
+};
+constexpr int cf_cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int cf_rup(int x, int m) { return (x + m - 1) / m * m; }
+constexpr int cf_max(int a, int b) { return a > b ? a : b; }
+constexpr int cf_stride(int width) { return 4 * (cf_cdiv(width, 4) | 1); }  // == wg_stride
+constexpr WgFwdDims wg_fwd_dims(int S, int V, int HID, int NW, int MT) {
+    WgFwdDims d{};
+    d.so = S; d.vo = V; d.nf = 9; d.si = S; d.vi = V; d.H = HID;
+    d.K = S + HID + 9; d.KG = cf_cdiv(d.K, 8);
+    d.NT = cf_cdiv(S, 32); d.NG = cf_cdiv(d.NT, NW * MT);
+    const int kmax = cf_max(8 * d.KG, cf_rup(S, 4));
+    d.KS = cf_stride(kmax); d.VS = cf_stride(3 * V); d.HS = cf_stride(3 * cf_max(HID, 1)); d.GS = cf_stride(cf_rup(cf_max(V, 1), 8));
+    const int HF = HID + 3;
+    d.ws_floats = cf_rup(cf_rup(HF * cf_stride(V) + V * cf_stride(cf_max(HID, 1)) + V, 4) + cf_rup(S, 4), 4);
+    int off = 0;
+    d.o_x = off; off += 32 * d.KS;
+    d.st_floats = cf_max(WG_STAGE_FLOATS, 32 * d.GS);
+    d.o_st = off; off += NW * d.st_floats;
+    d.o_ws = off; off += 2 * d.ws_floats;
+    d.o_v = off; off += cf_rup(32 * d.VS, 4);
+    d.o_vh = off; off += cf_rup(32 * d.HS, 4);
+    d.o_fr = off; off += 32 * 9;
+    d.lds_floats = off;
+    return d;
+}
+template <int SHP> struct WgFwdShape { static constexpr int S = 0, V = 0, HID = 0; };
+template <> struct WgFwdShape<1> { static constexpr int S = 128, V = 16, HID = 4; };
+template <> struct WgFwdShape<2> { static constexpr int S = 256, V = 32, HID = 8; };
+
+template <int NW, int MT, bool PWL, int SHP>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32, U = 4 / MT;
@@ -61,6 +104,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     typedef const __attribute__((address_space(4))) WgFwdParams* Karg;
     Karg kp = (Karg)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*(const WgFwdParams*)kp)
+    constexpr WgFwdDims CF = wg_fwd_dims(WgFwdShape<SHP>::S, WgFwdShape<SHP>::V, WgFwdShape<SHP>::HID, NW, MT);
+#define DM(f) (SHP ? CF.f : p.f)       // a launch-wide shape value: immediate for the compile-time shapes
+#define DB(blk, f) (SHP ? CF.f : (blk).f)  // a per-block one
     int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63, e = lane & 31, hi = lane >> 5;
@@ -74,11 +120,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     do {                                                                                                                 \
         rows = p.rows;                                                                                                   \
         nvalid = min(32, rows - r0);                                                                                     \
-        X = lds + p.o_x; V = lds + p.o_v; VH = lds + p.o_vh; FR = lds + p.o_fr;                                          \
-        ST = lds + p.o_st + w * p.st_floats; /* wave-private staging tile; waves 0..3: also their gate-partial slot */   \
-        KS = p.KS; VS = p.VS; HS = p.HS; GS = p.GS;                                                                      \
-        so = p.so; vo = p.vo; nf = p.nf; NT = p.NT;                                                                      \
-        scalar_gate = p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0;                                                        \
+        X = lds + DM(o_x); V = lds + DM(o_v); VH = lds + DM(o_vh); FR = lds + DM(o_fr);                                  \
+        ST = lds + DM(o_st) + w * DM(st_floats); /* wave-private staging tile; waves 0..3: also their gate-partial slot */ \
+        KS = DM(KS); VS = DM(VS); HS = DM(HS); GS = DM(GS);                                                              \
+        so = DM(so); vo = DM(vo); nf = DM(nf); NT = DM(NT);                                                              \
+        scalar_gate = SHP ? true : (p.vmode == GCP_VMODE_SCALAR_GATE && vo > 0);                                         \
         slope = p.slope;                                                                                                 \
     } while (0)
     // per-lane addresses are invariant over the block loop as well: hipcc hoists them out of it and spills them; laundering
@@ -96,7 +142,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     constexpr int WSR = 4;
     float wsr[WSR];
     auto ws_src = [&](const WgBlk& B, int i, int& dst) -> const float* {  // flat index over [down ; frames | up | gate bias]
-        const int H = B.H, vi = B.vi, HF = H + (nf ? 3 : 0), WSV = wg_stride(vi), WSU = wg_stride(H);
+        const int H = DB(B, H), vi = DB(B, vi), HF = H + (nf ? 3 : 0), WSV = wg_stride(vi), WSU = wg_stride(H);
         const int n1 = HF * vi, n2 = n1 + vo * H;
         if (i < n1) {
             const int x = i / vi, c = i - x * vi;
@@ -116,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         dst = gcp_round_up(HF * WSV + vo * WSU + vo, 4) + (i - n3);
         return B.b_scalar + (i - n3);
     };
-    auto ws_count = [&](const WgBlk& B) { return (B.H + (nf ? 3 : 0)) * B.vi + vo * B.H + (scalar_gate ? vo : 0) + so; };
+    auto ws_count = [&](const WgBlk& B) { return (DB(B, H) + (nf ? 3 : 0)) * DB(B, vi) + vo * DB(B, H) + (scalar_gate ? vo : 0) + so; };
     auto ws_request = [&](int b) {
         const WgBlk& B = p.blk[b];
         const int n = ws_count(B);
@@ -128,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     };
     auto ws_commit = [&](int b) {
         const WgBlk& B = p.blk[b];
-        float* ws = lds + p.o_ws + (b & 1) * p.ws_floats;
+        float* ws = lds + DM(o_ws) + (b & 1) * DM(ws_floats);
         const int n = ws_count(B);
 #pragma unroll
         for (int k = 0; k < WSR; ++k) {
@@ -147,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     // ---- the tile: scalars -> X[:, 0:si0), vectors -> V, frames -> FR (flat, coalesced copies: tile rows are contiguous) ----
     {
         const WgBlk& B0 = p.blk[0];
-        const int si0 = B0.si, vw = 3 * B0.vi;
+        const int si0 = DB(B0, si), vw = 3 * DB(B0, vi);
         const float* src = p.s_in + (int64_t)r0 * si0;
         if ((si0 & 3) == 0 && wg_aligned16(p.s_in)) {
             const int q = si0 >> 2, n4 = nvalid * q;
@@ -204,12 +250,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
 #define RB_LAUNDER()                                                                                                     \
     do {                                                                                                                 \
         WG_LAUNDER();                                                                                                    \
-        ws = lds + p.o_ws + (b & 1) * p.ws_floats;                                                                       \
-        H = B.H; vi = B.vi; si = B.si; HF = H + (nf ? 3 : 0); WSV = wg_stride(vi); WSU = wg_stride(H);                   \
+        ws = lds + DM(o_ws) + (b & 1) * DM(ws_floats);                                                                   \
+        H = DB(B, H); vi = DB(B, vi); si = DB(B, si); HF = H + (nf ? 3 : 0); WSV = wg_stride(vi); WSU = wg_stride(H);    \
         wu = ws + HF * WSV;                                                                                              \
         bg = wu + vo * WSU;                                                                                              \
         bs = ws + gcp_round_up(HF * WSV + vo * WSU + vo, 4);                                                             \
-        KG = B.KG; K = B.K; KP = 8 * KG;                                                                                 \
+        KG = DB(B, KG); K = DB(B, K); KP = 8 * KG;                                                                       \
         ns_s = gcp_neg_slope(B.act_s, slope); ns_v = gcp_neg_slope(B.act_v, slope);                                      \
     } while (0)
 
@@ -284,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         float zero = 0.f;  // (laundered: hipcc otherwise hoists the zero-initialised accumulators above the VALU phases in
         asm volatile("" : "+v"(zero));  //  front of them and spills sixteen registers of zeros across each)
         bool gacc_set = false;
-        for (int og = 0; og < p.NG; ++og) {
+        for (int og = 0; og < DM(NG); ++og) {
             const int ot0 = og * NW * MT + w;
             if (ot0 >= NT) continue;  // (wave-uniform) nothing for this wave in this group
             int otc[MT];
@@ -468,7 +514,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 wg_barrier();
                 if (w >= 4)
                     for (int q = 0; 8 * q < vo; ++q) {
-                        float* gp = lds + p.o_st + (w - 4) * p.st_floats + e * GS + 8 * q + 4 * hi;
+                        float* gp = lds + DM(o_st) + (w - 4) * DM(st_floats) + e * GS + 8 * q + 4 * hi;
                         const f32x4 v = gp_quad(q);
                         f32x4 o = *reinterpret_cast<const f32x4*>(gp);
                         o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
@@ -505,7 +551,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                 if (scalar_gate) {
                     float s = bg[o];
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) s += lds[p.o_st + ww * p.st_floats + prow * GS + o];
+                    for (int ww = 0; ww < 4; ++ww) s += lds[DM(o_st) + ww * DM(st_floats) + prow * GS + o];
                     g = gcp_sigmoid(s);
                 }
                 float u0 = 0.f, u1 = 0.f, u2 = 0.f;
@@ -553,6 +599,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
 }
 #undef B
 #undef p
+#undef DM
+#undef DB
 #undef RB_LAUNDER
 #undef WG_RELOAD
 #undef WG_LAUNDER
@@ -609,7 +657,23 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view
     out[idx] = v;
 }
 
-template <int NW, int MT>
+template <int SHP, int NW, int MT>
+bool wg_fwd_is_shape(const WgFwdParams& p, size_t lds_bytes) {
+    constexpr WgFwdDims CF = wg_fwd_dims(WgFwdShape<SHP>::S, WgFwdShape<SHP>::V, WgFwdShape<SHP>::HID, NW, MT);
+    if (p.n < 2 || p.vmode != GCP_VMODE_SCALAR_GATE || lds_bytes != (size_t)CF.lds_floats * sizeof(float)) return false;
+    bool same = true;
+#define X(f) same = same && p.f == CF.f;
+    WG_FWD_DIMS(X)
+#undef X
+    for (int b = 0; b < p.n; ++b) {
+#define X(f) same = same && p.blk[b].f == CF.f;
+        WG_FWD_BLK_DIMS(X)
+#undef X
+    }
+    return same;
+}
+
+template <int NW, int MT, int SHP = 0>
 int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st) {
     auto go = [&](auto kern) -> int {
         if (lds_bytes > 64 * 1024) {
@@ -620,7 +684,8 @@ int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st)
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     };
-    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true>) : go(gcp_wg_fwd_kernel<NW, MT, false>);
+    if constexpr (SHP != 0) return go(gcp_wg_fwd_kernel<NW, MT, true, SHP>);  // (compile-time shapes: PWL activations only)
+    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true, 0>) : go(gcp_wg_fwd_kernel<NW, MT, false, 0>);
 }
 
 }  // namespace
@@ -748,6 +813,10 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
+    if (pwl && !getenv("GCPNET_WG_FWD_NOSHAPE")) {
+        if (NW == 4 && wg_fwd_is_shape<1, 4, 1>(p, lds_bytes)) return launch_fwd<4, 1, 1>(p, pwl, lds_bytes, st);
+        if (NW == 8 && MT == 1 && wg_fwd_is_shape<2, 8, 1>(p, lds_bytes)) return launch_fwd<8, 1, 2>(p, pwl, lds_bytes, st);
+    }
     if (NW == 4) return launch_fwd<4, 1>(p, pwl, lds_bytes, st);
     if (MT == 1) return launch_fwd<8, 1>(p, pwl, lds_bytes, st);
     return launch_fwd<8, 2>(p, pwl, lds_bytes, st);
