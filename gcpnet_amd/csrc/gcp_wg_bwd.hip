@@ -391,8 +391,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 }
             }
         }
-        wg_barrier();
-        if constexpr (!FUSED) {
+        // P2 reads, of what P1 wrote, only the vh rows of its own thread's row -- threads of a row sit in one wave (row = tid / TPR):
+        // a wave-level LDS sync suffices unless the extras tile leaves for HBM here (not fused)
+        if constexpr (FUSED) {
+            gcp_wave_lds_sync();
+        } else {
+            wg_barrier();
             if (p.ext) wg_tile_store<NTH>(p.ext + (int64_t)r0 * EP, DEXT, EXS, EP, nvalid, tid, wg_aligned16(p.ext), DM(mg_ep));
         }
 
@@ -505,6 +509,48 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                         if (r < nvalid && c < so) *reinterpret_cast<f32x4*>(p.ds_pre + (int64_t)(r0 + r) * so + c) = wv[j];
                     }
                 }
+            }
+            if constexpr (FUSED) {
+                // ---- (P6) dWg[vo][own 32 columns of so] += dgate^T act_v(s_pre): reduction over the tile's rows.  The B operand is
+                //      the transposed act_v(s_pre) tile: through the wave-private staging tile, 16 columns at a time (no workgroup
+                //      barrier, no second pass over DS) ---------------------------------------------------------------------------
+                if (gated) {
+                    float bt[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        gcp_wave_lds_sync();
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const f32x4 v = {spa[8 * h + 4 * q], spa[8 * h + 4 * q + 1], spa[8 * h + 4 * q + 2], spa[8 * h + 4 * q + 3]};
+                            *reinterpret_cast<f32x4*>(ST + e * 20 + 8 * q + 4 * hi) = v;
+                        }
+                        gcp_wave_lds_sync();
+                        const float* sb = ST + hi * 20 + (e & 15);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float x = sb[2 * j * 20];
+                            bt[j] = (e >> 4) == h ? x : bt[j];
+                        }
+                    }
+                    const float* ga = DG + hi * DGS + min(e, DGS - 1);
+                    float at[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) at[j] = ga[2 * j * DGS];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) dWg = __builtin_amdgcn_mfma_f32_32x32x2f32(e < vo ? at[j] : 0.f, bt[j], dWg, 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (FUSED) {
+            if (gated && tid < 8 * vo) {  // gate bias gradient: column sums of dgate, 8 threads (4 rows each) per channel
+                const int o = tid >> 3, part = tid & 7;
+                float sacc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sacc += DG[(4 * part + k) * DGS + o];
+                sacc += __shfl_xor(sacc, 1);
+                sacc += __shfl_xor(sacc, 2);
+                sacc += __shfl_xor(sacc, 4);
+                dbg += sacc;
             }
         }
         wg_barrier();
@@ -657,38 +703,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                         if (n < NNT) dW[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[n], dW[n], 0, 0, 0);
                 }
             }
-            // ---- P6: dWg[vo][own 32 columns of so] += dgate^T act_v(s_pre) -------------------------------------------------
-            if (gated) {
-                wg_barrier();  // everybody is done with ds_pre in DS
-                if (w < NT) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = {spa[4 * q], spa[4 * q + 1], spa[4 * q + 2], spa[4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * w + 8 * q + 4 * hi) = v;
-                    }
-                }
-                wg_barrier();
-                if (w < NT) {
-                    const float* ga = DG + hi * DGS + min(e, DGS - 1);
-                    const float* sb = DS + hi * DSS + 32 * w + e;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float a = e < vo ? ga[2 * j * DGS] : 0.f;
-                        const float b = sb[2 * j * DSS];
-                        dWg = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dWg, 0, 0, 0);
-                    }
-                }
-                if (tid < 8 * vo) {  // gate bias gradient: column sums of dgate, 8 threads (4 rows each) per channel
-                    const int o = tid >> 3, part = tid & 7;
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sacc += DG[(4 * part + k) * DGS + o];
-                    sacc += __shfl_xor(sacc, 1);
-                    sacc += __shfl_xor(sacc, 2);
-                    sacc += __shfl_xor(sacc, 4);
-                    dbg += sacc;
-                }
-            }
         }
 
         stamp(6);
@@ -777,9 +791,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             const float* wt = WDT + c * WTV;
             const float* dq = DVHF + prow * FS;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            for (int x = 0; x < HF; ++x) {
-                const float wv = wt[x];
-                a0 = fmaf(wv, dq[3 * x + 0], a0); a1 = fmaf(wv, dq[3 * x + 1], a1); a2 = fmaf(wv, dq[3 * x + 2], a2);
+            // four hidden channels per step, 16-byte LDS reads (both rows are 16-byte aligned: WTV, FS are multiples of 4 floats;
+            // a last partial group reads past the row's entries, inside the LDS allocation, and does not use them)
+            for (int x0 = 0; x0 < HF; x0 += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + x0);
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(dq + 3 * x0);
+                const f32x4 qb = *reinterpret_cast<const f32x4*>(dq + 3 * x0 + 4);
+                const f32x4 qc = *reinterpret_cast<const f32x4*>(dq + 3 * x0 + 8);
+                a0 = fmaf(wv[0], qa[0], a0); a1 = fmaf(wv[0], qa[1], a1); a2 = fmaf(wv[0], qa[2], a2);
+                if (x0 + 1 < HF) { a0 = fmaf(wv[1], qa[3], a0); a1 = fmaf(wv[1], qb[0], a1); a2 = fmaf(wv[1], qb[1], a2); }
+                if (x0 + 2 < HF) { a0 = fmaf(wv[2], qb[2], a0); a1 = fmaf(wv[2], qb[3], a1); a2 = fmaf(wv[2], qc[0], a2); }
+                if (x0 + 3 < HF) { a0 = fmaf(wv[3], qc[1], a0); a1 = fmaf(wv[3], qc[2], a1); a2 = fmaf(wv[3], qc[3], a2); }
             }
             if (p.vres && vo > 0) { a0 += DVU[prow * US + 3 * c + 0]; a1 += DVU[prow * US + 3 * c + 1]; a2 += DVU[prow * US + 3 * c + 2]; }
             if (prow < nvalid) {

@@ -565,12 +565,12 @@ class _Gcp2(torch.autograd.Function):
             d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
         si, vi = spec.si, spec.vi
         need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:2 + n_s + n_v + 9]
+        side = ctx.w_leaf and _side_stream_ok(ctx.weights)
         d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
-                                                 d_v_out, need_w=any(need_w), vadds=vadds)
+                                                 d_v_out, need_w=any(need_w), vadds=vadds, side_reduce=side)
         wgrads = [None] * 7
         if any(need_w):
-            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr,
-                                       in_backward_of_leaves=ctx.w_leaf and _side_stream_ok(ctx.weights))
+            wgrads = gcp2_weight_grads(spec, rows, s_src, s_pre, scr, in_backward_of_leaves=side)
 
         # ---- input gradients: un-concatenate, scatter-add the gathered sources back to their rows -----------------
         grads_s: List[Optional[Tensor]] = []
@@ -678,14 +678,16 @@ def _vadd_concat(tables: Sequence[Tensor], plans: Sequence[Optional[GatherPlan]]
 
 
 def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out,
-                       need_w: bool = True, vadds: Sequence[Tensor] = ()):
-    """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs)."""
+                       need_w: bool = True, vadds: Sequence[Tensor] = (), side_reduce: bool = False):
+    """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs).
+    `side_reduce`: the weights are leaves whose gradients nothing reads before the end of the backward pass (_side_stream_ok): the
+    fused kernel's partial-sum reductions may then run on the weight-gradient stream."""
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=s_pre.device)
     si, vi, vo = spec.si, spec.vi, spec.vo
     if (USE_WG_KERNELS and USE_WG_BACKWARD and len(s_src) == 1 and spec.s_plans[0] is None and len(v_src) == 1
             and spec.v_plans[0] is None and vi > 0 and rows > 0):
-        res = _wg_backward(spec, rows, s_src[0], v_src[0], frames, w, s_pre, gate, d_s_out, d_v_out, need_w, vadds)
+        res = _wg_backward(spec, rows, s_src[0], v_src[0], frames, w, s_pre, gate, d_s_out, d_v_out, need_w, vadds, side_reduce)
         if res is not None:
             return res
     d_s_in = torch.empty((rows, si), **f32)
@@ -720,7 +722,8 @@ def _wg_backward_supported(spec: Gcp2Spec, rows: int, w) -> bool:
     return lib.gcpnet_wg_backward_plan(rows, C.byref(ws), C.byref(opts), 1, C.byref(plan)) == 0
 
 
-def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, d_s_out, d_v_out, need_w: bool, vadds):
+def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, d_s_out, d_v_out, need_w: bool, vadds,
+                 side_reduce: bool = False):
     """Backward of one block through the workgroup kernel (gcp_wg_bwd.hip).  Returns (d_s_in, d_v_in, scratch dict) like
     gcp2_backward_data, or None when the shape is outside that kernel.  In fused mode the scratch dict carries the finished
     weight gradients under "fused" (summed over the persistent workgroups' partials in a fixed order); otherwise the per-row
@@ -779,16 +782,27 @@ def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, 
     del wg_pack
     WG_STATS["bwd"] += 1
     if fused:
-        st = _stream()
         K = spec.K
         g: List[Optional[Tensor]] = [None] * 7
         g[0], g[1] = torch.empty((so, K), **f32), torch.empty((so,), **f32)
-        check(lib.gcpnet_wg_reduce(_p(dw_part), grid, so, plan.kw, K, _p(g[0]), _p(g[1]), st), "wg_reduce")
         if gated:
             g[5], g[6] = torch.empty((vo, so), **f32), torch.empty((vo,), **f32)
-            check(lib.gcpnet_wg_reduce(_p(dwg_part), grid, vo, so + 1, so, _p(g[5]), _p(g[6]), st), "wg_reduce")
         wv = torch.empty((plan.n_small,), **f32)
-        check(lib.gcpnet_wg_reduce(_p(t["w_part"]), grid, 1, plan.n_small, plan.n_small, _p(wv), None, st), "wg_reduce")
+        w_part = t["w_part"]
+        n_small, kw = plan.n_small, plan.kw
+
+        def reduces():  # per-workgroup partial sums -> gradients, fixed order (three small HBM-bound launches)
+            st = _stream()
+            check(lib.gcpnet_wg_reduce(_p(dw_part), grid, so, kw, K, _p(g[0]), _p(g[1]), st), "wg_reduce")
+            if gated:
+                check(lib.gcpnet_wg_reduce(_p(dwg_part), grid, vo, so + 1, so, _p(g[5]), _p(g[6]), st), "wg_reduce")
+            check(lib.gcpnet_wg_reduce(_p(w_part), grid, 1, n_small, n_small, _p(wv), None, st), "wg_reduce")
+
+        if side_reduce and WEIGHT_GRADS_ON_SIDE_STREAM:
+            # off the critical path, like the TN GEMMs of the unfused route: they run under the next block's kernel
+            _side_submit(reduces, (dw_part, dwg_part, w_part, g, wv))
+        else:
+            reduces()
         o1, o2 = vo * H, vo * H + H * vi
         if vo:
             g[4] = wv[:o1].view(vo, H)
@@ -1072,11 +1086,12 @@ class _Gcp2Chain(torch.autograd.Function):
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k])
         else:
+            side = ctx.w_leaf and _side_stream_ok(ctx.weights)
             for k in range(n - 1, -1, -1):
                 s_in, v_in = ins[k]
                 _, _, s_pre, gate = outs[k]
                 d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s,
-                                                   d_v, need_w=nws[k])
+                                                   d_v, need_w=nws[k], side_reduce=side)
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
