@@ -96,6 +96,12 @@ struct GcpShape {
     int SVA, SVB, SVC, SVD;  // k-pair steps of the four products, CT = 32-wide tiles of vi
     int CT;
     int64_t offA, offB, offC, offD, offF, offVA, offVB, offVC, offVD, total;  // section offsets (floats) inside the packed image
+    // B6: the backward-data weights once more as THREE bf16 terms (w = h + m + l exactly, by truncation) in the operand layout of
+    // v_mfma_f32_32x32x16_bf16, for the chain backward kernel's fp32-exact product on the bf16 matrix pipe (gcp_bf16x3.h):
+    // [slab j < 2 NTG][tile uu < NKT of the merged axis][term][64 lanes][4 dwords of two bf16]; 0 floats when the block cannot
+    // run in that kernel
+    int NKT;
+    int64_t offB6;
 };
 
 __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, int H, int use_frames) {
@@ -131,7 +137,10 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.offVB = s.offVA + (s.vmm ? (int64_t)s.SVA * 64 : 0);
     s.offVC = s.offVB + (s.vmm ? (int64_t)s.SVB * 64 : 0);
     s.offVD = s.offVC + (s.vmm ? (int64_t)s.SVC * 64 : 0);
-    s.total = s.offVD + (s.vmm ? (int64_t)s.CT * s.SVD * 64 : 0);
+    s.offB6 = s.offVD + (s.vmm ? (int64_t)s.CT * s.SVD * 64 : 0);
+    s.NKT = gcp_cdiv(s.K, 32);
+    const bool chainable = s.NG == 1 && si == so && vi == vo && vi > 0 && si == 32 * s.NTG && s.NKT == s.NTG + 1;
+    s.total = s.offB6 + (chainable ? (int64_t)2 * s.NTG * s.NKT * 3 * 256 : 0);
     return s;
 }
 

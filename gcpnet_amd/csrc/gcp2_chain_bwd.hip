@@ -18,7 +18,9 @@
 #include "common.h"
 #include "tile_io.h"
 #include "vec_mfma.h"
+#include "gcp_bf16x3.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
@@ -132,7 +134,8 @@ __device__ __forceinline__ void gcp_load_gate(const float* __restrict__ gate, in
     for (int q = 0; q < VQ; ++q) { sg[4 * q] = g[q].x; sg[4 * q + 1] = g[q].y; sg[4 * q + 2] = g[q].z; sg[4 * q + 3] = g[q].w; }
 }
 
-template <int NTG, int VQ, bool PWL, int HC>
+// B6: W^T ds_pre on the bf16 matrix pipe, both operands as three bf16 terms, six products (gcp_bf16x3.h: exact to fp32 round-off)
+template <int NTG, int VQ, bool PWL, int HC, bool B6>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 4 * VQ;  // registers per xyz component of a vector-channel quantity
@@ -425,6 +428,47 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if constexpr (B6) {
+            // 2 NTG slabs of K = 16 (eight ds_pre registers each, split into three bf16 terms on the fly) x (NTG + 1) output tiles
+            // of the merged axis; one stage = (slab, tile) = three 16-byte weight fragments per lane and six MFMAs, fragments
+            // requested three stages ahead
+            constexpr int NKT = NTG + 1, NST = 2 * NTG * NKT;
+            const float* wq = it.pack + S.offB6 + (int64_t)lane * 4;
+            f32x16 accx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+            gcp_u32x4 A0[3], A1[3], A2[3];
+            auto ld = [&](gcp_u32x4(&a)[3], int sg) {
+                const float* q = wq + (int64_t)(sg < NST ? sg : NST - 1) * 768;
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
+            };
+            ld(A0, 0);
+            ld(A1, 1);
+            ld(A2, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            gcp_u32x4 bh, bm, bl;
+#pragma unroll
+            for (int sg = 0; sg < NST; ++sg) {
+                const int j = sg / NKT, uu = sg % NKT;
+                if (uu == 0) {
+                    float x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = spr[j / 2][8 * (j % 2) + i];
+                    gcp_bf16x3_split8(x, bh, bm, bl);
+                }
+                gcp_u32x4(&a)[3] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
+                if (uu < NTG) dyr[uu < NTG ? uu : 0] = gcp_mfma_bf16x6(a, bh, bm, bl, dyr[uu < NTG ? uu : 0]);
+                else accx = gcp_mfma_bf16x6(a, bh, bm, bl, accx);
+                if (sg + 3 < NST) ld(a, sg + 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = gcp_crow(r, hi);
+                if (x < H + S.nf) dext[e * L.DS + x] = accx[r];
+            }
+        } else {
         data_gemm(std::integral_constant<int, NTG>{}, it.pack + S.offB + (int64_t)lane * NUG, dyr);
         {  // the tile of the merged axis that holds the norms and frame scalars
             f32x16 accx[1];
@@ -436,6 +480,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 const int x = gcp_crow(r, hi);
                 if (x < H + S.nf) dext[e * L.DS + x] = accx[0][r];
             }
+        }
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         CB_LAUNDER();
@@ -534,14 +579,18 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 
 template <int NTG, int VQ, bool PWL>
 int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
+    // W^T ds_pre on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_BWD_FP32_MFMA is set (A/B switch: the
+    // fp32 MFMA form of the same product)
+    static const bool b6 = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
+    const dim3 grid((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS));
     if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4): hidden channel count known at compile time
-        hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)),
-                           dim3(GCP_WAVE), lds_bytes, st, p);
+        if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+        else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, false>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE),
-                       lds_bytes, st, p);
+    if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+    else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0, false>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "tile_io.h"
 #include "vec_mfma.h"
+#include "gcp_bf16x3.h"
 
 int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const float* frames, int n,
                              const gcp2_chain_item_t* items, hipStream_t st);
@@ -575,6 +576,22 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
         const int a = x / S.NS;
         const int o = 32 * a + (lane & 31), j = 32 * (st / 16) + gcp_crow(st % 16, lane >> 5);
         if (w.w_gate && o < S.vo && j < S.so) val = w.w_gate[(int64_t)o * S.so + j];
+    } else if (i >= S.offB6) {  // B6: backward-data weights as three bf16 terms, [slab][tile of K][term][64][4 x 2 bf16] (gcp_bf16x3.h)
+        int64_t x = i - S.offB6;
+        const int d = x % 4; x /= 4;
+        const int lane = x % 64; x /= 64;
+        const int term = x % 3; x /= 3;
+        const int uu = x % S.NKT;
+        const int j = (int)(x / S.NKT);
+        const int k = 32 * uu + (lane & 31);
+        unsigned bits = 0;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = 8 * (j & 1) + 2 * d + h2;  // accumulator register of tile j / 2 that is element 2 d + h2 of the slab
+            const int c = 32 * (j >> 1) + gcp_crow(r, lane >> 5);
+            const float wv = (c < S.so && k < S.K) ? w.w_scalar[(int64_t)c * S.K + k] : 0.f;
+            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+        }
+        val = __uint_as_float(bits);
     } else if (i >= S.offVA) {  // V: the small vector Linears as MFMA A fragments (vec_mfma.h), all [step][64]
         // Wdf = [vector_down ; vector_down_frames] is [HF, vi]; Wu = vector_up is [vo, H]
         auto wdf = [&](int x, int c) -> float {
