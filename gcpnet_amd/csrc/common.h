@@ -102,6 +102,10 @@ struct GcpShape {
     // run in that kernel
     int NKT;
     int64_t offB6;
+    // F6 / C6: the same three-term bf16 images of the forward scalar_out weights over a register-resident state
+    // ([slab j < 2 NTG][output tile t < NTG][term][64][4]) and of the gate Linear ([slab][term][64][4]), for the wave-per-tile
+    // chain forward kernel; 0 floats when the block cannot run there
+    int64_t offF6, offC6;
 };
 
 __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, int H, int use_frames) {
@@ -140,7 +144,10 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.offB6 = s.offVD + (s.vmm ? (int64_t)s.CT * s.SVD * 64 : 0);
     s.NKT = gcp_cdiv(s.K, 32);
     const bool chainable = s.NG == 1 && si == so && vi == vo && vi > 0 && si == 32 * s.NTG && s.NKT == s.NTG + 1;
-    s.total = s.offB6 + (chainable ? (int64_t)2 * s.NTG * s.NKT * 3 * 256 : 0);
+    s.offF6 = s.offB6 + (chainable ? (int64_t)2 * s.NTG * s.NKT * 3 * 256 : 0);
+    const bool fwd6 = s.NG == 1 && s.NTG >= 2 && s.NTS == s.NTG && s.GT == 1 && vi > 0 && vo > 0;
+    s.offC6 = s.offF6 + (fwd6 ? (int64_t)2 * s.NTG * s.NTG * 3 * 256 : 0);
+    s.total = s.offC6 + (fwd6 ? (int64_t)2 * s.NTG * 3 * 256 : 0);
     return s;
 }
 
@@ -149,6 +156,8 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
 #define GCP_MAX_STAMPS 8
 extern unsigned long long* g_gcp_phase_buf;  // host-side copy of the registered device pointer (graph_ops.hip)
 extern long long g_gcp_phase_cap;
+// gcpnet_debug_set_fp32_mfma: -1 = not set (each launcher's environment variable decides), 0 = bf16 x 6, 1 = fp32 MFMA
+extern int g_gcp_fp32_mfma;
 __device__ __forceinline__ void gcp_stamp(unsigned long long* buf, long long cap, int k, int lane) {
     if (buf && lane == 0 && (long long)blockIdx.x < cap) buf[(long long)blockIdx.x * GCP_MAX_STAMPS + k] = __builtin_amdgcn_s_memtime();
 }

@@ -579,9 +579,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 
 template <int NTG, int VQ, bool PWL>
 int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
-    // W^T ds_pre on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_BWD_FP32_MFMA is set (A/B switch: the
-    // fp32 MFMA form of the same product)
-    static const bool b6 = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
+    // W^T ds_pre on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_BWD_FP32_MFMA / gcpnet_debug_set_fp32_mfma select the
+    // fp32 MFMA form of the same product (A/B switch)
+    static const bool b6_env = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
+    const bool b6 = g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0;
     const dim3 grid((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS));
     if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4): hidden channel count known at compile time
         if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);

@@ -12,9 +12,12 @@
 // layout, and the H norms and 9 frame scalars -- the only inputs of scalar_out that are not state -- go through a 32 x 16 LDS
 // tile as ordinary B fragments.  ~17 KB of LDS per wave (vector tile, frames, extras tile, a 4.6 KB transposition tile for
 // full-line stores) lets two waves share a SIMD: one wave's VALU / LDS / store phases run under the other's MFMAs.
+#include <cstdlib>
+
 #include "common.h"
 #include "tile_io.h"
 #include "vec_mfma.h"
+#include "gcp_bf16x3.h"
 
 namespace {
 
@@ -112,9 +115,12 @@ __device__ __forceinline__ const HeadParams& head_of(const ChainParams& p) { ret
 
 // HEAD: a head block (HeadParams) runs first; ONLY: ... and nothing else (n == 0), so that the compiler sees one block shape.
 // HC: hidden vector channels of the chain blocks as a compile-time constant (0 = run-time; plain instantiations only).
-template <int NT, bool PWL, bool HEAD, bool ONLY = false, int HC = 0>
+// F6: scalar_out over the state and the gate Linear on the bf16 matrix pipe, both operands as three bf16 terms, six products
+// (gcp_bf16x3.h: exact to fp32 round-off); plain instantiations only.
+template <int NT, bool PWL, bool HEAD, bool ONLY = false, int HC = 0, bool F6 = false>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename ChainArg<HEAD>::type p) {
     static_assert(!(HEAD && HC), "the head block has its own shape");
+    static_assert(!(HEAD && F6), "the bf16 forms exist for the chain blocks");
     constexpr int NXR = HC ? 4 * ((HC + 3 + 7) / 8) : 16;  // registers that can hold a [vh | vf] channel
     constexpr int NVR = HC ? 8 : 16;  // registers that can hold an output vector channel (the HC instantiations: vo <= 16)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         // ---- scalar_out: acc = b + W[:, state] x^T + W[:, extras] ext^T --------------------------------------------------
         f32x16 gacc;     // vector-gate pre-activations (initialised with the bias while the extras tile is multiplied)
         float gwa[16];   // first batch of the gate GEMM's weight fragments
+        gcp_u32x4 G0[3], G1[3];  // (F6: the first two slabs' fragments)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gacc[r] = 0.f; gwa[r] = 0.f; }
         if constexpr (HEAD) load_bias();
@@ -297,7 +304,37 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         {
             const float* wf = it.pack + S.offF + (int64_t)lane * NT;  // [step][64][NT]
             constexpr int U = 4;
-            if (!head) {
+            if constexpr (F6) {
+                // 2 NT slabs of K = 16 (eight state registers each, split once per slab) x NT output tiles; one stage = three
+                // 16-byte weight fragments per lane and six MFMAs, fragments requested three stages ahead
+                constexpr int NSTG = 2 * NT * NT;
+                const float* wq = it.pack + S.offF6 + (int64_t)lane * 4;
+                gcp_u32x4 A0[3], A1[3], A2[3];
+                auto ld6 = [&](gcp_u32x4(&a)[3], int sg) {
+                    const float* q = wq + (int64_t)(sg < NSTG ? sg : NSTG - 1) * 768;
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
+                };
+                ld6(A0, 0);
+                ld6(A1, 1);
+                ld6(A2, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                gcp_u32x4 bh, bm, bl;
+#pragma unroll
+                for (int sg = 0; sg < NSTG; ++sg) {
+                    const int j2 = sg / NT, t = sg % NT;
+                    if (t == 0) {
+                        float x[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] = xs[j2 / 2][8 * (j2 % 2) + i];
+                        gcp_bf16x3_split8(x, bh, bm, bl);
+                    }
+                    gcp_u32x4(&a)[3] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
+                    acc[t] = gcp_mfma_bf16x6(a, bh, bm, bl, acc[t]);
+                    if (sg + 3 < NSTG) ld6(a, sg + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (!head) {
             WF<NT> A0[U], A1[U], A2[U];
             auto ld = [&](WF<NT>(&a)[U], int st0) {
 #pragma unroll
@@ -337,9 +374,17 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             // (the gate GEMM's first weight fragments and its bias are requested here, one phase ahead)
             if (scalar_gate) {
                 const float* wg0 = it.pack + B.offC + lane;
+                if constexpr (F6) {
+                    const float* q = it.pack + S.offC6 + (int64_t)lane * 4;
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm) {
+                        G0[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
+                        G1[tm] = *reinterpret_cast<const gcp_u32x4*>(q + 768 + tm * 256);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    gwa[r] = wg0[(int64_t)r * 64];
+                    if constexpr (!F6) gwa[r] = wg0[(int64_t)r * 64];
                     const float bg = it.b_gate[min(gcp_crow(r, hi), vo - 1)];  // unconditional (clamped) load, then select:
                     gacc[r] = gcp_crow(r, hi) < vo ? bg : 0.f;                   // a guarded load is waited for on the spot
                 }
@@ -371,7 +416,24 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
 #endif
         // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
-        if (scalar_gate) {
+        if (F6 && scalar_gate) {
+            const float* q6 = it.pack + S.offC6 + (int64_t)lane * 4;
+#pragma unroll
+            for (int j2 = 0; j2 < 2 * NT; ++j2) {
+                gcp_u32x4(&g)[3] = (j2 & 1) ? G1 : G0;
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = gcp_actf<PWL>(it.act_v, ns_v, slope, acc[j2 / 2][8 * (j2 % 2) + i]);
+                gcp_u32x4 bh, bm, bl;
+                gcp_bf16x3_split8(x, bh, bm, bl);
+                gacc = gcp_mfma_bf16x6(g, bh, bm, bl, gacc);
+                if (j2 + 2 < 2 * NT) {
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm) g[tm] = *reinterpret_cast<const gcp_u32x4*>(q6 + (int64_t)(j2 + 2) * 768 + tm * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (scalar_gate) {
             const float* wg = it.pack + B.offC + lane;
             float(&wa)[16] = gwa;
             float wb[16];
@@ -459,9 +521,18 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 template <int NT, bool PWL, bool HEAD = false, bool ONLY = false>
 int launch_chain(const typename ChainArg<HEAD>::type& p, size_t lds_bytes, hipStream_t st) {
     if constexpr (!HEAD) {
+        // scalar_out / gate Linear on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_FWD_FP32_MFMA is set
+        static const bool f6_env = getenv("GCPNET_CHAIN_FWD_FP32_MFMA") == nullptr;
+        const bool f6 = g_gcp_fp32_mfma < 0 ? f6_env : g_gcp_fp32_mfma == 0;
+        const dim3 grid((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS));
         if (p.sh.H == 4 && p.sh.nf && p.sh.vo <= 16) {  // the shipped shape (V = 16, bottleneck 4)
-            hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, false, false, 4>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)),
-                               dim3(GCP_WAVE), lds_bytes, st, p);
+            if (f6) hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, false, false, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+            else hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, false, false, 4, false>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+            GCP_HIP_CHECK_LAUNCH();
+            return 0;
+        }
+        if (f6) {
+            hipLaunchKernelGGL((gcp2_chain_fwd_kernel<NT, PWL, false, false, 0, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
             GCP_HIP_CHECK_LAUNCH();
             return 0;
         }

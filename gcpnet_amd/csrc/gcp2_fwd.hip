@@ -576,6 +576,25 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
         const int a = x / S.NS;
         const int o = 32 * a + (lane & 31), j = 32 * (st / 16) + gcp_crow(st % 16, lane >> 5);
         if (w.w_gate && o < S.vo && j < S.so) val = w.w_gate[(int64_t)o * S.so + j];
+    } else if (i >= S.offF6) {  // F6 / C6: forward weights over the register-resident state / gate Linear as three bf16 terms
+        const bool gate = i >= S.offC6;
+        int64_t x = i - (gate ? S.offC6 : S.offF6);
+        const int d = x % 4; x /= 4;
+        const int lane = x % 64; x /= 64;
+        const int term = x % 3; x /= 3;
+        const int t = gate ? 0 : (int)(x % S.NTG);
+        const int j = (int)(gate ? x : x / S.NTG);
+        const int orow = 32 * t + (lane & 31);  // output column of scalar_out / gate channel
+        unsigned bits = 0;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = 8 * (j & 1) + 2 * d + h2;
+            const int k = 32 * (j >> 1) + gcp_crow(r, lane >> 5);  // state column / s_pre column
+            float wv = 0.f;
+            if (gate) { if (w.w_gate && orow < S.vo && k < S.so) wv = w.w_gate[(int64_t)orow * S.so + k]; }
+            else if (orow < S.so && k < S.si) wv = w.w_scalar[(int64_t)orow * S.K + k];
+            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+        }
+        val = __uint_as_float(bits);
     } else if (i >= S.offB6) {  // B6: backward-data weights as three bf16 terms, [slab][tile of K][term][64][4 x 2 bf16] (gcp_bf16x3.h)
         int64_t x = i - S.offB6;
         const int d = x % 4; x /= 4;

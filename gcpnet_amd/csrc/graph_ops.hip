@@ -5,6 +5,7 @@
 #include "common.h"
 
 unsigned long long* g_gcp_phase_buf = nullptr;
+int g_gcp_fp32_mfma = -1;
 long long g_gcp_phase_cap = 0;
 
 namespace {
@@ -676,6 +677,12 @@ extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, floa
     hipLaunchKernelGGL(axpy_clamp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b, alpha, clamp, lo, hi, y);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gcpnet_debug_set_fp32_mfma(int on) {
+    const int prev = g_gcp_fp32_mfma;
+    g_gcp_fp32_mfma = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles) {

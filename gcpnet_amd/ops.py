@@ -5,6 +5,8 @@ PyTorch provides device allocations, the current stream and the autograd graph -
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass, field, replace
 from typing import List, Optional, Sequence, Tuple
@@ -434,6 +436,7 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
 USE_WG_KERNELS = True  # module switch: multi-wave workgroup kernels (gcp_wg_*.hip) where the shape fits, else the wave-per-tile ones
 USE_WG_BACKWARD = True  # (separately for the backward; both need USE_WG_KERNELS)
 PREFER_WG_CHAIN_BACKWARD = True  # chains wider than 128 scalars: block by block through the workgroup backward kernel
+PREFER_WAVE_CHAIN_FORWARD = os.environ.get("GCPNET_CHAIN_FWD", "wg") == "wave"  # experiment switch
 FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains the wave-per-tile chain kernel covers
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
@@ -1039,7 +1042,7 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].gate = gate.data_ptr() if gate is not None else None
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         rc = _lib.E_UNSUPPORTED
-        if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS:
+        if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS and not (PREFER_WAVE_CHAIN_FORWARD and specs[0].so <= 128):
             keep: list = []
             blks = (WgBlock * n)(*[_wg_block(spec, w, *outs[k], True, keep) for k, (spec, w) in enumerate(zip(specs, ws))])
             rc = lib.gcpnet_wg_forward(rows, _p(s0), _p(v0), _p(frames), None, None, n, blks, _stream())

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Profile passes of one round (run on the GPU box from the repo root): bench line, rocprofv3 kernel stats of the same command,
+# PMC passes (separate runs, no tracing).  usage: tools/profile_round.sh <tag>   -> gpurun_out/<tag>/
+set -u
+TAG=${1:-rXX}
+R=$PWD
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -- python $R/bench.py --no-cpu-baseline --no-c5-block > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_c5 -- python $R/bench.py --config c5 --steps 3 --warmup 1 --step-only > $OUT/c5_step.json 2> /dev/null
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 3 --warmup 1 --step-only > /dev/null 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python $R/bench.py --steps 3 --warmup 1 --step-only > /dev/null 2>&1
+cd $R
+find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
+# (the traces themselves are large: keep only the stats / counter tables)
+find $OUT -name "*kernel_trace.csv" -delete
