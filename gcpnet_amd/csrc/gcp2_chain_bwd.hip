@@ -255,14 +255,18 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             float f[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
+            const bool ext_staged = 32 * EP <= GCP_ACC_STAGE_HALF_FLOATS && gcp_aligned16(it.ext);  // (wave-uniform)
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
                 const int x = gcp_crow(r, hi);
                 const float u0 = u[0][r], u1 = u[1][r], u2 = u[2][r];
+                // norms / frame scalars of the tile: rows of EP floats, contiguous in memory over the tile's rows -- collected in
+                // the (idle) transposition tile and written below as full lines instead of EP scattered 4-byte stores per row
                 if (x < H) {
                     const float nr = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
                     vht[e * L.HS + 3 * x + 0] = u0; vht[e * L.HS + 3 * x + 1] = u1; vht[e * L.HS + 3 * x + 2] = u2;
-                    if (row_ok) it.ext[(int64_t)row * EP + x] = nr + 1e-8f;
+                    if (ext_staged) stage[e * EP + x] = nr + 1e-8f;
+                    else if (row_ok) it.ext[(int64_t)row * EP + x] = nr + 1e-8f;
                 } else if (x < HF) {
                     const int kk = x - H;
 #pragma unroll
@@ -272,14 +276,25 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                             e3t[e * 3 + kk] = pr < 0.f ? -1.f : 1.f;  // sign for the adjoint of |.|
                             pr = fabsf(pr);
                         }
-                        if (row_ok) it.ext[(int64_t)row * EP + H + 3 * kk + a] = pr;
+                        if (ext_staged) stage[e * EP + H + 3 * kk + a] = pr;
+                        else if (row_ok) it.ext[(int64_t)row * EP + H + 3 * kk + a] = pr;
                     }
                 }
             }
-            if (row_ok && hi == 0) {  // zero the stride padding
-                for (int c = H + S.nf; c < EP; ++c) it.ext[(int64_t)row * EP + c] = 0.f;
-                if (scalar_gate)
+            if (hi == 0) {  // zero the stride padding
+                for (int c = H + S.nf; c < EP; ++c) {
+                    if (ext_staged) stage[e * EP + c] = 0.f;
+                    else if (row_ok) it.ext[(int64_t)row * EP + c] = 0.f;
+                }
+                if (row_ok && scalar_gate)
                     for (int c = vi; c < VOP; ++c) it.dgate[(int64_t)row * VOP + c] = 0.f;
+            }
+            gcp_wave_lds_sync();
+            if (ext_staged) {
+                const int nval = min(GCP_TILE_ROWS, rows - r0) * EP;  // floats of the tile's valid rows (EP % 4 == 0)
+                float* dst = it.ext + (int64_t)r0 * EP;
+                for (int i = 4 * lane; i < nval; i += 4 * GCP_WAVE)
+                    *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(stage + i);
             }
             // ---- B. vu = vector_up(vh), B fragments = the registers just produced ------------------------------------
             gcp_xyz_acc vu;
