@@ -412,6 +412,11 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                 "traffic_source": PMC_FILE if pmc_traffic(dom) is not None else None,
+                "traffic_note": (_pmc_file().get(dom + "_parts") or {}).get("note"),
+                "arithmetic": ("fp32 results; the large products of the chain backward (W^T ds_pre) run on the bf16 matrix pipe with "
+                               "both operands split into three bf16 terms and six products kept, fp32 accumulation (error <= 3*2^-24 "
+                               "of sum|a b|: csrc/gcp_bf16x3.h, tests/test_bf16x3.py); every other product is v_mfma_f32_32x32x2_f32. "
+                               "`peak` stays the fp32 MFMA peak"),
                 "mfma_busy_frac_pmc": pmc_mfma_busy(dom),
                 "median_launch_ms": times[dom] * 1e3, "flop_per_launch": kr["flops"][dom],
                 "algorithmic_hbm_gbs": kbytes[dom] / times[dom] / 1e9,
