@@ -13,6 +13,7 @@
 // (column 8 q + 4 hi + i of row e), so accumulators feed the next GEMM without any data movement.
 #pragma once
 #include "common.h"
+#include "gcp_bf16x3.h"
 
 // (GCP_WG_MAX_BLOCKS = 9: head + 8 residual blocks, include/gcpnet_hip.h)
 
@@ -29,7 +30,10 @@ struct WgShape {
     int NKT;         // 32-wide tiles of K
     int VG;          // groups of 8 gate outputs
     int gated;
-    int64_t offA1, offG1, offA2, offG2, total;
+    // A2b [NKT][2 NT slabs][term][64][4 x 2 bf16]: section A2 once more as three bf16 terms per weight in the operand layout
+    // of v_mfma_f32_32x32x16_bf16 (gcp_bf16x3.h); element i' < 8 of lane (m, hi) in slab j is W[32 (j / 2) + 16 (j % 2) +
+    // 8 (i' / 4) + 4 hi + i' % 4][32 kt + m] -- the column set of eight consecutive accumulator registers
+    int64_t offA1, offG1, offA2, offG2, offA2b, total;
 };
 
 __host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int H, int use_frames, int gated) {
@@ -47,7 +51,8 @@ __host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int 
     s.offG1 = s.offA1 + (int64_t)s.NT * s.KG * 256;
     s.offA2 = s.offG1 + (s.gated ? (int64_t)4 * s.NT * 256 : 0);
     s.offG2 = s.offA2 + (int64_t)s.NKT * 4 * s.NT * 256;
-    s.total = s.offG2 + (s.gated ? (int64_t)s.NT * s.VG * 256 : 0);
+    s.offA2b = s.offG2 + (s.gated ? (int64_t)s.NT * s.VG * 256 : 0);
+    s.total = s.offA2b + (int64_t)s.NKT * 2 * s.NT * 3 * 256;
     return s;
 }
 

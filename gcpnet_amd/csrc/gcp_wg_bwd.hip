@@ -50,7 +50,8 @@ constexpr unsigned c_magic(int d) { return d > 1 ? (unsigned)(((1ull << 32) + (u
 
 // (si, vi, so, vo, hidden: as in gcp2_weights_t; gated: scalar gate in use; want_fused: the caller asked for fused weight
 // gradients; NW: waves per workgroup)
-constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int use_frames, int gated, int want_fused, int NW) {
+constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int use_frames, int gated, int want_fused, int NW,
+                                int b6 = 0) {
     WgBwdDims d{};
     d.si = si; d.vi = vi; d.so = so; d.vo = vo;
     d.H = vi > 0 ? hidden : 0;
@@ -88,7 +89,8 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     d.WSV = c_stride(vi); d.WTV = c_stride(d.HF); d.WSU = c_stride(c_max(d.H, 1)); d.WTU = c_stride(c_max(vo, 1));
     int off = 0;
     d.o_x = off; off += d.fused ? 32 * d.KS : 0;
-    d.o_ds = off; off += 32 * d.DSS;
+    // (b6: the ds_pre tile as three bf16 planes in MFMA operand order, [2 NT slabs][term][64 lanes][16 bytes], instead of fp32 rows)
+    d.o_ds = off; off += b6 ? c_max(32 * d.DSS, 2 * d.NT * 768) : 32 * d.DSS;
     d.o_epart = off; off += NW * 32 * d.EPS;
     d.o_v = off; off += 32 * d.VS;
     d.o_dvu = off; off += 32 * d.US;
@@ -133,7 +135,7 @@ struct WgBwdParams {
     float* d_s_in;
     float* d_v_in;
     const float* pk;
-    int64_t offA2, offG2;
+    int64_t offA2, offG2, offA2b;
     const float* w_down;
     const float* w_frames;
     const float* w_up;
@@ -163,8 +165,12 @@ constexpr int NSW = 2;  // 16 x 16 tiles of the small vector weight gradients pe
 
 // NW waves; KT = full K tiles per wave in P4; FN = 32-wide tiles of the fused weight gradient's K + 1 columns (0 = not fused);
 // SHP: compile-time shape (WgBwdShape), 0 = every dimension from the parameters
-template <int NW, int KT, int FN, bool PWL, int SHP>
+// B6 (not fused, KT == 1): P4 on the bf16 matrix pipe -- ds_pre is split into three bf16 terms where it is produced (P3, in
+// registers) and kept in LDS as operand-ordered planes, the weights come pre-split from section A2b; six products, fp32
+// accumulation (gcp_bf16x3.h: exact to fp32 round-off)
+template <int NW, int KT, int FN, bool PWL, int SHP, bool B6 = false>
 __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParams p_kernarg) {
+    static_assert(!B6 || (KT == 1 && FN == 0), "bf16 form: plain mode, one K tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32;
     constexpr bool FUSED = FN > 0;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
     int lane = tid & 63, e = lane & 31, hi = lane >> 5;
     int prow = tid / TPR, psub = tid - prow * TPR;
     constexpr WgBwdDims CD = wg_bwd_dims(WgBwdShape<SHP>::S, WgBwdShape<SHP>::V, WgBwdShape<SHP>::S, WgBwdShape<SHP>::V,
-                                         WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW);
+                                         WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW, B6);
 #define DM(f) (SHP ? CD.f : p.f)  // a shape value: immediate for the compile-time shapes
     int rows, KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, si, vi, so, vo, H, nf, K, HF, NT, SG, exs;
     int NKT, VG, split, LW, KW, NNT, EP, VOP, HFP, WSV, WSU, WTV, WTU, n_up, n_sm, sm_tiles, sm_up_tiles, sm_nu, sm_nd;
@@ -240,7 +246,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             wut[h * WTU + o] = v;
         }
         for (int i = tid; i < 32 * DGS; i += NTH) DG[i] = 0.f;
-        for (int i = tid; i < 32 * DSS; i += NTH) DS[i] = 0.f;
+        if constexpr (!B6)
+            for (int i = tid; i < 32 * DSS; i += NTH) DS[i] = 0.f;
     }
     // persistent accumulators
     f32x16 dW[FNR], dWg;
@@ -486,8 +493,22 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                     dsp[4 * q + i] = in ? d : 0.f;
                     spa[4 * q + i] = in ? gcp_actf<PWL>(p.act_v, ns_v, slope, sp) : 0.f;
                 }
-                const f32x4 v = {dsp[4 * q], dsp[4 * q + 1], dsp[4 * q + 2], dsp[4 * q + 3]};
-                *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * ot + 8 * q + 4 * hi) = v;
+                if constexpr (!B6) {
+                    const f32x4 v = {dsp[4 * q], dsp[4 * q + 1], dsp[4 * q + 2], dsp[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * ot + 8 * q + 4 * hi) = v;
+                }
+            }
+            if constexpr (B6) {  // the tile's two K = 16 slabs: eight registers each, split here, once for every wave's P4
+                gcp_u32x4* pl = reinterpret_cast<gcp_u32x4*>(DS) + (int64_t)(2 * ot) * 192 + lane;
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    float x8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x8[i] = dsp[8 * jh + i];
+                    gcp_u32x4 th, tm, tl;
+                    gcp_bf16x3_split8(x8, th, tm, tl);
+                    pl[jh * 192] = th; pl[jh * 192 + 64] = tm; pl[jh * 192 + 128] = tl;
+                }
             }
             if (p.ds_pre) {  // (head block: summed per source node afterwards; not fused: operand of gcpnet_tn_gemm)
                 const int sub = lane >> 2, c4 = 4 * (lane & 3);
@@ -577,6 +598,33 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 for (int j = 0; j < KT; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+                if constexpr (B6) {
+                    const int NSL = 2 * NT;  // slabs of the reduction over so
+                    const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)ktc[0] * NSL * 192 + lane;
+                    const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(DS) + lane;
+                    auto lda = [&](gcp_u32x4(&a)[3], int sj) {
+                        const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSL - 1) * 192;
+                        a[0] = q[0]; a[1] = q[64]; a[2] = q[128];
+                    };
+                    gcp_u32x4 a0[3], a1[3], a2[3], a3[3];
+                    lda(a0, 0); lda(a1, 1); lda(a2, 2); lda(a3, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    for (int sj = 0; sj < NSL; sj += 4) {  // (NSL = 2 NT; a trailing pair is guarded)
+#define WG_B6_STEP(A, S)                                                                                       \
+    if ((S) < NSL) {                                                                                           \
+        const gcp_u32x4* qb = pb6 + (int64_t)(S) * 192;                                                        \
+        const gcp_u32x4 bh = qb[0], bm = qb[64], bl = qb[128];                                                 \
+        acc2[0] = gcp_mfma_bf16x6(A, bh, bm, bl, acc2[0]);                                                     \
+        lda(A, (S) + 4);                                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+                        WG_B6_STEP(a0, sj)
+                        WG_B6_STEP(a1, sj + 1)
+                        WG_B6_STEP(a2, sj + 2)
+                        WG_B6_STEP(a3, sj + 3)
+#undef WG_B6_STEP
+                    }
+                } else {
                 constexpr int U = KT == 1 ? 4 : 1;
                 const float* pa = p.pk + p.offA2 + (int64_t)lane * 4;
                 const float* db = DS + e * DSS + 4 * hi;
@@ -609,6 +657,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                     ld(a0, b0, g0 + 2 * U);
                     __builtin_amdgcn_sched_barrier(0);
                     mm(a1, b1, g0 + U);
+                }
                 }
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
@@ -645,6 +694,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
                 for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
                 const float* pa = p.pk + p.offA2 + ((int64_t)kt * SG * 64 + lane) * 4;
                 const float* db = DS + e * DSS + 4 * hi;
+                if constexpr (B6) {
+                    const int NSL = 2 * NT, ss = gcp_cdiv(NSL, NW), s_lo = w * ss, s_hi = min(NSL, s_lo + ss);
+                    const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)kt * NSL * 192 + lane;
+                    const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(DS) + lane;
+                    for (int sj = s_lo; sj < s_hi; ++sj) {
+                        const gcp_u32x4* qa = pa6 + (int64_t)sj * 192;
+                        const gcp_u32x4* qb = pb6 + (int64_t)sj * 192;
+                        const gcp_u32x4 a6[3] = {qa[0], qa[64], qa[128]};
+                        acc3 = gcp_mfma_bf16x6(a6, qb[0], qb[64], qb[128], acc3);
+                    }
+                } else
                 for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
                     f32x4 a[4], bb[4];
 #pragma unroll
@@ -960,7 +1020,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
 
 int g_wg_cus = 0;
 
-template <int NW, int KT, int FN, int SHP = 0>
+template <int NW, int KT, int FN, int SHP = 0, bool B6 = false>
 int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipStream_t st) {
     auto go = [&](auto kern) -> int {
         if (lds_bytes > 64 * 1024) {
@@ -971,18 +1031,18 @@ int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipSt
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     };
-    if constexpr (SHP != 0) return go(gcp_wg_bwd_kernel<NW, KT, FN, true, SHP>);  // (the compile-time shapes exist for PWL only)
-    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true, 0>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false, 0>);
+    if constexpr (SHP != 0) return go(gcp_wg_bwd_kernel<NW, KT, FN, true, SHP, B6>);  // (the compile-time shapes exist for PWL only)
+    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true, 0, B6>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false, 0, B6>);
 }
 
 // True if the launch's shape is exactly the compile-time shape SHP (every integer the kernel would otherwise read).
-template <int SHP, int NW, int FN>
+template <int SHP, int NW, int FN, bool B6 = false>
 bool wg_bwd_is_shape(const WgBwdParams& p, const gcp2_weights_t& w, bool gated) {
     if (!(w.si == WgBwdShape<SHP>::S && w.so == WgBwdShape<SHP>::S && w.vi == WgBwdShape<SHP>::V && w.vo == WgBwdShape<SHP>::V &&
           w.hidden == WgBwdShape<SHP>::HID && w.use_frames && gated))
         return false;
     constexpr WgBwdDims CD = wg_bwd_dims(WgBwdShape<SHP>::S, WgBwdShape<SHP>::V, WgBwdShape<SHP>::S, WgBwdShape<SHP>::V,
-                                         WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW);
+                                         WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW, B6);
     bool same = true;
 #define X(f) same = same && p.f == CD.f;
     WG_BWD_DIMS(X)
@@ -1068,12 +1128,18 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     if (a->v_add) p.v_add = *a->v_add;
     if (p.v_add.n < 0 || p.v_add.n > GCP_MAX_SEG) return GCPNET_E_BADARG;
     p.d_s_in = a->d_s_in; p.d_v_in = a->d_v_in;
-    p.pk = w.pack; p.offA2 = S.offA2; p.offG2 = S.offG2;
+    p.pk = w.pack; p.offA2 = S.offA2; p.offG2 = S.offG2; p.offA2b = S.offA2b;
     p.w_down = w.w_down; p.w_frames = w.w_frames; p.w_up = w.w_up;
     p.ds_pre = a->ds_pre; p.dvhf = a->dvhf; p.ext = a->ext; p.dgate = a->dgate;
     p.dw_part = a->dw_part; p.dwg_part = a->dwg_part; p.wsm_part = a->wsm_part;
     const int NW = pl.nw;
-    const WgBwdDims D = wg_bwd_dims(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated, pl.fused, NW);
+    // P4 on the bf16 pipe (plain mode, one K tile per wave, the operand planes fit in LDS) unless GCPNET_WG_BWD_FP32_MFMA /
+    // gcpnet_debug_set_fp32_mfma select the fp32 MFMA form
+    static const bool b6_env = getenv("GCPNET_WG_BWD_FP32_MFMA") == nullptr;
+    bool b6 = !pl.fused && pl.kt == 1 && (g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0);
+    if (b6 && (size_t)wg_bwd_dims(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated, pl.fused, NW, 1).lds_floats * sizeof(float) > 160 * 1024)
+        b6 = false;
+    const WgBwdDims D = wg_bwd_dims(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated, pl.fused, NW, b6);
     if (D.fused != pl.fused || D.split != pl.split || D.KW != pl.kw) return GCPNET_E_BADARG;  // (same function: cannot differ)
 #define X(f) p.f = D.f;
     WG_BWD_DIMS(X)
@@ -1092,9 +1158,12 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     // compile-time shapes: the residual message GCPs of BASELINE configs[1] (fused, 4 waves) and configs[4] (8 waves)
     if (pwl && !getenv("GCPNET_WG_BWD_NOSHAPE")) {
         if (pl.fused && NW == 4 && wg_bwd_is_shape<1, 4, 5>(p, w, gated)) return launch_bwd<4, 1, 5, 1>(p, pwl, grid, lds_bytes, st);
-        if (!pl.fused && NW == 8 && pl.kt == 1 && wg_bwd_is_shape<2, 8, 0>(p, w, gated))
+        if (!pl.fused && NW == 8 && pl.kt == 1 && b6 && wg_bwd_is_shape<2, 8, 0, true>(p, w, gated))
+            return launch_bwd<8, 1, 0, 2, true>(p, pwl, grid, lds_bytes, st);
+        if (!pl.fused && NW == 8 && pl.kt == 1 && !b6 && wg_bwd_is_shape<2, 8, 0>(p, w, gated))
             return launch_bwd<8, 1, 0, 2>(p, pwl, grid, lds_bytes, st);
     }
+    if (b6) return NW == 4 ? launch_bwd<4, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st);
     if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);
     if (NW == 4) return pl.kt == 1 ? launch_bwd<4, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<4, 4, 0>(p, pwl, grid, lds_bytes, st);
     return pl.kt == 1 ? launch_bwd<8, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 4, 0>(p, pwl, grid, lds_bytes, st);

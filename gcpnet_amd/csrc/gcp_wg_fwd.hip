@@ -643,6 +643,20 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view
         const int g = (int)((idx - S.offG1) >> 8);
         const int c = 8 * g + 4 * hi + i;
         if (m < S.vo && c < S.so) v = Wg[(int64_t)m * S.so + c];
+    } else if (idx >= S.offA2b) {
+        int64_t blk = (idx - S.offA2b) >> 8;  // (kt, slab, term)
+        const int term = (int)(blk % 3); blk /= 3;
+        const int NSL = 2 * S.NT;
+        const int kt = (int)(blk / NSL), j = (int)(blk - (int64_t)kt * NSL);
+        const int c = 32 * kt + m;
+        unsigned bits = 0;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int ip = 2 * i + h2;  // element of the lane's eight
+            const int r = 32 * (j >> 1) + 16 * (j & 1) + 8 * (ip >> 2) + 4 * hi + (ip & 3);
+            const float wv = (r < S.so && c < S.K) ? wg_view_at(view, r, c) : 0.f;
+            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+        }
+        v = __uint_as_float(bits);
     } else if (idx < S.offG2) {
         const int64_t blk = (idx - S.offA2) >> 8;
         const int kt = (int)(blk / G4), g = (int)(blk - (int64_t)kt * G4);
