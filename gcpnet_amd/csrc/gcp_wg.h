@@ -33,7 +33,10 @@ struct WgShape {
     // A2b [NKT][2 NT slabs][term][64][4 x 2 bf16]: section A2 once more as three bf16 terms per weight in the operand layout
     // of v_mfma_f32_32x32x16_bf16 (gcp_bf16x3.h); element i' < 8 of lane (m, hi) in slab j is W[32 (j / 2) + 16 (j % 2) +
     // 8 (i' / 4) + 4 hi + i' % 4][32 kt + m] -- the column set of eight consecutive accumulator registers
-    int64_t offA1, offG1, offA2, offG2, offA2b, total;
+    // A1b [NT][NSLf = ceil(KG / 2) slabs][term][64][4]: section A1 as three bf16 terms; element i' of lane (m, hi) in slab j is
+    // W[32 ot + m][16 j + 8 hi + i'] (natural column order: the forward's operand planes are split from the fp32 tile X)
+    int64_t offA1, offG1, offA2, offG2, offA2b, offA1b, total;
+    int NSLf;
 };
 
 __host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int H, int use_frames, int gated) {
@@ -52,7 +55,9 @@ __host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int 
     s.offA2 = s.offG1 + (s.gated ? (int64_t)4 * s.NT * 256 : 0);
     s.offG2 = s.offA2 + (int64_t)s.NKT * 4 * s.NT * 256;
     s.offA2b = s.offG2 + (s.gated ? (int64_t)s.NT * s.VG * 256 : 0);
-    s.total = s.offA2b + (int64_t)s.NKT * 2 * s.NT * 3 * 256;
+    s.offA1b = s.offA2b + (int64_t)s.NKT * 2 * s.NT * 3 * 256;
+    s.NSLf = gcp_cdiv(s.KG, 2);
+    s.total = s.offA1b + (int64_t)s.NT * s.NSLf * 3 * 256;
     return s;
 }
 

@@ -28,7 +28,7 @@ struct WgBlk {
     float* v_out;
     float* s_pre;
     float* gate;
-    int64_t offG1;
+    int64_t offG1, offA1b;
     int act_s, act_v;
     int si, vi, H, K, KG;
     int residual;
@@ -46,6 +46,7 @@ struct WgFwdParams {
     int n;
     int KS, VS, HS, GS;
     int o_x, o_v, o_vh, o_fr, o_ws, o_st, ws_floats, st_floats;
+    int o_xp;  // (B6) operand planes of X: [slab][term][64 lanes][16 bytes]
     unsigned long long* stamps;  // profiling hook (gcpnet_debug_set_phase_timing): s_memtime stamps of wave 0, last block
     long long stamp_cap;
     WgBlk blk[GCP_WG_MAX_BLOCKS];
@@ -57,7 +58,7 @@ struct WgFwdParams {
 // (s, V) -> (s, V) with frames and a scalar gate -- the ResGCP chain of BASELINE configs[1] (128, 16, hidden 4) and configs[4]
 // (256, 32, hidden 8).  One constexpr function gives every integer of such a launch; the host takes the instantiation only when the
 // parameters it computed the general way are exactly these (wg_fwd_is_shape), and in the kernel they fold into immediates.
-#define WG_FWD_DIMS(X) X(so) X(vo) X(nf) X(NT) X(NG) X(KS) X(VS) X(HS) X(GS) X(o_x) X(o_v) X(o_vh) X(o_fr) X(o_ws) X(o_st) X(ws_floats) X(st_floats)
+#define WG_FWD_DIMS(X) X(so) X(vo) X(nf) X(NT) X(NG) X(KS) X(VS) X(HS) X(GS) X(o_x) X(o_v) X(o_vh) X(o_fr) X(o_ws) X(o_st) X(ws_floats) X(st_floats) X(o_xp)
 #define WG_FWD_BLK_DIMS(X) X(si) X(vi) X(H) X(K) X(KG)
 struct WgFwdDims {
 #define X(f) int f;
@@ -70,7 +71,7 @@ constexpr int cf_cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int cf_rup(int x, int m) { return (x + m - 1) / m * m; }
 constexpr int cf_max(int a, int b) { return a > b ? a : b; }
 constexpr int cf_stride(int width) { return 4 * (cf_cdiv(width, 4) | 1); }  // == wg_stride
-constexpr WgFwdDims wg_fwd_dims(int S, int V, int HID, int NW, int MT) {
+constexpr WgFwdDims wg_fwd_dims(int S, int V, int HID, int NW, int MT, int b6 = 0) {
     WgFwdDims d{};
     d.so = S; d.vo = V; d.nf = 9; d.si = S; d.vi = V; d.H = HID;
     d.K = S + HID + 9; d.KG = cf_cdiv(d.K, 8);
@@ -87,6 +88,7 @@ constexpr WgFwdDims wg_fwd_dims(int S, int V, int HID, int NW, int MT) {
     d.o_v = off; off += cf_rup(32 * d.VS, 4);
     d.o_vh = off; off += cf_rup(32 * d.HS, 4);
     d.o_fr = off; off += 32 * 9;
+    d.o_xp = off; off += b6 ? cf_cdiv(d.KG, 2) * 768 : 0;
     d.lds_floats = off;
     return d;
 }
@@ -94,8 +96,12 @@ template <int SHP> struct WgFwdShape { static constexpr int S = 0, V = 0, HID = 
 template <> struct WgFwdShape<1> { static constexpr int S = 128, V = 16, HID = 4; };
 template <> struct WgFwdShape<2> { static constexpr int S = 256, V = 32, HID = 8; };
 
-template <int NW, int MT, bool PWL, int SHP>
+// B6 (MT == 1): the K loop on the bf16 matrix pipe -- once the tile X of a block is complete every thread splits a share of
+// it into three bf16 terms (operand-ordered planes in LDS, shared by all waves), the weights come pre-split from section A1b;
+// six products, fp32 accumulation (gcp_bf16x3.h: exact to fp32 round-off)
+template <int NW, int MT, bool PWL, int SHP, bool B6 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p_kernarg) {
+    static_assert(!B6 || MT == 1, "bf16 form: one output tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32, U = 4 / MT;
     // Parameters are read through the kernarg segment pointer, laundered at the phase boundaries: the uniform values are
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
     typedef const __attribute__((address_space(4))) WgFwdParams* Karg;
     Karg kp = (Karg)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*(const WgFwdParams*)kp)
-    constexpr WgFwdDims CF = wg_fwd_dims(WgFwdShape<SHP>::S, WgFwdShape<SHP>::V, WgFwdShape<SHP>::HID, NW, MT);
+    constexpr WgFwdDims CF = wg_fwd_dims(WgFwdShape<SHP>::S, WgFwdShape<SHP>::V, WgFwdShape<SHP>::HID, NW, MT, B6);
 #define DM(f) (SHP ? CF.f : p.f)       // a launch-wide shape value: immediate for the compile-time shapes
 #define DB(blk, f) (SHP ? CF.f : (blk).f)  // a per-block one
     int tid = threadIdx.x;
@@ -320,6 +326,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         }
         stamp(1);
         wg_barrier();  // B1
+        if constexpr (B6) {
+            // X is complete: eight consecutive columns of a row at a time -> three bf16 terms -> the lane's 16 bytes of the
+            // slab's planes (lane = 32 (group & 1) + row: consecutive threads write consecutive 16-byte pieces)
+            const int NG2 = 2 * gcp_cdiv(KG, 2);
+            gcp_u32x4* XP = reinterpret_cast<gcp_u32x4*>(lds + DM(o_xp));
+            for (int u = tid; u < 32 * NG2; u += NTH) {
+                const int r = u & 31, g = u >> 5;
+                const bool in = g < KG;
+                const float* xr = X + r * KS + 8 * (in ? g : 0);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi4 = *reinterpret_cast<const f32x4*>(xr + 4);
+                const float x8[8] = {in ? lo[0] : 0.f, in ? lo[1] : 0.f, in ? lo[2] : 0.f, in ? lo[3] : 0.f,
+                                     in ? hi4[0] : 0.f, in ? hi4[1] : 0.f, in ? hi4[2] : 0.f, in ? hi4[3] : 0.f};
+                gcp_u32x4 th, tm, tl;
+                gcp_bf16x3_split8(x8, th, tm, tl);
+                gcp_u32x4* q = XP + (g >> 1) * 192 + 32 * (g & 1) + r;
+                q[0] = th; q[64] = tm; q[128] = tl;
+            }
+            wg_barrier();
+        }
         stamp(2);
         if (b + 1 < p.n) ws_request(b + 1);
 
@@ -351,7 +376,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
             // arrive under the reduction's MFMAs instead of costing a round trip to L2 afterwards.
             f32x4 a0[U][MT], a1[U][MT], b0[U], b1[U];
             int nb_;
-            {
+            if constexpr (B6) {
+                const int NSLf = gcp_cdiv(KG, 2);
+                const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(B.pk + B.offA1b) + (int64_t)otc[0] * NSLf * 192 + lane;
+                const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(lds + DM(o_xp)) + lane;
+                auto lda = [&](gcp_u32x4(&a)[3], int sj) {
+                    const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSLf - 1) * 192;
+                    a[0] = q[0]; a[1] = q[64]; a[2] = q[128];
+                };
+                gcp_u32x4 f0[3], f1[3], f2[3], f3[3];
+                lda(f0, 0); lda(f1, 1); lda(f2, 2); lda(f3, 3);
+                if (scalar_gate) {  // the gate Linear's four fragments for this wave's columns arrive under the reduction
+                    const float* pkG = B.pk + B.offG1 + (int64_t)lane * 4;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) a0[u][0] = *reinterpret_cast<const f32x4*>(pkG + (int64_t)(4 * otc[0] + u) * 256);
+                }
+                nb_ = 0;  // (the gate Linear below takes its fragments from a0)
+                __builtin_amdgcn_sched_barrier(0);
+                for (int sj = 0; sj < NSLf; sj += 4) {
+#define WG_B6_STEP(A, S)                                                                                       \
+    if ((S) < NSLf) {                                                                                          \
+        const gcp_u32x4* qb = pb6 + (int64_t)(S) * 192;                                                        \
+        const gcp_u32x4 bh = qb[0], bm = qb[64], bl = qb[128];                                                 \
+        acc[0] = gcp_mfma_bf16x6(A, bh, bm, bl, acc[0]);                                                       \
+        lda(A, (S) + 4);                                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+                    WG_B6_STEP(f0, sj)
+                    WG_B6_STEP(f1, sj + 1)
+                    WG_B6_STEP(f2, sj + 2)
+                    WG_B6_STEP(f3, sj + 3)
+#undef WG_B6_STEP
+                }
+            } else {
                 const float* pkA = B.pk + (int64_t)lane * 4;
                 const float* pkG = B.pk + B.offG1 + (int64_t)lane * 4;
                 const float* xb = X + e * KS + 4 * hi;
@@ -643,6 +700,18 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view
         const int g = (int)((idx - S.offG1) >> 8);
         const int c = 8 * g + 4 * hi + i;
         if (m < S.vo && c < S.so) v = Wg[(int64_t)m * S.so + c];
+    } else if (idx >= S.offA1b) {
+        int64_t blk = (idx - S.offA1b) >> 8;  // (ot, slab, term)
+        const int term = (int)(blk % 3); blk /= 3;
+        const int ot = (int)(blk / S.NSLf), j = (int)(blk - (int64_t)ot * S.NSLf);
+        const int r = 32 * ot + m;
+        unsigned bits = 0;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int c = 16 * j + 8 * hi + 2 * i + h2;
+            const float wv = (r < S.so && c < S.K) ? wg_view_at(view, r, c) : 0.f;
+            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+        }
+        v = __uint_as_float(bits);
     } else if (idx >= S.offA2b) {
         int64_t blk = (idx - S.offA2b) >> 8;  // (kt, slab, term)
         const int term = (int)(blk % 3); blk /= 3;
@@ -671,9 +740,9 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view
     out[idx] = v;
 }
 
-template <int SHP, int NW, int MT>
+template <int SHP, int NW, int MT, bool B6 = false>
 bool wg_fwd_is_shape(const WgFwdParams& p, size_t lds_bytes) {
-    constexpr WgFwdDims CF = wg_fwd_dims(WgFwdShape<SHP>::S, WgFwdShape<SHP>::V, WgFwdShape<SHP>::HID, NW, MT);
+    constexpr WgFwdDims CF = wg_fwd_dims(WgFwdShape<SHP>::S, WgFwdShape<SHP>::V, WgFwdShape<SHP>::HID, NW, MT, B6);
     if (p.n < 2 || p.vmode != GCP_VMODE_SCALAR_GATE || lds_bytes != (size_t)CF.lds_floats * sizeof(float)) return false;
     bool same = true;
 #define X(f) same = same && p.f == CF.f;
@@ -687,7 +756,7 @@ bool wg_fwd_is_shape(const WgFwdParams& p, size_t lds_bytes) {
     return same;
 }
 
-template <int NW, int MT, int SHP = 0>
+template <int NW, int MT, int SHP = 0, bool B6 = false>
 int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st) {
     auto go = [&](auto kern) -> int {
         if (lds_bytes > 64 * 1024) {
@@ -698,8 +767,8 @@ int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st)
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     };
-    if constexpr (SHP != 0) return go(gcp_wg_fwd_kernel<NW, MT, true, SHP>);  // (compile-time shapes: PWL activations only)
-    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true, 0>) : go(gcp_wg_fwd_kernel<NW, MT, false, 0>);
+    if constexpr (SHP != 0) return go(gcp_wg_fwd_kernel<NW, MT, true, SHP, B6>);  // (compile-time shapes: PWL activations only)
+    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true, 0, B6>) : go(gcp_wg_fwd_kernel<NW, MT, false, 0, B6>);
 }
 
 }  // namespace
@@ -769,7 +838,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     p.n = n;
     const bool gated = p.vmode == GCP_VMODE_SCALAR_GATE;
     bool pwl = true;
-    int kmax = 0, vmax = vo, hmax = 1, wsmax = 0;
+    int kmax = 0, vmax = vo, hmax = 1, wsmax = 0, nslf_max = 0;
     auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
     for (int b = 0; b < n; ++b) {
         const gcp_wg_block_t& c = blocks[b];
@@ -788,7 +857,8 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
         WgBlk& k = p.blk[b];
         k.pk = w.pack; k.b_scalar = w.b_scalar; k.b_gate = w.b_gate; k.w_down = w.w_down; k.w_frames = w.w_frames; k.w_up = w.w_up;
         k.s_out = c.s_out; k.v_out = c.v_out; k.s_pre = c.s_pre; k.gate = c.gate;
-        k.offG1 = S.offG1;
+        k.offG1 = S.offG1; k.offA1b = S.offA1b;
+        nslf_max = max(nslf_max, S.NSLf);
         k.act_s = c.o.act_s; k.act_v = c.o.act_v;
         k.si = w.si; k.vi = w.vi; k.H = S.H; k.K = S.K; k.KG = S.KG;
         k.residual = c.residual;
@@ -823,14 +893,24 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     p.o_v = off; off += gcp_round_up(32 * p.VS, 4);
     p.o_vh = off; off += gcp_round_up(32 * p.HS, 4);
     p.o_fr = off; off += 32 * 9;
+    // K loop on the bf16 pipe: one output tile per wave, by default for the 8-wave shapes (one workgroup per CU anyway; at 4
+    // waves the operand planes cost the third workgroup of a CU: GCPNET_WG_FWD_B6=all), if the planes fit
+    static const char* b6_env = getenv("GCPNET_WG_FWD_B6");  // "0" = off, "all" = also 4-wave shapes
+    bool b6 = MT == 1 && p.NG == 1 && (g_gcp_fp32_mfma < 0 ? !(b6_env && b6_env[0] == '0') : g_gcp_fp32_mfma == 0) &&
+              (NW == 8 || (b6_env && b6_env[0] == 'a'));
+    if (b6 && (size_t)(off + nslf_max * 768) * sizeof(float) > 160 * 1024) b6 = false;
+    p.o_xp = off; off += b6 ? nslf_max * 768 : 0;
     const size_t lds_bytes = (size_t)off * sizeof(float);
     if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
     if (pwl && !getenv("GCPNET_WG_FWD_NOSHAPE")) {
-        if (NW == 4 && wg_fwd_is_shape<1, 4, 1>(p, lds_bytes)) return launch_fwd<4, 1, 1>(p, pwl, lds_bytes, st);
-        if (NW == 8 && MT == 1 && wg_fwd_is_shape<2, 8, 1>(p, lds_bytes)) return launch_fwd<8, 1, 2>(p, pwl, lds_bytes, st);
+        if (NW == 4 && !b6 && wg_fwd_is_shape<1, 4, 1>(p, lds_bytes)) return launch_fwd<4, 1, 1>(p, pwl, lds_bytes, st);
+        if (NW == 4 && b6 && wg_fwd_is_shape<1, 4, 1, true>(p, lds_bytes)) return launch_fwd<4, 1, 1, true>(p, pwl, lds_bytes, st);
+        if (NW == 8 && MT == 1 && !b6 && wg_fwd_is_shape<2, 8, 1>(p, lds_bytes)) return launch_fwd<8, 1, 2>(p, pwl, lds_bytes, st);
+        if (NW == 8 && MT == 1 && b6 && wg_fwd_is_shape<2, 8, 1, true>(p, lds_bytes)) return launch_fwd<8, 1, 2, true>(p, pwl, lds_bytes, st);
     }
+    if (b6) return NW == 4 ? launch_fwd<4, 1, 0, true>(p, pwl, lds_bytes, st) : launch_fwd<8, 1, 0, true>(p, pwl, lds_bytes, st);
     if (NW == 4) return launch_fwd<4, 1>(p, pwl, lds_bytes, st);
     if (MT == 1) return launch_fwd<8, 1>(p, pwl, lds_bytes, st);
     return launch_fwd<8, 2>(p, pwl, lds_bytes, st);
