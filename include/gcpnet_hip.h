@@ -431,12 +431,14 @@ int gcpnet_radius_graph(int N, const float* x_sorted, const int32_t* order, cons
  * forward / backward kernels writes s_memtime stamps at its phase boundaries; NULL switches it off. */
 int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);
 
-/* ---- arithmetic switch (tests / A-B measurements).  The chain kernels compute their large fp32 products -- W^T ds_pre in
- * gcpnet_gcp2_chain_backward, scalar_out over the state and the gate Linear in gcpnet_gcp2_chain_forward -- on the bf16
- * matrix pipe with both operands split into three bf16 terms and six products kept (fp32 accumulation; the result is exact to
- * fp32 round-off: csrc/gcp_bf16x3.h).  on != 0 selects the v_mfma_f32_32x32x2_f32 form of the same products instead; the
- * environment variables GCPNET_CHAIN_BWD_FP32_MFMA / GCPNET_CHAIN_FWD_FP32_MFMA set the initial state.  Returns the previous
- * setting. */
+/* ---- arithmetic switch (tests / A-B measurements).  Several kernels compute their large fp32 products -- W^T ds_pre in
+ * gcpnet_gcp2_chain_backward and in gcpnet_wg_backward (plain mode, one K tile per wave), scalar_out over the state and the
+ * gate Linear in gcpnet_gcp2_chain_forward, scalar_out in gcpnet_wg_forward (8-wave shapes) -- on the bf16 matrix pipe with
+ * both operands split into three bf16 terms and six products kept (fp32 accumulation; the result is exact to fp32 round-off:
+ * csrc/gcp_bf16x3.h).  on != 0 selects the v_mfma_f32_32x32x2_f32 form of the same products instead; the environment
+ * variables GCPNET_CHAIN_BWD_FP32_MFMA, GCPNET_CHAIN_FWD_FP32_MFMA, GCPNET_WG_BWD_FP32_MFMA and GCPNET_WG_FWD_B6=0 set the
+ * initial state per kernel (GCPNET_WG_FWD_B6=all: the bf16 form for the 4-wave shapes of gcpnet_wg_forward too).  Returns
+ * the previous setting (-1: never set). */
 int gcpnet_debug_set_fp32_mfma(int on);
 
 int gcpnet_abi_version(void);

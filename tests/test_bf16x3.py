@@ -48,7 +48,8 @@ def test_six_products_match_fp32_roundoff():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,act", [((128, 16), "relu"), ((128, 16), "silu"), ((64, 16), "relu"), ((100, 16), "silu")])
+@pytest.mark.parametrize("dims,act", [((128, 16), "relu"), ((128, 16), "silu"), ((64, 16), "relu"), ((100, 16), "silu"),
+                                      ((256, 32), "silu")])  # (256,32): the workgroup kernels' bf16 forms (8 waves)
 def test_chain_kernels_bf16_and_fp32_forms_agree(dims, act):
     import gcpnet_amd as G
     from gcpnet_amd import _lib, ops
@@ -87,9 +88,10 @@ def test_chain_kernels_bf16_and_fp32_forms_agree(dims, act):
             if prev >= 0:
                 lib.gcpnet_debug_set_fp32_mfma(prev)
 
-    fp32 = run(True, wg_forward=False)       # wave-per-tile forward + chain backward, v_mfma_f32_32x32x2_f32
+    # so <= 128: wave-per-tile forward + chain backward; wider: workgroup forward + workgroup backward block by block
+    fp32 = run(True, wg_forward=False)       # v_mfma_f32_32x32x2_f32 everywhere
     bf16 = run(False, wg_forward=False)      # the same kernels, bf16 x 6
-    wg = run(False, wg_forward=True)         # workgroup forward (fp32 MFMA) + chain backward (bf16 x 6): the default route
+    wg = run(False, wg_forward=True)         # the default route (so <= 128: workgroup forward with fp32 MFMA + chain backward)
     assert any(not torch.equal(fp32[k], bf16[k]) for k in fp32), "the switch did not change the arithmetic"
     for k in fp32:
         scale = max(float(fp32[k].abs().max()), 1e-6)
