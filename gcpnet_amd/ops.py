@@ -8,6 +8,7 @@ from __future__ import annotations
 import os
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass, field, replace
 from typing import List, Optional, Sequence, Tuple
 
@@ -472,6 +473,7 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
 
 
 _ZERO_BIAS: dict = {}
+_LINEAR_PACKS: dict = {}  # wg_linear: (epoch, weight pointer, version, view) -> packed image
 
 
 def wg_linear(x: Tensor, W: Tensor, out_dim: int, in_dim: int, col0: int = 0, trans: bool = False,
@@ -492,12 +494,22 @@ def wg_linear(x: Tensor, W: Tensor, out_dim: int, in_dim: int, col0: int = 0, tr
         if zb is None:
             zb = _ZERO_BIAS[(dev, out_dim)] = torch.zeros(out_dim, dtype=torch.float32, device=dev)
     w = (None, zb, None, None, None, None, None)
-    npk = lib.gcpnet_wg_pack_floats(in_dim, 0, out_dim, 0, 0, 0, 0)
-    pack = torch.empty(int(npk), dtype=torch.float32, device=dev)
+    # packed image of the view: cached per weight version like every other pack (a weight's column ranges / its transpose are
+    # packed once per optimizer step, not once per call)
+    key = (_PACK_EPOCH, W.data_ptr(), W._version, W.stride(0), col0, bool(trans), in_dim, out_dim, dev)
+    hit = _LINEAR_PACKS.get(key)
+    pack = hit[1] if hit is not None and hit[0]() is W else None  # (the very tensor object: an address can be recycled)
+    if pack is None:
+        if len(_LINEAR_PACKS) >= 512:  # (stale versions of updated weights)
+            _LINEAR_PACKS.clear()
+        npk = lib.gcpnet_wg_pack_floats(in_dim, 0, out_dim, 0, 0, 0, 0)
+        pack = torch.empty(int(npk), dtype=torch.float32, device=dev)
+        ws = _weights_struct(spec, w, pack)
+        start, length = (C.c_int * 1)(0), (C.c_int * 1)(in_dim)
+        base = C.c_void_p(W.data_ptr() + 4 * col0)
+        check(lib.gcpnet_wg_pack_view(C.byref(ws), 0, base, W.stride(0), int(trans), 1, start, length, _p(pack), _stream()), "wg_pack_view")
+        _LINEAR_PACKS[key] = (weakref.ref(W), pack)
     ws = _weights_struct(spec, w, pack)
-    start, length = (C.c_int * 1)(0), (C.c_int * 1)(in_dim)
-    base = C.c_void_p(W.data_ptr() + 4 * col0)
-    check(lib.gcpnet_wg_pack_view(C.byref(ws), 0, base, W.stride(0), int(trans), 1, start, length, _p(pack), _stream()), "wg_pack_view")
     out = torch.empty((n, out_dim), dtype=torch.float32, device=dev)
     blk = WgBlock()
     blk.w, blk.o = ws, _opts_struct(spec)
@@ -1306,7 +1318,10 @@ class _Gcp2Projected(torch.autograd.Function):
                 vadds.append(_rows_matmul_small(vt.view(-1, chans[k]), wk.t().contiguous()).view(vt.shape[0], 3, hfp))
             wd_rest = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
             wf_rest = torch.cat([w_frames[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
-        spec2 = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=None,
+        # (its packed image -- a view over scalar_out.weight -- is cached next to the block's own, per weight version: the
+        # forward and the backward of a step share it, and so do the steps between two optimizer updates)
+        sub_cache = spec.pack_cache.setdefault("projected", {}) if spec.pack_cache is not None and use_view else None
+        spec2 = replace(spec, si=sum(dims[k] for k in rest), s_plans=[spec.s_plans[k] for k in rest], pack_cache=sub_cache,
                         add_plans=[spec.s_plans[k] for k in sg], vi=sum(chans[k] for k in vr),
                         v_plans=[spec.v_plans[k] for k in vr], vadd_plans=[spec.v_plans[k] for k in vg],
                         w_view=(w_scalar, segs) if use_view else None)
