@@ -1310,14 +1310,26 @@ class _Gcp2Projected(torch.autograd.Function):
         wvs, vts, vadds = [], [], []
         wd_rest, wf_rest = w_down, w_frames
         if vg:
-            for k in vg:
-                wk = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]], w_frames[:, voffs[k]:voffs[k] + chans[k]]], dim=0)
-                wk = torch.nn.functional.pad(wk, (0, 0, 0, hfp - (H + 3)))  # [HF', V], zero rows past H + 3
-                vt = v_src[k].transpose(1, 2).contiguous()  # [n, 3, V]
-                wvs.append(wk); vts.append(vt)
-                vadds.append(_rows_matmul_small(vt.view(-1, chans[k]), wk.t().contiguous()).view(vt.shape[0], 3, hfp))
-            wd_rest = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
-            wf_rest = torch.cat([w_frames[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1)
+            # column slices of the small vector weights in the forms the launches want -- [HF', V_k] (zero rows past H + 3), its
+            # transpose, the un-gathered rest -- derived once per weight version, not once per call (a dozen tiny launches)
+            vkey = (_PACK_EPOCH, tuple(vg), tuple(chans), w_down.data_ptr(), w_down._version, w_frames.data_ptr(), w_frames._version)
+            vc = spec.pack_cache.get("vproj") if spec.pack_cache is not None else None
+            if vc is None or vc["key"] != vkey:
+                vc = dict(key=vkey, wk=[], wkt=[])
+                for k in vg:
+                    wk = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]], w_frames[:, voffs[k]:voffs[k] + chans[k]]], dim=0).detach()
+                    wk = torch.nn.functional.pad(wk, (0, 0, 0, hfp - (H + 3)))  # [HF', V], zero rows past H + 3
+                    vc["wk"].append(wk); vc["wkt"].append(wk.t().contiguous())
+                vc["wd_rest"] = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1).detach()
+                vc["wf_rest"] = torch.cat([w_frames[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1).detach()
+                if spec.pack_cache is not None:
+                    spec.pack_cache["vproj"] = vc
+            for j, k in enumerate(vg):
+                same = [i for i in range(j) if v_src[vg[i]] is v_src[k]]  # (chi gathered by row and by col: one transposition)
+                vt = vts[same[0]] if same else v_src[k].transpose(1, 2).contiguous()  # [n, 3, V]
+                wvs.append(vc["wk"][j]); vts.append(vt)
+                vadds.append(_rows_matmul_small(vt.view(-1, chans[k]), vc["wkt"][j]).view(vt.shape[0], 3, hfp))
+            wd_rest, wf_rest = vc["wd_rest"], vc["wf_rest"]
         # (its packed image -- a view over scalar_out.weight -- is cached next to the block's own, per weight version: the
         # forward and the backward of a step share it, and so do the steps between two optimizer updates)
         sub_cache = spec.pack_cache.setdefault("projected", {}) if spec.pack_cache is not None and use_view else None
