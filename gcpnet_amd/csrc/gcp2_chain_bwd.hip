@@ -23,6 +23,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef GCP_CB_TNC
+#define GCP_CB_TNC 3  // independent accumulator chains of a pass (1..3)
+#endif
+#ifndef GCP_CB_TNB
+#define GCP_CB_TNB 6  // operand pairs of a small weight-gradient pass read from LDS per batch (3, 6, 12 or 24)
+#endif
+
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
                              const float* d_v_out, float* d_s_in, float* d_v_in, hipStream_t st);
 
@@ -255,18 +262,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             float f[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
-            const bool ext_staged = 32 * EP <= GCP_ACC_STAGE_HALF_FLOATS && gcp_aligned16(it.ext);  // (wave-uniform)
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
                 const int x = gcp_crow(r, hi);
                 const float u0 = u[0][r], u1 = u[1][r], u2 = u[2][r];
-                // norms / frame scalars of the tile: rows of EP floats, contiguous in memory over the tile's rows -- collected in
-                // the (idle) transposition tile and written below as full lines instead of EP scattered 4-byte stores per row
                 if (x < H) {
                     const float nr = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
                     vht[e * L.HS + 3 * x + 0] = u0; vht[e * L.HS + 3 * x + 1] = u1; vht[e * L.HS + 3 * x + 2] = u2;
-                    if (ext_staged) stage[e * EP + x] = nr + 1e-8f;
-                    else if (row_ok) it.ext[(int64_t)row * EP + x] = nr + 1e-8f;
+                    if (row_ok) it.ext[(int64_t)row * EP + x] = nr + 1e-8f;
                 } else if (x < HF) {
                     const int kk = x - H;
 #pragma unroll
@@ -276,25 +279,16 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                             e3t[e * 3 + kk] = pr < 0.f ? -1.f : 1.f;  // sign for the adjoint of |.|
                             pr = fabsf(pr);
                         }
-                        if (ext_staged) stage[e * EP + H + 3 * kk + a] = pr;
-                        else if (row_ok) it.ext[(int64_t)row * EP + H + 3 * kk + a] = pr;
+                        if (row_ok) it.ext[(int64_t)row * EP + H + 3 * kk + a] = pr;
                     }
                 }
             }
-            if (hi == 0) {  // zero the stride padding
-                for (int c = H + S.nf; c < EP; ++c) {
-                    if (ext_staged) stage[e * EP + c] = 0.f;
-                    else if (row_ok) it.ext[(int64_t)row * EP + c] = 0.f;
-                }
-                if (row_ok && scalar_gate)
+            // (staging these rows in LDS and writing them as full lines was tried: same time, -1 % counter traffic, but the extra
+            // control flow cost the kernel 67 spilled registers)
+            if (row_ok && hi == 0) {  // zero the stride padding
+                for (int c = H + S.nf; c < EP; ++c) it.ext[(int64_t)row * EP + c] = 0.f;
+                if (scalar_gate)
                     for (int c = vi; c < VOP; ++c) it.dgate[(int64_t)row * VOP + c] = 0.f;
-            }
-            gcp_wave_lds_sync();
-            if (ext_staged) {
-                const int nval = min(GCP_TILE_ROWS, rows - r0) * EP;  // floats of the tile's valid rows (EP % 4 == 0)
-                float* dst = it.ext + (int64_t)r0 * EP;
-                for (int i = 4 * lane; i < nval; i += 4 * GCP_WAVE)
-                    *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(stage + i);
             }
             // ---- B. vu = vector_up(vh), B fragments = the registers just produced ------------------------------------
             gcp_xyz_acc vu;
@@ -350,31 +344,54 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         // per-tile partial sums of the small vector weight gradients (v_mfma_f32_16x16x4_f32 over the tile's 96 (row, xyz)
         // pairs, operands = the row-major LDS copies); reduced over tiles by gcpnet_reduce_partials
         const int l16 = lane & 15, kq = lane >> 4;
+        // (step st = 3 u + v covers the reduction index 12 u + 4 v + kq: row 4 u + (4 v + kq) / 3, component (4 v + kq) % 3 -- three
+        // per-lane (row, component) pairs for the whole pass; the 24 operand pairs are read from LDS in batches of GCP_CB_TNB and
+        // accumulated in three independent chains: the pass is a latency chain, 6.6 k -> ~2 k cycles with this)
         auto small_tn = [&](const float* A, int ars, int ams, int ads, int M, const float* B, int brs, int bms, int bds, int N,
                             float* out, bool transposed) {
+            int aoff[3], boff[3], rv[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int kk = 4 * v + kq, rr = kk / 3, d = kk - 3 * rr;
+                rv[v] = rr; aoff[v] = rr * ars + d * ads; boff[v] = rr * brs + d * bds;
+            }
             for (int mt = 0; mt < M; mt += 16)
                 for (int nt = 0; nt < N; nt += 16) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     const int m = mt + l16, n = nt + l16;
                     const bool mok = m < M, nok = n < N;
                     const float* ap = A + (mok ? m : 0) * ams;
                     const float* bp = B + (nok ? n : 0) * bms;
-#pragma unroll 8
-                    for (int st = 0; st < 24; ++st) {
-                        const int kidx = 4 * st + kq, rr = kidx / 3, d = kidx - 3 * rr;
-                        float a = ap[rr * ars + d * ads], b = bp[rr * brs + d * bds];
-                        a = (mok && r0 + rr < rows) ? a : 0.f;
-                        b = nok ? b : 0.f;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+                    f32x4 acc[3];
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int part4 = 0; part4 < 24 / GCP_CB_TNB; ++part4) {
+                        constexpr int NB = GCP_CB_TNB, UB = NB / 3;
+                        float av[NB], bv[NB];
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            const int u = UB * part4 + i / 3, v = i % 3;
+                            av[i] = ap[4 * u * ars + aoff[v]];
+                            bv[i] = bp[4 * u * brs + boff[v]];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            const int u = UB * part4 + i / 3, v = i % 3;
+                            const float a = (mok && r0 + 4 * u + rv[v] < rows) ? av[i] : 0.f;
+                            acc[v % GCP_CB_TNC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, nok ? bv[i] : 0.f, acc[v % GCP_CB_TNC], 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = mt + 4 * kq + r;
-                        if (i < M && nok) out[transposed ? n * M + i : i * N + n] = acc[r];
+                        if (i < M && nok) out[transposed ? n * M + i : i * N + n] = (acc[0][r] + acc[1][r]) + acc[2][r];
                     }
                 }
         };
         float* part = it.w_part ? it.w_part + (int64_t)blockIdx.x * (vi * H + vi * HF) : nullptr;
+#ifdef GCP_CB_FINE2
+        if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+#endif
         if (part) small_tn(xt, L.VS, 3, 1, vi, vht, L.HS, 3, 1, H, part, false);  // d vector_up[o, h] = sum dvu[row, o, d] vh[row, h, d]
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
         CB_LAUNDER();
@@ -577,6 +594,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             __builtin_amdgcn_sched_barrier(0);
         }
         gcp_wave_lds_sync();
+#ifdef GCP_CB_FINE2
+        if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
+#endif
         // d [vector_down ; vector_down_frames][x, c] = sum v[row, c, d] [dvh | dvf][row, d, x], stored as [H + 3, vi]
         if (part) small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF, part + vi * H, true);
         gcp_wave_lds_sync();
