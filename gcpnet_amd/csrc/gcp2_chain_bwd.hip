@@ -326,8 +326,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             if (scalar_gate) {
 #pragma unroll
                 for (int q = 0; q < VQ; ++q)
-                    gcp_store4(it.dgate, row, VOP, 8 * q + 4 * hi, make_float4(dgr[4 * q], dgr[4 * q + 1], dgr[4 * q + 2], dgr[4 * q + 3]),
-                               row_ok, true);
+                    if (row_ok && 8 * q + 4 * hi < VOP)  // (VOP % 4 == 0, dgate 16-byte aligned: one guarded 16-byte store)
+                        *reinterpret_cast<float4*>(it.dgate + (int64_t)row * VOP + 8 * q + 4 * hi) =
+                            make_float4(dgr[4 * q], dgr[4 * q + 1], dgr[4 * q + 2], dgr[4 * q + 3]);
             }
         }
         gcp_wave_lds_sync();
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 }
             }
         }
-        gcp_store_acc_rows_half<NTG>(it.ds_pre, so, 0, so, r0, rows, spr, stage, lane);
+        gcp_store_acc_rows_half_dense<NTG>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG, 16-byte aligned: host checks)
         CB_LAUNDER();
 
         // ---- E. d(s) += W^T ds_pre: 16 * NTG k-pair steps whose B operands are the ds_pre registers; the weight
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         CB_LAUNDER();
 
-        if (k == 0) gcp_store_acc_rows_half<NTG>(p.d_s_in, so, 0, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
+        if (k == 0) gcp_store_acc_rows_half_dense<NTG>(p.d_s_in, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
 
         // ---- F. adjoint of the vector prologue: d[vh | vf] = Wu^T dvu + (norm and frame-scalar terms), d(V) += Wdf^T d[vh | vf] ---
@@ -577,10 +578,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         t[3 * i + d] = st[d][4 * q + i] + dv[d][4 * q + i] + (p.o.vector_residual ? dvu[d][4 * q + i] : 0.f);
+                if (row_ok && o0 < vi) {  // (vi % 4 == 0: the lane's 48 bytes are three aligned 16-byte pieces, one guard for all)
+                    float4* dp = reinterpret_cast<float4*>(p.d_v_in + (int64_t)row * 3 * vi + 3 * o0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    gcp_store4(p.d_v_in, row, 3 * vi, 3 * o0 + 4 * j, make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]),
-                               row_ok && o0 < vi, vec_vo);
+                    for (int j = 0; j < 3; ++j) dp[j] = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+                }
             }
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
@@ -688,8 +690,9 @@ extern "C" int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, 
     if (rows == 0) return 0;
     auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
     for (int k = 0; k < n; ++k)  // the deferred tile loads and the accumulator-layout accesses are 16-byte accesses
-        if (misaligned(items[k].v_in) || misaligned(items[k].s_pre) || misaligned(items[k].gate) || misaligned(items[k].sc.ds_pre))
+        if (misaligned(items[k].v_in) || misaligned(items[k].s_pre) || misaligned(items[k].gate) || misaligned(items[k].sc.ds_pre) ||
+            misaligned(items[k].sc.dgate))
             return GCPNET_E_UNSUPPORTED;
-    if (misaligned(d_s_out) || misaligned(d_v_out) || misaligned(d_s_in)) return GCPNET_E_UNSUPPORTED;
+    if (misaligned(d_s_out) || misaligned(d_v_out) || misaligned(d_s_in) || misaligned(d_v_in)) return GCPNET_E_UNSUPPORTED;
     return gcp2_chain_bwd_registers(rows, frames, n, items, d_s_out, d_v_out, d_s_in, d_v_in, (hipStream_t)stream);
 }

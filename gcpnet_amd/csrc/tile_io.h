@@ -2,6 +2,7 @@
 // issues a batch of 16-byte loads (up to 8 per lane, 8 KiB per wave) before it touches any of the results, instead of
 // one dependent row at a time; a tile is then on chip after about one HBM latency.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 __device__ __forceinline__ bool gcp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -383,6 +384,40 @@ __device__ __forceinline__ void gcp_store_acc_rows(float* __restrict__ dst, int 
             }
         }
     }
+}
+
+// gcp_store_acc_rows_half for a destination the caller knows to be 16-byte aligned with ld % 4 == 0 and width == ld == 32 NT:
+// no per-piece column tests, and one wave-uniform test for a tile without rows past the end instead of a branch per store (the
+// general form compiles to ~8 branches per 32-column tile; inside an unrolled kernel body every one of them is a scheduling fence).
+template <int NT>
+__device__ __forceinline__ void gcp_store_acc_rows_half_dense(float* __restrict__ dst, int ld, int r0, int rows, const f32x16 (&acc)[NT],
+                                                              float* stage, int lane) {
+    const int e = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 2, c4 = 4 * (lane & 3);
+    const bool full = r0 + 32 <= rows;  // wave-uniform
+    float* p0 = dst + (int64_t)(r0 + sub) * ld + c4;
+    float* p1 = p0 + (int64_t)16 * ld;
+    const bool ok0 = r0 + sub < rows, ok1 = r0 + 16 + sub < rows;
+    auto pieces = [&](auto full_tag) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous piece's reads are done
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    *reinterpret_cast<float4*>(stage + e * 20 + 8 * q + 4 * hi) =
+                        make_float4(acc[t][8 * h + 4 * q], acc[t][8 * h + 4 * q + 1], acc[t][8 * h + 4 * q + 2], acc[t][8 * h + 4 * q + 3]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float4 w0 = *reinterpret_cast<const float4*>(stage + sub * 20 + c4);
+                const float4 w1 = *reinterpret_cast<const float4*>(stage + (16 + sub) * 20 + c4);
+                const int c = 32 * t + 16 * h;
+                if (decltype(full_tag)::value || ok0) *reinterpret_cast<float4*>(p0 + c) = w0;
+                if (decltype(full_tag)::value || ok1) *reinterpret_cast<float4*>(p1 + c) = w1;
+            }
+    };
+    if (full) pieces(std::true_type{});
+    else pieces(std::false_type{});
 }
 
 // Same through a 32 x 20 staging tile (2.5 KB): half tiles at a time, 64-byte pieces per row, 16 rows per store instruction
