@@ -141,6 +141,33 @@ __device__ __forceinline__ void gcp_load_gate(const float* __restrict__ gate, in
     for (int q = 0; q < VQ; ++q) { sg[4 * q] = g[q].x; sg[4 * q + 1] = g[q].y; sg[4 * q + 2] = g[q].z; sg[4 * q + 3] = g[q].w; }
 }
 
+// The block's input vectors, a 32-row tile of [rows, 3 vi] (vi % 4 == 0, 16-byte aligned: host checks) = 32 * q contiguous
+// 16-byte pieces (q = 3 vi / 4 <= 12), six per lane: all requests first (clamped: no branches), one guarded LDS write per piece
+// later.  (The general segment loader of tile_io.h carries its fallback paths and ~60 branches into the unrolled block body.)
+struct CbVin {
+    float4 v[6];
+};
+__device__ __forceinline__ void cb_vin_issue(CbVin& b, const float* __restrict__ v_in, int vi, int r0, int rows, int lane) {
+    const int q = (3 * vi) >> 2, n4 = min(rows - r0, GCP_TILE_ROWS) * q;
+    const float4* src = reinterpret_cast<const float4*>(v_in + (int64_t)r0 * 3 * vi);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b.v[k] = src[min(lane + 64 * k, n4 - 1)];
+}
+__device__ __forceinline__ void cb_vin_commit(const CbVin& b, float* vt, int VS, int vi, int r0, int rows, int lane) {
+    const int q = (3 * vi) >> 2, n4 = min(rows - r0, GCP_TILE_ROWS) * q, tot = GCP_TILE_ROWS * q;
+    const unsigned magic = (unsigned)(((1ull << 32) + (unsigned)q - 1) / (unsigned)q);  // idx / q for idx < 2^16
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < tot) {
+            const int r = (int)__umulhi((unsigned)idx, magic), c4 = idx - r * q;
+            const bool ok = idx < n4;
+            float* d = vt + r * VS + 4 * c4;
+            d[0] = ok ? b.v[k].x : 0.f; d[1] = ok ? b.v[k].y : 0.f; d[2] = ok ? b.v[k].z : 0.f; d[3] = ok ? b.v[k].w : 0.f;
+        }
+    }
+}
+
 // B6: W^T ds_pre on the bf16 matrix pipe, both operands as three bf16 terms, six products (gcp_bf16x3.h: exact to fp32 round-off)
 template <int NTG, int VQ, bool PWL, int HC, bool B6>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p_kernarg) {
@@ -205,8 +232,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     float sg[NV];  // sigmoid(gate) of the current block: channel crow(r, hi) of row e
     // ---- prologue: everything the LAST block needs, plus the incoming gradients, in one memory round trip ----------
     {
-        GcpSegBuf<8> vb;
-        gcp_seg_issue(vb, it.v_in, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
+        CbVin vb;
+        cb_vin_issue(vb, it.v_in, vi, r0, rows, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
         gcp_load_gate<VQ>(scalar_gate ? it.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
 #pragma unroll
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 const float4 b = gcp_load4(p.d_s_out, row, so, j0, row_ok, true);
                 dyr[t][4 * q] = b.x; dyr[t][4 * q + 1] = b.y; dyr[t][4 * q + 2] = b.z; dyr[t][4 * q + 3] = b.w;
             }
-        gcp_seg_commit(vb, vt, L.VS, 0);
+        cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
     }
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
@@ -590,9 +617,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         // ---- G. requests for the next block (k-1) -- gates, vectors -- and, while they are in flight, the second
         //         partial-sum pass -------------------------------------------------------------------------------------------
         if (k > 0) gcp_load_gate<VQ>(scalar_gate ? p.it[k - 1].gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
-        GcpSegBuf<8> vb;
+        CbVin vb;
         if (k > 0) {
-            gcp_seg_issue(vb, p.it[k - 1].v_in, nullptr, 3 * vi, r0, rows, vt, L.VS, 0, lane);
+            cb_vin_issue(vb, p.it[k - 1].v_in, vi, r0, rows, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
         gcp_wave_lds_sync();
@@ -603,7 +630,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (part) small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF, part + vi * H, true);
         gcp_wave_lds_sync();
         if (k > 0) {
-            gcp_seg_commit(vb, vt, L.VS, 0);
+            cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
     }
