@@ -214,7 +214,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;                                                                 \
         NUG = S.NUG;                                                                                                      \
         xg = NTG / NUG; xs = NTG - xg * NUG; /* group / slot of the 32-wide tile holding the norms and frame scalars */   \
-        vec_vo = (vi & 3) == 0;                                                                                           \
+        vec_vo = true; /* vi % 4 == 0 and 16-byte aligned gates: checked by the host */                                                                                           \
         ns_s = gcp_neg_slope(it.act_s, slope); ns_v = gcp_neg_slope(it.act_v, slope);                                     \
     } while (0)
     // (the per-lane addresses of the loop body would be hoisted out of the loop and spilled, too: lane indices laundered with it)
@@ -614,14 +614,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
         CB_LAUNDER();
-        // ---- G. requests for the next block (k-1) -- gates, vectors -- and, while they are in flight, the second
-        //         partial-sum pass -------------------------------------------------------------------------------------------
-        if (k > 0) gcp_load_gate<VQ>(scalar_gate ? p.it[k - 1].gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
-        CbVin vb;
-        if (k > 0) {
-            cb_vin_issue(vb, p.it[k - 1].v_in, vi, r0, rows, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // ---- G. the second partial-sum pass, then the next block's (k-1) gates and vectors in ONE batch of requests.  (Requested
+        //         before the pass, to fly under it, hipcc spilled the 24 destination registers -- and waits vmcnt(0) in front of
+        //         each spill: six serial memory round trips per block.) ------------------------------------------------------------
         gcp_wave_lds_sync();
 #ifdef GCP_CB_FINE2
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
@@ -629,7 +624,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         // d [vector_down ; vector_down_frames][x, c] = sum v[row, c, d] [dvh | dvf][row, d, x], stored as [H + 3, vi]
         if (part) small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF, part + vi * H, true);
         gcp_wave_lds_sync();
+        CB_LAUNDER();
         if (k > 0) {
+            CbVin vb;
+            cb_vin_issue(vb, p.it[k - 1].v_in, vi, r0, rows, lane);
+            gcp_load_gate<VQ>(scalar_gate ? p.it[k - 1].gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
             cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
