@@ -288,7 +288,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_vmm_down<10>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
             float f[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
+            for (int i = 0; i < 9; ++i) f[i] = fr[e * 9 + i];  // (unconditional: only the channels [H, HF) use them, and they exist only with frames)
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
                 const int x = gcp_crow(r, hi);
@@ -322,14 +322,16 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_xyz_zero(vu);
             gcp_vmm_regs<NX>(it.pack + S.offVB + lane, SVB, u, vu);
             // ---- C. adjoint of the vector epilogue (gcpnet.py:364-391), element-wise: d(vector_up output), d(gate) ------
+            const bool vres = p.o.vector_residual != 0;
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 const int o = gcp_crow(r, hi);
                 const bool on = o < vi;
                 const int oc = on ? o : 0;
                 float u0 = vu[0][r], u1 = vu[1][r], u2 = vu[2][r];
-                if (p.o.vector_residual) {
-                    u0 += vt[e * L.VS + 3 * oc + 0]; u1 += vt[e * L.VS + 3 * oc + 1]; u2 += vt[e * L.VS + 3 * oc + 2];
+                {  // (no branch around three LDS reads: read, then select)
+                    const float t0 = vt[e * L.VS + 3 * oc + 0], t1 = vt[e * L.VS + 3 * oc + 1], t2 = vt[e * L.VS + 3 * oc + 2];
+                    u0 += vres ? t0 : 0.f; u1 += vres ? t1 : 0.f; u2 += vres ? t2 : 0.f;
                 }
                 const float g0 = dvs[0][r], g1 = dvs[1][r], g2 = dvs[2][r];
                 float d0 = g0, d1 = g1, d2 = g2, dg = 0.f;
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_vmm_arr<NV>(it.pack + S.offVC + lane, S.SVC, dvu, dacc);
             float f[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) f[i] = S.nf ? fr[e * 9 + i] : 0.f;
+            for (int i = 0; i < 9; ++i) f[i] = fr[e * 9 + i];  // (unconditional: only the channels [H, HF) use them, and they exist only with frames)
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
                 const int x = gcp_crow(r, hi);
