@@ -103,6 +103,14 @@ struct WF<4> {
     }
 };
 
+// s_pre / s_out rows of a tile: the branch-free form when the destination allows 16-byte stores (tile_io.h)
+template <int NT>
+__device__ __forceinline__ void gcp_store_acc_rows_any(float* __restrict__ dst, int so, int r0, int rows, const f32x16 (&acc)[NT],
+                                                       float* stage, int lane) {
+    if ((so & 3) == 0 && gcp_aligned16(dst)) gcp_store_acc_rows_dense<NT>(dst, so, so, r0, rows, acc, stage, lane);
+    else gcp_store_acc_rows<NT>(dst, so, 0, so, r0, rows, acc, stage, lane);
+}
+
 // NT = 32-wide tiles of the scalar state (so <= 32 * NT); PWL as in gcp2_fwd.hip.
 template <bool HEAD>
 struct ChainArg { typedef ChainParams type; };
@@ -382,12 +390,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                         G1[tm] = *reinterpret_cast<const gcp_u32x4*>(q + 768 + tm * 256);
                     }
                 }
-#pragma unroll
+                float bgv[16];  // unconditional (clamped) loads, ALL requested before the first select (a guarded load, or one
+#pragma unroll          //  selected right behind its request, is waited for on the spot: sixteen serial round trips to L2)
                 for (int r = 0; r < 16; ++r) {
                     if constexpr (!F6) gwa[r] = wg0[(int64_t)r * 64];
-                    const float bg = it.b_gate[min(gcp_crow(r, hi), vo - 1)];  // unconditional (clamped) load, then select:
-                    gacc[r] = gcp_crow(r, hi) < vo ? bg : 0.f;                   // a guarded load is waited for on the spot
+                    bgv[r] = it.b_gate[min(gcp_crow(r, hi), vo - 1)];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gacc[r] = gcp_crow(r, hi) < vo ? bgv[r] : 0.f;
             }
             // norms and frame scalars: ordinary B fragments from the 32 x 16 LDS tile, weights from section A
             const float* wa = it.pack + B.offA + (int64_t)lane * NT;
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
 #endif
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
-        if (it.s_pre) gcp_store_acc_rows<NT>(it.s_pre, so, 0, so, r0, rows, acc, stage, lane);
+        if (it.s_pre) gcp_store_acc_rows_any<NT>(it.s_pre, so, r0, rows, acc, stage, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 const float y = gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][r]);
                 xs[t][r] = head ? y : xs[t][r] + y;
             }
-        if (it.s_out) gcp_store_acc_rows<NT>(it.s_out, so, 0, so, r0, rows, xs, stage, lane);
+        if (it.s_out) gcp_store_acc_rows_any<NT>(it.s_out, so, r0, rows, xs, stage, lane);
 
 #ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);

@@ -386,6 +386,34 @@ __device__ __forceinline__ void gcp_store_acc_rows(float* __restrict__ dst, int 
     }
 }
 
+// gcp_store_acc_rows for a destination the caller knows to be 16-byte aligned with ld % 4 == 0: one wave-uniform test for a
+// tile without rows or columns past the end (then: no branch per store), the general form otherwise.
+template <int NT>
+__device__ __forceinline__ void gcp_store_acc_rows_dense(float* __restrict__ dst, int ld, int width, int r0, int rows,
+                                                         const f32x16 (&acc)[NT], float* stage, int lane) {
+    if (!(r0 + 32 <= rows && width == 32 * NT)) {  // (wave-uniform)
+        gcp_store_acc_rows<NT>(dst, ld, 0, width, r0, rows, acc, stage, lane);
+        return;
+    }
+    const int e = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 3, c4 = 4 * (lane & 7);
+    float* p0 = dst + (int64_t)(r0 + sub) * ld + c4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(stage + e * 36 + 8 * q + 4 * hi) =
+                make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const float4*>(stage + (8 * j + sub) * 36 + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(p0 + (int64_t)8 * j * ld + 32 * t) = w[j];
+    }
+}
+
 // gcp_store_acc_rows_half for a destination the caller knows to be 16-byte aligned with ld % 4 == 0 and width == ld == 32 NT:
 // no per-piece column tests, and one wave-uniform test for a tile without rows past the end instead of a branch per store (the
 // general form compiles to ~8 branches per 32-column tile; inside an unrolled kernel body every one of them is a scheduling fence).
