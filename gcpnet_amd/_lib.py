@@ -16,7 +16,7 @@ MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
-    "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_headchain_forward",
+    "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_chain_forward_registers_ok", "gcpnet_gcp2_headchain_forward",
     "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
@@ -61,6 +61,7 @@ class WgBlock(C.Structure):
 
 
 WG_MAX_BLOCKS = 9
+MAX_CHAIN = 8  # GCP_MAX_CHAIN: blocks per launch of the wave-per-tile chain kernels
 
 
 class AdamTensor(C.Structure):
@@ -161,6 +162,7 @@ def load():
     lib.gcpnet_row_gate_bwd_blocks.argtypes = [i64]
     lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
     lib.gcpnet_debug_set_fp32_mfma.argtypes = [i32]
+    lib.gcpnet_gcp2_chain_forward_registers_ok.argtypes = [i32] * 6
     lib.gcpnet_wg_pack_floats.restype = i64
     lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
     lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]

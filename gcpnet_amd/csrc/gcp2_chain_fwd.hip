@@ -596,6 +596,17 @@ int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const f
     return pwl ? launch_chain<4, true>(p, lds_bytes, st) : launch_chain<4, false>(p, lds_bytes, st);
 }
 
+// 1 if a chain of residual blocks of this shape runs in the register-resident kernel above (callers that have another fast
+// route -- the workgroup kernel -- ask before choosing; gcpnet_gcp2_chain_forward itself falls back to the LDS-resident chain).
+extern "C" int gcpnet_gcp2_chain_forward_registers_ok(int si, int vi, int so, int vo, int hidden, int use_frames) {
+    if (si != so || vi != vo) return 0;
+    gcp2_weights_t w0{};
+    w0.si = si; w0.vi = vi; w0.so = so; w0.vo = vo; w0.hidden = hidden; w0.use_frames = use_frames;
+    const GcpShape S = gcp_shape(si, vi, so, vo, hidden, use_frames);
+    if (!chain_shape_ok(S, w0)) return 0;
+    return (size_t)chain_lds(S).total * sizeof(float) <= 64 * 1024 ? 1 : 0;
+}
+
 // The first message GCP after project-then-gather (gcp2_head_t), alone (n == 0) or fused in front of the chain of residual
 // blocks it feeds (its outputs are then still written: the backward needs them).
 extern "C" int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, const float* frames, int n,

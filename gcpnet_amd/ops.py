@@ -437,7 +437,9 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
 USE_WG_KERNELS = True  # module switch: multi-wave workgroup kernels (gcp_wg_*.hip) where the shape fits, else the wave-per-tile ones
 USE_WG_BACKWARD = True  # (separately for the backward; both need USE_WG_KERNELS)
 PREFER_WG_CHAIN_BACKWARD = True  # chains wider than 128 scalars: block by block through the workgroup backward kernel
-PREFER_WAVE_CHAIN_FORWARD = os.environ.get("GCPNET_CHAIN_FWD", "wg") == "wave"  # experiment switch
+# ResGCP chains with so <= 128: the register-resident wave-per-tile forward kernel (bf16 x 6 form; 0.62 ms per 7-block launch at
+# (128,16) on 160 k rows against 0.73 ms for the workgroup forward) where its shape test passes; GCPNET_CHAIN_FWD=wg switches back
+PREFER_WAVE_CHAIN_FORWARD = os.environ.get("GCPNET_CHAIN_FWD", "wave") == "wave"
 FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains the wave-per-tile chain kernel covers
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
@@ -1054,7 +1056,10 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].gate = gate.data_ptr() if gate is not None else None
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         rc = _lib.E_UNSUPPORTED
-        if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS and not (PREFER_WAVE_CHAIN_FORWARD and specs[0].so <= 128):
+        sp0 = specs[0]
+        wave_first = (PREFER_WAVE_CHAIN_FORWARD and sp0.so <= 128 and n <= _lib.MAX_CHAIN and
+                      lib.gcpnet_gcp2_chain_forward_registers_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
+        if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS and not wave_first:
             keep: list = []
             blks = (WgBlock * n)(*[_wg_block(spec, w, *outs[k], True, keep) for k, (spec, w) in enumerate(zip(specs, ws))])
             rc = lib.gcpnet_wg_forward(rows, _p(s0), _p(v0), _p(frames), None, None, n, blks, _stream())

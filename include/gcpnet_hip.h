@@ -117,6 +117,10 @@ typedef struct {
 #define GCP_MAX_CHAIN 8
 int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const float* frames, int n,
                               const gcp2_chain_item_t* items, void* stream);
+/* 1 if a chain of residual blocks (si == so, vi == vo) of this shape runs in gcpnet_gcp2_chain_forward's register-resident
+ * kernel (state in MFMA accumulator-layout registers for the whole chain), 0 if it would take the LDS-resident fallback. */
+int gcpnet_gcp2_chain_forward_registers_ok(int si, int vi, int so, int vo, int hidden, int use_frames);
+
 
 /* ---- the first message GCP after project-then-gather, alone (n == 0) or fused in front of the chain it feeds:
  * scalar input e_in [rows, w.si] and vector input xi_in [rows, w.vi, 3] are plain (un-gathered) tensors, the gathered

@@ -108,8 +108,9 @@ def test_message_chain_vs_oracle(G, n, e, dims, blocks, act, wg_bwd):
     ws64, wv64 = O.message_passing(P64, "", c64["h"], c64["chi"], c64["e"], c64["xi"], ei, fr.double(), ocfg, olcfg["mp_cfg"])
     gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
     before = dict(ops.WG_STATS)
-    saved = ops.FORCE_WG_CHAIN_BACKWARD
+    saved, saved_fwd = ops.FORCE_WG_CHAIN_BACKWARD, ops.PREFER_WAVE_CHAIN_FORWARD
     ops.FORCE_WG_CHAIN_BACKWARD = wg_bwd
+    ops.PREFER_WAVE_CHAIN_FORWARD = False  # (this test is about the workgroup kernels; the wave-per-tile route: test_bf16x3, parity tests)
     out = mp((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
     assert ops.WG_STATS["fwd_chain"] == before["fwd_chain"] + 1, "the chain did not run in the workgroup kernel"
     assert ops.WG_STATS["fwd"] >= before["fwd"] + 1, "the first message GCP did not run in the workgroup kernel"
@@ -134,7 +135,7 @@ def test_message_chain_vs_oracle(G, n, e, dims, blocks, act, wg_bwd):
     try:
         ((out[0] * ls.cuda()).sum() + (out[1] * lv.cuda()).sum()).backward()
     finally:
-        ops.FORCE_WG_CHAIN_BACKWARD = saved
+        ops.FORCE_WG_CHAIN_BACKWARD, ops.PREFER_WAVE_CHAIN_FORWARD = saved, saved_fwd
     if wg_bwd or dims[0] > 128:
         assert ops.WG_STATS["bwd"] >= before["bwd"] + blocks, "the chain backward did not run in the workgroup kernel"
 
