@@ -248,6 +248,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     }
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
+    float dvs[3][NV];  // d(V) state entering the current block: channel crow(r, hi) of row e
     for (int k = p.n - 1; k >= 0; --k) {
         kcur = k;
         CB_LAUNDER();
@@ -282,8 +283,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         //         (element-wise) go to the weight-gradient GEMM's operand `ext`; 1/|vh| and the e3 signs stay in registers --
         float dgr[NV];
         {
-            float dvs[3][NV];
-            load_state(dvs);
+            // (the state this block receives: loaded for the last block only -- afterwards it is carried over in registers from
+            // the end of the block before, where it is computed: one L2 / HBM round trip and 192 bytes per row and block less)
+            if (k == p.n - 1) load_state(dvs);
             gcp_xyz_acc u;
             gcp_vmm_down<10>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
             float f[9];
@@ -607,6 +609,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         t[3 * i + d] = st[d][4 * q + i] + dv[d][4 * q + i] + (p.o.vector_residual ? dvu[d][4 * q + i] : 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) dvs[d][4 * q + i] = (row_ok && o0 < vi) ? t[3 * i + d] : 0.f;  // -> the next block
                 if (row_ok && o0 < vi) {  // (vi % 4 == 0: the lane's 48 bytes are three aligned 16-byte pieces, one guard for all)
                     float4* dp = reinterpret_cast<float4*>(p.d_v_in + (int64_t)row * 3 * vi + 3 * o0);
 #pragma unroll
