@@ -415,8 +415,8 @@ def main():
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                 "traffic_source": PMC_FILE if pmc_traffic(dom) is not None else None,
                 "traffic_note": (_pmc_file().get(dom + "_parts") or {}).get("note"),
-                "arithmetic": ("fp32 results; the large products of the chain backward (W^T ds_pre; at (256,32) also scalar_out of the "
-                               "workgroup forward and W^T ds_pre of the workgroup backward) run on the bf16 matrix pipe with both "
+                "arithmetic": ("fp32 results; the large products of the chain kernels (W^T ds_pre backward, scalar_out and the gate Linear "
+                               "forward; at (256,32) scalar_out / W^T ds_pre of the workgroup kernels) run on the bf16 matrix pipe with both "
                                "operands split into three bf16 terms and six products kept, fp32 accumulation (error <= 3*2^-24 of "
                                "sum|a b|: csrc/gcp_bf16x3.h, tests/test_bf16x3.py); every other product is v_mfma_f32_32x32x2_f32. "
                                "`peak` stays the fp32 MFMA peak"),
@@ -427,6 +427,8 @@ def main():
                 "all_kernels_ms": {k: v * 1e3 for k, v in times.items()},
                 "all_kernels_tflops": {k: kr["flops"][k] / v / 1e12 for k, v in times.items()},
                 "all_kernels_algorithmic_hbm_gbs": {k: kbytes[k] / v / 1e9 for k, v in times.items()},
+                "all_kernels_traffic": {k: pmc_traffic(k) for k in times},
+                "all_kernels_algorithmic_bytes": {k: float(kbytes[k]) for k in times},
             }
             width = args.sdim + 3 * args.vdim
             # the gather / aggregate kernel against the HBM roofline, at this run's size and at BASELINE configs[4]'s

@@ -248,7 +248,26 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     }
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
-    float dvs[3][NV];  // d(V) state entering the current block: channel crow(r, hi) of row e
+    auto load_state = [&](const float* state_src, float(&out)[3][NV]) {
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+            const int o0 = 8 * q + 4 * hi;
+            const bool on = row_ok && o0 < vi;
+            const float4* sp = reinterpret_cast<const float4*>(state_src + (on ? (int64_t)row * 3 * vi + 3 * o0 : 0));
+            float t[12];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 x = sp[j];
+                t[4 * j] = on ? x.x : 0.f; t[4 * j + 1] = on ? x.y : 0.f; t[4 * j + 2] = on ? x.z : 0.f; t[4 * j + 3] = on ? x.w : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) out[d][4 * q + i] = t[3 * i + d];
+        }
+    };
+    float dvs[3][NV];  // d(V) state entering the current block: channel crow(r, hi) of row e.  Loaded here for the last block;
+    load_state(p.d_v_out, dvs);  // afterwards carried over in registers from the end of the block before, where it is computed
     for (int k = p.n - 1; k >= 0; --k) {
         kcur = k;
         CB_LAUNDER();
@@ -257,25 +276,6 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         // output buffer d_v_in between blocks (each lane re-reads exactly the 48 bytes it wrote itself a whole block earlier,
         // so ordinary single-thread memory ordering applies; the lines come back from L2) -- 6 KB of LDS per wave less, which
         // is what lets eight waves share a CU.
-        const float* state_src = (k == p.n - 1) ? p.d_v_out : p.d_v_in;
-        auto load_state = [&](float(&out)[3][NV]) {
-#pragma unroll
-            for (int q = 0; q < VQ; ++q) {
-                const int o0 = 8 * q + 4 * hi;
-                const bool on = row_ok && o0 < vi;
-                const float4* sp = reinterpret_cast<const float4*>(state_src + (on ? (int64_t)row * 3 * vi + 3 * o0 : 0));
-                float t[12];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float4 x = sp[j];
-                    t[4 * j] = on ? x.x : 0.f; t[4 * j + 1] = on ? x.y : 0.f; t[4 * j + 2] = on ? x.z : 0.f; t[4 * j + 3] = on ? x.w : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) out[d][4 * q + i] = t[3 * i + d];
-            }
-        };
         gcp_wave_lds_sync();
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
 
@@ -283,9 +283,6 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         //         (element-wise) go to the weight-gradient GEMM's operand `ext`; 1/|vh| and the e3 signs stay in registers --
         float dgr[NV];
         {
-            // (the state this block receives: loaded for the last block only -- afterwards it is carried over in registers from
-            // the end of the block before, where it is computed: one L2 / HBM round trip and 192 bytes per row and block less)
-            if (k == p.n - 1) load_state(dvs);
             gcp_xyz_acc u;
             gcp_vmm_down<10>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
             float f[9];
@@ -599,7 +596,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_xyz_zero(dv);
             gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
             float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
-            load_state(st);
+            load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st);
 #pragma unroll
             for (int q = 0; q < VQ; ++q) {
                 const int o0 = 8 * q + 4 * hi;
