@@ -35,6 +35,17 @@ def test_host_only_entry_points():
                  + SV * 64)
     assert lib.gcpnet_tn_splits(160000, 128, 142) == 250
     assert lib.gcpnet_tn_splits(0, 1, 1) == 1
+    # packed image of a chainable block: the fp32 sections + the three-term bf16 sections B6 / F6 / C6 (csrc/gcp_bf16x3.h):
+    # (128,16,H=4): NTG = 4, NKT = 5 -> 2*4*5*768 + 2*4*4*768 + 2*4*768 floats on top
+    base = lambda si, vi, so, vo, H: lib.gcpnet_gcp2_pack_floats(si, vi, so, vo, H, 1)
+    S = 128
+    fp32_part = (1 * 72 * 64 * 4) + (2 * 64 * 64 * 4) + (1 * 64 * 64) + (8 * 1 * 64 * 4) + (4 * 16 * 64 * 4) + (8 + 4 + 8 + 4) * 64
+    assert base(S, 16, S, 16, 4) == fp32_part + (2 * 4 * 5 + 2 * 4 * 4 + 2 * 4) * 768
+    # which residual chains the register-resident forward kernel takes (ops asks before preferring it to the workgroup kernel)
+    ok = lib.gcpnet_gcp2_chain_forward_registers_ok
+    assert ok(128, 16, 128, 16, 4, 1) == 1 and ok(64, 16, 64, 16, 4, 1) == 1 and ok(100, 16, 100, 16, 4, 1) == 1
+    assert ok(256, 32, 256, 32, 8, 1) == 0  # two output groups: the workgroup kernels
+    assert ok(128, 16, 64, 16, 4, 1) == 0 and ok(32, 4, 32, 4, 1, 1) == 0  # not a residual shape / a single 32-wide tile
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
