@@ -69,7 +69,11 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     d.LW = d.K - 32 * (d.NKT - 1);
     d.KW = d.K + 1;
     d.NNT = c_cdiv(d.KW, 32);
-    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5) ? 1 : 0;
+    // (the fused form is used inside the envelope the parity tests cover -- the first message GCPs and the residual message GCPs of
+    // the shipped configurations: vo <= 16, si % 4 == 0.  The randomised sweeps of tests/sweep_*.py found wrong gate-weight
+    // gradients at (128,32) and an out-of-bounds access at (3,12)->(100,24) in it; those shapes take the plain form + TN GEMMs,
+    // which the sweeps pass)
+    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5 && vo <= 16 && (si & 3) == 0) ? 1 : 0;
     d.EP = c_rup(d.H + d.nf, 4);
     d.VOP = c_rup(vo, 4);
     d.HFP = c_rup(d.HF, 4);
