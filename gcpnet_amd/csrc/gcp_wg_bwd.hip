@@ -73,7 +73,11 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     // the shipped configurations: vo <= 16, si % 4 == 0.  The randomised sweeps of tests/sweep_*.py found wrong gate-weight
     // gradients at (128,32) and an out-of-bounds access at (3,12)->(100,24) in it; those shapes take the plain form + TN GEMMs,
     // which the sweeps pass)
+#ifdef GCP_WG_FUSE_ANY  // (debugging: the fused form outside its verified envelope)
+    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5) ? 1 : 0;
+#else
     d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5 && vo <= 16 && (si & 3) == 0) ? 1 : 0;
+#endif
     d.EP = c_rup(d.H + d.nf, 4);
     d.VOP = c_rup(vo, 4);
     d.HFP = c_rup(d.HF, 4);
