@@ -38,8 +38,12 @@ def _run(fn, world=2):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+        p.join(600)  # (a spawned interpreter's first `import torch` on a fresh or busy box can take minutes)
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.exitcode is None:
+            p.kill()
+    assert codes == [0] * world, codes
     return dict(ret)
 
 
