@@ -23,13 +23,21 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    extra = os.environ.get("GCPNET_HIPCC_EXTRA", "")
+    flag_file = os.path.join(HERE, ".build_flags")
+    flags_same = os.path.exists(flag_file) and open(flag_file).read() == extra
+    dep_t = max(os.path.getmtime(os.path.join(HERE, f)) for f in HEADERS + ["build.py"])
     for src in SOURCES:
         obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        objs.append(obj)
+        # incremental: an object newer than its source, every header and this script (built with the same extra flags) is kept
+        if (not force and flags_same and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(dep_t, os.path.getmtime(os.path.join(HERE, src)))):
+            continue
         cmd = [hipcc] + FLAGS + os.environ.get("GCPNET_HIPCC_EXTRA", "").split() + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -38,6 +46,8 @@ def build(force=False, verbose=False):
             print(out.decode())
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
+    with open(flag_file, "w") as f:
+        f.write(extra)
     return LIB
 
 

@@ -69,14 +69,10 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     d.LW = d.K - 32 * (d.NKT - 1);
     d.KW = d.K + 1;
     d.NNT = c_cdiv(d.KW, 32);
-    // (the fused form is used inside the envelope the parity tests cover -- the first message GCPs and the residual message GCPs of
-    // the shipped configurations: vo <= 16, si % 4 == 0.  The randomised sweeps of tests/sweep_*.py found wrong gate-weight
-    // gradients at (128,32) and an out-of-bounds access at (3,12)->(100,24) in it; those shapes take the plain form + TN GEMMs,
-    // which the sweeps pass)
-#ifdef GCP_WG_FUSE_ANY  // (debugging: the fused form outside its verified envelope)
-    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5) ? 1 : 0;
-#else
+#ifdef GCP_WG_FUSE_FENCE  // (the round-2 envelope: vo <= 16, si % 4 == 0; kept as a debugging switch)
     d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5 && vo <= 16 && (si & 3) == 0) ? 1 : 0;
+#else
+    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5) ? 1 : 0;
 #endif
     d.EP = c_rup(d.H + d.nf, 4);
     d.VOP = c_rup(vo, 4);
@@ -289,22 +285,28 @@ __global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParam
             spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + trow * so + c);
             dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + trow * so + c);
         }
+        // A tile that is absent (no output vectors, no gate, no frames) or not in the 16-byte form (its commit loads it itself)
+        // still issues its requests -- no branches around loads -- but from `safe`, one row of s_pre (so >= 4: 16 valid bytes),
+        // never from another tile's address with this tile's width: that over-read the last tile of v_in by up to
+        // 32 (max(vo, 9) - 3 vi) floats, past the end of the caller's allocation when vi is small
+        const float* safe = p.s_pre + (int64_t)tr0 * so;
         const float* vsrc = p.v_in + (int64_t)tr0 * 3 * vi;
         const bool v_vec = ((3 * vi) & 3) == 0 && wg_aligned16(p.v_in);
-        const float* osrc = vo > 0 ? p.d_v_out + (int64_t)tr0 * 3 * vo : vsrc;
         const bool o_vec = vo > 0 && ((3 * vo) & 3) == 0 && wg_aligned16(p.d_v_out);
-        const float* gsrc = gated ? p.gate + (int64_t)tr0 * vo : vsrc;
+        const float* osrc = o_vec ? p.d_v_out + (int64_t)tr0 * 3 * vo : safe;
         const bool g_vec = gated && vec_o && wg_aligned16(p.gate);
-        wg_tile_request<NTH, 2>(rv, vsrc, 3 * vi, tnv, tid, v_vec);
-        wg_tile_request<NTH, 2>(ro, osrc, 3 * max(vo, 1), tnv, tid, o_vec);
-        wg_tile_request<NTH, 1>(rg, gsrc, max(vo, 1), tnv, tid, g_vec);
+        const float* gsrc = g_vec ? p.gate + (int64_t)tr0 * vo : safe;
+        wg_tile_request<NTH, 2>(rv, v_vec ? vsrc : safe, 3 * vi, v_vec ? tnv : 0, tid, v_vec);
+        wg_tile_request<NTH, 2>(ro, osrc, 3 * max(vo, 1), o_vec ? tnv : 0, tid, o_vec);
+        wg_tile_request<NTH, 1>(rg, gsrc, max(vo, 1), g_vec ? tnv : 0, tid, g_vec);
         if constexpr (FUSED) {
-            const float* xsrc = p.s_in + (int64_t)tr0 * si;
-            wg_tile_request<NTH, 4>(rx, xsrc, si, tnv, tid, (si & 3) == 0 && wg_aligned16(p.s_in));
+            const bool x_vec = (si & 3) == 0 && wg_aligned16(p.s_in);
+            const float* xsrc = x_vec ? p.s_in + (int64_t)tr0 * si : safe;
+            wg_tile_request<NTH, 4>(rx, xsrc, si, x_vec ? tnv : 0, tid, x_vec);
         }
-        const float* fsrc = nf ? p.frames + (int64_t)tr0 * 9 : vsrc;
+        const float* fsrc = nf ? p.frames + (int64_t)tr0 * 9 : safe;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) frv[k] = fsrc[min(tid + k * NTH, tnv * 9 - 1)];
+        for (int k = 0; k < 2; ++k) frv[k] = fsrc[nf ? min(tid + k * NTH, tnv * 9 - 1) : 0];
     };
     request(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {

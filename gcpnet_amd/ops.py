@@ -563,6 +563,7 @@ class _Gcp2(torch.autograd.Function):
             ctx.has_res = (tensors[n_s + n_v] is not None, tensors[n_s + n_v + 1] is not None)
             ctx.w_leaf = not spec.shared_weights  # (checked again, against the live tensors, in the backward: _side_stream_ok)
             ctx.weights = w
+            ctx.use_cells = _note_uses(w)
             ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate, *vadds)
         if spec.vo:
             return s_out, v_out
@@ -582,7 +583,7 @@ class _Gcp2(torch.autograd.Function):
             d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
         si, vi = spec.si, spec.vi
         need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:2 + n_s + n_v + 9]
-        side = ctx.w_leaf and _side_stream_ok(ctx.weights)
+        side = ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells)
         d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
                                                  d_v_out, need_w=any(need_w), vadds=vadds, side_reduce=side)
         wgrads = [None] * 7
@@ -816,17 +817,24 @@ def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, 
             check(lib.gcpnet_wg_reduce(_p(w_part), grid, 1, n_small, n_small, _p(wv), None, st), "wg_reduce")
 
         if side_reduce and WEIGHT_GRADS_ON_SIDE_STREAM:
-            # off the critical path, like the TN GEMMs of the unfused route: they run under the next block's kernel
-            _side_submit(reduces, (dw_part, dwg_part, w_part, g, wv))
+            # off the critical path, like the TN GEMMs of the unfused route: they run under the next block's kernel.  Only the
+            # PARTIAL buffers are kept alive until the join -- never the gradients themselves (`g`, `wv`): a tensor that is
+            # still referenced from Python when AccumulateGrad receives it is CLONED (on the caller's stream, which has no
+            # dependency on the weight-gradient stream: .grad would be a copy of memory the reduction has not written yet)
+            # instead of adopted (tests/test_side_stream.py)
+            _side_submit(reduces, (dw_part, dwg_part, w_part))
         else:
             reduces()
+        if _DEBUG_GRAD_PTRS is not None:
+            _DEBUG_GRAD_PTRS.extend(t_.data_ptr() for t_ in (g[0], g[1], g[5], g[6], wv) if t_ is not None)
+        del reduces  # (the closure references g / wv)
         o1, o2 = vo * H, vo * H + H * vi
         if vo:
             g[4] = wv[:o1].view(vo, H)
         g[2] = wv[o1:o2].view(H, vi)
         if nf:
             g[3] = wv[o2:].view(3, vi)
-        t["fused"] = g
+        t["fused"] = g  # (popped by _WeightGradJob: the scratch dict outlives the backward call on the side-stream keep lists)
         t["keep"] = (dw_part, dwg_part)
     return d_s_in, d_v_in, t
 
@@ -865,7 +873,7 @@ class _WeightGradJob:
         nf = 9 if (spec.use_frames and vi > 0) else 0
         self.spec, self.nf = spec, nf
         if "fused" in t:  # the workgroup backward kernel has produced the gradients itself
-            self.probs, self.keep, self.reduce, self.g = [], [t], None, t["fused"]
+            self.probs, self.keep, self.reduce, self.g = [], [t], None, t.pop("fused")
             return
         self.has_vec, self.has_vout = vi > 0, vi > 0 and vo > 0
         self.gated = spec.vmode == VMODE_SCALAR_GATE and self.has_vout
@@ -937,6 +945,7 @@ class _WeightGradJob:
 
 
 WEIGHT_GRADS_ON_SIDE_STREAM = True  # module switch, see set_weight_grad_stream()
+_DEBUG_GRAD_PTRS: Optional[list] = None  # tests: addresses of the gradient buffers the fused backward produced (adoption check)
 
 
 def set_weight_grad_stream(enabled: bool) -> None:
@@ -951,11 +960,39 @@ _side_streams: dict = {}
 _side_pending: list = []
 
 
-def _side_stream_ok(weights) -> bool:
+_weight_uses: dict = {}  # id(weight) -> [the weight, number of autograd Functions of the graph being built that take it]
+
+
+def _note_uses(weights) -> list:
+    """Called by the forward of every Function that may put weight gradients on the side stream: counts, per weight tensor, the
+    Functions of the graph under construction that take it as an input.  A weight used twice (autoregressive_forward applies
+    `interaction` twice; any module called twice per step) receives two gradients that the autograd engine SUMS on the caller's
+    stream as soon as the second arrives -- inside the backward pass, before the end-of-backward join -- so both must be complete
+    on the caller's stream.  Returns the shared counter cells; the backward reads them through _side_stream_ok.
+    The table is dropped at the end of every backward pass (the cells live on in the contexts that hold them: a second backward
+    over a retained graph still sees its counts); forwards whose graphs are never differentiated only make the next step's
+    answer conservative."""
+    cells = []
+    for t in weights:
+        if t is None:
+            continue
+        cell = _weight_uses.get(id(t))
+        if cell is None or cell[0] is not t:
+            cell = _weight_uses[id(t)] = [t, 0]
+        cell[1] += 1
+        cells.append(cell)
+    if len(_weight_uses) > 4096:  # (forward-only loops with grad enabled: bounded)
+        _weight_uses.clear()
+    return cells
+
+
+def _side_stream_ok(weights, use_cells=None) -> bool:
     """The weight-gradient stream may be used only when nothing can READ the returned gradients before the end-of-backward join:
     every weight is a leaf that autograd will simply adopt as .grad -- no existing .grad to accumulate into (gradient
-    accumulation, zero_grad(set_to_none=False)), no tensor hooks -- and no distributed wrapper is reducing gradients from inside
-    the backward pass (DistributedDataParallel's bucket hooks; gcpnet_amd.parallel.GradAllReducer runs after it and opts in)."""
+    accumulation, zero_grad(set_to_none=False)), no tensor hooks, no second Function of the same graph using it (`use_cells`,
+    see _note_uses) -- and no distributed wrapper is reducing gradients from inside the backward pass
+    (DistributedDataParallel's bucket hooks; gcpnet_amd.parallel.GradAllReducer runs after it and opts in)."""
+    _ensure_end_of_backward_callback()
     if not WEIGHT_GRADS_ON_SIDE_STREAM:
         return False
     if torch.distributed.is_available() and torch.distributed.is_initialized() and not SIDE_STREAM_UNDER_DISTRIBUTED:
@@ -965,14 +1002,41 @@ def _side_stream_ok(weights) -> bool:
             continue
         if not t.is_leaf or t.grad is not None or t._backward_hooks or getattr(t, "_post_accumulate_grad_hooks", None):
             return False
+    if use_cells is not None and any(c[1] > 1 for c in use_cells):
+        return False
     return True
 
 
 SIDE_STREAM_UNDER_DISTRIBUTED = False  # set by gcpnet_amd.parallel.GradAllReducer (it reduces after the backward pass)
 
 
+_end_callback_task = -1  # id of the backward pass (graph task) that has _end_of_backward queued
+
+
+def _ensure_end_of_backward_callback() -> None:
+    """Queues _end_of_backward once per backward pass.  Keyed on the engine's graph-task id, not on a flag: a pass that dies
+    with an exception never runs its callbacks, and a flag would then keep every later pass from queueing its join.  Outside a
+    backward pass (id -1: a test calling a backward helper directly) nothing is queued."""
+    global _end_callback_task
+    task = torch._C._current_graph_task_id()
+    if task < 0 or task == _end_callback_task:
+        return
+    if _side_pending:  # left over from a pass that raised: its launches are long enqueued, join them now
+        _join_side_stream()
+    torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+    _end_callback_task = task
+
+
+def _end_of_backward():
+    """End-of-backward callback: the caller's stream waits for the weight-gradient stream; scratch is released; the table of
+    weight uses of the graph that was just differentiated is dropped."""
+    global _end_callback_task
+    _end_callback_task = -1
+    _weight_uses.clear()
+    _join_side_stream()
+
+
 def _join_side_stream():
-    """End-of-backward callback: the caller's stream waits for the weight-gradient stream; scratch is released."""
     for main, side in {(m, s) for m, s, _ in _side_pending}:
         main.wait_stream(side)
     _side_pending.clear()
@@ -981,14 +1045,16 @@ def _join_side_stream():
 def _side_submit(fn, keep) -> None:
     """Runs fn() with the weight-gradient stream current (ordered after everything enqueued on the caller's stream so far);
     `keep` stays referenced until the caller's stream has joined at the end of the backward pass."""
+    if torch._C._current_graph_task_id() < 0:  # not inside a backward pass: nothing would join the side stream
+        fn()
+        return
     dev = torch.cuda.current_device()
     main = torch.cuda.current_stream()
     side = _side_streams.get(dev)
     if side is None:
         side = _side_streams[dev] = torch.cuda.Stream(device=dev)
     side.wait_stream(main)
-    if not _side_pending:
-        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+    _ensure_end_of_backward_callback()
     _side_pending.append((main, side, keep))
     with torch.cuda.stream(side):
         fn()
@@ -1076,6 +1142,7 @@ class _Gcp2Chain(torch.autograd.Function):
             ctx.state = (s0, v0, ws, packs, saved)
             ctx.w_leaf = not any(sp.shared_weights for sp in specs)
             ctx.weights = weights
+            ctx.use_cells = _note_uses(weights)
         return outs[-1][0], outs[-1][1]
 
     @staticmethod
@@ -1106,7 +1173,7 @@ class _Gcp2Chain(torch.autograd.Function):
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k])
         else:
-            side = ctx.w_leaf and _side_stream_ok(ctx.weights)
+            side = ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells)
             for k in range(n - 1, -1, -1):
                 s_in, v_in = ins[k]
                 _, _, s_pre, gate = outs[k]
@@ -1116,7 +1183,7 @@ class _Gcp2Chain(torch.autograd.Function):
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
         if live:
-            run_weight_grad_jobs(live, in_backward_of_leaves=ctx.w_leaf and _side_stream_ok(ctx.weights))
+            run_weight_grad_jobs(live, in_backward_of_leaves=ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells))
         wgrads: List[Optional[Tensor]] = []
         for k in range(n):
             g = jobs[k].grads() if jobs[k] is not None else [None] * 7
@@ -1352,6 +1419,7 @@ class _Gcp2Projected(torch.autograd.Function):
             ctx.has_res = (res_s is not None, res_v is not None)
             ctx.w_leaf = not spec.shared_weights
             ctx.weights = w
+            ctx.use_cells = _note_uses(w)
             ctx.n_w2 = [t is not None for t in w2]
             ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre, gate, *wvs, *vts, *vadds)
         if spec.vo:
@@ -1461,7 +1529,7 @@ class _Gcp2Projected(torch.autograd.Function):
                         gf[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[H:H + 3])
 
             keep = [job.keep, dP, dQ, list(s_src), list(vts), scr]
-            if ctx.w_leaf and _side_stream_ok(ctx.weights):
+            if ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells):
                 _side_submit(assemble, keep)
             else:
                 assemble()

@@ -23,6 +23,8 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 Params = Mapping[str, Tensor]
+# Tests may set this to a list: gcp2() then appends (prefix, pre-activation of scalar_out) of every block it evaluates.
+TRACE_PRE: Optional[list] = None
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -228,6 +230,8 @@ def gcp2(
         merged = s
 
     s_pre = merged @ W_s.t() + b_s  # gcpnet.py:441
+    if TRACE_PRE is not None:  # (tests: the ReLU census of tests/test_full_size.py)
+        TRACE_PRE.append((pre, s_pre.detach()))
     if two_layer:  # Linear -> act -> Linear
         s_pre = nonlinearity(scalar_out_nonlinearity, s_pre, slope) @ P[pre + "scalar_out.2.weight"].t() \
             + P[pre + "scalar_out.2.bias"]

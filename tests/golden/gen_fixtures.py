@@ -254,6 +254,31 @@ def fx_interactions():
          inputs=dict(h=h2, chi=chi2, e=e2, xi=xi2, edge_index=ei, frames=frames), outputs=dict(h=ho, chi=co))
 
 
+def fx_ablations():
+    """ablate_scalars / ablate_vectors through GCPMessagePassing (the flags zero a block's inputs and outputs, reference
+    gcpnet.py:416-417,466-467); same graph, seeds and inputs as `message_passing`."""
+    lc = ref_stubs.make_layer_cfg()
+    nd, ed = SV(64, 16), SV(32, 4)
+    ei, x = rand_graph(24, 96, 50)
+    frames = comp.localize(x, ei)
+    for name, over in (("message_passing_ablate_scalars", dict(ablate_scalars=True)),
+                       ("message_passing_ablate_vectors", dict(ablate_vectors=True))):
+        cfg = ref_stubs.make_cfg(**over)
+        torch.manual_seed(51)
+        mp = gn.GCPMessagePassing(nd, nd, ed, cfg=cfg, mp_cfg=lc.mp_cfg)
+        h, chi = randn(24, 64, seed=52).requires_grad_(), randn(24, 16, 3, seed=53).requires_grad_()
+        e, xi = randn(96, 32, seed=54).requires_grad_(), randn(96, 4, 3, seed=55).requires_grad_()
+        msg = mp.message(SV(h, chi), SV(e, xi), ei, frames)
+        out = mp(SV(h, chi), SV(e, xi), ei, frames)
+        lw_s, lw_v = randn(*out[0].shape, seed=56), randn(*out[1].shape, seed=57)
+        ((out[0] * lw_s).sum() + (out[1] * lw_v).sum() + sq_loss(out[0], out[1])).backward()
+        zero = lambda t, like: t if t is not None else torch.zeros_like(like)
+        grads = dict(h=zero(h.grad, h), chi=zero(chi.grad, chi), e=zero(e.grad, e), xi=zero(xi.grad, xi))
+        grads.update({"w." + k: zero(p.grad, p) for k, p in mp.named_parameters()})
+        save(name, params=mp.state_dict(), inputs=dict(h=h, chi=chi, e=e, xi=xi, edge_index=ei, frames=frames, lw_s=lw_s, lw_v=lw_v),
+             outputs=dict(s=out[0], v=out[1], messages=msg), grads=grads)
+
+
 def fx_masked():
     """Masked / autoregressive call paths: node_mask in centralize / localize / scalarize / vectorize
     (components/__init__.py:177-193,229-264,294-300,346-357), GCP2 with a mask, GCPInteractions with a mask (sub-graph
@@ -517,6 +542,7 @@ if __name__ == "__main__":
     fx_layernorm()
     fx_embedding()
     fx_interactions()
+    fx_ablations()
     fx_interactions2()
     fx_masked()
     fx_models()

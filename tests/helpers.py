@@ -58,3 +58,45 @@ def as_accurate(got, cpu32, cpu64, name="", factor=4.0, floor=2e-3, abs_floor=0.
     e_got, e_cpu = float((got - cpu64).norm()), float((cpu32 - cpu64).norm())
     bound = max(factor * e_cpu, floor * max(ref, 1e-30), abs_floor)  # abs_floor: for tensors whose gradient is ~0 overall
     assert e_got <= bound, f"{name}: |hip - f64| = {e_got:.3e} > max({factor} x |cpu32 - f64| ({e_cpu:.3e}), {floor} x |f64| ({ref:.3e}))"
+
+
+def poison_allocations():
+    """Debugging aid for the GPU sweeps (SWEEP_POISON=1): every fresh float32 device buffer from torch.empty / empty_like starts
+    as NaN, so a kernel that reads memory nobody has written shows it deterministically instead of depending on what the caching
+    allocator hands back.  Returns a function that restores the originals."""
+    import torch
+
+    orig_empty, orig_like = torch.empty, torch.empty_like
+
+    def fill(t):
+        if t.is_cuda and t.dtype == torch.float32 and t.numel():
+            t.fill_(float("nan"))
+        return t
+
+    def empty(*a, **k):
+        return fill(orig_empty(*a, **k))
+
+    def empty_like(*a, **k):
+        return fill(orig_like(*a, **k))
+
+    torch.empty, torch.empty_like = empty, empty_like
+
+    def restore():
+        torch.empty, torch.empty_like = orig_empty, orig_like
+
+    return restore
+
+
+def bit_identical(runs):
+    """`runs`: list of dicts name -> tensor from repeated executions of the same step; returns the names that differ bitwise
+    from the first run (NaN == NaN counts as equal)."""
+    import torch
+
+    bad = []
+    for r in runs[1:]:
+        for k, t in r.items():
+            a, b = runs[0][k], t
+            if a.shape != b.shape or not torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                                                     b.view(torch.int32) if b.dtype == torch.float32 else b):
+                bad.append(k)
+    return sorted(set(bad))

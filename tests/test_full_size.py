@@ -58,12 +58,57 @@ def _layer_case(G, n_nodes, k, dims, act, seed):
         for k_, p in layer.named_parameters():
             close(p.grad.cpu(), P[k_].grad, atol=2e-5 * float(P[k_].grad.abs().max()), rtol=1e-4)
     else:
-        P64, c64, wh64, wc64 = oracle(torch.float64)
+        O.TRACE_PRE = []
+        try:
+            P64, c64, wh64, wc64 = oracle(torch.float64)
+        finally:
+            trace, O.TRACE_PRE = O.TRACE_PRE, None
         ((wh64 * lh.double()).sum() + (wc64 * lc.double()).sum()).backward()
         for k_ in ins:
             as_accurate(gi[k_].grad.cpu(), ci[k_].grad, c64[k_].grad, k_)
         for k_, p in layer.named_parameters():
             as_accurate(p.grad.cpu(), P[k_].grad, P64[k_].grad, k_)
+        _relu_census(trace, ei, n_nodes, gi, c64)
+
+
+def _relu_census(trace, ei, n_nodes, gi, c64, tau=1e-5, tol=1e-4):
+    """The element-wise half of the ReLU comparison.  `trace` holds the float64 pre-activation of
+    every ReLU block of the layer.  A unit whose |pre-activation| is below `tau` x the block's scale may take the other branch
+    in ANY fp32 evaluation (two summation orders of a K = 141 product differ by ~1e-6 of that scale, and the later blocks inherit
+    the earlier ones' differences); the rows such a unit can reach in ONE layer are
+      * for an edge-row unit of edge e: d e[e], d xi[e], and d h / d chi of its end points row(e), col(e);
+      * for a node-row unit of node n (feed-forward): everything upstream of n's aggregate -- n itself, its in-edges, their sources.
+    Every OTHER row of every input gradient must agree with the float64 oracle element-wise at `tol` of the tensor's scale; the
+    census (how many units / rows were set aside) is asserted to stay a small fraction, so the exemption cannot hide a real error."""
+    row, col = ei[0], ei[1]
+    n_edges = ei.shape[1]
+    edge_risk = torch.zeros(n_edges, dtype=torch.bool)
+    node_risk = torch.zeros(n_nodes, dtype=torch.bool)
+    units = 0
+    for pre, sp in trace:
+        scale = float(sp.abs().mean())
+        risky = sp.abs() < tau * scale
+        units += int(risky.sum())
+        rows = risky.any(dim=1)
+        if sp.shape[0] == n_edges and n_edges != n_nodes:
+            edge_risk |= rows
+        else:
+            node_risk |= rows
+    # node-level flips reach the node's in-edges and their sources
+    in_edges_of_risky = node_risk[col]
+    edge_rows = edge_risk | in_edges_of_risky
+    node_rows = node_risk.clone()
+    node_rows[row[edge_rows]] = True
+    node_rows[col[edge_rows]] = True
+    frac_e, frac_n = float(edge_rows.float().mean()), float(node_rows.float().mean())
+    print(f"ReLU census: {units} near-zero units of {sum(t.numel() for _, t in trace)}; set aside {int(edge_rows.sum())} edge rows "
+          f"({100 * frac_e:.2f} %), {int(node_rows.sum())} node rows ({100 * frac_n:.2f} %)")
+    assert frac_e < 0.05 and frac_n < 0.5, "the near-zero census is not a small exemption any more"
+    for k_, keep in (("e", ~edge_rows), ("xi", ~edge_rows), ("h", ~node_rows), ("chi", ~node_rows)):
+        got, want = gi[k_].grad.cpu().double()[keep], c64[k_].grad[keep]
+        err = (got - want).abs().max().item()
+        top = want.abs().max().item()
+        assert err <= tol * top, f"d{k_}: rows outside the ReLU census differ by {err:.3e} (scale {top:.3e})"
 
 
 @pytest.mark.parametrize("act", ["silu", "relu"])

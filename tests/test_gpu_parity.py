@@ -274,6 +274,34 @@ def test_message_passing_golden(G):
         close(p.grad.cpu(), f.g["w." + k], atol=1e-5, rtol=5e-4)
 
 
+@pytest.mark.parametrize("flag", ["ablate_scalars", "ablate_vectors"])
+def test_message_passing_ablations_golden(G, flag):
+    """ablate_scalars / ablate_vectors on the message path (reference gcpnet.py:416-417,466-467): the
+    project-then-gather / chain routes must honour the flags -- reference fixture, forward and every gradient."""
+    f = Fixture("message_passing_" + flag)
+    mp = G.GCPMessagePassing((64, 16), (64, 16), (32, 4), cfg=G.default_module_cfg(**{flag: True}),
+                             mp_cfg=G.default_layer_cfg().mp_cfg).cuda()
+    mp.load_state_dict(f.p)
+    ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
+    msg = mp.message((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
+    close(msg.detach().cpu(), f.o["messages"], atol=2e-5, rtol=2e-5)
+    s, v = mp((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
+    close(s.detach().cpu(), f.o["s"], atol=2e-5, rtol=2e-5)
+    close(v.detach().cpu(), f.o["v"], atol=2e-5, rtol=2e-5)
+    if flag == "ablate_scalars":
+        assert float(s.detach().abs().max()) == 0.0
+    else:
+        assert float(v.detach().abs().max()) == 0.0
+    ((s * f.i["lw_s"].cuda()).sum() + (v * f.i["lw_v"].cuda()).sum() + sq_loss(s, v)).backward()
+    for k, t in ins.items():
+        g = torch.zeros_like(t) if t.grad is None else t.grad
+        close(g.cpu(), f.g[k], atol=1e-5 * max(1.0, float(f.g[k].abs().max())), rtol=5e-4)
+    for k, p in mp.named_parameters():
+        g = torch.zeros_like(p) if p.grad is None else p.grad
+        close(g.cpu(), f.g["w." + k], atol=1e-5 * max(1.0, float(f.g["w." + k].abs().max())), rtol=5e-4)
+
+
 @pytest.mark.parametrize("name", ["interactions", "interactions_posupd", "interactions_force"])
 def test_interactions_golden(G, name):
     f = Fixture(name)

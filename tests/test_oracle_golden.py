@@ -145,6 +145,26 @@ def test_message_passing():
         close(g, f.g[n], atol=5e-6, rtol=5e-4)
 
 
+@pytest.mark.parametrize("flag", ["ablate_scalars", "ablate_vectors"])
+def test_message_passing_ablations(flag):
+    """ablate_scalars / ablate_vectors (reference gcpnet.py:416-417,466-467) through the whole message function."""
+    f = Fixture("message_passing_" + flag)
+    i = f.i
+    P = {k: v.clone().requires_grad_() for k, v in f.p.items()}
+    ins = {k: i[k].clone().requires_grad_() for k in ("h", "chi", "e", "xi")}
+    cfg, lc = O.default_module_cfg(**{flag: True}), O.default_layer_cfg()
+    (s, v), msg = O.message_passing(P, "", ins["h"], ins["chi"], ins["e"], ins["xi"], i["edge_index"], i["frames"],
+                                    cfg, lc["mp_cfg"], return_messages=True)
+    close(msg, f.o["messages"], atol=5e-6, rtol=5e-5)
+    close(s, f.o["s"], atol=5e-6, rtol=5e-5)
+    close(v, f.o["v"], atol=5e-6, rtol=5e-5)
+    loss = (s * i["lw_s"]).sum() + (v * i["lw_v"]).sum() + sq_loss(s, v)
+    names = list(ins) + ["w." + k for k in P]
+    for n, g in zip(names, torch.autograd.grad(loss, list(ins.values()) + list(P.values()), allow_unused=True)):
+        g = torch.zeros_like(f.g[n]) if g is None else g
+        close(g, f.g[n], atol=5e-6 * max(1.0, float(f.g[n].abs().max())), rtol=5e-4)
+
+
 @pytest.mark.parametrize("name", ["interactions", "interactions_posupd", "interactions_force"])
 def test_interactions(name):
     f = Fixture(name)
