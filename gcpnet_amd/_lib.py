@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgcpnet_hip.so")
+# (GCPNET_HIP_LIB: debugging knob -- load another build of the same ABI, e.g. an older kernel revision when bisecting a fault)
+LIB_PATH = os.environ.get("GCPNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libgcpnet_hip.so")
 
 ACT = {None: 0, "relu": 1, "leakyrelu": 2, "selu": 3, "silu": 4, "sigmoid": 5}
 VMODE_NONE, VMODE_SCALAR_GATE, VMODE_SELF_GATE = 0, 1, 2
@@ -24,7 +25,7 @@ EXPORTS = [
     "gcpnet_debug_set_phase_timing", "gcpnet_debug_set_fp32_mfma",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
     "gcpnet_wg_reduce", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
-    "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize",
+    "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
 ]
 
 
@@ -175,6 +176,7 @@ def load():
     lib.gcpnet_adam_step.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, i32, vp]
     lib.gcpnet_nms_edge_features.argtypes = [i64, vp, vp, vp, vp, i32, f32, i32, vp, vp, vp]
     lib.gcpnet_nms_node_features.argtypes = [i64, vp, vp, vp, vp, vp, vp]
+    lib.gcpnet_orientations.argtypes = [i64, vp, vp, vp, vp]
     lib.gcpnet_activation.argtypes = [i64, vp, vp, i32, f32, vp, vp]
     lib.gcpnet_frame_gate_forward.argtypes = [i64, i32, vp, i32, vp, vp, vp, i32, f32, vp, vp]
     lib.gcpnet_frame_gate_backward.argtypes = [i64, i32, vp, i32, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp]

@@ -62,6 +62,26 @@ __global__ __launch_bounds__(256) void nms_node_features_kernel(int64_t N, const
     }
 }
 
+__global__ __launch_bounds__(256) void orientations_kernel(int64_t N, const float* __restrict__ x, const int32_t* __restrict__ batch,
+                                                           float* __restrict__ chi_out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const int g = batch ? batch[i] : 0;
+        const bool has_next = i + 1 < N && (batch ? batch[i + 1] : 0) == g;
+        const bool has_prev = i > 0 && (batch ? batch[i - 1] : 0) == g;
+        float* c = chi_out + 6 * i;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bool ok = s == 0 ? has_next : has_prev;
+            const int64_t j = s == 0 ? i + 1 : i - 1;
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (ok) { dx = x[3 * j] - x[3 * i]; dy = x[3 * j + 1] - x[3 * i + 1]; dz = x[3 * j + 2] - x[3 * i + 2]; }
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float inv = d > 0.f ? 1.0f / d : 0.f;
+            c[3 * s] = dx * inv; c[3 * s + 1] = dy * inv; c[3 * s + 2] = dz * inv;
+        }
+    }
+}
+
 constexpr int RG_MAX_K = 64;
 
 // One thread per target node (in cell-sorted order).  cell_start[c] .. cell_start[c + 1] are the sorted positions of the nodes
@@ -136,6 +156,15 @@ extern "C" int gcpnet_nms_node_features(int64_t N, const float* vel, const float
     const int64_t nb = (N + 255) / 256;
     hipLaunchKernelGGL(nms_node_features_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, N, vel, x, batch,
                        h_out, chi_out);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_orientations(int64_t N, const float* x, const int32_t* batch, float* chi_out, void* stream) {
+    if (N < 0 || !x || !chi_out) return GCPNET_E_BADARG;
+    if (N == 0) return 0;
+    const int64_t nb = (N + 255) / 256;
+    hipLaunchKernelGGL(orientations_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, N, x, batch, chi_out);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

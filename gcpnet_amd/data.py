@@ -1,11 +1,12 @@
 """Input side of the hot path on the GPU: the NMS featuriser
-(src/datamodules/components/nms_dataset.py:23-61, helper.py:16-59) and the radius-graph builder (atom3d_dataset.py:110-112
-recipe).  HIP kernels do the arithmetic and the neighbour search; index preprocessing (cell ids, one sort, prefix sums) is torch
-plumbing, as for the CSR plans."""
+(src/datamodules/components/nms_dataset.py:23-61, helper.py:16-59), the ATOM3D / LBA featuriser (atom3d_dataset.py:42-149), the
+radius-graph builder (atom3d_dataset.py:110-112 recipe) and the collation of per-graph samples into one batch
+(torch_geometric `Batch.from_data_list` semantics).  HIP kernels do the arithmetic and the neighbour search; index preprocessing
+(cell ids, one sort, prefix sums, concatenation) is torch plumbing, as for the CSR plans."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, Mapping, Optional, Sequence
 
 import torch
 
@@ -68,3 +69,87 @@ def radius_graph(x: Tensor, r: float = 4.5, max_num_neighbors: int = 32, batch: 
     keep = nbr >= 0
     col = torch.arange(n, device=dev).unsqueeze(1).expand(n, max_num_neighbors)[keep]
     return torch.stack((nbr[keep].long(), col))
+
+
+# ---- ATOM3D / LBA (src/datamodules/components/atom3d_dataset.py) -----------------------------------------------------------
+ATOM_TYPES: Dict[str, int] = {"H": 0, "C": 1, "N": 2, "O": 3, "F": 4, "S": 5, "Cl": 6, "CL": 6, "P": 7}  # :20-30
+NUM_ATOM_TYPES = 9  # the eight elements above + "anything else" = 8 (:36-37)
+
+
+def element_mapping(elements: Sequence[str]) -> Tensor:
+    """`_element_mapping` (atom3d_dataset.py:35-37) over a column of element symbols -> int64 atom types (host-side: strings)."""
+    return torch.tensor([ATOM_TYPES.get(e, 8) for e in elements], dtype=torch.long)
+
+
+def lba_featurize(coords: Tensor, atom_types: Tensor, n_ligand: Optional[int] = None, edge_cutoff: float = 4.5, num_rbf: int = 16,
+                  max_num_neighbors: int = 32, batch: Optional[Tensor] = None, edge_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """`BaseTransform.__call__` / `LBATransform.__call__` (atom3d_dataset.py:101-149) for one structure -- or, with `batch`, for
+    the concatenated atoms of several -- on the GPU: radius graph (r = edge_cutoff, <= max_num_neighbors in-edges per atom, no
+    self loops), e = 16 RBFs of the edge length with D_max = edge_cutoff (`_edge_features`, :42-62; `_rbf`, helper.py:29-49), xi =
+    unit(x_row - x_col) [E, 1, 3], h = atom types (int64), chi = forward / backward orientations along the atom order [N, 2, 3]
+    (`_node_features`, :65-84; `_orientations`, helper.py:52-59); `lig_flag` marks the last `n_ligand` atoms (:146-148).
+
+    Neighbour selection when an atom has MORE than `max_num_neighbors` atoms within the cutoff: this builder keeps the nearest
+    ones (deterministic, order-independent); torch_cluster 1.6.0's `radius_graph` keeps whichever it meets first (an unsorted
+    nanoflann radius search on the CPU, index order on the GPU) -- unpinned by the reference's tests and not
+    reproducible without that library.  Below the cap the edge SETS are identical; the edge order here is col-sorted with each
+    atom's neighbours by ascending distance.  Pass `edge_index` to featurise a given graph instead."""
+    lib = _lib.load()
+    coords = _req(coords, "coords")
+    n = coords.shape[0]
+    dev = coords.device
+    if edge_index is None:
+        edge_index = radius_graph(coords, r=edge_cutoff, max_num_neighbors=max_num_neighbors, batch=batch)
+    e_cnt = edge_index.shape[1]
+    row, col = edge_index[0].to(torch.int32).contiguous(), edge_index[1].to(torch.int32).contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    e = torch.empty((e_cnt, num_rbf), **f32)
+    xi = torch.empty((e_cnt, 1, 3), **f32)
+    check(lib.gcpnet_nms_edge_features(e_cnt, _p(coords), _p(row), _p(col), None, 0, float(edge_cutoff), int(num_rbf), _p(e), _p(xi),
+                                       _stream()), "lba edge features")
+    chi = torch.empty((n, 2, 3), **f32)
+    b32 = batch.to(torch.int32).contiguous() if batch is not None else None
+    check(lib.gcpnet_orientations(n, _p(coords), _p(b32), _p(chi), _stream()), "orientations")
+    out = dict(h=atom_types.to(device=dev, dtype=torch.long), chi=chi, e=e, xi=xi, x=coords, edge_index=edge_index)
+    if n_ligand is not None:
+        if batch is not None:
+            raise ValueError("lba_featurize: n_ligand marks the tail of ONE structure; featurise per structure, then collate()")
+        flag = torch.zeros(n, dtype=torch.bool, device=dev)
+        if n_ligand > 0:
+            flag[n - int(n_ligand):] = True
+        out["lig_flag"] = flag
+    return out
+
+
+def collate(graphs: Sequence[Mapping[str, Tensor]]) -> Dict[str, Tensor]:
+    """torch_geometric 2.1 `Batch.from_data_list` for plain dict samples (what the reference's DataLoader does to the `Data`
+    objects its transforms return, atom3d_dataset.py:122-129): every tensor attribute with at least one dimension is
+    concatenated along dim 0 in list order -- per-node, per-edge and per-graph tensors alike (`Data.__cat_dim__` = 0) --, except
+    attributes whose name contains "index" (`edge_index`), which are concatenated along the LAST dimension with each graph's
+    entries incremented by the number of nodes before it (`Data.__inc__`: block-diagonal adjacency); 0-dim tensors and Python
+    numbers (LBA's `label`) become one entry each of a [G] tensor.  Adds `batch` [N] (graph id per node) and `ptr` [G + 1]
+    (node offsets).  A graph's node count is the first dimension of `x` (else `h`), as PyG infers `num_nodes`."""
+    if not graphs:
+        raise ValueError("collate: empty list")
+    counts = []
+    for g in graphs:
+        ref = g["x"] if "x" in g else g["h"]
+        counts.append(int(ref.shape[0]))
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    dev = (graphs[0]["x"] if "x" in graphs[0] else graphs[0]["h"]).device
+    out: Dict[str, Tensor] = {}
+    for k in graphs[0].keys():
+        vals = [g[k] for g in graphs]
+        if not torch.is_tensor(vals[0]):
+            out[k] = torch.tensor(vals, device=dev)
+        elif vals[0].dim() == 0:
+            out[k] = torch.stack(list(vals))
+        elif "index" in k:
+            out[k] = torch.cat([v + o for v, o in zip(vals, offs[:-1])], dim=-1)
+        else:
+            out[k] = torch.cat(list(vals), dim=0)
+    out["batch"] = torch.repeat_interleave(torch.arange(len(graphs), device=dev), torch.tensor(counts, device=dev))
+    out["ptr"] = torch.tensor(offs, dtype=torch.long, device=dev)
+    return out

@@ -730,11 +730,19 @@ class GCPInteractions(nn.Module):
         (pre-normed) input."""
         if self.pre_norm:
             node_rep = self.gcp_norm[0](node_rep)
+        # The reference writes the new rows INTO the tensors it was given (:1248-1251 `node_rep_residual[0][node_mask] = ...`;
+        # with pre_norm, into the normed copies) and returns those very tensors -- callers alias them: the CPD module's
+        # `encoder_embedding = (h, chi)` is overwritten by its first decoder layer (gcpnet_cpd_module.py:183-201), the sampling
+        # loop's `node_rep_cache[j]` by every layer call (:341-349).  Mirrored here: the computation runs on a private copy (the
+        # autograd Functions of this package save their inputs; an in-place write to a saved tensor would invalidate them), the
+        # result rows are then index_copy_'d into the caller's tensors, which are returned.
+        target = node_rep
+        node_rep = ScalarVector(target[0].clone(), target[1].clone())
         if node_rep_regressive is not None:
-            hidden = self.autoregressive_forward(node_rep, edge_rep, edge_index, frames, node_rep_regressive, node_mask=node_mask)
+            reg = tuple(node_rep[k] if node_rep_regressive[k] is target[k] else node_rep_regressive[k] for k in (0, 1))
+            hidden = self.autoregressive_forward(node_rep, edge_rep, edge_index, frames, reg, node_mask=node_mask)
         else:
             hidden = self.interaction(node_rep, edge_rep, edge_index, frames, node_mask=node_mask)
-        full = node_rep
         idx = torch.nonzero(node_mask).squeeze(1)
         sel = lambda sv: ScalarVector(sv[0].index_select(0, idx), sv[1].index_select(0, idx))
         node_rep, hidden = sel(node_rep), sel(hidden)
@@ -752,7 +760,9 @@ class GCPInteractions(nn.Module):
         if self.gcp_dropout[1].active:
             hidden = self.gcp_dropout[1](hidden)
         node_rep = _sv_add(node_rep, hidden) if self.pre_norm else self.gcp_norm[1](node_rep, residual=hidden)
-        node_rep = ScalarVector(full[0].index_copy(0, idx, node_rep[0]), full[1].index_copy(0, idx, node_rep[1]))  # :1248-1251
+        target[0].index_copy_(0, idx, node_rep[0])  # :1248-1251, in place (raises for a leaf that requires grad, as the
+        target[1].index_copy_(0, idx, node_rep[1])  # reference's indexed assignment does: feed such a leaf as `t.clone()`)
+        node_rep = ScalarVector(target[0], target[1])
         if not self.updating_node_positions:
             return node_rep
         upd = self.derive_x_update(node_rep, edge_index, frames, node_mask=node_mask)

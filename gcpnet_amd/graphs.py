@@ -1,4 +1,5 @@
-"""hipGraph capture of a whole training step (forward + loss + backward [+ optimizer]) for launch-bound configurations.
+"""hipGraph capture of a whole training step (forward + loss + backward) for launch-bound configurations.  The optimizer stays
+outside the capture: FusedAdam.step() takes the step count as a host value and refuses to run under capture.
 
 A GCPNet step on the n-body batches of the NMS task is ~700 kernel launches for 2 000 - 38 000 edges: the GPU idles between launches
 while Python and the HIP runtime enqueue them.  Captured once into a hipGraph (torch.cuda.CUDAGraph; the ctypes launches of this

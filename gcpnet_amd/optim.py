@@ -25,6 +25,10 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # the step count and the bias corrections derived from it are host values passed as kernel arguments: a captured
+            # step() would replay the capture-time corrections for ever and state["step"] would stop advancing
+            raise RuntimeError("FusedAdam.step() cannot be captured into a hipGraph: call it eagerly after GraphedStep's replay")
         lib = _lib.load()
         for group in self.param_groups:
             items, step = [], None

@@ -241,6 +241,10 @@ def sharded_interactions_forward(layer, node_rep, edge_rep, sg: ShardedGraph, fr
     node_rep = (layer.gcp_norm[1] if layer.pre_norm else layer.gcp_norm[0])(node_rep, residual=hidden)
 
     def node_gcp(module, rep):  # GCP2.forward(node_inputs=True) on local rows with the precomputed mean frames
+        if getattr(module, "enable_e3_equivariance", False) and not getattr(module, "ablate_frame_updates", False):
+            # |.| of the x_cross projections is taken per out-edge BEFORE the mean (GCP2._forward_node_e3): the mean out-edge
+            # frame used here would silently give other numbers
+            raise NotImplementedError("sharded_interactions_forward: enable_e3_equivariance on node rows")
         out = module.apply_rows([rep[0]], [None], [rep[1]], [None], node_frames)
         return ScalarVector(*out) if isinstance(out, tuple) else out
 

@@ -423,6 +423,12 @@ int gcpnet_nms_edge_features(int64_t E, const float* x, const int32_t* row, cons
                              float d_max, int n_rbf, float* e_out, float* xi_out, void* stream);
 int gcpnet_nms_node_features(int64_t N, const float* vel, const float* x, const int32_t* batch, float* h_out, float* chi_out,
                              void* stream);
+/* ATOM3D / LBA node vectors, src/datamodules/components/atom3d_dataset.py:65-84 (`_node_features`) -> helper.py:52-59
+ * (`_orientations`): chi_out [N, 2, 3] = [unit(x[i+1] - x[i]), unit(x[i-1] - x[i])] along the node order inside each graph (`batch`
+ * = graph id per node, NULL = one graph; zero rows at a graph's two ends, 0 for coincident points: nan_to_num).  The LBA edge
+ * features (`_edge_features`, atom3d_dataset.py:42-62: 16 RBFs of the edge length + the unit difference) are
+ * gcpnet_nms_edge_features with n_attr = 0. */
+int gcpnet_orientations(int64_t N, const float* x, const int32_t* batch, float* chi_out, void* stream);
 /* Radius graph (atom3d_dataset.py:110-112 recipe): for every node the `max_neighbors` (<= 64) nearest other nodes of its graph
  * within `radius`, ascending by distance (ties: lower node id), nbr [N, max_neighbors] (-1 padded) and count [N], indexed by node
  * id.  The caller provides the cell list: nodes sorted by global cell = graph * (nx*ny*nz) + (cz*ny + cy)*nx + cx with cell edge

@@ -74,7 +74,7 @@ def safe_norm(x: Tensor, dim: int = -1, eps: float = 1e-8, keepdim: bool = False
 
 def flatten_sv(s: Tensor, v: Tensor) -> Tensor:
     """ScalarVector.flatten, components/__init__.py:61-63: [s | V x 3 row-major]."""
-    return torch.cat((s, v.reshape(v.shape[0], -1)), dim=-1)
+    return torch.cat((s, v.reshape(v.shape[0], v.shape[1] * v.shape[2])), dim=-1)  # (explicit width: rows may be 0)
 
 
 def recover_sv(x: Tensor, vdim: int) -> Tuple[Tensor, Tensor]:
@@ -656,6 +656,100 @@ def lba_forward(P: Params, batch: Mapping[str, Tensor], cfg: Mapping, layer_cfg:
 
 
 # ----------------------------------------------------------------------------------------------------------
+# CPD task module -- src/models/gcpnet_cpd_module.py: forward :153-218, sampling loop :281-360
+# (pinned by tests/golden/model_cpd_small.npz, generated by the reference's real LitModule)
+# ----------------------------------------------------------------------------------------------------------
+def _cpd_decoder_cfg(cfg: Mapping) -> Dict:
+    c = dict(cfg)  # gcpnet_cpd_module.py:94-97
+    c["vector_gate"], c["frame_gate"], c["ablate_frame_updates"] = cfg["frame_gate"], False, True
+    return c
+
+
+def _cpd_embed(P: Params, h, chi, e, xi, edge_index, frames, cfg, mask):
+    kw = dict(vector_gate=cfg["vector_gate"], frame_gate=cfg["frame_gate"], ablate_frame_updates=cfg["ablate_frame_updates"],
+              ablate_scalars=cfg["ablate_scalars"], ablate_vectors=cfg["ablate_vectors"],
+              enable_e3_equivariance=cfg["enable_e3_equivariance"], nonlinearities=(None, None), node_mask=mask)
+    er = gcp2(P, "gcp_embedding.edge_embedding.", e, xi, edge_index, frames, node_inputs=False, **kw)
+    nr = gcp2(P, "gcp_embedding.node_embedding.", h, chi, edge_index, frames, node_inputs=True, **kw)
+    return gcp_layer_norm(P, "gcp_embedding.node_normalization.", *nr), gcp_layer_norm(P, "gcp_embedding.edge_normalization.", *er)
+
+
+def _cpd_project(P: Params, h, chi, edge_index, frames, cfg, mask):
+    return gcp2(P, "invariant_node_projection.", h, chi, edge_index, frames, node_inputs=True, nonlinearities=(None, None),
+                vector_gate=cfg["vector_gate"], frame_gate=cfg["frame_gate"], ablate_frame_updates=cfg["ablate_frame_updates"],
+                ablate_scalars=cfg["ablate_scalars"], ablate_vectors=cfg["ablate_vectors"],
+                enable_e3_equivariance=cfg["enable_e3_equivariance"], node_mask=mask)
+
+
+def cpd_forward(P: Params, batch: Mapping[str, Tensor], cfg: Mapping, layer_cfg: Mapping, num_encoder_layers: int,
+                num_decoder_layers: int, autoregressive_decoder: bool, decoder_residual_updates: bool = True):
+    """Returns dict(out=...) with `out` the [N, vocab] projection (autoregressive decoder, teacher forcing on batch["seq"]) or
+    (logits, log_probs) of the MLP decoder; plus h, chi."""
+    mask, ei = batch["mask"], batch["edge_index"]
+    _, x = centralize(batch["x"], batch["batch"], node_mask=mask)
+    frames = localize(x, ei, norm_x_diff=cfg["norm_x_diff"], node_mask=mask)
+    (h, chi), (e, xi) = _cpd_embed(P, batch["h"], batch["chi"], batch["e"], batch["xi"], ei, frames, cfg, mask)
+    for k in range(num_encoder_layers):
+        h, chi = gcp_interactions(P, f"encoder_layers.{k}.", h, chi, e, xi, ei, frames, cfg, layer_cfg, node_mask=mask)
+    pcfg = cfg
+    if autoregressive_decoder:
+        pcfg = _cpd_decoder_cfg(cfg)
+        seq_emb = P["atom_embedding.weight"][batch["seq"]][ei[0]]  # :186-188
+        seq_emb = torch.where((ei[0] >= ei[1])[:, None], torch.zeros_like(seq_emb), seq_emb)
+        e = torch.cat((e, seq_emb), dim=-1)
+        for k in range(num_decoder_layers):
+            # `encoder_embedding = (h, chi)` (:183) names the very tensors the masked layers update IN PLACE and return
+            # (gcpnet.py:1248-1251): from the second decoder layer on, "the encoder's representation" is the previous decoder
+            # layer's output -- node_rep_regressive is always the layer's own input
+            h, chi = gcp_interactions(P, f"decoder_layers.{k}.", h, chi, e, xi, ei, frames, pcfg, layer_cfg, node_mask=mask,
+                                      regressive=(h, chi))
+    out = _cpd_project(P, h, chi, ei, frames, pcfg, mask)
+    if not autoregressive_decoder:
+        out = mlp_decoder(P, "decoder.", out, residual_updates=decoder_residual_updates)
+    return dict(out=out, h=h, chi=chi, f_ij=frames)
+
+
+def cpd_sample(P: Params, h, chi, e, xi, edge_index, frames, encoder_node_mask, cfg: Mapping, layer_cfg: Mapping,
+               num_encoder_layers: int, num_decoder_layers: int, num_samples: int, temperature: float = 0.1, sampler=None) -> Tensor:
+    """`autoregressively_generate_samples` (:281-360), step by step as written there; `sampler(logits) -> indices` stands in for
+    `Categorical(logits=...).sample()` (tests pass argmax)."""
+    n = h.shape[0]
+    (h, chi), (e, xi) = _cpd_embed(P, h, chi, e, xi, edge_index, frames, cfg, encoder_node_mask)
+    for k in range(num_encoder_layers):
+        h, chi = gcp_interactions(P, f"encoder_layers.{k}.", h, chi, e, xi, edge_index, frames, cfg, layer_cfg, node_mask=encoder_node_mask)
+    dcfg = _cpd_decoder_cfg(cfg)
+    h, chi = h.repeat(num_samples, 1), chi.repeat(num_samples, 1, 1)  # :309-310
+    e, xi = e.repeat(num_samples, 1), xi.repeat(num_samples, 1, 1)
+    ei = torch.cat([edge_index + k * n for k in range(num_samples)], dim=-1)  # :312-316
+    fr = frames.repeat(num_samples, 1, 1)
+    seq = torch.zeros(num_samples * n, dtype=torch.long)
+    seq_emb = torch.zeros(num_samples * n, P["atom_embedding.weight"].shape[0], dtype=h.dtype)
+    cache = [(h.clone(), chi.clone()) for _ in range(num_decoder_layers)]
+    mask_all = encoder_node_mask.repeat(num_samples)
+    for i in range(n):
+        se = seq_emb[ei[0]]  # :326-328
+        se = torch.where((ei[0] >= ei[1])[:, None], torch.zeros_like(se), se)
+        em = (ei[1] % n) == i  # :330-333
+        ei_i, e_i, xi_i, fr_i = ei[:, em], torch.cat((e, se), dim=-1)[em], xi[em], fr[em]
+        nm = torch.zeros(num_samples * n, dtype=torch.bool)
+        nm[i::n] = True
+        nm = nm & mask_all
+        for j in range(num_decoder_layers):  # :341-355
+            full = gcp_interactions(P, f"decoder_layers.{j}.", cache[j][0], cache[j][1], e_i, xi_i, ei_i, fr_i, dcfg, layer_cfg,
+                                    node_mask=nm, regressive=cache[0])
+            cache[j] = (full[0], full[1])  # (the layer writes its result into the tensors it was given: gcpnet.py:1248-1251)
+            oh, oc = full[0][nm], full[1][nm]
+            if j < num_decoder_layers - 1:
+                cache[j + 1][0][i::n] = oh
+                cache[j + 1][1][i::n] = oc
+        logits = _cpd_project(P, oh, oc, ei_i, fr_i, dcfg, nm)  # :357-363
+        scaled = logits / temperature
+        seq[i::n] = sampler(scaled) if sampler is not None else torch.distributions.Categorical(logits=scaled).sample()
+        seq_emb[i::n] = P["atom_embedding.weight"][seq[i::n]]
+    return seq.reshape(num_samples, n)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # reference-default configs (values of configs/model/module_cfg/gcp_module_nms.yaml etc.), as plain dicts
 # ----------------------------------------------------------------------------------------------------------
 def default_module_cfg(**over) -> Dict:
@@ -713,6 +807,46 @@ def nms_features(x: Tensor, vel: Tensor, edge_attr: Tensor, edge_index: Tensor, 
     bwd[1:][same_next] = -f[same_next]
     chi = torch.stack((vel, fwd, bwd), dim=1)
     return dict(h=h, chi=chi, e=e, xi=xi)
+
+
+def lba_features(x: Tensor, edge_index: Tensor, batch: Optional[Tensor] = None, d_max: float = 4.5, num_rbf: int = 16) -> Dict[str, Tensor]:
+    """ATOM3D / LBA featuriser, src/datamodules/components/atom3d_dataset.py:42-84: e = RBF(|x_row - x_col|) [E, num_rbf] with
+    D_max = the edge cutoff, xi = unit(x_row - x_col) [E, 1, 3] (both nan_to_num'ed), chi = `_orientations(x)` [N, 2, 3] along the
+    atom order of each graph (helper.py:52-59).  Pinned by tests/golden/lba_features.npz (the reference's real LBATransform)."""
+    row, col = edge_index[0], edge_index[1]
+    ev = x[row] - x[col]  # atom3d_dataset.py:53
+    d = ev.norm(dim=-1)
+    mu = torch.linspace(0.0, d_max, num_rbf).view(1, -1)  # helper.py:40-45
+    e = torch.nan_to_num(torch.exp(-(((d.unsqueeze(-1) - mu) / (d_max / num_rbf)) ** 2)))
+    xi = torch.nan_to_num(torch.nan_to_num(ev / d.unsqueeze(-1)).unsqueeze(-2))
+    fwd, bwd = torch.zeros_like(x), torch.zeros_like(x)
+    b = batch if batch is not None else torch.zeros(x.shape[0], dtype=torch.long)
+    same_next = b[1:] == b[:-1]
+    f = torch.nan_to_num((x[1:] - x[:-1]) / (x[1:] - x[:-1]).norm(dim=-1, keepdim=True))
+    fwd[:-1][same_next] = f[same_next]
+    bwd[1:][same_next] = -f[same_next]
+    return dict(e=e, xi=xi, chi=torch.stack((fwd, bwd), dim=1))
+
+
+def collate(graphs: Sequence[Mapping[str, Tensor]]) -> Dict[str, Tensor]:
+    """torch_geometric 2.1 `Batch.from_data_list` for dict samples: tensors cat along dim 0, `*index*` attributes along the last
+    dim with node offsets, scalars -> [G]; plus `batch` and `ptr` (documented PyG semantics restated; PyG is not in the image)."""
+    counts = [int((g["x"] if "x" in g else g["h"]).shape[0]) for g in graphs]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    out: Dict[str, Tensor] = {}
+    for k in graphs[0]:
+        vals = [torch.as_tensor(g[k]) for g in graphs]
+        if vals[0].dim() == 0:
+            out[k] = torch.stack(vals)
+        elif "index" in k:
+            out[k] = torch.cat([v + o for v, o in zip(vals, offs[:-1])], dim=-1)
+        else:
+            out[k] = torch.cat(vals, dim=0)
+    out["batch"] = torch.repeat_interleave(torch.arange(len(graphs)), torch.tensor(counts))
+    out["ptr"] = torch.tensor(offs)
+    return out
 
 
 def radius_graph(x: Tensor, batch: Tensor, radius: float = 4.5, max_neighbors: int = 32) -> Tensor:

@@ -530,6 +530,110 @@ def fx_input_side():
          outputs=dict(edge_index=torch.from_numpy(np.concatenate(eis, 1))), meta=dict(radius=4.5, max_neighbors=16))
 
 
+def fx_cpd():
+    """CPD task module: the reference's REAL `GCPNetCPDLitModule` (src/models/gcpnet_cpd_module.py,
+    imported through ref_stubs.install_lightning_stubs) with the autoregressive decoder -- forward with teacher forcing (:153-218),
+    the training-step loss and every gradient (:220-231), and `autoregressively_generate_samples` (:281-360) with
+    `Categorical(...).sample()` replaced by argmax (the only way two implementations can agree on a sampled sequence); plus the
+    direct-shot (MLP decoder) variant's forward."""
+    import functools
+
+    ref_stubs.install_lightning_stubs()
+    import src.models.gcpnet_cpd_module as cpd
+
+    class ArgmaxCategorical:
+        def __init__(self, logits=None):
+            self.logits = logits
+
+        def sample(self):
+            top2 = torch.topk(self.logits, 2, dim=-1).values
+            ArgmaxCategorical.margin = min(ArgmaxCategorical.margin, float((top2[:, 0] - top2[:, 1]).min()))
+            return self.logits.argmax(-1)
+
+    ArgmaxCategorical.margin = float("inf")
+    cpd.Categorical = ArgmaxCategorical
+    n, k_nn = 12, 5
+    g = torch.Generator().manual_seed(120)
+    x = torch.randn(n, 3, generator=g) * 3
+    d = torch.cdist(x, x)
+    d.fill_diagonal_(float("inf"))
+    nbr = d.topk(k_nn, largest=False).indices  # kNN graph (CATH recipe), edges source -> target
+    ei = torch.stack((nbr.reshape(-1), torch.arange(n).repeat_interleave(k_nn)))
+    e_cnt = ei.shape[1]
+    mask = torch.ones(n, dtype=torch.bool)
+    model_cfg = ref_stubs.DictConfig(h_hidden_dim=32, chi_hidden_dim=8, e_hidden_dim=16, xi_hidden_dim=4, output_dim=20,
+                                     num_encoder_layers=2, num_decoder_layers=2, dropout=0.0, decoder_residual_updates=True)
+    lc = ref_stubs.make_layer_cfg(num_message_layers=4)
+    inputs = dict(h=randn(n, 6, seed=121), chi=randn(n, 3, 3, seed=122), e=randn(e_cnt, 32, seed=123), xi=randn(e_cnt, 1, 3, seed=124),
+                  x=x, edge_index=ei, batch=torch.zeros(n, dtype=torch.long), mask=mask,
+                  seq=torch.randint(0, 20, (n,), generator=g))
+    for name, ar in (("model_cpd_small", True), ("model_cpd_direct", False)):
+        torch.manual_seed(125)
+        model = cpd.GCPNetCPDLitModule(layer_class=functools.partial(gn.GCPInteractions), optimizer=None, scheduler=None,
+                                       node_input_dims=[6, 3], edge_input_dims=[32, 1], model_cfg=model_cfg, module_cfg=ref_stubs.make_cfg(),
+                                       layer_cfg=lc, dropout=0.0, autoregressive_decoder=ar)
+        model.eval()
+        ins = {k: (v.clone().requires_grad_() if v.is_floating_point() and k != "x" else v.clone()) for k, v in inputs.items()}
+        bag = ref_stubs.Bag(**ins)
+        _, out = model.forward(bag)
+        preds = out if ar else out[0]
+        loss = model.criterion(preds[bag.mask], bag.seq[bag.mask])
+        loss.backward()
+        grads = {k: ins[k].grad for k in ("h", "chi", "e", "xi")}
+        grads.update({"w." + k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+        outs = dict(preds=preds, loss=loss, h=bag.h, chi=bag.chi, f_ij=bag.f_ij)
+        if ar:
+            # the sampling loop takes RAW features and frames; positions centred as forward() does it
+            with torch.no_grad():
+                _, xc = comp.centralize(ref_stubs.Bag(x=x, batch=inputs["batch"]), "x", inputs["batch"], node_mask=mask)
+                frames = comp.localize(xc, ei, norm_x_diff=True, node_mask=mask)
+                seqs = model.autoregressively_generate_samples(SV(inputs["h"], inputs["chi"]), SV(inputs["e"], inputs["xi"]), ei, frames,
+                                                               mask, num_samples=2, temperature=0.1)
+            assert ArgmaxCategorical.margin > 1e-2, ArgmaxCategorical.margin  # (no near-ties: argmax is implementation-independent)
+            outs.update(samples=seqs, sample_frames=frames)
+            print("argmax margin of the sampled logits / temperature:", ArgmaxCategorical.margin)
+        save(name, params=model.state_dict(), inputs=inputs, outputs=outs, grads=grads,
+             meta=dict(num_encoder_layers=2, num_decoder_layers=2, num_message_layers=4, autoregressive=int(ar)))
+
+
+def fx_lba_features():
+    """ATOM3D / LBA input side: the reference's REAL `LBATransform` (atom3d_dataset.py:134-149 ->
+    BaseTransform.__call__ :101-129 -> `_edge_features` :42-62, `_node_features` :65-84, helper.py) on two synthetic pocket +
+    ligand structures (pandas frames with x, y, z, element), with `torch_cluster.radius_graph` = the brute-force stub (graphs kept
+    below the neighbour cap, so the edge SET is independent of torch_cluster's selection order).  Then the collated batch, written
+    out with PyG's `Batch.from_data_list` rules (cat along dim 0; edge_index along dim 1 with node offsets; scalars -> [G])."""
+    import pandas as pd
+    from src.datamodules.components import atom3d_dataset as A
+
+    rng = np.random.default_rng(95)
+    elements = ["C", "N", "O", "S", "H", "F", "Cl", "CL", "P", "Zn", "Fe"]
+    tf = A.LBATransform()
+    graphs = []
+    for k, (n_pocket, n_lig, side) in enumerate(((70, 14, 16.0), (48, 9, 13.0))):
+        def frame(n, lo):
+            xyz = rng.uniform(lo, lo + side, size=(n, 3)).astype(np.float32)
+            if k == 0 and n > 20:
+                xyz[11] = xyz[10]  # coincident atoms: 0 / 0 in _normalize -> nan_to_num -> 0
+            return pd.DataFrame(dict(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2], element=rng.choice(elements, size=n)))
+        elem = dict(atoms_pocket=frame(n_pocket, 0.0), atoms_ligand=frame(n_lig, 2.0), scores=dict(neglog_aff=4.5 + k))
+        d = tf(elem)
+        graphs.append(d)
+    ins, outs = {}, {}
+    for k, (d, n_lig) in enumerate(zip(graphs, (14, 9))):
+        ins[f"x{k}"] = d.x
+        ins[f"n_ligand{k}"] = torch.tensor(n_lig)
+        for key in ("h", "chi", "e", "xi", "edge_index", "lig_flag"):
+            outs[f"{key}{k}"] = getattr(d, key)
+        outs[f"label{k}"] = torch.tensor(d.label)
+    offs = [0, graphs[0].x.shape[0]]
+    for key in ("h", "chi", "e", "xi", "x", "lig_flag"):
+        outs["batch_" + key] = torch.cat([getattr(d, key) for d in graphs], dim=0)
+    outs["batch_edge_index"] = torch.cat([d.edge_index + o for d, o in zip(graphs, offs)], dim=1)
+    outs["batch_label"] = torch.tensor([d.label for d in graphs])
+    outs["batch_batch"] = torch.cat([torch.full((d.x.shape[0],), i) for i, d in enumerate(graphs)])
+    save("lba_features", inputs=ins, outputs=outs, meta=dict(edge_cutoff=4.5, num_rbf=16, max_num_neighbors=32))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:  # only the named groups, e.g. `gen_fixtures.py fx_gcp_original`
@@ -547,3 +651,5 @@ if __name__ == "__main__":
     fx_masked()
     fx_models()
     fx_input_side()
+    fx_lba_features()
+    fx_cpd()

@@ -101,6 +101,25 @@ def _subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes
     return ei, (edge_attr[keep] if edge_attr is not None else None)
 
 
+def _radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", num_workers=1):
+    """torch_cluster.radius_graph (1.6.0), documented semantics restated by brute force: edge (j -> i) for every pair of the same
+    graph with |x_j - x_i| <= r, j != i (loop=False), at most `max_num_neighbors` per target i; edge_index = [source j; target i],
+    grouped by target.  WHICH neighbours survive the cap is implementation-defined in torch_cluster (an unsorted nanoflann search);
+    this stub refuses inputs that hit the cap, so fixtures built with it do not depend on that choice."""
+    import torch
+
+    assert flow == "source_to_target" and not loop
+    n = x.shape[0]
+    d = torch.cdist(x.double(), x.double())
+    ok = d <= float(r)
+    ok.fill_diagonal_(False)
+    if batch is not None:
+        ok &= batch.view(-1, 1) == batch.view(1, -1)
+    assert int(ok.sum(0).max()) <= max_num_neighbors, "the fixture graph must stay below the neighbour cap"
+    col, row = torch.nonzero(ok.t(), as_tuple=True)  # grouped by target (col), sources ascending
+    return torch.stack((row, col))
+
+
 def install():
     """Insert the stub modules into ``sys.modules`` and put the reference on ``sys.path``."""
     if "src.models.components.gcpnet" in sys.modules:
@@ -117,7 +136,7 @@ def install():
     tg.data = mod("torch_geometric.data", Batch=_Bag, Data=_Bag)
     tg.utils = mod("torch_geometric.utils", subgraph=_subgraph)
     tg.loader = mod("torch_geometric.loader", DataLoader=object)
-    mod("torch_cluster")
+    mod("torch_cluster", radius_graph=_radius_graph)
     mod("omegaconf", OmegaConf=_OmegaConf, DictConfig=DictConfig)
     mod("torchtyping", TensorType=_TensorType, patch_typeguard=lambda: None)
     mod("typeguard", typechecked=_identity_decorator)
@@ -135,6 +154,44 @@ def install():
 
     utils = mod("src.utils", get_pylogger=lambda name=None: logging.getLogger(name or "ref"))
     src.utils = utils
+
+
+def install_lightning_stubs():
+    """Import stubs for the reference's LitModules (pytorch_lightning / torchmetrics are not in the image): `LightningModule` is a
+    plain nn.Module whose `save_hyperparameters` records the constructor arguments of the calling frame as `self.hparams`;
+    `torchmetrics.MeanMetric / CatMetric` are inert modules.  No arithmetic."""
+    import inspect
+
+    install()
+    if "pytorch_lightning" in sys.modules:
+        return
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *args, logger=True, ignore=None, **kw):
+            frame = inspect.currentframe().f_back
+            loc = dict(frame.f_locals)
+            loc.pop("self", None)
+            loc.pop("__class__", None)
+            extra = loc.pop("kwargs", {}) or {}
+            loc.update(extra)
+            for k in ignore or []:
+                loc.pop(k, None)
+            self.hparams = DictConfig(loc)
+
+    class _Metric(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, *a, **k):
+            return None
+
+    m = types.ModuleType("pytorch_lightning")
+    m.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = m
+    tm = types.ModuleType("torchmetrics")
+    tm.MeanMetric = tm.CatMetric = _Metric
+    sys.modules["torchmetrics"] = tm
+    sys.modules["torch_geometric.utils"].unbatch = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("unbatch"))
 
 
 def load_reference():

@@ -378,12 +378,20 @@ def test_interactions_masked_and_autoregressive_golden(G, name):
         kw["node_mask"] = f.i["mask"].bool().cuda()
     if auto:
         kw["node_rep_regressive"] = (ins["h_reg"], ins["chi_reg"])
+    # with a mask the reference writes the new rows INTO its node input and returns it (gcpnet.py:1248-1251): clones are fed, as
+    # the fixture generator does, and the returned tensors must be those very objects (no pre-norm: the normed copies otherwise)
+    masked = "mask" in f.i
+    h_in, chi_in = (ins["h"].clone(), ins["chi"].clone()) if masked else (ins["h"], ins["chi"])
     if upd:
-        (h, chi), x = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, node_pos=f.i["x"].cuda(), **kw)
+        (h, chi), x = layer((h_in, chi_in), (ins["e"], ins["xi"]), ei, fr, node_pos=f.i["x"].cuda(), **kw)
         outs = dict(h=h, chi=chi, x=x)
     else:
-        h, chi = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, **kw)
+        h, chi = layer((h_in, chi_in), (ins["e"], ins["xi"]), ei, fr, **kw)
         outs = dict(h=h, chi=chi)
+    if masked and not pre_norm:
+        assert h is h_in and chi is chi_in, "the masked forward must update its node input in place"
+        with pytest.raises(RuntimeError):  # (a leaf that requires grad cannot be written in place: same error as the reference)
+            layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr, **({"node_pos": f.i["x"].cuda()} if upd else {}), **kw)
     for k, t in outs.items():
         t = t.detach().cpu()
         fin = torch.isfinite(f.o[k])

@@ -366,3 +366,72 @@ def test_radius_graph_golden():
     f = Fixture("radius_graph")
     ei = O.radius_graph(f.i["x"], f.i["batch"], float(f.m["radius"]), int(f.m["max_neighbors"]))
     assert torch.equal(ei, f.o["edge_index"])
+
+
+def _by_col_row(ei):
+    """Canonical edge order (target, then source): the order inside a target's neighbour list is implementation-defined."""
+    key = ei[1] * (int(ei.max()) + 1) + ei[0]
+    return torch.argsort(key)
+
+
+def test_lba_features_golden():
+    """Oracle restatement of the ATOM3D / LBA featuriser and of PyG collation against the fixture built by the reference's real
+    LBATransform (atom3d_dataset.py:134-149) on two pocket + ligand structures."""
+    f = Fixture("lba_features")
+    graphs = []
+    for k in range(2):
+        x = f.i[f"x{k}"]
+        ei = O.radius_graph(x, torch.zeros(x.shape[0], dtype=torch.long), 4.5, 32)
+        pw, pg = _by_col_row(f.o[f"edge_index{k}"]), _by_col_row(ei)
+        assert torch.equal(ei[:, pg], f.o[f"edge_index{k}"][:, pw])  # same edge SET (the fixture stays below the neighbour cap)
+        out = O.lba_features(x, ei)
+        close(out["e"][pg], f.o[f"e{k}"][pw], atol=1e-6, rtol=1e-6)
+        close(out["xi"][pg], f.o[f"xi{k}"][pw], atol=1e-6, rtol=1e-6)
+        close(out["chi"], f.o[f"chi{k}"], atol=1e-6, rtol=1e-6)
+        n_lig = int(f.i[f"n_ligand{k}"])
+        flag = torch.zeros(x.shape[0], dtype=torch.bool)
+        flag[x.shape[0] - n_lig:] = True
+        assert torch.equal(flag, f.o[f"lig_flag{k}"])
+        graphs.append(dict(h=f.o[f"h{k}"], chi=f.o[f"chi{k}"], e=f.o[f"e{k}"], xi=f.o[f"xi{k}"], x=x, edge_index=f.o[f"edge_index{k}"],
+                           lig_flag=f.o[f"lig_flag{k}"], label=f.o[f"label{k}"]))
+    b = O.collate(graphs)
+    for key in ("h", "chi", "e", "xi", "x", "lig_flag", "edge_index", "label", "batch"):
+        assert torch.equal(b[key], f.o["batch_" + key].to(b[key].dtype)), key
+    assert b["ptr"].tolist() == [0, graphs[0]["x"].shape[0], graphs[0]["x"].shape[0] + graphs[1]["x"].shape[0]]
+
+
+@pytest.mark.parametrize("name", ["model_cpd_small", "model_cpd_direct"])
+def test_cpd_model_golden(name):
+    """Oracle restatement of the CPD task module (forward with teacher forcing / MLP decoder, cross-entropy step, every gradient,
+    and the autoregressive sampling loop with an argmax sampler) against the fixtures generated by the reference's real
+    GCPNetCPDLitModule (gcpnet_cpd_module.py:153-231, 281-360)."""
+    f = Fixture(name)
+    ar = bool(f.m["autoregressive"])
+    P = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in f.p.items()}
+    b = dict(f.i)
+    for k in ("h", "chi", "e", "xi"):
+        b[k] = b[k].clone().requires_grad_()
+    cfg, lc = O.default_module_cfg(), O.default_layer_cfg(num_message_layers=int(f.m["num_message_layers"]))
+    out = O.cpd_forward(P, b, cfg, lc, int(f.m["num_encoder_layers"]), int(f.m["num_decoder_layers"]), ar)
+    preds = out["out"] if ar else out["out"][0]
+    close(preds, f.o["preds"], atol=2e-5, rtol=1e-4)
+    close(out["h"], f.o["h"], atol=1e-5, rtol=1e-4)
+    loss = torch.nn.functional.cross_entropy(preds[b["mask"]], b["seq"][b["mask"]])
+    close(loss, f.o["loss"], atol=1e-5, rtol=1e-5)
+    loss.backward()
+    for k in ("h", "chi", "e", "xi"):
+        close(b[k].grad, f.g[k], atol=1e-6 + 2e-5 * float(f.g[k].abs().max()), rtol=1e-3)
+    n = 0
+    for k, p in P.items():
+        if "w." + k in f.g:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            close(g, f.g["w." + k], atol=1e-6 + 2e-5 * float(f.g["w." + k].abs().max()), rtol=1e-3)
+            n += 1
+    assert n > 100
+    if ar:
+        with torch.no_grad():
+            Pd = {k: v.detach() for k, v in P.items()}
+            seqs = O.cpd_sample(Pd, f.i["h"], f.i["chi"], f.i["e"], f.i["xi"], f.i["edge_index"], f.o["sample_frames"], f.i["mask"], cfg, lc,
+                                int(f.m["num_encoder_layers"]), int(f.m["num_decoder_layers"]), num_samples=2, temperature=0.1,
+                                sampler=lambda lg: lg.argmax(-1))
+        assert torch.equal(seqs, f.o["samples"].long())

@@ -104,6 +104,47 @@ def test_nms_featurize_golden(G):
         close(out[k].cpu(), f.o[k], atol=2e-6, rtol=1e-5)
 
 
+def test_lba_featurize_and_collate_golden(G):
+    """GPU LBA featuriser (radius graph + RBF / unit-difference edge features + orientations + ligand flag) and collate() against
+    the fixture built by the reference's real LBATransform; edges compared in canonical (target, source) order."""
+    from tests.helpers import Fixture, close
+
+    def by_col_row(ei):
+        return torch.argsort(ei[1] * (int(ei.max()) + 1) + ei[0])
+
+    f = Fixture("lba_features")
+    graphs = []
+    for k in range(2):
+        x = f.i[f"x{k}"].cuda()
+        out = G.lba_featurize(x, f.o[f"h{k}"], n_ligand=int(f.i[f"n_ligand{k}"]), edge_cutoff=float(f.m["edge_cutoff"]),
+                              num_rbf=int(f.m["num_rbf"]), max_num_neighbors=int(f.m["max_num_neighbors"]))
+        want_ei = f.o[f"edge_index{k}"]
+        pg, pw = by_col_row(out["edge_index"].cpu()), by_col_row(want_ei)
+        assert torch.equal(out["edge_index"].cpu()[:, pg], want_ei[:, pw])
+        assert bool((out["edge_index"][1, 1:] >= out["edge_index"][1, :-1]).all())  # col-sorted, as the kernels want it
+        close(out["e"].cpu()[pg], f.o[f"e{k}"][pw], atol=2e-6, rtol=1e-5)
+        close(out["xi"].cpu()[pg], f.o[f"xi{k}"][pw], atol=2e-6, rtol=1e-5)
+        close(out["chi"].cpu(), f.o[f"chi{k}"], atol=2e-6, rtol=1e-5)
+        assert torch.equal(out["h"].cpu(), f.o[f"h{k}"]) and torch.equal(out["lig_flag"].cpu(), f.o[f"lig_flag{k}"])
+        out["label"] = f.o[f"label{k}"].cuda()
+        graphs.append(out)
+    b = G.collate(graphs)
+    n0 = graphs[0]["x"].shape[0]
+    assert torch.equal(b["batch"].cpu(), f.o["batch_batch"]) and b["ptr"].tolist() == [0, n0, n0 + graphs[1]["x"].shape[0]]
+    assert torch.equal(b["label"].cpu(), f.o["batch_label"]) and torch.equal(b["h"].cpu(), f.o["batch_h"])
+    assert torch.equal(b["lig_flag"].cpu(), f.o["batch_lig_flag"])
+    close(b["x"].cpu(), f.o["batch_x"], atol=0, rtol=0)
+    pg, pw = by_col_row(b["edge_index"].cpu()), by_col_row(f.o["batch_edge_index"])
+    assert torch.equal(b["edge_index"].cpu()[:, pg], f.o["batch_edge_index"][:, pw])
+    close(b["e"].cpu()[pg], f.o["batch_e"][pw], atol=2e-6, rtol=1e-5)
+    # the collated batch featurised in ONE call (batch vector) gives the same tensors as per-structure calls + collate()
+    one = G.lba_featurize(b["x"], b["h"], batch=b["batch"])
+    assert torch.equal(one["edge_index"], b["edge_index"])
+    for key in ("e", "xi", "chi"):
+        close(one[key].cpu(), b[key].cpu(), atol=1e-6, rtol=1e-6)
+    assert G.element_mapping(["C", "Cl", "CL", "Zn", "H"]).tolist() == [1, 6, 6, 8, 0]
+
+
 def test_radius_graph_matches_scipy_bit_for_bit(G):
     """GPU cell-list radius graph: the committed scipy fixture (3 graphs: dense, sparse, fewer nodes than K) and a fresh 20 000-node
     cloud against gcpnet_amd.synthetic.radius_graph -- identical edge_index arrays, col-sorted."""
