@@ -37,6 +37,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
+# fp32 products that run on the bf16 matrix pipe as three-term splits cost six bf16 MFMAs each (csrc/gcp_bf16x3.h): the dense bf16
+# peak (2 500 TFLOP/s) / 6 is the ceiling of THAT pipe in fp32-equivalent FLOPs -- reported next to the fp32 MFMA peak, which stays
+# `roofline.peak` (the kernels mix both forms)
+PEAK_BF16X6_EQUIV_TFLOPS = 2500.0 / 6.0
 
 
 def parse():
@@ -52,7 +56,11 @@ def parse():
     ap.add_argument("--neighbors", type=int, default=None)
     ap.add_argument("--sdim", type=int, default=None)
     ap.add_argument("--vdim", type=int, default=None)
-    ap.add_argument("--no-c5-block", action="store_true", help="skip the short configs[4]-size measurement of the default run")
+    ap.add_argument("--no-c5-block", action="store_true", help="skip the configs[4]-size measurement of the default run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c1 / c3 / c4 blocks of the default run")
+    ap.add_argument("--dry-run-world", type=int, default=0, metavar="N",
+                    help="no timing: execute the N-rank index bookkeeping of `--shard graph` for this configuration on one GPU and print "
+                         "per-rank node / edge counts and the bytes each rank exchanges per layer")
     ap.add_argument("--hip-graph", action="store_true", help="capture the step in a hipGraph and time replays (launch-bound configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step-only", action="store_true", help="profiling runs: only the timed steps (no per-kernel timing, no CPU baseline)")
@@ -197,6 +205,98 @@ def aggregate_roofline(G, ops, n_nodes, n_edges, width, label, iters=30):
             "bytes_per_launch": nbytes}
 
 
+def aggregate_product_path(G, ops, n_nodes, n_edges, sdim, vdim, iters=30):
+    """The aggregation as GCPMessagePassing.forward launches it (gcpnet_amd/gcpnet.py: the chain kernel leaves the scalar and the
+    vector part of the messages in two tensors, so the scatter-mean is TWO segmented reductions, [E, s] and [E, 3V]) against the
+    HBM roofline, next to the single [E, s + 3V] launch of `aggregate_kernel`."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    col = torch.sort(torch.randint(0, n_nodes, (n_edges,), device="cuda", generator=g)).values
+    plan = ops.GatherPlan(col, n_nodes)
+    ms = torch.randn(n_edges, sdim, device="cuda", generator=g)
+    mv = torch.randn(n_edges, 3 * vdim, device="cuda", generator=g)
+
+    def both():
+        ops.segment_reduce(ms, plan, True)
+        ops.segment_reduce(mv, plan, True)
+
+    for _ in range(3):
+        both()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        both()
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) / iters * 1e-3
+    nbytes = 4.0 * (sdim + 3 * vdim) * (n_edges + n_nodes) + 2 * 4.0 * (n_nodes + 1)
+    return {"kernel": "segment_reduce_kernel<mean> x2 (scalars [E,s], vectors [E,3V]): the launches of the product path",
+            "achieved": nbytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / PEAK_HBM_GBS,
+            "ms_for_both_launches": t * 1e3, "bytes": nbytes}
+
+
+def other_configs_block(G, ops, args):
+    """The BASELINE configurations that are model steps -- c1 (NMS 5-body), c4 (NMS 20-body), c3 (LBA) -- on this one GPU, eager
+    and as a hipGraph replay of the captured step (these are launch-bound: ~700 launches for 2 000 .. 250 000 edges): median
+    ms/step of HIP-event pairs, edges/s = edges x layers / step."""
+    import copy
+    from gcpnet_amd.graphs import GraphedStep
+
+    out = {}
+    for cfg in ("c1", "c4", "c3"):
+        a = copy.copy(args)
+        a.config = cfg
+        wl = build_model_workload(a, 0, 1, G, ops)
+        steps = 20
+        _, med = timed_steps(wl["step"], steps, 5, 1, None)
+        rec = {"workload": wl["label"], "n_edges": wl["n_edges"], "layers": wl["n_layers"], "steps": steps, "warmup": 5,
+               "eager_ms_per_step_median": med, "eager_edges_per_s": wl["n_edges"] * wl["n_layers"] / (med * 1e-3)}
+        try:
+            graphed = GraphedStep(wl["step"], warmup=3)
+            _, gmed = timed_steps(graphed, steps, 3, 1, None)
+            rec.update({"hipgraph_ms_per_step_median": gmed, "hipgraph_edges_per_s": wl["n_edges"] * wl["n_layers"] / (gmed * 1e-3)})
+            del graphed
+        except Exception as exc:  # (a capture failure must not cost the run its headline line)
+            rec["hipgraph_error"] = f"{type(exc).__name__}: {exc}"[:300]
+        out[cfg] = rec
+        del wl
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def dry_run_world(args, G, ops):
+    """`--dry-run-world N`: the index bookkeeping of the one-graph sharding (gcpnet_amd.parallel.ShardedGraph) for N ranks, executed
+    here rank by rank on one GPU, with the volume each rank would exchange per GCPInteractions layer: all-gather of node features
+    forward + reduce-scatter of their gradients backward (full table or only the halo: the source nodes its in-edges actually
+    reference), and the flat-bucket all-reduce of the weight gradients once per step."""
+    from gcpnet_amd.parallel import ShardedGraph
+    from gcpnet_amd.synthetic import make_inputs
+
+    n = args.dry_run_world
+    host = make_inputs(args.nodes, args.neighbors, (args.sdim, args.vdim), (32, 4), seed=0)
+    ei = host["edge_index"].cuda()
+    width = args.sdim + 3 * args.vdim
+    layer = G.GCPInteractions((args.sdim, args.vdim), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0)
+    n_params = sum(p.numel() for p in layer.parameters())
+    ranks = []
+    for r in range(n):
+        sg = ShardedGraph(ei, args.nodes, r, n)
+        halo = sg.halo_nodes()
+        ranks.append({"rank": r, "nodes": sg.n_local, "in_edges": sg.e1 - sg.e0, "out_edges": int(sg.out_row_local.shape[0]),
+                      "halo_nodes": int(halo.numel()),
+                      "allgather_recv_MB_per_layer": (args.nodes - sg.n_local) * width * 4 / 1e6,
+                      "halo_recv_MB_per_layer": int(halo.numel()) * width * 4 / 1e6,
+                      "send_MB_per_layer_full_table": sg.n_local * width * 4 * (n - 1) / 1e6})
+    edges = [x["in_edges"] for x in ranks]
+    out = {"dry_run_world": n, "config": args.config, "n_nodes": args.nodes, "n_edges": int(ei.shape[1]), "row_bytes": width * 4,
+           "ranks": ranks, "edge_imbalance_max_over_mean": max(edges) / (sum(edges) / n),
+           "weight_grad_allreduce_MB_per_step": n_params * 4 * args.layers / 1e6,
+           "note": "xGMI: 7 links x ~153 GB/s per GPU, point to point; the all-gather of a layer moves allgather_recv_MB into each rank "
+                   "over its 7 links in parallel; forward + backward (reduce-scatter) = twice that per layer"}
+    print(json.dumps(out))
+
+
 def build_layer_workload(args, rank, world, G, ops):
     """c2 / c5: a stack of GCPInteractions layers on one synthetic radius graph per rank (or, with --shard graph, on this rank's
     target-node range of ONE graph).  Returns a dict with the step function and bookkeeping."""
@@ -220,10 +320,10 @@ def build_layer_workload(args, rank, world, G, ops):
     if sharded:
         sg = ShardedGraph(host["edge_index"], args.nodes, rank, world)
         x = host["x"].cuda()
-        sg.edge_index, sg.col_local = sg.edge_index.cuda(), sg.col_local.cuda()
-        frames = G.localize(x, sg.edge_index)
-        fr_out = G.localize(x, sg.out_edge_index_global.cuda())
-        node_frames = ops.segment_reduce(fr_out.reshape(-1, 9), ops.GatherPlan(sg.out_row_local.cuda(), sg.n_local),
+        sg.to("cuda")
+        frames = G.localize(x, sg.edge_index_global)
+        fr_out = G.localize(x, sg.out_edge_index_global)
+        node_frames = ops.segment_reduce(fr_out.reshape(-1, 9), ops.GatherPlan(sg.out_row_local, sg.n_local),
                                          mean=True).reshape(sg.n_local, 3, 3)
         ins = {"h": sg.local_nodes(host["h"]), "chi": sg.local_nodes(host["chi"]), "e": sg.local_edges(host["e"]),
                "xi": sg.local_edges(host["xi"])}
@@ -333,12 +433,13 @@ def c5_block(G, ops, args):
     a.config, a.nodes, a.neighbors, a.sdim, a.vdim, a.layers, a.shard = "c5", 100000, 10, 256, 32, 4, "batch"
     wl = build_layer_workload(a, 0, 1, G, ops)
     # (two warm-up steps: the first ones grow the caching allocator's pool by ~75 GB of saved activations)
-    elapsed, med = timed_steps(wl["step"], 3, 2, 1, None)
+    k = 10
+    elapsed, med = timed_steps(wl["step"], k, 2, 1, None)
     fl = layer_flops(a.nodes, wl["n_edges"], (256, 32), (32, 4))["fwd_bwd"] * a.layers
-    out = {"workload": wl["label"], "n_edges": wl["n_edges"], "steps": 3, "warmup": 2, "ms_per_step": elapsed / 3 * 1e3,
-           "ms_per_step_median": med, "edges_per_s": wl["n_edges"] * a.layers * 3 / elapsed,
-           "algorithmic_tflops_per_s": fl * 3 / elapsed / 1e12,
-           "frac_of_fp32_mfma_peak": fl * 3 / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+    out = {"workload": wl["label"], "n_edges": wl["n_edges"], "steps": k, "warmup": 2, "ms_per_step": elapsed / k * 1e3,
+           "ms_per_step_median": med, "edges_per_s": wl["n_edges"] * a.layers * k / elapsed,
+           "algorithmic_tflops_per_s": fl * k / elapsed / 1e12,
+           "frac_of_fp32_mfma_peak": fl * k / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            "frac_of_fp32_mfma_peak_median_step": fl / (med * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     del wl
     torch.cuda.empty_cache()
@@ -370,6 +471,10 @@ def main():
     from gcpnet_amd.synthetic import layer_flops
 
     is_stack = args.config in ("c2", "c5")
+    if args.dry_run_world:
+        assert is_stack and world == 1, "--dry-run-world: c2 / c5, one process"
+        dry_run_world(args, G, ops)
+        return
     wl = (build_layer_workload if is_stack else build_model_workload)(args, rank, world, G, ops)
     step_fn = wl["step"]
     if args.hip_graph:
@@ -412,7 +517,8 @@ def main():
             out["roofline"] = {
                 "kernel": f"{dom} on the {kr['n_blocks']}-block residual message chain (s,V)->(s,V) of one layer, E rows",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "peak_bf16x6_equiv": PEAK_BF16X6_EQUIV_TFLOPS,
+                "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "traffic": pmc_traffic(dom),
                 "traffic_source": PMC_FILE if pmc_traffic(dom) is not None else None,
                 "traffic_note": (_pmc_file().get(dom + "_parts") or {}).get("note"),
                 "arithmetic": ("fp32 results; the large products of the chain kernels (W^T ds_pre backward, scalar_out and the gate Linear "
@@ -437,12 +543,17 @@ def main():
                                                          f"{args.nodes} nodes / {wl['n_edges']} edges, width s+3V = {width}")
             out["aggregate_kernel_c5"] = aggregate_roofline(G, ops, 100000, 1000000, 256 + 96,
                                                             "100000 nodes / 1000000 edges, width s+3V = 352", iters=10)
+            out["aggregate_product_path"] = aggregate_product_path(G, ops, args.nodes, wl["n_edges"], args.sdim, args.vdim)
+            out["aggregate_product_path_c5"] = aggregate_product_path(G, ops, 100000, 1000000, 256, 32, iters=10)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], out["parity_check"] = cpu_baseline(wl, args)
-            if world == 1 and args.config == "c2" and not args.no_c5_block:
+            if world == 1 and args.config == "c2" and not (args.no_c5_block and args.no_other_configs):
                 wl.clear()
                 torch.cuda.empty_cache()
-                out["c5_single_gpu"] = c5_block(G, ops, args)
+                if not args.no_other_configs:
+                    out["other_configs"] = other_configs_block(G, ops, args)
+                if not args.no_c5_block:
+                    out["c5_single_gpu"] = c5_block(G, ops, args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

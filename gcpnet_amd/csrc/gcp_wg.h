@@ -12,14 +12,27 @@
 // (row e, half hi) reads X[e][8 g + 4 hi .. + 3] -- which is also the layout of an accumulator register quad
 // (column 8 q + 4 hi + i of row e), so accumulators feed the next GEMM without any data movement.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "gcp_bf16x3.h"
+
+// GCPNET_DEBUG_UNSUPPORTED=1: the host entry points of the workgroup kernels say on stderr WHY a launch was refused (the caller
+// then takes the wave-per-tile kernels: a routing question one otherwise answers by reading profiles)
+inline int wg_unsupported(const char* file, int line, const char* why) {
+    static const bool on = getenv("GCPNET_DEBUG_UNSUPPORTED") != nullptr;
+    if (on) fprintf(stderr, "gcpnet: %s:%d refuses the launch: %s\n", file, line, why);
+    return GCPNET_E_UNSUPPORTED;
+}
+#define WG_UNSUPPORTED(why) wg_unsupported(__FILE__, __LINE__, why)
 
 // (GCP_WG_MAX_BLOCKS = 9: head + 8 residual blocks, include/gcpnet_hip.h)
 
 // Packed image of one block's dense weights (floats; all sections are [..][64 lanes][4]):
 //   A1 [NT][KG]   forward scalar_out:       W[32 ot + m][8 g + 4 hi + i]
-//   G1 [4 NT]     forward gate Linear:      Wg[m][8 g + 4 hi + i]                 (m < vo, reduction over so)
+//   G1 [GM][4 NT] forward gate Linear:      Wg[32 gm + m][8 g + 4 hi + i]         (gm < GM = ceil(vo / 32) tiles of gate outputs,
+//                                                                                reduction over so)
 //   A2 [NKT][4 NT] backward-data scalar_out: W[8 g + 4 hi + i][32 kt + m]          (reduction over so, output tile kt of K)
 //   G2 [NT][VG]   backward gate Linear:     Wg[8 g + 4 hi + i][32 ot + m]         (reduction over vo)
 // with m = lane & 31, hi = lane >> 5, zeros outside the matrices.
@@ -29,6 +42,7 @@ struct WgShape {
     int NT;          // 32-wide tiles of so
     int NKT;         // 32-wide tiles of K
     int VG;          // groups of 8 gate outputs
+    int GM;          // 32-row tiles of gate outputs (forward gate Linear): 1 or 2 (vo <= 64)
     int gated;
     // A2b [NKT][2 NT slabs][term][64][4 x 2 bf16]: section A2 once more as three bf16 terms per weight in the operand layout
     // of v_mfma_f32_32x32x16_bf16 (gcp_bf16x3.h); element i' < 8 of lane (m, hi) in slab j is W[32 (j / 2) + 16 (j % 2) +
@@ -49,10 +63,11 @@ __host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int 
     s.NT = gcp_cdiv(so, 32);
     s.NKT = gcp_cdiv(s.K, 32);
     s.VG = gcp_cdiv(vo, 8);
+    s.GM = vo > 32 ? gcp_cdiv(vo, 32) : 1;
     s.gated = (gated && vo > 0 && vi > 0) ? 1 : 0;
     s.offA1 = 0;
     s.offG1 = s.offA1 + (int64_t)s.NT * s.KG * 256;
-    s.offA2 = s.offG1 + (s.gated ? (int64_t)4 * s.NT * 256 : 0);
+    s.offA2 = s.offG1 + (s.gated ? (int64_t)s.GM * 4 * s.NT * 256 : 0);
     s.offG2 = s.offA2 + (int64_t)s.NKT * 4 * s.NT * 256;
     s.offA2b = s.offG2 + (s.gated ? (int64_t)s.NT * s.VG * 256 : 0);
     s.offA1b = s.offA2b + (int64_t)s.NKT * 2 * s.NT * 3 * 256;

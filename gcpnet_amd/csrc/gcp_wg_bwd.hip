@@ -72,7 +72,8 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
 #ifdef GCP_WG_FUSE_FENCE  // (the round-2 envelope: vo <= 16, si % 4 == 0; kept as a debugging switch)
     d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5 && vo <= 16 && (si & 3) == 0) ? 1 : 0;
 #else
-    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5) ? 1 : 0;
+    // (the fused gate weight gradient holds ONE 32-row tile of gate outputs per wave: gated blocks with vo > 32 take the plain form)
+    d.fused = (want_fused && d.NT <= NW && d.KTn == 1 && d.NNT <= 5 && !(gated && vo > 32)) ? 1 : 0;
 #endif
     d.EP = c_rup(d.H + d.nf, 4);
     d.VOP = c_rup(vo, 4);
@@ -113,6 +114,9 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     if (d.fused) { d.o_dext = off + dq; off += c_max(dvo, dq + dx); }
     else { d.o_dext = off + c_max(dvo, dq); off += c_max(dvo, dq) + dx; }
     d.lds_floats = off;
+    // (the fused form adds the 32 x (K + 1) input tile X: when that pushes the tile set past the 160 KB of a CU -- the second
+    // feed-forward GCP of BASELINE configs[4] after its leading columns were split off, (128,64) -> (256,32) -- take the plain form)
+    if (d.fused && (long long)off * 4 > 160 * 1024) return wg_bwd_dims(si, vi, so, vo, hidden, use_frames, gated, 0, NW, b6);
     d.mg_v = c_magic(3 * vi / 4); d.mg_o = c_magic(3 * vo / 4); d.mg_g = c_magic(vo / 4); d.mg_x = c_magic(si / 4);
     d.mg_xpad = c_magic(8 * c_cdiv(d.KW, 8) - d.K); d.mg_epad = c_magic(d.EP - (d.H + d.nf));
     d.mg_ns = c_magic(c_min(si, d.K) - 32 * (d.NKT - 1)); d.mg_wdt = c_magic(3 * d.HFP); d.mg_hfp = c_magic(d.HFP);
@@ -172,8 +176,10 @@ constexpr int NSW = 2;  // 16 x 16 tiles of the small vector weight gradients pe
 // B6 (not fused, KT == 1): P4 on the bf16 matrix pipe -- ds_pre is split into three bf16 terms where it is produced (P3, in
 // registers) and kept in LDS as operand-ordered planes, the weights come pre-split from section A2b; six products, fp32
 // accumulation (gcp_bf16x3.h: exact to fp32 round-off)
+// (fused with at most two tiles of K + 1 columns -- the first message GCP after project-then-gather: K + 1 = 51 -- carries 32
+// instead of 80 persistent accumulator registers: a third workgroup per CU hides more of the per-tile phase latencies)
 template <int NW, int KT, int FN, bool PWL, int SHP, bool B6 = false>
-__global__ __launch_bounds__(64 * NW, 2) void gcp_wg_bwd_kernel(const WgBwdParams p_kernarg) {
+__global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) void gcp_wg_bwd_kernel(const WgBwdParams p_kernarg) {
     static_assert(!B6 || (KT == 1 && FN == 0), "bf16 form: plain mode, one K tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32;
@@ -1074,20 +1080,20 @@ extern "C" int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, i
 // Plan of one backward launch: workgroup count (= rows of the partial buffers), fused or not, scratch widths.
 extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const gcp2_opts_t* o, int want_fused, gcp_wg_bwd_plan_t* plan) {
     if (!w || !o || !plan) return GCPNET_E_BADARG;
-    if (w->vi <= 0 || (w->so & 3) || w->so < 4) return GCPNET_E_UNSUPPORTED;
+    if (w->vi <= 0 || (w->so & 3) || w->so < 4) return WG_UNSUPPORTED("no vector input, or so not a multiple of 4");
     const bool gated = o->vmode == GCP_VMODE_SCALAR_GATE && w->vo > 0;
-    if (gated && w->vo > 32) return GCPNET_E_UNSUPPORTED;  // (one 32-row tile of gate outputs)
+    if (gated && w->vo > 64) return WG_UNSUPPORTED("scalar gate with more than 64 output vectors");  // (the request of the gate tile: 16 pieces of 16 bytes per row)
     const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
     int NW = (w->so > 160 || S.K > 160) ? 8 : 4;
     if (const char* ev = getenv("GCPNET_WG_BWD_NW")) {  // (tuning knob: 4 or 8 waves per workgroup)
         if (ev[0] == '4') NW = 4;
         if (ev[0] == '8') NW = 8;
     }
-    if (gcp_cdiv(S.NT, NW) > 4) return GCPNET_E_UNSUPPORTED;
+    if (gcp_cdiv(S.NT, NW) > 4) return WG_UNSUPPORTED("more than four output tiles per wave");
     const WgBwdDims D = wg_bwd_dims(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated,
                                     want_fused && !getenv("GCPNET_WG_BWD_NOFUSE"), NW);
-    if (D.KTn > 4) return GCPNET_E_UNSUPPORTED;
-    if (D.sm_tiles > NSW * NW) return GCPNET_E_UNSUPPORTED;
+    if (D.KTn > 4) return WG_UNSUPPORTED("more than four K tiles per wave");
+    if (D.sm_tiles > NSW * NW) return WG_UNSUPPORTED("small vector weight gradients: more 16 x 16 tiles than the waves hold");
     const int KTn = D.KTn, fused = D.fused, KW = D.KW, n_sm = D.n_sm, split = D.split;
     if (!g_wg_cus) {
         int dev = 0, cus = 0;
@@ -1099,7 +1105,8 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     plan->nw = NW;
     plan->kt = KTn == 1 ? 1 : 4;
     plan->fused = fused;
-    plan->grid = ntiles <= 0 ? 1 : min(ntiles, 2 * g_wg_cus);
+    const int per_cu = (fused && NW == 4 && D.NNT <= 2) ? 3 : 2;  // resident workgroups per CU of the instantiation that will run
+    plan->grid = ntiles <= 0 ? 1 : min(ntiles, per_cu * g_wg_cus);
     plan->kw = KW;
     plan->n_small = n_sm;
     plan->ext_w = gcp_round_up(S.H + S.nf, 4);
@@ -1124,8 +1131,8 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     if (o.vector_residual && w.vi != w.vo) return GCPNET_E_BADARG;
     auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
     if (misaligned(a->s_pre) || misaligned(a->d_s_out) || misaligned(a->d_s_in) || misaligned(w.pack) || misaligned(a->ds_pre))
-        return GCPNET_E_UNSUPPORTED;
-    if (a->residual && (w.si & 3)) return GCPNET_E_UNSUPPORTED;
+        return WG_UNSUPPORTED("a scalar tensor is not 16-byte aligned");
+    if (a->residual && (w.si & 3)) return WG_UNSUPPORTED("residual block with si not a multiple of 4");
     const WgShape S = wg_shape(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated);
     if (S.nf && (!a->frames || !w.w_frames)) return GCPNET_E_BADARG;
     if (pl.fused && (!a->s_in || (gated && !a->dwg_part))) return GCPNET_E_BADARG;
@@ -1160,7 +1167,12 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     for (int k = 0; k < p.v_add.n; ++k)
         if (!p.v_add.ptr[k] || p.v_add.dim[k] != p.HFP) return GCPNET_E_BADARG;
     const size_t lds_bytes = (size_t)D.lds_floats * sizeof(float);
-    if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
+    if (lds_bytes > 160 * 1024) {
+        char why[200];
+        snprintf(why, sizeof why, "the tile set (%zu bytes: (%d,%d)->(%d,%d), hidden %d, %d waves, K tiles per wave %d) does not fit in 160 KB of LDS",
+                 lds_bytes, w.si, w.vi, w.so, w.vo, w.hidden, NW, D.KTn);
+        return WG_UNSUPPORTED(why);
+    }
     const bool pwl = gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
@@ -1174,6 +1186,7 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
             return launch_bwd<8, 1, 0, 2>(p, pwl, grid, lds_bytes, st);
     }
     if (b6) return NW == 4 ? launch_bwd<4, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st);
+    if (pl.fused && NW == 4 && D.NNT <= 2 && !getenv("GCPNET_WG_BWD_FN5")) return launch_bwd<4, 1, 2>(p, pwl, grid, lds_bytes, st);
     if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);
     if (NW == 4) return pl.kt == 1 ? launch_bwd<4, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<4, 4, 0>(p, pwl, grid, lds_bytes, st);
     return pl.kt == 1 ? launch_bwd<8, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 4, 0>(p, pwl, grid, lds_bytes, st);

@@ -99,9 +99,12 @@ template <> struct WgFwdShape<2> { static constexpr int S = 256, V = 32, HID = 8
 // B6 (MT == 1): the K loop on the bf16 matrix pipe -- once the tile X of a block is complete every thread splits a share of
 // it into three bf16 terms (operand-ordered planes in LDS, shared by all waves), the weights come pre-split from section A1b;
 // six products, fp32 accumulation (gcp_bf16x3.h: exact to fp32 round-off)
-template <int NW, int MT, bool PWL, int SHP, bool B6 = false>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(const WgFwdParams p_kernarg) {
+// G2: 32 < vo <= 64 with a scalar gate -- two 32-row tiles of gate outputs per wave (sixteen more accumulator registers; these
+// shapes, the feed-forward GCP (s, V) -> (4 s, 2 V) of BASELINE configs[4], hold one workgroup per CU by their LDS anyway)
+template <int NW, int MT, bool PWL, int SHP, bool B6 = false, bool G2 = false>
+__global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_fwd_kernel(const WgFwdParams p_kernarg) {
     static_assert(!B6 || MT == 1, "bf16 form: one output tile per wave");
+    static_assert(!G2 || (SHP == 0 && !B6), "two gate tiles: run-time shapes, fp32 MFMA form");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32, U = 4 / MT;
     // Parameters are read through the kernarg segment pointer, laundered at the phase boundaries: the uniform values are
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
         // ---- scalar_out (+ gate partial) per output group ---------------------------------------------------------------
         f32x16 ynew[MT];  // the wave's slice of the block output (accumulator layout); the chain state when NG == 1
         f32x16 gacc;      // this wave's partial gate pre-activations (its columns of the reduction over so)
+        f32x16 gacc2;     // (G2) ... of the gate outputs 32 .. 63
         float zero = 0.f;  // (laundered: hipcc otherwise hoists the zero-initialised accumulators above the VALU phases in
         asm volatile("" : "+v"(zero));  //  front of them and spills sixteen registers of zeros across each)
         bool gacc_set = false;
@@ -493,20 +497,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                     asm volatile("" : "+v"(zero));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) gacc[r] = zero;
+                    if constexpr (G2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gacc2[r] = zero;
+                    }
                     gacc_set = true;
                 }
-                auto gate_mm = [&](const f32x16& av, auto frag) {
+                auto gate_mm = [&](const f32x16& av, auto frag, int otile) {
+                    f32x4 ag2[4];
+                    if constexpr (G2) {  // the second tile's fragments: section G1, tile gm = 1
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ag2[q] = *reinterpret_cast<const f32x4*>(B.pk + B.offG1 + ((int64_t)(4 * NT + 4 * otile + q) * 64 + lane) * 4);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 ag = frag(q);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[i], gcp_actf<PWL>(B.act_v, ns_v, slope, av[4 * q + i]), gacc, 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) {
+                            const float bv = gcp_actf<PWL>(B.act_v, ns_v, slope, av[4 * q + i]);
+                            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[i], bv, gacc, 0, 0, 0);
+                            if constexpr (G2) gacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2[q][i], bv, gacc2, 0, 0, 0);
+                        }
                     }
                 };
                 if constexpr (MT == 1 && U == 4) {  // the prefetched batch nb sits in a0 when nb is even, in a1 when it is odd
-                    if (nb_ & 1) gate_mm(acc[0], [&](int q) { return a1[q][0]; });
-                    else gate_mm(acc[0], [&](int q) { return a0[q][0]; });
+                    if (nb_ & 1) gate_mm(acc[0], [&](int q) { return a1[q][0]; }, otc[0]);
+                    else gate_mm(acc[0], [&](int q) { return a0[q][0]; }, otc[0]);
                 } else {
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
                                 ag[q] = *reinterpret_cast<const f32x4*>(B.pk + B.offG1 + ((int64_t)(4 * otc[t] + q) * 64 + lane) * 4);
-                            gate_mm(acc[t], [&](int q) { return ag[q]; });
+                            gate_mm(acc[t], [&](int q) { return ag[q]; }, otc[t]);
                         }
                 }
             }
@@ -556,6 +573,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
                     float sacc = 0.f;
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) sacc = qq == q ? gacc[4 * qq + i] : sacc;
+                    if constexpr (G2) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) sacc = qq + 4 == q ? gacc2[4 * qq + i] : sacc;
+                    }
                     v[i] = sacc;
                 }
                 return v;
@@ -563,6 +584,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 2)) void gcp_wg_fwd_kernel(
             if (!gacc_set) {  // (a wave without output tiles contributes zeros)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+                if constexpr (G2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gacc2[r] = 0.f;
+                }
             }
             gcp_wave_lds_sync();  // (the slot doubles as this wave's staging tile: its reads are done)
             if (w < 4)
@@ -697,9 +722,10 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view
         const int r = 32 * ot + m, c = 8 * g + 4 * hi + i;
         if (r < S.so && c < S.K) v = wg_view_at(view, r, c);
     } else if (idx < S.offA2) {
-        const int g = (int)((idx - S.offG1) >> 8);
-        const int c = 8 * g + 4 * hi + i;
-        if (m < S.vo && c < S.so) v = Wg[(int64_t)m * S.so + c];
+        const int gall = (int)((idx - S.offG1) >> 8);
+        const int gm = gall / G4, g = gall - gm * G4;
+        const int c = 8 * g + 4 * hi + i, o = 32 * gm + m;
+        if (o < S.vo && c < S.so) v = Wg[(int64_t)o * S.so + c];
     } else if (idx >= S.offA1b) {
         int64_t blk = (idx - S.offA1b) >> 8;  // (ot, slab, term)
         const int term = (int)(blk % 3); blk /= 3;
@@ -756,7 +782,7 @@ bool wg_fwd_is_shape(const WgFwdParams& p, size_t lds_bytes) {
     return same;
 }
 
-template <int NW, int MT, int SHP = 0, bool B6 = false>
+template <int NW, int MT, int SHP = 0, bool B6 = false, bool G2 = false>
 int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st) {
     auto go = [&](auto kern) -> int {
         if (lds_bytes > 64 * 1024) {
@@ -768,7 +794,7 @@ int launch_fwd(const WgFwdParams& p, bool pwl, size_t lds_bytes, hipStream_t st)
         return 0;
     };
     if constexpr (SHP != 0) return go(gcp_wg_fwd_kernel<NW, MT, true, SHP, B6>);  // (compile-time shapes: PWL activations only)
-    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true, 0, B6>) : go(gcp_wg_fwd_kernel<NW, MT, false, 0, B6>);
+    return pwl ? go(gcp_wg_fwd_kernel<NW, MT, true, 0, B6, G2>) : go(gcp_wg_fwd_kernel<NW, MT, false, 0, B6, G2>);
 }
 
 }  // namespace
@@ -820,7 +846,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     if (w0.vi < 0 || (w0.vi == 0 && (vo > 0 || n > 1))) return GCPNET_E_UNSUPPORTED;  // (vi == 0: one scalar-only Linear block)
     if (w0.vi > 0 && !v_in) return GCPNET_E_BADARG;
     if ((so & 3) || so < 4) return GCPNET_E_UNSUPPORTED;
-    if (vo > 32 && blocks[0].o.vmode == GCP_VMODE_SCALAR_GATE) return GCPNET_E_UNSUPPORTED;  // (one 32-row tile of gate outputs)
+    if (vo > 64 && blocks[0].o.vmode == GCP_VMODE_SCALAR_GATE) return WG_UNSUPPORTED("scalar gate with more than 64 output vectors");  // (two 32-row tiles of gate outputs)
     WgFwdParams p;
     p.rows = rows; p.s_in = s_in; p.v_in = v_in; p.frames = frames;
     p.s_add.n = 0; p.v_add.n = 0;
@@ -896,14 +922,20 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     // K loop on the bf16 pipe: one output tile per wave, by default for the 8-wave shapes (one workgroup per CU anyway; at 4
     // waves the operand planes cost the third workgroup of a CU: GCPNET_WG_FWD_B6=all), if the planes fit
     static const char* b6_env = getenv("GCPNET_WG_FWD_B6");  // "0" = off, "all" = also 4-wave shapes
-    bool b6 = MT == 1 && p.NG == 1 && (g_gcp_fp32_mfma < 0 ? !(b6_env && b6_env[0] == '0') : g_gcp_fp32_mfma == 0) &&
+    const bool g2 = gated && vo > 32;  // two tiles of gate outputs: the run-time-shape fp32 form
+    bool b6 = !g2 && MT == 1 && p.NG == 1 && (g_gcp_fp32_mfma < 0 ? !(b6_env && b6_env[0] == '0') : g_gcp_fp32_mfma == 0) &&
               (NW == 8 || (b6_env && b6_env[0] == 'a'));
     if (b6 && (size_t)(off + nslf_max * 768) * sizeof(float) > 160 * 1024) b6 = false;
     p.o_xp = off; off += b6 ? nslf_max * 768 : 0;
     const size_t lds_bytes = (size_t)off * sizeof(float);
-    if (lds_bytes > 160 * 1024) return GCPNET_E_UNSUPPORTED;
+    if (lds_bytes > 160 * 1024) return WG_UNSUPPORTED("the tile set does not fit in 160 KB of LDS");
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
+    if (g2) {
+        if (NW == 4) return launch_fwd<4, 1, 0, false, true>(p, pwl, lds_bytes, st);
+        if (MT == 1) return launch_fwd<8, 1, 0, false, true>(p, pwl, lds_bytes, st);
+        return launch_fwd<8, 2, 0, false, true>(p, pwl, lds_bytes, st);
+    }
     if (pwl && !getenv("GCPNET_WG_FWD_NOSHAPE")) {
         if (NW == 4 && !b6 && wg_fwd_is_shape<1, 4, 1>(p, lds_bytes)) return launch_fwd<4, 1, 1>(p, pwl, lds_bytes, st);
         if (NW == 4 && b6 && wg_fwd_is_shape<1, 4, 1, true>(p, lds_bytes)) return launch_fwd<4, 1, 1, true>(p, pwl, lds_bytes, st);

@@ -14,6 +14,8 @@
 // be passed through an activation (applied at fragment read) and carry a column of ones (bias gradients).
 // the row axis is split across workgroups (see tn_rows_per_split).
 // Per-split partial sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -359,6 +361,158 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     if (wave_active) store_partial(P, w, a.M[w.pi], a.N[w.pi], acc, wave, col, hi);
 }
 
+// ---- big-block path: ONE workgroup owns the whole output of a problem with 128 < M <= 256 or 160 < N <= 320 -------------------
+// The weight gradients of the (256,32) message GCPs of BASELINE configs[4] are 256 x 285 products: cut into 128 x 160 blocks every
+// operand row is fetched by two workgroups (4.3 KB per row for 2.2 KB of operands), and the kernel is bound by its DMA pipeline.
+// Here a workgroup of 8 waves stages 32 rows of BOTH complete operands (73.7 KB per chunk, double buffered: one workgroup per CU) and
+// wave w accumulates the 2 x 5 output tiles (m-tiles 2 (w & 3) .., n-tiles 5 (w >> 2) ..): 160 accumulator registers, seven LDS
+// fragment reads per ten MFMAs instead of ten per five.  Operands: plain segments (no row gather, no activation), DMA-able
+// (widths / strides multiples of four floats); everything else keeps the 128 x 160 kernel.
+constexpr int TB_BM = 256, TB_BN = 320, TB_NW = 8, TB_NTH = 64 * TB_NW;
+constexpr int TB_A_SLOTS = TN_RK * TB_BM / 4 / TB_NTH, TB_B_SLOTS = TN_RK * TB_BN / 4 / TB_NTH;  // 4 and 5 pieces per thread
+constexpr int TB_LDS_FLOATS = 2 * TN_RK * (TB_BM + TB_BN);
+static_assert(TN_RK * TB_BM / 4 % TB_NTH == 0 && TN_RK * TB_BN / 4 % TB_NTH == 0, "whole pieces per thread");
+
+struct BigSlot {
+    const float* base;  // segment pointer + column offset of the 16-byte piece; nullptr: no column of the operand there
+    int ld, row;
+};
+
+template <int NSLOT, int LD>
+__device__ __forceinline__ void big_slots(const gcp_operand_t& op, BigSlot* s, int tid) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int f = tid + TB_NTH * k;
+        const int row = f / (LD / 4), c = 4 * (f % (LD / 4));
+        s[k].row = row; s[k].base = nullptr; s[k].ld = 0;
+        int cbase = 0;
+        for (int sg = 0; sg < op.n; ++sg) {
+            if (c >= cbase && c < cbase + op.dim[sg]) { s[k].base = op.ptr[sg] + (c - cbase); s[k].ld = op.ld[sg]; }
+            cbase += op.dim[sg];
+        }
+    }
+}
+
+template <int NSLOT>
+__device__ __forceinline__ void big_issue(const BigSlot* s, float* buf, int r0, int r_last, int tid) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        float* dst = buf + (TB_NTH * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
+        if (s[k].base)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(s[k].base + (int64_t)min(r0 + s[k].row, r_last) * s[k].ld),
+                (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    int pi = 0;
+    while (pi + 1 < a.n && (int)blockIdx.x >= a.block_start[pi + 1]) ++pi;
+    const gcp_tn_problem_t& P = a.p[pi];
+    const int M = a.M[pi], N = a.N[pi];
+    const int split = blockIdx.x - a.block_start[pi];
+    const int rps = tn_rows_per_split(P.rows);
+    const int r_begin = split * rps, r_end = min(P.rows, r_begin + rps), r_last = r_end - 1;
+    const int mtiles = gcp_cdiv(M, 32), ntiles = gcp_cdiv(N, 32);
+    const int mt0 = 2 * (wave & 3), nt0 = 5 * (wave >> 2);
+    auto Abuf = [&](int b) { return lds + b * (TN_RK * (TB_BM + TB_BN)); };
+    auto Bbuf = [&](int b) { return lds + b * (TN_RK * (TB_BM + TB_BN)) + TN_RK * TB_BM; };
+
+    BigSlot sa[TB_A_SLOTS], sb[TB_B_SLOTS];
+    big_slots<TB_A_SLOTS, TB_BM>(P.a, sa, tid);
+    big_slots<TB_B_SLOTS, TB_BN>(P.b, sb, tid);
+    const int a_ones = P.a.ones ? M - 1 : -1, b_ones = P.b.ones ? N - 1 : -1;  // the ones column (bias gradients) is written by hand
+
+    for (int i = tid; i < TB_LDS_FLOATS; i += TB_NTH) lds[i] = 0.f;  // columns no piece covers stay zero
+    __syncthreads();
+
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    const int nchunks = gcp_cdiv(r_end - r_begin, TN_RK);
+    auto stage = [&](int chunk, int b) {
+        const int r0 = r_begin + chunk * TN_RK;
+        big_issue<TB_A_SLOTS>(sa, Abuf(b), r0, r_last, tid);
+        big_issue<TB_B_SLOTS>(sb, Bbuf(b), r0, r_last, tid);
+        if (tid < TN_RK) {
+            const float one = (r0 + tid <= r_last) ? 1.f : 0.f;
+            if (a_ones >= 0) Abuf(b)[tid * TB_BM + a_ones] = one;
+            if (b_ones >= 0) Bbuf(b)[tid * TB_BN + b_ones] = one;
+        }
+    };
+    if (nchunks > 0) stage(0, 0);
+    const bool m_on[2] = {mt0 < mtiles, mt0 + 1 < mtiles};
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        __syncthreads();  // vmcnt(0) + barrier: this chunk has landed, and every wave is done with the other buffer
+        const int nvalid = min(TN_RK, r_end - (r_begin + c * TN_RK));
+        if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
+            for (int i = tid; i < (TN_RK - nvalid) * TB_BM; i += TB_NTH) Abuf(cur)[nvalid * TB_BM + i] = 0.f;
+            for (int i = tid; i < (TN_RK - nvalid) * TB_BN; i += TB_NTH) Bbuf(cur)[nvalid * TB_BN + i] = 0.f;
+            __syncthreads();
+        }
+        if (c + 1 < nchunks) stage(c + 1, cur ^ 1);
+        if (m_on[0] && nt0 < ntiles) {  // (wave-uniform: waves whose tiles lie outside a narrower problem only keep the barriers)
+            const float* As = Abuf(cur) + hi * TB_BM + 32 * mt0 + col;
+            const float* Bs = Bbuf(cur) + hi * TB_BN + 32 * nt0 + col;
+            float fa[2], fb[5];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fa[j] = As[32 * j];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) fb[i] = Bs[32 * i];
+#pragma unroll
+            for (int ss = 0; ss < TN_RK / 2; ++ss) {
+                float na[2], nb[5];
+                if (ss + 1 < TN_RK / 2) {  // fragments of the next step before this step's MFMAs
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) na[j] = As[2 * (ss + 1) * TB_BM + 32 * j];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) nb[i] = Bs[2 * (ss + 1) * TB_BN + 32 * i];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if (m_on[j] && nt0 + i < ntiles) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[i], acc[j][i], 0, 0, 0);
+                if (ss + 1 < TN_RK / 2) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fa[j] = na[j];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) fb[i] = nb[i];
+                }
+            }
+        }
+    }
+    float* part = P.partial + (int64_t)split * M * N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (!(m_on[j] && nt0 + i < ntiles)) continue;
+            const int n = 32 * (nt0 + i) + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * (mt0 + j) + gcp_crow(r, hi);
+                if (m < M && n < N) part[(int64_t)m * N + n] = acc[j][i][r];
+            }
+        }
+}
+
+inline bool big_ok(const gcp_operand_t& o) {
+    if (o.act) return false;
+    for (int k = 0; k < o.n; ++k)
+        if (o.idx[k]) return false;
+    return true;
+}
+
 // Deterministic reduction of the per-split partial sums.  A workgroup handles 64 consecutive output elements; its four
 // waves take the splits k = w, w+4, ... (coalesced 256-byte rows, eight loads in flight per lane) and are combined in a
 // fixed order through LDS.
@@ -464,9 +618,49 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     }
     a.block_start[n_problems] = blocks;
     hipStream_t st = (hipStream_t)stream;
+    // problems whose output needs more than one 128 x 160 block (and fits 256 x 320) go through the big-block kernel, one
+    // workgroup per split; the others keep the launch below
+    static const bool big_env = getenv("GCPNET_TN_NO_BIG") == nullptr;
+    if (dma && big_env) {
+        TnArgs big, rest;
+        big.n = rest.n = 0;
+        int bblocks = 0, rblocks_ = 0, big_mn = 0, rest_mn = 0;
+        for (int i = 0; i < n_problems; ++i) {
+            const gcp_tn_problem_t& P = problems[i];
+            const bool is_big = (a.M[i] > TN_BM || a.N[i] > TN_BN) && a.M[i] <= TB_BM && a.N[i] <= TB_BN && big_ok(P.a) && big_ok(P.b);
+            TnArgs& d = is_big ? big : rest;
+            const int k = d.n++;
+            d.p[k] = a.p[i]; d.M[k] = a.M[i]; d.N[k] = a.N[i]; d.mb[k] = a.mb[i]; d.nb[k] = a.nb[i];
+            if (is_big) { d.block_start[k] = bblocks; bblocks += P.splits; big_mn = max(big_mn, a.M[i] * a.N[i]); }
+            else { d.block_start[k] = rblocks_; rblocks_ += a.mb[i] * a.nb[i] * P.splits; rest_mn = max(rest_mn, a.M[i] * a.N[i]); }
+        }
+        big.block_start[big.n] = bblocks;
+        rest.block_start[rest.n] = rblocks_;
+        if (big.n > 0) {
+            static bool big_configured = false;
+            const size_t big_lds = (size_t)TB_LDS_FLOATS * sizeof(float);
+            if (!big_configured) {
+                hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
+                if (err != hipSuccess) return (int)err;
+                big_configured = true;
+            }
+            hipLaunchKernelGGL(tn_gemm_big_kernel, dim3(bblocks), dim3(TB_NTH), big_lds, st, big);
+            GCP_HIP_CHECK_LAUNCH();
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(min(1024, gcp_cdiv(big_mn, 64)), big.n), dim3(256), 0, st, big);
+            GCP_HIP_CHECK_LAUNCH();
+            if (rest.n == 0) return 0;
+            a = rest;
+            blocks = rblocks_;
+            max_mn = rest_mn;
+            n_problems = rest.n;
+        }
+    }
     if (dma) {
         static bool configured = false;
-        const size_t lds_bytes = (size_t)TN_DMA_LDS_FLOATS * sizeof(float);
+        // (GCPNET_TN_LDS_PAD: tuning knob -- extra bytes of dynamic LDS per workgroup; >= 13 KB leaves ONE workgroup per CU, so that
+        // kernels of the caller's stream can share a CU with the weight-gradient GEMMs of the side stream)
+        static const size_t pad = getenv("GCPNET_TN_LDS_PAD") ? (size_t)atoi(getenv("GCPNET_TN_LDS_PAD")) : 0;
+        const size_t lds_bytes = (size_t)TN_DMA_LDS_FLOATS * sizeof(float) + pad;
         if (!configured) {
             hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)lds_bytes);

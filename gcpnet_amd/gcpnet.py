@@ -633,12 +633,13 @@ class GCPMessagePassing(nn.Module):
         mean = self.reduce_function == "mean"
         # scatter(message, col, reduce) (:939-947) as wavefront-segmented reductions over the CSR segments
         agg_s = ops.segment_reduce(m[0], side, mean)
-        agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], -1), side, mean).reshape(n, self.vector_output_dim, 3)
+        agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], 3 * self.vector_output_dim), side, mean).reshape(n, self.vector_output_dim, 3)
         return ScalarVector(agg_s, agg_v)
 
 
 class GCPInteractions(nn.Module):
-    """:963-1262 (non-autoregressive, unmasked call paths)."""
+    """:963-1262: the plain forward, the masked forward (`node_mask`: sub-graph feed-forward, in-place write-back of the unmasked
+    rows, :1201-1251) and `autoregressive_forward` (:1066-1116)."""
 
     def __init__(self, node_dims, edge_dims, cfg, layer_cfg, dropout: float = 0.1, autoregressive: bool = False,
                  nonlinearities: Optional[Tuple[Any, Any]] = None, updating_node_positions: bool = False):

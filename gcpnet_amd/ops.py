@@ -645,6 +645,8 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
     s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
     gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
     gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
+    if rows == 0:  # (an empty edge set: one half of autoregressive_forward's edge split, a node without in-edges in the CPD
+        return rows, s_out, v_out, pack, s_pre, gate  # sampling loop) -- nothing to launch, empty tensors have no address
     plain = len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
     if USE_WG_KERNELS and plain and (spec.residual or (res_s is None and res_v is None)) and spec.vi > 0:
         # one workgroup per 32-row tile, output columns split over its waves (gcp_wg_fwd.hip)
@@ -703,6 +705,22 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=s_pre.device)
     si, vi, vo = spec.si, spec.vi, spec.vo
+    if rows == 0:  # nothing to launch: empty input gradients, zero weight gradients (assembled like the fused form's)
+        H, K = spec.hidden, spec.K
+        nf = 9 if (spec.use_frames and vi > 0) else 0
+        g: List[Optional[Tensor]] = [torch.zeros((spec.so, K), **f32), torch.zeros((spec.so,), **f32), None, None, None, None, None]
+        if vi > 0:
+            g[2] = torch.zeros((H, vi), **f32)
+            if nf:
+                g[3] = torch.zeros((3, vi), **f32)
+            if vo > 0:
+                g[4] = torch.zeros((vo, H), **f32)
+                if spec.vmode == VMODE_SCALAR_GATE:
+                    g[5], g[6] = torch.zeros((vo, spec.so), **f32), torch.zeros((vo,), **f32)
+        t = dict(ds_pre=torch.zeros((0, spec.so), **f32), fused=g)
+        if len(vadds):
+            t["dvhf"] = torch.zeros((0, 3 * vadds[0].shape[2]), **f32)
+        return torch.zeros((0, si), **f32), (torch.zeros((0, vi, 3), **f32) if vi > 0 else None), t
     if (USE_WG_KERNELS and USE_WG_BACKWARD and len(s_src) == 1 and spec.s_plans[0] is None and len(v_src) == 1
             and spec.v_plans[0] is None and vi > 0 and rows > 0):
         res = _wg_backward(spec, rows, s_src[0], v_src[0], frames, w, s_pre, gate, d_s_out, d_v_out, need_w, vadds, side_reduce)
@@ -944,7 +962,7 @@ class _WeightGradJob:
         return g
 
 
-WEIGHT_GRADS_ON_SIDE_STREAM = True  # module switch, see set_weight_grad_stream()
+WEIGHT_GRADS_ON_SIDE_STREAM = os.environ.get("GCPNET_SIDE_STREAM", "1") != "0"  # module switch, see set_weight_grad_stream()
 _DEBUG_GRAD_PTRS: Optional[list] = None  # tests: addresses of the gradient buffers the fused backward produced (adoption check)
 
 
@@ -1042,6 +1060,27 @@ def _join_side_stream():
     _side_pending.clear()
 
 
+def _make_side_stream(dev: int):
+    """The weight-gradient stream.  GCPNET_SIDE_CU_MASK=<n> (tuning knob) confines it to the first n compute units of every XCD-
+    interleaved group through hipExtStreamCreateWithCUMask, so that the TN GEMMs cannot occupy the whole chip while the caller's
+    stream runs its small launches; default: an ordinary stream."""
+    n = int(os.environ.get("GCPNET_SIDE_CU_MASK", "0") or 0)
+    if n <= 0:
+        return torch.cuda.Stream(device=dev)
+    hip = C.CDLL("libamdhip64.so")
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (total + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for cu in range(min(n, total)):
+        mask[cu // 32] |= 1 << (cu % 32)
+    raw = C.c_void_p()
+    with torch.cuda.device(dev):
+        err = hip.hipExtStreamCreateWithCUMask(C.byref(raw), C.c_uint32(words), mask)
+    if err != 0:
+        raise _lib.GcpnetHipError(f"hipExtStreamCreateWithCUMask failed: {err}")
+    return torch.cuda.ExternalStream(raw.value, device=dev)
+
+
 def _side_submit(fn, keep) -> None:
     """Runs fn() with the weight-gradient stream current (ordered after everything enqueued on the caller's stream so far);
     `keep` stays referenced until the caller's stream has joined at the end of the backward pass."""
@@ -1052,7 +1091,7 @@ def _side_submit(fn, keep) -> None:
     main = torch.cuda.current_stream()
     side = _side_streams.get(dev)
     if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        side = _side_streams[dev] = _make_side_stream(dev)
     side.wait_stream(main)
     _ensure_end_of_backward_callback()
     _side_pending.append((main, side, keep))
@@ -1121,6 +1160,10 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
             items[k].gate = gate.data_ptr() if gate is not None else None
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
+        if rows == 0:  # (an empty edge set: nothing to launch)
+            if need_grad:
+                ctx.rows, ctx.n_weights = 0, len(weights)
+            return outs[-1][0], outs[-1][1]
         rc = _lib.E_UNSUPPORTED
         sp0 = specs[0]
         wave_first = (PREFER_WAVE_CHAIN_FORWARD and sp0.so <= 128 and n <= _lib.MAX_CHAIN and
@@ -1147,6 +1190,8 @@ class _Gcp2Chain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_s, d_v):
+        if ctx.rows == 0:  # no rows: the input gradients are empty, the weights receive none
+            return (None, None, d_s, d_v, *([None] * ctx.n_weights))
         specs, frames, rows = ctx.specs, ctx.frames, ctx.rows
         s0, v0, ws, packs, outs = ctx.state
         n = len(specs)

@@ -116,6 +116,8 @@ class ShardedGraph:
     frames, aggregation (scatter over the rank's own col range), node-level GCPs (their `scalarize(node_inputs=True)` needs the
     mean frame over each local node's OUT-edges, built once from the replicated positions and index arrays).  Weights are
     replicated; their gradients go through GradAllReducer with a SUM (each rank holds a disjoint share of the rows).
+    Bytes per rank and layer: it sends its [n_local, s + 3V] rows to 7 peers and receives the other ranks' rows (forward), the
+    reverse for the gradients (backward); `bench.py --dry-run-world N` prints the figures for a configuration.
 
     This class is index bookkeeping + collectives only (device-agnostic; the CPU tests drive it with the oracle)."""
 
@@ -140,13 +142,29 @@ class ShardedGraph:
         self.node_counts = [self.bounds[k + 1] - self.bounds[k] for k in range(world)]
         self.max_nodes = max(self.node_counts)
         self.edge_counts = [int(ptr[self.bounds[k + 1]] - ptr[self.bounds[k]]) for k in range(world)]
-        # local in-edges with GLOBAL node ids (gathers read the all-gathered tables) and with local target ids (aggregation)
-        self.edge_index = torch.stack((row[self.e0:self.e1], col[self.e0:self.e1]))
+        # local in-edges three ways: with GLOBAL node ids (frames are built from the replicated positions), with TABLE ids (the
+        # gathers read the all-gathered feature table, see _gather: rank k's nodes sit at rows k * max_nodes ..., so that the
+        # collective's output buffer IS the table and neither direction needs a re-packing pass) and with local target ids
+        # (aggregation)
+        self.edge_index_global = torch.stack((row[self.e0:self.e1], col[self.e0:self.e1]))
+        bnd = torch.tensor(self.bounds, dtype=torch.long, device=col.device)
+        owner = torch.bucketize(self.edge_index_global, bnd[1:-1], right=True)
+        self.edge_index = owner * self.max_nodes + (self.edge_index_global - bnd[owner])
         self.col_local = col[self.e0:self.e1] - self.n0
+        self.table_rows = world * self.max_nodes
+        self.table_slice = slice(rank * self.max_nodes, rank * self.max_nodes + (self.n1 - self.n0))
         # out-edges of the local nodes (row in range), for the node-level mean frames: [2, E_out] with LOCAL row ids
         out_mask = (row >= self.n0) & (row < self.n1)
         self.out_edge_index_global = torch.stack((row[out_mask], col[out_mask]))
         self.out_row_local = row[out_mask] - self.n0
+
+    def to(self, device) -> "ShardedGraph":
+        """Moves the index tensors (they are built where `edge_index` lives) to `device`."""
+        for name in ("edge_index", "edge_index_global", "col_local", "out_edge_index_global", "out_row_local", "edge_perm"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t.to(device))
+        return self
 
     @property
     def n_local(self) -> int:
@@ -158,44 +176,57 @@ class ShardedGraph:
     def local_edges(self, t: torch.Tensor) -> torch.Tensor:
         """Rows of a per-edge tensor (given in the caller's edge order) that belong to this rank, in col-sorted order."""
         if self.edge_perm is not None:
-            t = t[self.edge_perm]
+            t = t[self.edge_perm.to(t.device)]
         return t[self.e0:self.e1]
 
+    def halo_nodes(self) -> torch.Tensor:
+        """Global ids of the REMOTE source nodes this rank's in-edges reference (what a halo exchange would have to fetch instead
+        of the whole table; `bench.py --dry-run-world` prints its size next to the all-gather's)."""
+        src = torch.unique(self.edge_index_global[0])
+        return src[(src < self.n0) | (src >= self.n1)]
+
     # ---- collectives -----------------------------------------------------------------------------------------------
+    def _collectives(self) -> bool:
+        """One rank WITH a process group still goes through the collectives (tests/test_rccl_world1.py runs the RCCL branches that
+        way on a one-GPU box); one rank without torch.distributed does not."""
+        return self.world > 1 or (dist.is_available() and dist.is_initialized())
+
     def _gather(self, local: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
-            return local
+        """[n_local, D] -> the feature table [world * max_nodes, D]: rank k's rows at k * max_nodes ... (padding rows are zero and
+        never referenced: `edge_index` holds table ids).  ONE copy of the local rows into their slot of the output buffer and an
+        in-place all-gather; no concatenation afterwards."""
         D = local.shape[1]
-        pad = local.new_zeros((self.max_nodes, D))
-        pad[: self.n_local] = local
+        buf = local.new_empty((self.table_rows, D))
+        own = buf[self.rank * self.max_nodes: (self.rank + 1) * self.max_nodes]
+        own[: self.n_local].copy_(local)
+        if self.n_local < self.max_nodes:
+            own[self.n_local:].zero_()
+        if not self._collectives():
+            return buf
         if dist.get_backend(self.group) == "nccl":
-            buf = local.new_empty((self.world * self.max_nodes, D))
-            dist.all_gather_into_tensor(buf, pad, group=self.group)
-            parts = [buf[k * self.max_nodes: k * self.max_nodes + c] for k, c in enumerate(self.node_counts)]
+            dist.all_gather_into_tensor(buf, own, group=self.group)  # (in place: `own` is this rank's slot of `buf`)
         else:
-            bufs = [torch.empty_like(pad) for _ in range(self.world)]
-            dist.all_gather(bufs, pad, group=self.group)
-            parts = [b[:c] for b, c in zip(bufs, self.node_counts)]
-        return torch.cat(parts, dim=0)
+            chunks = [buf[k * self.max_nodes: (k + 1) * self.max_nodes] for k in range(self.world)]
+            dist.all_gather(chunks, own.clone(), group=self.group)  # gloo: list form, each chunk a view of the table
+        return buf
 
     def _scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
-        """Sum over ranks of `full` [N, D], rows of this rank's node range returned."""
-        if self.world == 1:
-            return full
+        """Sum over ranks of the table-shaped gradient `full` [world * max_nodes, D]; this rank's rows returned.  The table layout
+        is the reduce-scatter's input layout: no re-packing."""
+        if not self._collectives():
+            return full[self.table_slice].contiguous()
         D = full.shape[1]
         if dist.get_backend(self.group) == "nccl":
-            inp = full.new_zeros((self.world * self.max_nodes, D))
-            for k, c in enumerate(self.node_counts):
-                inp[k * self.max_nodes: k * self.max_nodes + c] = full[self.bounds[k]: self.bounds[k + 1]]
             out = full.new_empty((self.max_nodes, D))
-            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
             return out[: self.n_local].contiguous()
         total = full.clone()  # gloo has no reduce-scatter
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
-        return total[self.n0: self.n1].contiguous()
+        return total[self.table_slice].contiguous()
 
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
-        """[n_local, D] -> [N, D] over all ranks; backward = reduce-scatter (sum) of the gradient rows to their owners."""
+        """[n_local, D] -> the table [world * max_nodes, D] over all ranks (rows by TABLE id: `edge_index`, `table_slice`);
+        backward = reduce-scatter (sum) of the gradient rows to their owners."""
         return _AllGatherRows.apply(local, self)
 
 
@@ -234,7 +265,7 @@ def sharded_interactions_forward(layer, node_rep, edge_rep, sg: ShardedGraph, fr
     sg._col_plan = plan
     mean = mp.reduce_function == "mean"
     agg_s = ops.segment_reduce(m[0], plan, mean)
-    agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], -1), plan, mean).reshape(n_loc, v, 3)
+    agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], 3 * v), plan, mean).reshape(n_loc, v, 3)
     hidden = ScalarVector(agg_s, agg_v)
     if layer.gcp_dropout[0].active:
         hidden = layer.gcp_dropout[0](hidden)
@@ -256,10 +287,36 @@ def sharded_interactions_forward(layer, node_rep, edge_rep, sg: ShardedGraph, fr
     node_rep = _sv_add(node_rep, hidden) if layer.pre_norm else layer.gcp_norm[1](node_rep, residual=hidden)
     if not layer.updating_node_positions:
         return node_rep
-    if not layer.ablate_x_force_update:
-        raise NotImplementedError("sharded position update with the inter-node force term")
     rep = node_rep
     for gcp in layer.node_position_update_network:
         rep = node_gcp(gcp, rep)
     upd = rep[1].reshape(n_loc, 3)
+    if not layer.ablate_x_force_update:
+        # inter-node force term (reference gcpnet.py:1143-1153): coef[e] = W3 act(phi_i(h)[row] + phi_j(h)[col]) on the rank's
+        # in-edges -- phi_i of the SOURCE nodes comes through a second all-gather (an [n_local, s] table per layer), phi_j of the
+        # targets is local (placed in the rank's slot of a table-shaped buffer so that one index space serves both) -- then the
+        # mean over each local node's in-edges
+        hv = rep[0]
+        A = sg.all_gather_rows(ops.linear(hv, layer.phi_force_i.weight, layer.phi_force_i.bias))
+        Bl = ops.linear(hv, layer.phi_force_j.weight, layer.phi_force_j.bias)
+        B = _PlaceRows.apply(Bl, sg)
+        plan_t = ops.GraphPlan.get(sg.edge_index, sg.table_rows)
+        force = ops.edge_force(A, B, layer.phi_force_ij[1].weight, frames, plan_t, layer.force_act, layer.force_slope)
+        upd = ops.axpy(upd, ops.segment_reduce(force, plan, True), 1.0)
     return node_rep, ops.axpy_clamp(node_pos, upd, float(layer.node_positions_weight), -100.0, 100.0)
+
+
+class _PlaceRows(torch.autograd.Function):
+    """local [n_local, D] -> table-shaped [world * max_nodes, D] with the local rows in this rank's slot and zeros elsewhere
+    (no communication); backward = the slot of the gradient."""
+
+    @staticmethod
+    def forward(ctx, local, sg):
+        ctx.sg = sg
+        buf = local.new_zeros((sg.table_rows, local.shape[1]))
+        buf[sg.table_slice] = local
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.sg.table_slice].contiguous(), None

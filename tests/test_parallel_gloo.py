@@ -134,7 +134,7 @@ def _oracle_sharded_layer(O, P, pre, h, chi, e_loc, xi_loc, sg, frames_loc, out_
     h_full, chi_full = full[:, :s], full[:, s:].reshape(-1, v, 3)
     (rs, rv), _ = O.message_passing(P, pre + "interaction.", h_full, chi_full, e_loc, xi_loc, sg.edge_index, frames_loc, cfg,
                                     lcfg["mp_cfg"], return_messages=True)
-    h, chi = h + rs[sg.n0:sg.n1], chi + rv[sg.n0:sg.n1]  # (all in-edges of the local nodes are local: their mean is complete)
+    h, chi = h + rs[sg.table_slice], chi + rv[sg.table_slice]  # (all in-edges of the local nodes are local: their mean is complete)
     h, chi = O.gcp_layer_norm(P, pre + "gcp_norm.0.", h, chi)
     no_res = dict(cfg, vector_residual=False)
     kws = [O._gcp_kwargs(no_res, nonlinearities=tuple(cfg["nonlinearities"])), O._gcp_kwargs(no_res, nonlinearities=(None, None))]
@@ -150,7 +150,7 @@ def _sharded_job(rank, world):
     P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
     P = {k: v.clone().requires_grad_() for k, v in P.items()}
     sg = ShardedGraph(ei, n, rank, world)
-    frames_loc = O.localize(x, sg.edge_index)
+    frames_loc = O.localize(x, sg.edge_index_global)  # (positions are replicated, by global id)
     out_frames = O.localize(x, sg.out_edge_index_global)
     out_ei_local = torch.stack((sg.out_row_local, sg.out_edge_index_global[1]))
     h = sg.local_nodes(ins["h"]).clone().requires_grad_()

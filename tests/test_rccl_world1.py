@@ -42,10 +42,10 @@ for p in layer.parameters():
     p.grad = None
 # the sharded path with ONE rank over RCCL: all_gather_into_tensor / reduce_scatter_tensor / ReduceOp.AVG and SUM on the bucket
 sg = ShardedGraph(ei, n, 0, 1)
-sg.edge_index, sg.col_local = sg.edge_index.cuda(), sg.col_local.cuda()
-fr_l = G.localize(x.cuda(), sg.edge_index)
-fr_out = G.localize(x.cuda(), sg.out_edge_index_global.cuda())
-node_frames = ops.segment_reduce(fr_out.reshape(-1, 9), ops.GatherPlan(sg.out_row_local.cuda(), sg.n_local), mean=True).reshape(sg.n_local, 3, 3)
+sg.to("cuda")
+fr_l = G.localize(x.cuda(), sg.edge_index_global)
+fr_out = G.localize(x.cuda(), sg.out_edge_index_global)
+node_frames = ops.segment_reduce(fr_out.reshape(-1, 9), ops.GatherPlan(sg.out_row_local, sg.n_local), mean=True).reshape(sg.n_local, 3, 3)
 red = GradAllReducer(list(layer.parameters()))
 e_l, xi_l = sg.local_edges(ins["e"]), sg.local_edges(ins["xi"])
 h2, chi2 = sharded_interactions_forward(layer, (ins["h"], ins["chi"]), (e_l, xi_l), sg, fr_l, node_frames)

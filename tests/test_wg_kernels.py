@@ -27,7 +27,9 @@ SINGLE = [
     # rows, in dims, out dims, bottleneck, nonlinearities, extra kwargs
     (1000, (128, 16), (512, 32), 4, ("relu", None), {}),            # FF0 at C2 dims: two tiles per wave, 8 waves
     (333, (512, 32), (128, 16), 4, (None, None), {}),               # FF1 at C2 dims: K = 529
-    (97, (256, 32), (1024, 64), 4, ("relu", None), {}),             # FF0 at C5 dims: two output groups
+    (97, (256, 32), (1024, 64), 4, ("relu", None), {}),             # FF0 at C5 dims: two output groups, two tiles of gate outputs
+    (130, (64, 16), (64, 48), 4, ("silu", None), {}),               # 32 < vo <= 64 with four waves (vo = 48: a partial second gate tile)
+    (75, (160, 24), (192, 64), 4, ("relu", "sigmoid"), {}),         # ... with eight waves, one output tile per wave
     (70, (100, 16), (100, 16), 4, ("silu", "sigmoid"), {}),         # LBA width: so = 100 (partial last tile)
     (129, (128, 16), (128, 1), 4, ("relu", None), {}),              # position update: one output vector
     (64, (1, 3), (64, 16), 1, (None, None), {}),                    # NMS node embedding: si = 1, H = 16
@@ -63,7 +65,7 @@ def test_single_block_vs_oracle(G, rows, din, dout, bott, acts, kw):
     before = dict(ops.WG_STATS)
     got = mod((sg, vg), ei.cuda(), fr.cuda())
     got = tuple(got) if isinstance(got, tuple) else (got,)
-    expect_wg = not (dout[1] > 32 and kw.get("vector_gate", True))  # (gated blocks with more than 32 output vectors: wave kernels)
+    expect_wg = not (dout[1] > 64 and kw.get("vector_gate", True))  # (gated blocks with more than 64 output vectors: wave kernels)
     assert ops.WG_STATS["fwd"] == before["fwd"] + int(expect_wg), "the workgroup forward kernel did not run"
     scale = max(1.0, float(want[0].abs().max()))
     for a, b in zip(got, want):
