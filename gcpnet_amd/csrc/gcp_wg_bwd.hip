@@ -1105,7 +1105,7 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     plan->nw = NW;
     plan->kt = KTn == 1 ? 1 : 4;
     plan->fused = fused;
-    const int per_cu = (fused && NW == 4 && D.NNT <= 2) ? 3 : 2;  // resident workgroups per CU of the instantiation that will run
+    const int per_cu = (fused && NW == 4 && D.NNT <= 2 && getenv("GCPNET_WG_BWD_FN2")) ? 3 : 2;  // resident workgroups per CU of the instantiation that will run
     plan->grid = ntiles <= 0 ? 1 : min(ntiles, per_cu * g_wg_cus);
     plan->kw = KW;
     plan->n_small = n_sm;
@@ -1186,7 +1186,9 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
             return launch_bwd<8, 1, 0, 2>(p, pwl, grid, lds_bytes, st);
     }
     if (b6) return NW == 4 ? launch_bwd<4, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st);
-    if (pl.fused && NW == 4 && D.NNT <= 2 && !getenv("GCPNET_WG_BWD_FN5")) return launch_bwd<4, 1, 2>(p, pwl, grid, lds_bytes, st);
+    // (FN = 2, three workgroups per CU: measured in round 3 -- 429 us against 267 us per launch for the first message GCP of
+    // configs[1], same step time; opt-in for experiments)
+    if (pl.fused && NW == 4 && D.NNT <= 2 && getenv("GCPNET_WG_BWD_FN2")) return launch_bwd<4, 1, 2>(p, pwl, grid, lds_bytes, st);
     if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);
     if (NW == 4) return pl.kt == 1 ? launch_bwd<4, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<4, 4, 0>(p, pwl, grid, lds_bytes, st);
     return pl.kt == 1 ? launch_bwd<8, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 4, 0>(p, pwl, grid, lds_bytes, st);

@@ -209,3 +209,99 @@ def test_nms_step_20body_shape(G):
     b["label"] = b["x"] + 0.3 * torch.randn(2000, 3, generator=torch.Generator().manual_seed(43))
     fwd = lambda P, i: O.nms_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(), 4)
     _step_case(G, model, fwd, b, ("h", "chi", "e", "xi"), "x")
+
+
+# ---- BASELINE configs[4] at FULL size: 100 000 nodes / 1 000 000 edges, (256,32) ---------------------------------------------------
+def _subproblem(ei, n_nodes, targets):
+    """The part of a graph that ONE GCPInteractions layer's outputs at `targets` depend on, and through which a loss on those
+    outputs alone back-propagates: the targets' in-edges (messages + aggregate) and out-edges (their mean out-edge frame in the
+    node-level GCPs).  Returns (edge ids kept, node ids kept, relabelled edge_index, positions of the targets among the kept nodes)."""
+    row, col = ei[0], ei[1]
+    is_t = torch.zeros(n_nodes, dtype=torch.bool)
+    is_t[targets] = True
+    keep_e = torch.nonzero(is_t[col] | is_t[row]).squeeze(1)
+    sub = ei[:, keep_e]
+    nodes = torch.unique(torch.cat((sub.reshape(-1), targets)))
+    relabel = torch.full((n_nodes,), -1, dtype=torch.long)
+    relabel[nodes] = torch.arange(nodes.numel())
+    return keep_e, nodes, relabel[sub], relabel[targets]
+
+
+def test_layer_full_c5_graph_on_a_subproblem(G):
+    """One GCPInteractions layer, fwd + bwd, on the FULL configs[4] graph (100 000 nodes / ~1 000 000 edges, (256,32)) on the GPU.
+    The CPU oracle cannot hold that problem (its saved activations alone are ~100 GB), so the comparison uses a size-independent
+    property of the layer: with a loss that reads the outputs of 1 500 target nodes only, EVERY quantity -- those outputs, the
+    gradients of the inputs they depend on (the other rows' gradients are exactly zero) and all weight gradients -- equals that of
+    the sub-problem made of the targets' in- and out-edges, which the oracle evaluates in fp32 and float64 (relu: as_accurate)."""
+    from gcpnet_amd.synthetic import make_inputs
+
+    dims, n_nodes = (256, 32), 100000
+    ins = make_inputs(n_nodes, 10, node_dims=dims, seed=0)
+    ei, x = ins.pop("edge_index"), ins.pop("x")
+    assert ei.shape[1] > 990000
+    g = torch.Generator().manual_seed(11)
+    targets = torch.sort(torch.randperm(n_nodes, generator=g)[:1500]).values
+    torch.manual_seed(12)
+    layer = G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0).cuda().eval()
+    lh, lc = torch.randn(1500, dims[0], generator=g), torch.randn(1500, dims[1], 3, generator=g)
+    # ---- GPU: the whole graph
+    gi = {k_: t.cuda().requires_grad_() for k_, t in ins.items()}
+    fr = G.localize(x.cuda(), ei.cuda())
+    gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr)
+    tg = targets.cuda()
+    ((gh[tg] * lh.cuda()).sum() + (gc[tg] * lc.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    # ---- oracle: the sub-problem
+    keep_e, nodes, sub_ei, t_pos = _subproblem(ei, n_nodes, targets)
+    frames = O.localize(x, ei)[keep_e]  # (frames of the kept edges, from the full positions)
+    ocfg = O.default_module_cfg()
+
+    def oracle(dtype):
+        P = {k_: t.detach().cpu().to(dtype).requires_grad_() for k_, t in layer.state_dict().items()}
+        ci = dict(h=ins["h"][nodes], chi=ins["chi"][nodes], e=ins["e"][keep_e], xi=ins["xi"][keep_e])
+        ci = {k_: t.clone().to(dtype).requires_grad_() for k_, t in ci.items()}
+        wh, wc = O.gcp_interactions(P, "", ci["h"], ci["chi"], ci["e"], ci["xi"], sub_ei, frames.to(dtype), ocfg, O.default_layer_cfg())
+        ((wh[t_pos] * lh.to(dtype)).sum() + (wc[t_pos] * lc.to(dtype)).sum()).backward()
+        return P, ci, wh.detach()[t_pos], wc.detach()[t_pos]
+
+    P, ci, wh, wc = oracle(torch.float32)
+    P64, c64, _, _ = oracle(torch.float64)
+    close(gh.detach()[tg].cpu(), wh, atol=1e-5 * max(1.0, float(wh.abs().max())), rtol=1e-5)
+    close(gc.detach()[tg].cpu(), wc, atol=1e-5 * max(1.0, float(wc.abs().max())), rtol=1e-5)
+    rows = dict(h=nodes, chi=nodes, e=keep_e, xi=keep_e)
+    for k_ in ins:
+        got = gi[k_].grad.cpu()
+        as_accurate(got[rows[k_]], ci[k_].grad, c64[k_].grad, "d" + k_)
+        rest = torch.ones(got.shape[0], dtype=torch.bool)
+        rest[rows[k_]] = False
+        assert float(got[rest].abs().max()) == 0.0, f"d{k_}: rows outside the sub-problem must have exactly zero gradient"
+    n = 0
+    for k_, p in layer.named_parameters():
+        as_accurate(p.grad.cpu(), P[k_].grad, P64[k_].grad, k_)
+        n += 1
+    assert n > 60
+
+
+def test_lba_step_realistic_pocket_size(G):
+    """configs[2] at the size SURVEY.md section 8 names for it: 16 pocket-sized radius graphs of 400 - 600 atoms (r = 4.5, <= 32
+    neighbours: ~7 000 nodes / ~200 000 edges), the shipped LBA model ((100,16) x 8 layers + readout), step() fwd + bwd, featurised
+    and collated by the GPU input side (lba_featurize + collate)."""
+    from gcpnet_amd.synthetic import radius_graph
+
+    torch.manual_seed(51)
+    model_cfg = dict(chi_input_dim=2, e_input_dim=16, xi_input_dim=1, h_hidden_dim=100, chi_hidden_dim=16, e_hidden_dim=32,
+                     xi_hidden_dim=4, output_dim=1, output_scale_factor=2, num_encoder_layers=8, dropout=0.0, dense_dropout=0.1)
+    model = G.GCPNetLBA(model_cfg=model_cfg, module_cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg()).cuda().eval()
+    g = torch.Generator().manual_seed(52)
+    graphs = []
+    for i in range(16):
+        n = 400 + 13 * i  # 400 .. 595 atoms
+        x, _ = radius_graph(n, 32, seed=60 + i, expected_in_radius=40.0)
+        d = G.lba_featurize(x.cuda(), torch.randint(0, 9, (n,), generator=g), n_ligand=30)
+        d["label"] = torch.randn((), generator=g).cuda()
+        graphs.append(d)
+    b = {k: v.cpu() for k, v in G.collate(graphs).items()}
+    n, e = b["x"].shape[0], b["edge_index"].shape[1]
+    assert 6500 < n < 9000 and e > 150000, (n, e)
+    fwd = lambda P, i: O.lba_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(), 8)
+    _step_case(G, model, fwd, {k: b[k] for k in ("h", "chi", "e", "xi", "x", "edge_index", "batch", "label")}, ("chi", "e", "xi"), "pred")

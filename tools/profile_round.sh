@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -- python $R/bench.py --no-cpu-baseline --no-c5-block > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -- python $R/bench.py --no-cpu-baseline --no-c5-block --no-other-configs > $OUT/bench_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_c5 -- python $R/bench.py --config c5 --steps 3 --warmup 1 --step-only > $OUT/c5_step.json 2> /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 3 --warmup 1 --step-only > /dev/null 2>&1
@@ -19,3 +19,16 @@ cd $R
 find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
 # (the traces themselves are large: keep only the stats / counter tables)
 find $OUT -name "*kernel_trace.csv" -delete
+# condensed tables (what gets copied into profiles/)
+{
+  for C in FETCH_SIZE WRITE_SIZE mfma; do
+    f=$(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1)
+    echo "== rocprofv3 --pmc $C (mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB)"
+    python tools/pmc_summary.py $f
+  done
+} > $OUT/pmc_summary.txt 2>&1
+cp $(find $OUT/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+cp $(find $OUT/ks_c5 -name "*kernel_stats.csv" | head -1) $OUT/c5_kernel_stats.csv
+python tools/kstats.py $OUT/kernel_stats.csv 25 > $OUT/kernel_stats_per_step.txt
+python tools/kstats.py $OUT/c5_kernel_stats.csv 4 > $OUT/c5_kernel_stats_per_step.txt
+find $OUT -name "*counter_collection.csv" -size +8M -delete
