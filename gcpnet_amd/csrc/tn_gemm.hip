@@ -24,9 +24,15 @@ constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32;
 // Rows per split: about one split per CU for the big (edge-row) problems -- with one or two output blocks that is one
 // balanced wave of workgroups over the 256 CUs, two resident per CU -- and never fewer than 64 rows (node-row problems).
 constexpr int TN_TARGET_SPLITS = 256, TN_MIN_ROWS_PER_SPLIT = 64;
-__host__ __device__ inline int tn_rows_per_split(int rows) {
-    const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, TN_TARGET_SPLITS), TN_RK);
+// host side: rows per split for the target split count (GCPNET_TN_SPLITS overrides the 256: a tuning knob)
+inline int tn_rows_per_split_host(int rows) {
+    static const int target = getenv("GCPNET_TN_SPLITS") && atoi(getenv("GCPNET_TN_SPLITS")) > 0 ? atoi(getenv("GCPNET_TN_SPLITS")) : TN_TARGET_SPLITS;
+    const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, target), TN_RK);
     return r < TN_MIN_ROWS_PER_SPLIT ? TN_MIN_ROWS_PER_SPLIT : r;
+}
+// device side: derived from the problem's split count (whatever the host chose): whole chunks, every row covered
+__host__ __device__ inline int tn_rows_per_split(int rows, int splits) {
+    return gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, splits > 0 ? splits : 1), TN_RK);
 }
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
 constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread
@@ -63,7 +69,7 @@ __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
     w.mw = min(TN_BM, a.M[pi] - w.m0);
     w.nw = min(TN_BN, a.N[pi] - w.n0);
     w.ntiles = gcp_cdiv(w.nw, 32);
-    const int rps = tn_rows_per_split(P.rows);
+    const int rps = tn_rows_per_split(P.rows, P.splits);
     w.r_begin = w.split * rps;
     w.r_end = min(P.rows, w.r_begin + rps);
     return w;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
     const gcp_tn_problem_t& P = a.p[pi];
     const int M = a.M[pi], N = a.N[pi];
     const int split = blockIdx.x - a.block_start[pi];
-    const int rps = tn_rows_per_split(P.rows);
+    const int rps = tn_rows_per_split(P.rows, P.splits);
     const int r_begin = split * rps, r_end = min(P.rows, r_begin + rps), r_last = r_end - 1;
     const int mtiles = gcp_cdiv(M, 32), ntiles = gcp_cdiv(N, 32);
     const int mt0 = 2 * (wave & 3), nt0 = 5 * (wave >> 2);
@@ -589,7 +595,7 @@ inline bool dma_ok(const gcp_operand_t& o) {
 
 extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
     (void)M; (void)N;
-    return rows <= 0 ? 1 : gcp_cdiv(rows, tn_rows_per_split(rows));
+    return rows <= 0 ? 1 : gcp_cdiv(rows, tn_rows_per_split_host(rows));
 }
 
 extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream) {

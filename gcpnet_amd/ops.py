@@ -21,7 +21,15 @@ from ._lib import (ACT, WgBwdArgs, WgBwdPlan, BwdScratch, ChainBwdItem, ChainIte
 Tensor = torch.Tensor
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The caller's current HIP stream as a raw handle.  `torch.cuda.current_stream()` builds a Stream object through several Python
+    layers (11 us per call, ~70 calls per layer and step: 5 % of a launch-bound NMS step, tools/pyprofile_step.py); the raw getter
+    answers in well under a microsecond."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -1045,12 +1053,22 @@ def _ensure_end_of_backward_callback() -> None:
     _end_callback_task = task
 
 
+DEFER_CHAIN_WEIGHT_GRADS = os.environ.get("GCPNET_DEFER_TN", "0") == "1"
+_deferred_jobs: list = []
+
+
+def _flush_deferred_weight_grads() -> None:
+    while _deferred_jobs:
+        run_weight_grad_jobs(_deferred_jobs.pop(0), in_backward_of_leaves=True)
+
+
 def _end_of_backward():
     """End-of-backward callback: the caller's stream waits for the weight-gradient stream; scratch is released; the table of
     weight uses of the graph that was just differentiated is dropped."""
     global _end_callback_task
     _end_callback_task = -1
     _weight_uses.clear()
+    _flush_deferred_weight_grads()
     _join_side_stream()
 
 
@@ -1228,7 +1246,13 @@ class _Gcp2Chain(torch.autograd.Function):
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
         if live:
-            run_weight_grad_jobs(live, in_backward_of_leaves=ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells))
+            side = ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells)
+            if side and DEFER_CHAIN_WEIGHT_GRADS:
+                # (experiment, DESIGN.md 6b: the chain's TN GEMMs are handed to the side stream only after the first message GCP's
+                # backward and its HBM-bound input-gradient reductions have been enqueued -- _flush_deferred_weight_grads)
+                _deferred_jobs.append(live)
+            else:
+                run_weight_grad_jobs(live, in_backward_of_leaves=side)
         wgrads: List[Optional[Tensor]] = []
         for k in range(n):
             g = jobs[k].grads() if jobs[k] is not None else [None] * 7
@@ -1582,6 +1606,7 @@ class _Gcp2Projected(torch.autograd.Function):
             wgrads = [g if need else None for g, need in zip(full, need_w)]
         g_res_s = d_s_out if ctx.has_res[0] else None
         g_res_v = d_v_out if ctx.has_res[1] else None
+        _flush_deferred_weight_grads()
         return (None, None, None, None, *grads_s, *grads_v, g_res_s, g_res_v, *wgrads)
 
 
