@@ -28,7 +28,7 @@ namespace {
     X(si) X(vi) X(so) X(vo) X(H) X(nf) X(K) X(NT) X(NKT) X(SG) X(VG) X(HF) X(split) X(LW) X(KW) X(NNT) X(EP) X(VOP) X(HFP)  \
     X(KS) X(DSS) X(VS) X(US) X(HS) X(FS) X(DGS) X(EXS) X(EPS) X(WSV) X(WSU) X(WTV) X(WTU)                                   \
     X(o_x) X(o_ds) X(o_v) X(o_dvo) X(o_dvu) X(o_vh) X(o_dvhf) X(o_fr) X(o_dg) X(o_rn) X(o_sgn) X(o_dext) X(o_epart) X(o_ws) \
-    X(n_up) X(n_sm) X(sm_tiles) X(sm_up_tiles) X(sm_nu) X(sm_nd)
+    X(n_up) X(n_sm) X(sm_tiles) X(sm_up_tiles) X(sm_nu) X(sm_nd) X(npass)
 #define WG_BWD_MAGICS(X) X(mg_v) X(mg_o) X(mg_g) X(mg_x) X(mg_xpad) X(mg_epad) X(mg_ns) X(mg_wdt) X(mg_hfp) X(mg_ep) X(mg_vop)
 
 struct WgBwdDims {
@@ -50,9 +50,13 @@ constexpr unsigned c_magic(int d) { return d > 1 ? (unsigned)(((1ull << 32) + (u
 
 // (si, vi, so, vo, hidden: as in gcp2_weights_t; gated: scalar gate in use; want_fused: the caller asked for fused weight
 // gradients; NW: waves per workgroup)
+// npass: the ds_pre tile holds the so columns of ONE pass (1 / npass of the wave's output tiles), P3 -> P4 run npass times with
+// the W^T ds_pre accumulators kept across the passes (plain fp32 form only): the (s,V) -> (4s,2V) feed-forward GCP of BASELINE
+// configs[4] has so = 1024, its full ds_pre tile would be 131 KB
 constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int use_frames, int gated, int want_fused, int NW,
-                                int b6 = 0) {
+                                int b6 = 0, int npass = 1) {
     WgBwdDims d{};
+    d.npass = npass;
     d.si = si; d.vi = vi; d.so = so; d.vo = vo;
     d.H = vi > 0 ? hidden : 0;
     d.nf = (vi > 0 && use_frames) ? 9 : 0;
@@ -86,7 +90,7 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     d.sm_tiles = d.sm_up_tiles + c_cdiv(d.HF, 16) * d.sm_nd;
     const int xw = d.fused ? 8 * c_cdiv(d.KW, 8) : 0;
     d.KS = c_stride(c_max(xw, 4));
-    d.DSS = c_stride(32 * d.NT);
+    d.DSS = c_stride(32 * c_cdiv(d.NT, npass));
     d.VS = c_stride(3 * vi); d.US = c_stride(3 * c_max(vo, 1)); d.HS = c_stride(3 * c_max(d.H, 1)); d.FS = c_stride(3 * d.HF);
     d.DGS = c_stride(c_rup(c_max(vo, 1), 8));
     d.EXS = c_stride(c_max(d.EP, d.K - si));
@@ -116,7 +120,11 @@ constexpr WgBwdDims wg_bwd_dims(int si, int vi, int so, int vo, int hidden, int 
     d.lds_floats = off;
     // (the fused form adds the 32 x (K + 1) input tile X: when that pushes the tile set past the 160 KB of a CU -- the second
     // feed-forward GCP of BASELINE configs[4] after its leading columns were split off, (128,64) -> (256,32) -- take the plain form)
-    if (d.fused && (long long)off * 4 > 160 * 1024) return wg_bwd_dims(si, vi, so, vo, hidden, use_frames, gated, 0, NW, b6);
+    if (d.fused && (long long)off * 4 > 160 * 1024) return wg_bwd_dims(si, vi, so, vo, hidden, use_frames, gated, 0, NW, b6, npass);
+    // plain fp32 form that does not fit: two, then four passes over the output tiles (whole tiles per wave and pass)
+    if (!d.fused && !b6 && d.KTn == 1 && (long long)off * 4 > 160 * 1024 && npass < 4 && c_cdiv(d.NT, NW) % (2 * npass) == 0 &&
+        d.NT % (NW * 2 * npass) == 0)
+        return wg_bwd_dims(si, vi, so, vo, hidden, use_frames, gated, 0, NW, 0, 2 * npass);
     d.mg_v = c_magic(3 * vi / 4); d.mg_o = c_magic(3 * vo / 4); d.mg_g = c_magic(vo / 4); d.mg_x = c_magic(si / 4);
     d.mg_xpad = c_magic(8 * c_cdiv(d.KW, 8) - d.K); d.mg_epad = c_magic(d.EP - (d.H + d.nf));
     d.mg_ns = c_magic(c_min(si, d.K) - 32 * (d.NKT - 1)); d.mg_wdt = c_magic(3 * d.HFP); d.mg_hfp = c_magic(d.HFP);
@@ -165,6 +173,7 @@ struct WgBwdParams {
     int n_up, n_sm;  // small weight gradients: vector_up entries, all entries
     unsigned mg_v, mg_o, mg_g, mg_x, mg_xpad, mg_epad, mg_ns, mg_wdt, mg_hfp, mg_ep, mg_vop;  // wg_magic of the tile-copy divisors
     int sm_tiles, sm_up_tiles, sm_nu, sm_nd;  // their 16 x 16 tiles: all, those of vector_up, tiles along N (up / down)
+    int npass;                                // passes of P3 -> P4 over the output tiles (MP instantiations)
     unsigned long long* stamps;  // profiling hook: s_memtime stamps of wave 0 at the phase boundaries (last tile of the workgroup)
     long long stamp_cap;
 };
@@ -178,9 +187,11 @@ constexpr int NSW = 2;  // 16 x 16 tiles of the small vector weight gradients pe
 // accumulation (gcp_bf16x3.h: exact to fp32 round-off)
 // (fused with at most two tiles of K + 1 columns -- the first message GCP after project-then-gather: K + 1 = 51 -- carries 32
 // instead of 80 persistent accumulator registers: a third workgroup per CU hides more of the per-tile phase latencies)
-template <int NW, int KT, int FN, bool PWL, int SHP, bool B6 = false>
+// MP: P3 -> P4 in `npass` passes over the output tiles with a ds_pre tile of one pass's columns (plain fp32 form, run-time shapes)
+template <int NW, int KT, int FN, bool PWL, int SHP, bool B6 = false, bool MP = false>
 __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) void gcp_wg_bwd_kernel(const WgBwdParams p_kernarg) {
     static_assert(!B6 || (KT == 1 && FN == 0), "bf16 form: plain mode, one K tile per wave");
+    static_assert(!MP || (FN == 0 && !B6 && SHP == 0), "passes over so: plain fp32 form, run-time shapes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTH = 64 * NW, TPR = NTH / 32;
     constexpr bool FUSED = FN > 0;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                                          WgBwdShape<SHP>::HID, 1, 1, FN > 0, NW, B6);
 #define DM(f) (SHP ? CD.f : p.f)  // a shape value: immediate for the compile-time shapes
     int rows, KS, DSS, VS, US, HS, FS, DGS, EXS, EPS, si, vi, so, vo, H, nf, K, HF, NT, SG, exs;
-    int NKT, VG, split, LW, KW, NNT, EP, VOP, HFP, WSV, WSU, WTV, WTU, n_up, n_sm, sm_tiles, sm_up_tiles, sm_nu, sm_nd;
+    int NKT, VG, split, LW, KW, NNT, EP, VOP, HFP, WSV, WSU, WTV, WTU, n_up, n_sm, sm_tiles, sm_up_tiles, sm_nu, sm_nd, npass;
     float *X, *DS, *V, *DVO, *DVU, *VH, *DVHF, *FR, *DG, *RN, *SGN, *DEXT, *EPART, *ST, *extp;
     const float *WD, *WDT, *WU, *WUT;
 #define WG_RELOAD()                                                                                                        \
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         NT = DM(NT); SG = DM(SG); NKT = DM(NKT); VG = DM(VG); split = DM(split); LW = DM(LW); KW = DM(KW); NNT = DM(NNT);  \
         EP = DM(EP); VOP = DM(VOP); HFP = DM(HFP); WSV = DM(WSV); WSU = DM(WSU); WTV = DM(WTV); WTU = DM(WTU);             \
         n_up = DM(n_up); n_sm = DM(n_sm); sm_tiles = DM(sm_tiles); sm_up_tiles = DM(sm_up_tiles); sm_nu = DM(sm_nu);       \
-        sm_nd = DM(sm_nd);                                                                                                 \
+        sm_nd = DM(sm_nd); npass = DM(npass);                                                                              \
         X = lds + DM(o_x); DS = lds + DM(o_ds); V = lds + DM(o_v); DVO = lds + DM(o_dvo); DVU = lds + DM(o_dvu);           \
         VH = lds + DM(o_vh); DVHF = lds + DM(o_dvhf); FR = lds + DM(o_fr); DG = lds + DM(o_dg); RN = lds + DM(o_rn);       \
         SGN = lds + DM(o_sgn); DEXT = lds + DM(o_dext); EPART = lds + DM(o_epart);                                         \
@@ -473,9 +484,22 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 
         stamp(3);
         WG_LAUNDER();
+        // (MP: the W^T ds_pre accumulators of P4 live across the passes; otherwise they are declared here and first touched in P4)
+        f32x16 acc2[KT], acc3;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+        const int NP = MP ? npass : 1;
+        for (int hp = 0; hp < NP; ++hp) {
+        const int tpp = MP ? gcp_cdiv(gcp_cdiv(NT, NW), NP) : 4;  // output tiles per wave and pass
+        const int t_lo = MP ? hp * tpp : 0, ot_base = NW * t_lo;     // the pass covers the tiles [ot_base, ot_base + NW * tpp)
+        const int gb = 4 * ot_base, ge = MP ? min(SG, gb + 4 * NW * tpp) : SG;  // ... = these groups of eight columns of so
         // ---- P3: ds_pre = d(s_out) act_s'(s_pre) + act_v'(s_pre) (Wg^T dgate), this wave's tiles of so -> DS ---------------
         f32x16 spa;  // act_v(s_pre) of the wave's tile (fused: B operand of the gate weight gradient)
-        for (int t = 0; w + NW * t < NT; ++t) {
+        for (int t = t_lo; t < t_lo + tpp && w + NW * t < NT; ++t) {
             const int ot = w + NW * t;
             if (t > 0) {
 #pragma unroll
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 }
                 if constexpr (!B6) {
                     const f32x4 v = {dsp[4 * q], dsp[4 * q + 1], dsp[4 * q + 2], dsp[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * ot + 8 * q + 4 * hi) = v;
+                    *reinterpret_cast<f32x4*>(DS + e * DSS + 32 * (ot - ot_base) + 8 * q + 4 * hi) = v;
                 }
             }
             if constexpr (B6) {  // the tile's two K = 16 slabs: eight registers each, split here, once for every wave's P4
@@ -609,11 +633,6 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                         for (int q = 0; q < 4; ++q)
                             res[j][q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + min(32 * ktc[j] + 8 * q + 4 * hi, so - 4));
                 }
-                f32x16 acc2[KT];
-#pragma unroll
-                for (int j = 0; j < KT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
                 if constexpr (B6) {
                     const int NSL = 2 * NT;  // slabs of the reduction over so
                     const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)ktc[0] * NSL * 192 + lane;
@@ -647,8 +666,8 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 auto ld = [&](f32x4(&a)[U][KT], f32x4(&bb)[U], int g0) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const int g = min(g0 + u, SG - 1);
-                        bb[u] = *reinterpret_cast<const f32x4*>(db + 8 * g);
+                        const int g = min(g0 + u, ge - 1);
+                        bb[u] = *reinterpret_cast<const f32x4*>(db + 8 * (g - gb));
 #pragma unroll
                         for (int j = 0; j < KT; ++j) a[u][j] = *reinterpret_cast<const f32x4*>(pa + ((int64_t)ktc[j] * SG + g) * 256);
                     }
@@ -656,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 auto mm = [&](f32x4(&a)[U][KT], f32x4(&bb)[U], int g0) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        if (g0 + u < SG) {
+                        if (g0 + u < ge) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -665,8 +684,8 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                         }
                 };
                 f32x4 a0[U][KT], a1[U][KT], b0[U], b1[U];
-                ld(a0, b0, 0);
-                for (int g0 = 0; g0 < SG; g0 += 2 * U) {
+                ld(a0, b0, gb);
+                for (int g0 = gb; g0 < ge; g0 += 2 * U) {
                     ld(a1, b1, g0 + U);
                     __builtin_amdgcn_sched_barrier(0);
                     mm(a0, b0, g0);
@@ -675,6 +694,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     mm(a1, b1, g0 + U);
                 }
                 }
+                if (hp == NP - 1) {  // (the reduction over so is complete)
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     const int kt = w + NW * j;
@@ -700,14 +720,12 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                         }
                     }
                 }
+                }
             }
             WG_LAUNDER();
             if (split) {  // the last tile of K: every wave reduces over its share of so, partial sums -> EPART[w]
                 const int kt = NKT - 1;
-                const int gs = gcp_cdiv(SG, NW), g_lo = w * gs, g_hi = min(SG, g_lo + gs);
-                f32x16 acc3;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+                const int gs = gcp_cdiv(ge - gb, NW), g_lo = gb + w * gs, g_hi = min(ge, g_lo + gs);
                 const float* pa = p.pk + p.offA2 + ((int64_t)kt * SG * 64 + lane) * 4;
                 const float* db = DS + e * DSS + 4 * hi;
                 if constexpr (B6) {
@@ -725,9 +743,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     f32x4 a[4], bb[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int g = min(g0 + u, g_hi - 1);
+                        const int g = max(min(g0 + u, g_hi - 1), gb);  // (a wave whose share of the pass is empty reads, and skips, group gb)
                         a[u] = *reinterpret_cast<const f32x4*>(pa + (int64_t)g * 256);
-                        bb[u] = *reinterpret_cast<const f32x4*>(db + 8 * g);
+                        bb[u] = *reinterpret_cast<const f32x4*>(db + 8 * (g - gb));
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
@@ -737,6 +755,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                         }
                 }
                 gcp_wave_lds_sync();  // (ST shares this slot: its reads are done)
+                if (hp == NP - 1)
                 for (int q = 0; 8 * q < LW; ++q) {
                     f32x4 v;
 #pragma unroll
@@ -750,7 +769,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 }
             }
         }
-        wg_barrier();
+        wg_barrier();  // P4 is done with the ds_pre tile (last pass: its results are in place)
+        if (hp + 1 < NP) WG_LAUNDER();
+        }  // passes
 
         stamp(5);
         WG_LAUNDER();
@@ -1036,7 +1057,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
 
 int g_wg_cus = 0;
 
-template <int NW, int KT, int FN, int SHP = 0, bool B6 = false>
+template <int NW, int KT, int FN, int SHP = 0, bool B6 = false, bool MP = false>
 int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipStream_t st) {
     auto go = [&](auto kern) -> int {
         if (lds_bytes > 64 * 1024) {
@@ -1048,7 +1069,7 @@ int launch_bwd(const WgBwdParams& p, bool pwl, int grid, size_t lds_bytes, hipSt
         return 0;
     };
     if constexpr (SHP != 0) return go(gcp_wg_bwd_kernel<NW, KT, FN, true, SHP, B6>);  // (the compile-time shapes exist for PWL only)
-    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true, 0, B6>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false, 0, B6>);
+    return pwl ? go(gcp_wg_bwd_kernel<NW, KT, FN, true, 0, B6, MP>) : go(gcp_wg_bwd_kernel<NW, KT, FN, false, 0, B6, MP>);
 }
 
 // True if the launch's shape is exactly the compile-time shape SHP (every integer the kernel would otherwise read).
@@ -1185,6 +1206,8 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
         if (!pl.fused && NW == 8 && pl.kt == 1 && !b6 && wg_bwd_is_shape<2, 8, 0>(p, w, gated))
             return launch_bwd<8, 1, 0, 2>(p, pwl, grid, lds_bytes, st);
     }
+    if (D.npass > 1)
+        return NW == 4 ? launch_bwd<4, 1, 0, 0, false, true>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 0, 0, false, true>(p, pwl, grid, lds_bytes, st);
     if (b6) return NW == 4 ? launch_bwd<4, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 0, 0, true>(p, pwl, grid, lds_bytes, st);
     // (FN = 2, three workgroups per CU: measured in round 3 -- 429 us against 267 us per launch for the first message GCP of
     // configs[1], same step time; opt-in for experiments)

@@ -859,6 +859,13 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     if (p.nf && !frames) return GCPNET_E_BADARG;
     int NW, MT;
     wg_pick(so, NW, MT);
+    // A single non-residual block with few reduction columns on many rows -- the first message GCP of BASELINE configs[4] after
+    // project-then-gather: K = 58, so = 256, 10^6 rows -- is bound by the per-tile latencies of its gathers and barriers, not by its
+    // MFMAs: four waves with two output tiles each need half the staging LDS, so that two workgroups share a CU
+    // (GCPNET_WG_FWD_HEAD4=0 keeps the eight-wave form)
+    static const bool head4 = !(getenv("GCPNET_WG_FWD_HEAD4") && getenv("GCPNET_WG_FWD_HEAD4")[0] == '0');
+    const bool small_k = n == 1 && !blocks[0].residual && so > 128 && so <= 256 && vo <= 32 && w0.si + w0.hidden + 9 <= 96;
+    if (head4 && small_k) { NW = 4; MT = 2; }
     p.NT = gcp_cdiv(so, 32);
     p.NG = gcp_cdiv(p.NT, NW * MT);
     p.n = n;
@@ -932,7 +939,8 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
     if (g2) {
-        if (NW == 4) return launch_fwd<4, 1, 0, false, true>(p, pwl, lds_bytes, st);
+        if (NW == 4 && MT == 1) return launch_fwd<4, 1, 0, false, true>(p, pwl, lds_bytes, st);
+        if (NW == 4) return WG_UNSUPPORTED("two gate tiles in the four-wave / two-tile form");
         if (MT == 1) return launch_fwd<8, 1, 0, false, true>(p, pwl, lds_bytes, st);
         return launch_fwd<8, 2, 0, false, true>(p, pwl, lds_bytes, st);
     }
@@ -943,7 +951,7 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
         if (NW == 8 && MT == 1 && b6 && wg_fwd_is_shape<2, 8, 1, true>(p, lds_bytes)) return launch_fwd<8, 1, 2, true>(p, pwl, lds_bytes, st);
     }
     if (b6) return NW == 4 ? launch_fwd<4, 1, 0, true>(p, pwl, lds_bytes, st) : launch_fwd<8, 1, 0, true>(p, pwl, lds_bytes, st);
-    if (NW == 4) return launch_fwd<4, 1>(p, pwl, lds_bytes, st);
+    if (NW == 4) return MT == 1 ? launch_fwd<4, 1>(p, pwl, lds_bytes, st) : launch_fwd<4, 2>(p, pwl, lds_bytes, st);
     if (MT == 1) return launch_fwd<8, 1>(p, pwl, lds_bytes, st);
     return launch_fwd<8, 2>(p, pwl, lds_bytes, st);
 }
