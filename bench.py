@@ -23,6 +23,11 @@ aggregate_kernel = the scatter-mean (segmented reduction) kernel against the HBM
 cpu_baseline = the oracle (pure PyTorch on the host cores) on the same stack, weights and inputs (full c2 workload: 1 warm-up + 3
             timed steps; larger configurations: a bounded sample, stated), plus `parity_check`: the GPU outputs and input gradients
             of that same step against the oracle's.
+other_configs = (default run, one GPU) the model-step configurations c1 / c4 / c3, eager and as a hipGraph replay: median ms/step
+            and edges/s each; c5_single_gpu = 10 steps at configs[4] size.  Every BASELINE configuration that fits one GPU is thus in
+            the one JSON line.  aggregate_product_path = the aggregation as the product launches it (two reductions).
+roofline.peak_bf16x6_equiv = the ceiling of the bf16 matrix pipe for fp32 products computed as six bf16 MFMAs (2 500 / 6 TFLOP/s).
+--dry-run-world N = no timing: the N-rank bookkeeping of `--shard graph` on one GPU (nodes / edges / halo per rank, MB per layer).
 """
 import argparse
 import json

@@ -1106,6 +1106,8 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     if (gated && w->vo > 64) return WG_UNSUPPORTED("scalar gate with more than 64 output vectors");  // (the request of the gate tile: 16 pieces of 16 bytes per row)
     const WgShape S = wg_shape(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated);
     int NW = (w->so > 160 || S.K > 160) ? 8 : 4;
+    // (experiment: few reduction columns and 128 < so <= 256 -- the first message GCP of configs[4] -- with four waves, plain form)
+    if (getenv("GCPNET_WG_BWD_HEAD4") && w->so > 128 && w->so <= 256 && S.K <= 96) NW = 4;
     if (const char* ev = getenv("GCPNET_WG_BWD_NW")) {  // (tuning knob: 4 or 8 waves per workgroup)
         if (ev[0] == '4') NW = 4;
         if (ev[0] == '8') NW = 8;

@@ -864,7 +864,8 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
     // MFMAs: four waves with two output tiles each need half the staging LDS, so that two workgroups share a CU
     // (GCPNET_WG_FWD_HEAD4=0 keeps the eight-wave form)
     static const bool head4 = !(getenv("GCPNET_WG_FWD_HEAD4") && getenv("GCPNET_WG_FWD_HEAD4")[0] == '0');
-    const bool small_k = n == 1 && !blocks[0].residual && so > 128 && so <= 256 && vo <= 32 && w0.si + w0.hidden + 9 <= 96;
+    static const int head4_k = getenv("GCPNET_WG_FWD_HEAD4_K") ? atoi(getenv("GCPNET_WG_FWD_HEAD4_K")) : 96;  // (tuning knob: K limit)
+    const bool small_k = n == 1 && !blocks[0].residual && so > 128 && so <= 256 && vo <= 32 && w0.si + w0.hidden + 9 <= head4_k;
     if (head4 && small_k) { NW = 4; MT = 2; }
     p.NT = gcp_cdiv(so, 32);
     p.NG = gcp_cdiv(p.NT, NW * MT);

@@ -283,9 +283,10 @@ def test_layer_full_c5_graph_on_a_subproblem(G):
 
 
 def test_lba_step_realistic_pocket_size(G):
-    """configs[2] at the size SURVEY.md section 8 names for it: 16 pocket-sized radius graphs of 400 - 600 atoms (r = 4.5, <= 32
-    neighbours: ~7 000 nodes / ~200 000 edges), the shipped LBA model ((100,16) x 8 layers + readout), step() fwd + bwd, featurised
-    and collated by the GPU input side (lba_featurize + collate)."""
+    """configs[2] at the pocket size SURVEY.md section 8 names for it: radius graphs of 400 - 600 atoms (r = 4.5, <= 32 neighbours),
+    the shipped LBA model ((100,16) x 8 layers + readout), step() fwd + bwd, featurised and collated by the GPU input side
+    (lba_featurize + collate).  Six graphs (~3 000 nodes / ~80 000 edges) instead of the batch of 16: the float64 oracle of the
+    16-graph batch alone takes 3.5 minutes of the suite; bench.py's c3 block runs the full batch of 16."""
     from gcpnet_amd.synthetic import radius_graph
 
     torch.manual_seed(51)
@@ -294,14 +295,14 @@ def test_lba_step_realistic_pocket_size(G):
     model = G.GCPNetLBA(model_cfg=model_cfg, module_cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg()).cuda().eval()
     g = torch.Generator().manual_seed(52)
     graphs = []
-    for i in range(16):
-        n = 400 + 13 * i  # 400 .. 595 atoms
+    for i in range(6):
+        n = 400 + 39 * i  # 400 .. 595 atoms
         x, _ = radius_graph(n, 32, seed=60 + i, expected_in_radius=40.0)
         d = G.lba_featurize(x.cuda(), torch.randint(0, 9, (n,), generator=g), n_ligand=30)
         d["label"] = torch.randn((), generator=g).cuda()
         graphs.append(d)
     b = {k: v.cpu() for k, v in G.collate(graphs).items()}
     n, e = b["x"].shape[0], b["edge_index"].shape[1]
-    assert 6500 < n < 9000 and e > 150000, (n, e)
+    assert 2800 < n < 3200 and e > 60000, (n, e)
     fwd = lambda P, i: O.lba_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(), 8)
     _step_case(G, model, fwd, {k: b[k] for k in ("h", "chi", "e", "xi", "x", "edge_index", "batch", "label")}, ("chi", "e", "xi"), "pred")
