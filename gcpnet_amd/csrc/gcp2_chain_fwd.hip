@@ -126,35 +126,50 @@ __device__ __forceinline__ const HeadParams& head_of(const ChainParams& p) { ret
 // F6: scalar_out over the state and the gate Linear on the bf16 matrix pipe, both operands as three bf16 terms, six products
 // (gcp_bf16x3.h: exact to fp32 round-off); plain instantiations only.
 template <int NT, bool PWL, bool HEAD, bool ONLY = false, int HC = 0, bool F6 = false>
-__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename ChainArg<HEAD>::type p) {
+__global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename ChainArg<HEAD>::type p_kernarg) {
     static_assert(!(HEAD && HC), "the head block has its own shape");
+    // The parameters are read through the kernarg segment pointer, laundered at the top of every block (as in gcp2_chain_bwd.hip):
+    // the uniform values are re-loaded (s_load) per block instead of staying live in SGPRs across the whole chain loop, where
+    // they did not fit -- 169 SGPRs spilled into VGPR lanes, 947 v_readlane_b32 among the 4 461 VALU instructions of a block.
+    typedef typename ChainArg<HEAD>::type ParamT;
+    typedef const __attribute__((address_space(4))) ParamT* Karg;
+    Karg kp = (Karg)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*(const ParamT*)kp)
     static_assert(!(HEAD && F6), "the bf16 forms exist for the chain blocks");
     constexpr int NXR = HC ? 4 * ((HC + 3 + 7) / 8) : 16;  // registers that can hold a [vh | vf] channel
     constexpr int NVR = HC ? 8 : 16;  // registers that can hold an output vector channel (the HC instantiations: vo <= 16)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const GcpShape& S = p.sh;
-    const HeadParams& HD = head_of(p);
-    const ChainLds L = chain_lds(S, HEAD ? &HD.sh : nullptr);
+#define HD (head_of(p))
+    GcpShape S;
+    ChainLds L;
     int lane = threadIdx.x;
     int e = lane & 31, hi = lane >> 5;
     const int r0 = blockIdx.x * GCP_TILE_ROWS;
-    const int rows = p.rows;
-    int row = r0 + e;
-    bool row_ok = row < rows;
-    float* vt = lds + L.o_vt;
-    float* fr = lds + L.o_fr;
-    float* ext = lds + L.o_ext;
-    float* ust = lds + L.o_ust;
-    float* stage = lds + L.o_stage;
-    const int vi = S.vi, so = S.so, vo = S.vo, H = HC ? HC : S.H;
-    const int NX = gcp_round_up(H + S.nf, 2) / 2;  // k-pair steps over the norms / frame scalars
-    const float slope = p.o.slope;
-    const bool scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;
-    const bool vec_so = (so & 3) == 0;
+    int rows, row;
+    bool row_ok;
+    float *vt, *fr, *ext, *ust, *stage;
+    int vi, so, vo, H, NX;
+    float slope;
+    bool scalar_gate, vec_so;
+#define CF_RELOAD()                                                                                               \
+    do {                                                                                                          \
+        S = p.sh;                                                                                                 \
+        L = chain_lds(S, HEAD ? &HD.sh : nullptr);                                                                \
+        rows = p.rows;                                                                                            \
+        row = r0 + e;                                                                                             \
+        row_ok = row < rows;                                                                                      \
+        vt = lds + L.o_vt; fr = lds + L.o_fr; ext = lds + L.o_ext; ust = lds + L.o_ust; stage = lds + L.o_stage;  \
+        vi = S.vi; so = S.so; vo = S.vo; H = HC ? HC : S.H;                                                       \
+        NX = gcp_round_up(H + S.nf, 2) / 2; /* k-pair steps over the norms / frame scalars */                     \
+        slope = p.o.slope;                                                                                        \
+        scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;                                                         \
+        vec_so = (so & 3) == 0;                                                                                   \
+    } while (0)
+    CF_RELOAD();
     // ---- the tile: vectors + frames into LDS, scalars straight into the accumulator layout ---------------------------
     f32x16 xs[NT];
     float* et = stage;  // HEAD: the head's scalar inputs [32][ES] (consumed before the first row-wise store needs the tile)
-    const int ES = HEAD ? gcp_odd(HD.sh.si) : 1;
+    int ES = HEAD ? gcp_odd(HD.sh.si) : 1;
     if constexpr (HEAD) {
         GcpSegBuf<8> vb0, eb0;
         gcp_seg_issue(vb0, HD.xi_in, nullptr, 3 * HD.sh.vi, r0, rows, vt, L.VS, 0, lane);
@@ -173,9 +188,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 
     const int n_blocks = ONLY ? 0 : p.n;
     for (int ci = HEAD ? -1 : 0; ci < n_blocks; ++ci) {
-        asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi));  // keep per-lane addresses from being hoisted and spilled
-        row = r0 + e;
-        row_ok = row < rows;
+        asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi), "+s"(kp));  // keep per-lane addresses AND the uniform parameters from being hoisted and spilled
+        CF_RELOAD();
+        et = stage;
+        ES = HEAD ? gcp_odd(HD.sh.si) : 1;
         const bool head = HEAD && (ONLY || ci < 0);  // (compile-time false in the plain instantiations, true with ONLY)
         const ChainItemF& it = head ? HD.it : p.it[ci];
         const GcpShape& B = head ? HD.sh : S;  // the block's own shape: dims, step counts, section offsets of its pack
@@ -528,6 +544,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #endif
     }
 }
+#undef p
+#undef HD
+#undef CF_RELOAD
 
 template <int NT, bool PWL, bool HEAD = false, bool ONLY = false>
 int launch_chain(const typename ChainArg<HEAD>::type& p, size_t lds_bytes, hipStream_t st) {
