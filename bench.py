@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--shard", choices=["batch", "graph"], default="batch",
                     help="N > 1: 'batch' = one graph per rank (weak scaling); 'graph' = one graph split by node ranges (strong scaling)")
+    ap.add_argument("--halo", action="store_true",
+                    help="--shard graph: renumber the nodes along a Morton curve and exchange only the halo rows (all-to-all) instead of "
+                         "all-gathering the whole feature table")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--neighbors", type=int, default=None)
@@ -284,14 +287,25 @@ def dry_run_world(args, G, ops):
     width = args.sdim + 3 * args.vdim
     layer = G.GCPInteractions((args.sdim, args.vdim), (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0)
     n_params = sum(p.numel() for p in layer.parameters())
+    # the same graph with its nodes renumbered along a Morton curve (gcpnet_amd.parallel.spatial_order): what a halo exchange would
+    # have to move if the ids were spatially sorted, as they are for real structures
+    from gcpnet_amd.parallel import spatial_order
+    perm = spatial_order(host["x"].cuda())
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=perm.device)
+    ei_sorted = inv[ei]
+    ei_sorted = ei_sorted[:, torch.argsort(ei_sorted[1], stable=True)]
     ranks = []
     for r in range(n):
         sg = ShardedGraph(ei, args.nodes, r, n)
         halo = sg.halo_nodes()
+        halo_sorted = ShardedGraph(ei_sorted, args.nodes, r, n).halo_nodes()
         ranks.append({"rank": r, "nodes": sg.n_local, "in_edges": sg.e1 - sg.e0, "out_edges": int(sg.out_row_local.shape[0]),
                       "halo_nodes": int(halo.numel()),
                       "allgather_recv_MB_per_layer": (args.nodes - sg.n_local) * width * 4 / 1e6,
                       "halo_recv_MB_per_layer": int(halo.numel()) * width * 4 / 1e6,
+                      "halo_nodes_morton_sorted": int(halo_sorted.numel()),
+                      "halo_recv_MB_per_layer_morton_sorted": int(halo_sorted.numel()) * width * 4 / 1e6,
                       "send_MB_per_layer_full_table": sg.n_local * width * 4 * (n - 1) / 1e6})
     edges = [x["in_edges"] for x in ranks]
     out = {"dry_run_world": n, "config": args.config, "n_nodes": args.nodes, "n_edges": int(ei.shape[1]), "row_bytes": width * 4,
@@ -311,6 +325,11 @@ def build_layer_workload(args, rank, world, G, ops):
     node_dims, edge_dims = (args.sdim, args.vdim), (32, 4)
     sharded = world > 1 and args.shard == "graph"
     host = make_inputs(args.nodes, args.neighbors, node_dims, edge_dims, seed=0 if sharded else rank)
+    if sharded and args.halo:
+        from gcpnet_amd.parallel import spatial_order
+        from gcpnet_amd.synthetic import reorder_nodes
+
+        host = reorder_nodes(host, spatial_order(host["x"]))
     n_edges_global = host["edge_index"].shape[1]
     torch.manual_seed(0)  # identical replicated weights on every rank
     cfg, lcfg = G.default_module_cfg(), G.default_layer_cfg()
@@ -323,7 +342,7 @@ def build_layer_workload(args, rank, world, G, ops):
     lw = dict(h=torch.randn(args.nodes, node_dims[0], generator=g),  # final GCPLayerNorm has a vanishing gradient)
               chi=torch.randn(args.nodes, node_dims[1], 3, generator=g))
     if sharded:
-        sg = ShardedGraph(host["edge_index"], args.nodes, rank, world)
+        sg = ShardedGraph(host["edge_index"], args.nodes, rank, world, halo=args.halo)
         x = host["x"].cuda()
         sg.to("cuda")
         frames = G.localize(x, sg.edge_index_global)
@@ -503,8 +522,10 @@ def main():
                 "workload": f"{args.config}: {wl['label']}", "n_edges": wl["n_edges"], "layers": wl["n_layers"],
                 "launch": "hipGraph replay of the captured step" if args.hip_graph else "eager launches",
                 "parallelism": ("single GPU" if world == 1 else
-                                (f"one graph split by target-node ranges over {world} GPUs: per layer all-gather of node features / "
-                                 f"reduce-scatter of their gradients + all-reduce (sum) of weight grads, RCCL" if wl["sharded"] else
+                                (f"one graph split by target-node ranges over {world} GPUs: per layer "
+                                 + ("all-to-all of the halo rows (Morton-ordered nodes) forward and backward" if args.halo else
+                                    "all-gather of node features / reduce-scatter of their gradients")
+                                 + " + all-reduce (sum) of weight grads, RCCL" if wl["sharded"] else
                                  f"one graph (batch) per GPU x{world}, RCCL all-reduce (mean) of weight grads")),
             },
         }

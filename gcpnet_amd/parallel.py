@@ -121,8 +121,11 @@ class ShardedGraph:
 
     This class is index bookkeeping + collectives only (device-agnostic; the CPU tests drive it with the oracle)."""
 
-    def __init__(self, edge_index: torch.Tensor, n_nodes: int, rank: int, world: int, group=None):
-        self.rank, self.world, self.group, self.n_nodes = rank, world, group, int(n_nodes)
+    def __init__(self, edge_index: torch.Tensor, n_nodes: int, rank: int, world: int, group=None, halo: bool = False):
+        """`halo`: exchange only the rows a rank's in-edges actually reference (all-to-all of per-peer row lists built here, once,
+        from the replicated edge list -- no set-up communication) instead of all-gathering the whole table; pays when the node ids
+        are spatially sorted (`spatial_order`), where the halo is a surface term."""
+        self.rank, self.world, self.group, self.n_nodes, self.halo = rank, world, group, int(n_nodes), bool(halo)
         row, col = edge_index[0].long(), edge_index[1].long()
         n_edges = int(col.shape[0])
         if n_edges > 1 and not bool((col[1:] >= col[:-1]).all()):
@@ -153,6 +156,32 @@ class ShardedGraph:
         self.col_local = col[self.e0:self.e1] - self.n0
         self.table_rows = world * self.max_nodes
         self.table_slice = slice(rank * self.max_nodes, rank * self.max_nodes + (self.n1 - self.n0))
+        if self.halo:
+            # table = [own rows | halo rows]; the halo = the remote source nodes of the local in-edges, ascending by global id,
+            # which is also grouped by owner (owners hold contiguous id ranges).  Rank q's send list for rank r is
+            # halo(r) restricted to q's range -- every rank derives all of them from the replicated, col-sorted edge list.
+            src_owner = torch.bucketize(row, bnd[1:-1], right=True)   # owner of every edge's SOURCE node
+            dst_owner = torch.bucketize(col, bnd[1:-1], right=True)   # ... of its TARGET node = the rank that holds the edge
+            cross = src_owner != dst_owner
+            pair = dst_owner[cross] * self.n_nodes + row[cross]       # (consumer rank, source node), de-duplicated and sorted
+            pair = torch.unique(pair)
+            cons, gid = pair // self.n_nodes, pair % self.n_nodes
+            prod = torch.bucketize(gid, bnd[1:-1], right=True)        # the rank that owns (and sends) the row
+            mine = cons == rank
+            self.halo_ids = gid[mine]                                  # what this rank receives, in table order
+            self.recv_counts = torch.bincount(prod[mine], minlength=world).tolist()
+            send = prod == rank
+            send_cons, send_gid = cons[send], gid[send]                # sorted by consumer, then id: the all-to-all's send order
+            self.send_index = send_gid - self.n0                       # local row of every piece this rank sends
+            self.send_counts = torch.bincount(send_cons, minlength=world).tolist()
+            n_loc = self.n1 - self.n0
+            loc = self.edge_index_global[0]
+            remote = (loc < self.n0) | (loc >= self.n1)
+            pos = torch.searchsorted(self.halo_ids, loc.clamp(min=0))
+            src_t = torch.where(remote, n_loc + pos, loc - self.n0)
+            self.edge_index = torch.stack((src_t, self.col_local))
+            self.table_rows = n_loc + int(self.halo_ids.numel())
+            self.table_slice = slice(0, n_loc)
         # out-edges of the local nodes (row in range), for the node-level mean frames: [2, E_out] with LOCAL row ids
         out_mask = (row >= self.n0) & (row < self.n1)
         self.out_edge_index_global = torch.stack((row[out_mask], col[out_mask]))
@@ -160,8 +189,9 @@ class ShardedGraph:
 
     def to(self, device) -> "ShardedGraph":
         """Moves the index tensors (they are built where `edge_index` lives) to `device`."""
-        for name in ("edge_index", "edge_index_global", "col_local", "out_edge_index_global", "out_row_local", "edge_perm"):
-            t = getattr(self, name)
+        for name in ("edge_index", "edge_index_global", "col_local", "out_edge_index_global", "out_row_local", "edge_perm", "halo_ids",
+                     "send_index"):
+            t = getattr(self, name, None)
             if t is not None:
                 setattr(self, name, t.to(device))
         return self
@@ -196,6 +226,8 @@ class ShardedGraph:
         never referenced: `edge_index` holds table ids).  ONE copy of the local rows into their slot of the output buffer and an
         in-place all-gather; no concatenation afterwards."""
         D = local.shape[1]
+        if self.halo:
+            return self._halo_forward(local)
         buf = local.new_empty((self.table_rows, D))
         own = buf[self.rank * self.max_nodes: (self.rank + 1) * self.max_nodes]
         own[: self.n_local].copy_(local)
@@ -213,6 +245,8 @@ class ShardedGraph:
     def _scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
         """Sum over ranks of the table-shaped gradient `full` [world * max_nodes, D]; this rank's rows returned.  The table layout
         is the reduce-scatter's input layout: no re-packing."""
+        if self.halo:
+            return self._halo_backward(full)
         if not self._collectives():
             return full[self.table_slice].contiguous()
         D = full.shape[1]
@@ -224,10 +258,61 @@ class ShardedGraph:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
         return total[self.table_slice].contiguous()
 
+    # ---- halo exchange: only the rows the peers' in-edges reference ---------------------------------------------------------
+    def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, recv_counts, send_counts) -> None:
+        """recv rows grouped by source rank <- send rows grouped by destination rank.  RCCL: one all_to_all_single; gloo (CPU
+        tests; it has no all-to-all): one isend / irecv pair per peer."""
+        if not self._collectives():
+            return
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
+            return
+        ops_, so, ro = [], 0, 0
+        for k in range(self.world):
+            if send_counts[k]:
+                ops_.append(dist.P2POp(dist.isend, send[so:so + send_counts[k]].contiguous(), k, group=self.group))
+            if recv_counts[k]:
+                ops_.append(dist.P2POp(dist.irecv, recv[ro:ro + recv_counts[k]], k, group=self.group))
+            so, ro = so + send_counts[k], ro + recv_counts[k]
+        if ops_:
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
+
+    def _halo_forward(self, local: torch.Tensor) -> torch.Tensor:
+        n_loc, D = self.n_local, local.shape[1]
+        table = local.new_empty((self.table_rows, D))
+        table[:n_loc].copy_(local)
+        send = local.index_select(0, self.send_index)  # rows grouped by consumer rank
+        self._all_to_all(table[n_loc:], send, self.recv_counts, self.send_counts)
+        return table
+
+    def _halo_backward(self, g_table: torch.Tensor) -> torch.Tensor:
+        """The gradient rows of the halo go back to their owners, which add them to their own rows' gradients."""
+        n_loc = self.n_local
+        g_local = g_table[:n_loc].clone()
+        back = g_table.new_zeros((int(self.send_index.numel()), g_table.shape[1]))
+        self._all_to_all(back, g_table[n_loc:].contiguous(), self.send_counts, self.recv_counts)
+        if back.shape[0]:
+            g_local.index_add_(0, self.send_index, back)
+        return g_local
+
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
         """[n_local, D] -> the table [world * max_nodes, D] over all ranks (rows by TABLE id: `edge_index`, `table_slice`);
         backward = reduce-scatter (sum) of the gradient rows to their owners."""
         return _AllGatherRows.apply(local, self)
+
+
+def spatial_order(x: torch.Tensor, cell: float = 4.5) -> torch.Tensor:
+    """Permutation that sorts nodes along a Morton (Z-order) curve over cells of edge `cell` (the radius-graph cutoff): nodes that
+    are close in space get close ids, so that a contiguous node range is a compact region and the SOURCE nodes of its in-edges that
+    live on other ranks (the halo) are a surface term instead of "almost everybody" (`bench.py --dry-run-world` prints both).
+    Data preparation, like the CSR sort: new_id[perm[k]] = k; apply with `x[perm]`, `h[perm]`, `inv[edge_index]`."""
+    c = torch.floor((x - x.min(dim=0).values) / float(cell)).long().clamp_(min=0, max=(1 << 20) - 1)
+    code = torch.zeros(x.shape[0], dtype=torch.long, device=x.device)
+    for b in range(20):
+        for d in range(3):
+            code |= ((c[:, d] >> b) & 1) << (3 * b + d)
+    return torch.argsort(code, stable=True)
 
 
 class _AllGatherRows(torch.autograd.Function):

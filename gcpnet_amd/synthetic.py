@@ -113,3 +113,26 @@ def model_batch(config: str, seed: int = 0):
                  f"GPU, (100,16) hidden, 8 GCPInteractions layers + invariant projection + graph-mean readout + dense head, MSE loss")
         return b, cfg, "lba", label
     raise ValueError(config)
+
+
+def reorder_nodes(inputs: Dict[str, torch.Tensor], perm: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """The same graph with node k renamed to the position of k in `perm` (new node j = old node perm[j]): per-node tensors are
+    permuted, edge_index relabelled and re-sorted by target (per-edge tensors follow).  Used with parallel.spatial_order to give
+    the synthetic graphs the id locality real structures have."""
+    perm = perm.to(inputs["edge_index"].device)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=perm.device)
+    ei = inv[inputs["edge_index"]]
+    order = torch.argsort(ei[1], stable=True)
+    n, e = perm.numel(), ei.shape[1]
+    out = {}
+    for k, v in inputs.items():
+        if k == "edge_index":
+            out[k] = ei[:, order]
+        elif torch.is_tensor(v) and v.shape[:1] == (n,) and k not in ("e", "xi"):
+            out[k] = v[perm]
+        elif torch.is_tensor(v) and v.shape[:1] == (e,):
+            out[k] = v[order]
+        else:
+            out[k] = v
+    return out

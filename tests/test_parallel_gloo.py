@@ -144,12 +144,16 @@ def _oracle_sharded_layer(O, P, pre, h, chi, e_loc, xi_loc, sg, frames_loc, out_
     return O.gcp_layer_norm(P, pre + "gcp_norm.1.", h + fs, chi + fv)
 
 
-def _sharded_job(rank, world):
+def _sharded_job_halo(rank, world):
+    return _sharded_job(rank, world, halo=True)
+
+
+def _sharded_job(rank, world, halo=False):
     from oracle import gcp_oracle as O
 
     P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
     P = {k: v.clone().requires_grad_() for k, v in P.items()}
-    sg = ShardedGraph(ei, n, rank, world)
+    sg = ShardedGraph(ei, n, rank, world, halo=halo)
     frames_loc = O.localize(x, sg.edge_index_global)  # (positions are replicated, by global id)
     out_frames = O.localize(x, sg.out_edge_index_global)
     out_ei_local = torch.stack((sg.out_row_local, sg.out_edge_index_global[1]))
@@ -172,7 +176,9 @@ def _sharded_job(rank, world):
                 w={k: v.grad.clone() for k, v in P.items()})
 
 
-def test_sharded_graph_matches_unsharded():
+@pytest.mark.parametrize("halo", [False, True])
+def test_sharded_graph_matches_unsharded(halo):
+    """halo=False: all-gather of the whole feature table; halo=True: all-to-all of the rows the peers' in-edges reference."""
     from oracle import gcp_oracle as O
 
     P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
@@ -183,7 +189,7 @@ def test_sharded_graph_matches_unsharded():
     for i in range(2):
         hh, cc = O.gcp_interactions(P, f"{i}.", hh, cc, ci["e"], ci["xi"], ei, fr, cfg, lcfg)
     ((hh * lw["h"]).sum() + (cc * lw["chi"]).sum()).backward()
-    out = _run(_sharded_job)
+    out = _run(_sharded_job_halo if halo else _sharded_job)
     assert out[0]["n0"] == 0 and out[0]["n1"] == out[1]["n0"] and out[1]["n1"] == n
     assert sum(out[0]["edges"]) == ei.shape[1] and abs(out[0]["edges"][0] - out[0]["edges"][1]) <= 40  # equal-edge cut
     perm = out[0]["perm"]

@@ -27,7 +27,11 @@ def _case():
     return layers, ei, x, ins, lw, n
 
 
-def _sharded_gpu_job(rank, world):
+def _sharded_gpu_job_halo(rank, world):
+    return _sharded_gpu_job(rank, world, halo=True)
+
+
+def _sharded_gpu_job(rank, world, halo=False):
     import gcpnet_amd as G
     from gcpnet_amd import ops
     from gcpnet_amd.parallel import GradAllReducer, ShardedGraph, sharded_interactions_forward
@@ -35,7 +39,7 @@ def _sharded_gpu_job(rank, world):
     torch.cuda.set_device(0)
     layers, ei, x, ins, lw, n = _case()
     layers = layers.cuda().eval()
-    sg = ShardedGraph(ei, n, rank, world)
+    sg = ShardedGraph(ei, n, rank, world, halo=halo)
     xg = x.cuda()
     sg.to("cuda")
     frames = G.localize(xg, sg.edge_index_global)
@@ -58,7 +62,8 @@ def _sharded_gpu_job(rank, world):
                 d={k: v.grad.cpu() for k, v in loc.items()}, w={k: p.grad.cpu() for k, p in layers.named_parameters()})
 
 
-def test_sharded_gpu_forward_backward_matches_unsharded():
+@pytest.mark.parametrize("halo", [False, True])
+def test_sharded_gpu_forward_backward_matches_unsharded(halo):
     layers, ei, x, ins, lw, n = _case()
     layers = layers.cuda().eval()
     import gcpnet_amd as G
@@ -71,7 +76,7 @@ def test_sharded_gpu_forward_backward_matches_unsharded():
     ((h * lw["h"].cuda()).sum() + (chi * lw["chi"].cuda()).sum()).backward()
     ref = dict(h=h.detach().cpu(), chi=chi.detach().cpu(), d={k: v.grad.cpu() for k, v in gi.items()},
                w={k: p.grad.cpu() for k, p in layers.named_parameters()})
-    out = _run(_sharded_gpu_job)
+    out = _run(_sharded_gpu_job_halo if halo else _sharded_gpu_job)
     perm = out[0]["perm"]
 
     def ok(a, b, name):
@@ -117,7 +122,7 @@ def _sharded_force_job(rank, world):
     torch.cuda.set_device(0)
     layers, ei, x, ins, lw, n = _force_case()
     layers = layers.cuda().eval()
-    sg = ShardedGraph(ei, n, rank, world).to("cuda")
+    sg = ShardedGraph(ei, n, rank, world, halo=True).to("cuda")  # (the halo exchange: also under the force term's second gather)
     xg = x.cuda()
     frames = G.localize(xg, sg.edge_index_global)  # frames are constants of the step, built from the INPUT positions
     fr_out = G.localize(xg, sg.out_edge_index_global)
