@@ -260,30 +260,18 @@ class ShardedGraph:
 
     # ---- halo exchange: only the rows the peers' in-edges reference ---------------------------------------------------------
     def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, recv_counts, send_counts) -> None:
-        """recv rows grouped by source rank <- send rows grouped by destination rank.  RCCL: one all_to_all_single; gloo (CPU
-        tests; it has no all-to-all): one isend / irecv pair per peer."""
+        """recv rows grouped by source rank <- send rows grouped by destination rank: one all_to_all_single (RCCL; gloo in the
+        CPU tests implements it too)."""
         if not self._collectives():
             return
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
-            return
-        ops_, so, ro = [], 0, 0
-        for k in range(self.world):
-            if send_counts[k]:
-                ops_.append(dist.P2POp(dist.isend, send[so:so + send_counts[k]].contiguous(), k, group=self.group))
-            if recv_counts[k]:
-                ops_.append(dist.P2POp(dist.irecv, recv[ro:ro + recv_counts[k]], k, group=self.group))
-            so, ro = so + send_counts[k], ro + recv_counts[k]
-        if ops_:
-            for req in dist.batch_isend_irecv(ops_):
-                req.wait()
+        dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
 
     def _halo_forward(self, local: torch.Tensor) -> torch.Tensor:
         n_loc, D = self.n_local, local.shape[1]
         table = local.new_empty((self.table_rows, D))
         table[:n_loc].copy_(local)
         send = local.index_select(0, self.send_index)  # rows grouped by consumer rank
-        self._all_to_all(table[n_loc:], send, self.recv_counts, self.send_counts)
+        self._all_to_all(table[n_loc:], send, self.recv_counts, self.send_counts)  # (a row slice of the table: contiguous)
         return table
 
     def _halo_backward(self, g_table: torch.Tensor) -> torch.Tensor:
