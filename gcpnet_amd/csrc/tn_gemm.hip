@@ -17,8 +17,22 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gcp_bf16x3.h"
 
 namespace {
+
+// -DGCP_TN_TIMING: every wave sums s_memtime deltas of the four phases of its chunk loop (0 = wait + barrier, 1 = DMA issue + index
+// requests, 2 = products, 3 = rest) and writes them OVER its split's partial sums (element 4 wave + phase of row 0): after the
+// reduction out[0][4 w + k] is the sum over the splits, tools/tn_phase_timing.py prints it.  A measurement build, never shipped.
+#ifdef GCP_TN_TIMING
+#define TN_T_DECL unsigned long long tn_t_[4] = {0, 0, 0, 0}, tn_t0_ = __builtin_amdgcn_s_memtime()
+#define TN_T_MARK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tn_t_[k] += t_ - tn_t0_; tn_t0_ = t_; } while (0)
+#define TN_T_STORE(part, wave, lane) do { if ((lane) == 0) for (int k_ = 0; k_ < 4; ++k_) (part)[4 * (wave) + k_] = (float)tn_t_[k_]; } while (0)
+#else
+#define TN_T_DECL
+#define TN_T_MARK(k)
+#define TN_T_STORE(part, wave, lane)
+#endif
 
 constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32;
 // Rows per split: about one split per CU for the big (edge-row) problems -- with one or two output blocks that is one
@@ -35,7 +49,7 @@ __host__ __device__ inline int tn_rows_per_split(int rows, int splits) {
     return gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, splits > 0 ? splits : 1), TN_RK);
 }
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
-constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread
+constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread (4 waves)
 constexpr int TN_DMA_LDS_FLOATS = 2 * TN_RK * (TN_BM + TN_BN);
 
 struct TnArgs {
@@ -44,6 +58,8 @@ struct TnArgs {
     int M[GCP_TN_MAX_PROBLEMS], N[GCP_TN_MAX_PROBLEMS];
     int mb[GCP_TN_MAX_PROBLEMS], nb[GCP_TN_MAX_PROBLEMS];
     int block_start[GCP_TN_MAX_PROBLEMS + 1];
+    int debug;   // measurement knob GCPNET_TN_DEBUG: bit 0 = no products, bit 1 = no DMA after the first chunk (results are then wrong)
+    int cyclic;  // 32-row chunks dealt round-robin to the splits (chunk c of split s = chunk s + c * splits of the operand)
 };
 
 __host__ __device__ inline int operand_width(const gcp_operand_t& o) {
@@ -53,8 +69,24 @@ __host__ __device__ inline int operand_width(const gcp_operand_t& o) {
 }
 
 struct BlockWork {
-    int pi, split, m0, n0, mw, nw, ntiles, r_begin, r_end;
+    int pi, split, m0, n0, mw, nw, ntiles;
+    int r_first, r_step, r_end, nchunks;  // chunk c covers rows r_first + c * r_step .. + 31, cut at r_end
 };
+
+// Rows of a split.  Blocked: one contiguous range per split.  Cyclic (the default): 32-row chunks dealt round-robin, so that the
+// workgroups of a launch, which advance in lockstep, read ONE contiguous window of the operands at any time (splits x 32 rows:
+// every HBM channel busy) instead of `splits` windows a fixed stride apart (which camp on a few channels).
+__device__ __forceinline__ void split_rows(int rows, int splits, int split, bool cyclic, int& r_first, int& r_step, int& r_end, int& nchunks) {
+    if (cyclic) {
+        const int total = gcp_cdiv(rows, TN_RK);
+        r_first = split * TN_RK; r_step = splits * TN_RK; r_end = rows;
+        nchunks = total > split ? gcp_cdiv(total - split, splits) : 0;
+    } else {
+        const int rps = tn_rows_per_split(rows, splits);
+        r_first = split * rps; r_step = TN_RK; r_end = min(rows, r_first + rps);
+        nchunks = r_end > r_first ? gcp_cdiv(r_end - r_first, TN_RK) : 0;
+    }
+}
 
 __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
     BlockWork w;
@@ -69,9 +101,7 @@ __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
     w.mw = min(TN_BM, a.M[pi] - w.m0);
     w.nw = min(TN_BN, a.N[pi] - w.n0);
     w.ntiles = gcp_cdiv(w.nw, 32);
-    const int rps = tn_rows_per_split(P.rows, P.splits);
-    w.r_begin = w.split * rps;
-    w.r_end = min(P.rows, w.r_begin + rps);
+    split_rows(P.rows, P.splits, w.split, a.cyclic != 0, w.r_first, w.r_step, w.r_end, w.nchunks);
     return w;
 }
 
@@ -147,7 +177,8 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
     for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int r0 = w.r_begin; r0 < w.r_end; r0 += TN_RK) {
+    for (int c = 0; c < w.nchunks; ++c) {
+        const int r0 = w.r_first + c * w.r_step;
         stage_operand(P.a, w.m0, gcp_round_up(w.mw, 32), r0, w.r_end, As, TN_LDA, wave, lane);
         stage_operand(P.b, w.n0, w.ntiles * 32, r0, w.r_end, Bs, TN_LDB, wave, lane);
         __syncthreads();
@@ -175,16 +206,17 @@ struct Slot {
     bool on;             // piece belongs to a real column group of the operand
 };
 
-template <int NSLOT, int LD>
+template <int NSLOT, int LD, int NTH = 256>
 __device__ __forceinline__ void make_slots(const gcp_operand_t& op, int c0, Slot* s, int tid) {
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-        const int f = tid + 256 * k;
-        const int row = f / (LD / 4), c = c0 + 4 * (f % (LD / 4));
+        const int f = tid + NTH * k;
+        const bool piece = f < TN_RK * LD / 4;  // (a thread count that does not divide the pieces: the slots past the end stay off)
+        const int row = piece ? f / (LD / 4) : 0, c = c0 + 4 * (f % (LD / 4));
         s[k].row = row; s[k].on = false; s[k].base = nullptr; s[k].idx = nullptr; s[k].ld = 0;
         int cbase = 0;
         for (int sg = 0; sg < op.n; ++sg) {
-            if (c >= cbase && c < cbase + op.dim[sg]) {
+            if (piece && c >= cbase && c < cbase + op.dim[sg]) {
                 s[k].base = op.ptr[sg] + (c - cbase);
                 s[k].idx = op.idx[sg];
                 s[k].ld = op.ld[sg];
@@ -219,11 +251,11 @@ __device__ __forceinline__ void fetch_finish(const Slot* s, const int* v, int64_
     }
 }
 
-template <int NSLOT>
+template <int NSLOT, int NTH = 256>
 __device__ __forceinline__ void issue_dma(const Slot* s, const int64_t* src, float* buf, int tid) {
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-        float* dst = buf + (256 * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
+        float* dst = buf + (NTH * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
         if (s[k].on)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s[k].base + src[k] * s[k].ld),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -238,34 +270,124 @@ __device__ __forceinline__ const int32_t* any_gather(const gcp_operand_t& op) {
 }
 
 // activation on the landed tile: real data columns of valid rows only (never the ones column or padding)
-__device__ __forceinline__ void act_in_lds(float* buf, int LD, int data_cols, int nvalid, int act, float slope, int tid) {
-    for (int i = tid; i < nvalid * data_cols; i += 256) {
+__device__ __forceinline__ void act_in_lds(float* buf, int LD, int data_cols, int nvalid, int act, float slope, int tid, int nth = 256) {
+    for (int i = tid; i < nvalid * data_cols; i += nth) {
         const int r = i / data_cols, c = i - r * data_cols;
         buf[r * LD + c] = gcp_act(act, buf[r * LD + c], slope);
     }
 }
 
-__global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
+// One 16-row step of the three-term bf16 form for a wave's MT x (up to five) tiles.  As / Bs point at the wave's first row (8 hi)
+// and column of the step; a fragment is eight rows of one column.  Per n-tile: split its fragment (44 VALU instructions), six
+// products per m-tile; the rows of the next tile are requested before the products of this one.
+// What was measured on the way (tools/ubench/x3_overlap.hip, profiles/r03_x3_overlap_ubench.txt; tools/tn_phase_timing.py): the
+// split costs ~1.6 cycles an instruction and hides under the MFMAs wherever it is placed; a v_mfma_f32_32x32x16_bf16 stream of
+// this shape runs at ~45 cycles a product (not 32) whether two or ten accumulators rotate; placing the split units, or the next
+// chunk's DMA pieces, BETWEEN the products by hand (sched_barrier) bought nothing, the DMA pieces there cost more than in a phase
+// of their own, and a (m half, row half) wave layout with 2 x 5 tiles per wave was slower in the step than this form.
+template <int MT, int LDA, int LDB>
+__device__ __forceinline__ void x3_step(const float* As, const float* Bs, const int (&boff)[5], int nt, f32x16 (&acc)[MT][5]) {
+    gcp_u32x4 a3[MT][3];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = As[q * LDA + 32 * j];
+        gcp_bf16x3_split8(x, a3[j][0], a3[j][1], a3[j][2]);
+    }
+    float y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = Bs[q * LDB + boff[0]];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float yn[8];
+        if (i + 1 < 5) {  // the next tile's rows before this tile's products (offsets of absent tiles are clamped to valid ones)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) yn[q] = Bs[q * LDB + boff[i + 1 < 5 ? i + 1 : 4]];
+        }
+        if (i < nt) {  // (wave-uniform)
+            gcp_u32x4 bh, bm, bl;
+            gcp_bf16x3_split8(y, bh, bm, bl);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[j][i] = gcp_mfma_bf16x6(a3[j], bh, bm, bl, acc[j][i]);
+        }
+        if (i + 1 < 5) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[q] = yn[q];
+        }
+    }
+}
+
+// X3: the products run on the bf16 pipe as three-term splits (gcp_bf16x3.h: six v_mfma_f32_32x32x16_bf16 per 16-row step, fp32
+// round-off).  A lane's fragment is then eight ROWS of one column (the reduction axis is the row axis, and a sum does not care in
+// which order the rows sit in the k slots: lane half `hi` takes rows 8 hi .. 8 hi + 7 of the step for both operands), read with
+// eight ds_read_b32 and split in registers.  To split every A fragment once, a wave owns ONE m-tile and up to five n-tiles:
+// waves are laid out mt_c (1, 2 or 4) along m and G = 4 / mt_c along n, n-tiles g, g + G, ... going to group g.
+struct X3Tiles {
+    int mi, g, G, my_n;
+};
+__device__ __forceinline__ X3Tiles x3_tiles(const BlockWork& w, int wave) {
+    X3Tiles t;
+    const int mtiles = gcp_cdiv(w.mw, 32);
+    const int mt_c = mtiles > 2 ? 4 : mtiles;
+    t.G = 4 / mt_c;
+    t.mi = wave % mt_c;
+    t.g = wave / mt_c;
+    t.my_n = (t.mi < mtiles && t.g < w.ntiles) ? (w.ntiles - t.g + t.G - 1) / t.G : 0;
+    return t;
+}
+__device__ __forceinline__ void store_partial_x3(const gcp_tn_problem_t& P, const BlockWork& w, int M, int N, const f32x16* acc,
+                                                 const X3Tiles& t, int col, int hi) {
+    float* part = P.partial + (int64_t)w.split * M * N;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (i < t.my_n) {
+            const int n = w.n0 + 32 * (t.g + t.G * i) + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = w.m0 + 32 * t.mi + gcp_crow(r, hi);
+                if (m < M && n < N) part[(int64_t)m * N + n] = acc[i][r];
+            }
+        }
+    }
+}
+
+// MODE 0: fp32 MFMA, tiles dealt round-robin, four waves.  MODE 1: three-term bf16, one m-tile per wave (X3Tiles), four waves.
+// MODE 2: as 1 with EIGHT waves on the same staging buffers -- waves 0-3 take rows 0-15 of every chunk, waves 4-7 rows 16-31, and
+// the two halves are added through LDS at the end -- so that every SIMD holds two waves that cover each other's stalls (DMA issue,
+// LDS latency, barrier skew) without a second set of staging buffers and without more partial sums.
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 512 : 256) void tn_gemm_dma_kernel(TnArgs a) {
+    constexpr bool X3 = MODE >= 1;
+    constexpr int MT = 1;
+    constexpr int NTH = MODE == 2 ? 512 : 256;
+    constexpr int A_SLOTS = (TN_RK * TN_BM / 4 + NTH - 1) / NTH, B_SLOTS = (TN_RK * TN_BN / 4 + NTH - 1) / NTH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;  // (wave: position in the tile layout)
     const int col = lane & 31, hi = lane >> 5;
     const BlockWork w = locate(a);
     const gcp_tn_problem_t& P = a.p[w.pi];
     const int total_tiles = gcp_cdiv(w.mw, 32) * w.ntiles;
-    const int my_tiles = __builtin_amdgcn_readfirstlane(wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0);  // wave-uniform
+    X3Tiles xt = x3_tiles(w, wave);
+    xt.my_n = __builtin_amdgcn_readfirstlane(xt.my_n);
+    const int my_tiles = X3 ? xt.my_n : __builtin_amdgcn_readfirstlane(wave < total_tiles ? (total_tiles - wave + 3) / 4 : 0);  // wave-uniform
     const bool wave_active = my_tiles > 0;
     int aoff[5], boff[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const int id = min(wave + 4 * i, total_tiles - 1), mi = id / w.ntiles;
-        aoff[i] = 32 * mi; boff[i] = 32 * (id - mi * w.ntiles);
+        if (X3) {
+            aoff[i] = 32 * xt.mi; boff[i] = 32 * min(xt.g + xt.G * i, w.ntiles - 1);
+        } else {
+            const int id = min(wave + 4 * i, total_tiles - 1), mi = id / w.ntiles;
+            aoff[i] = 32 * mi; boff[i] = 32 * (id - mi * w.ntiles);
+        }
     }
     auto Abuf = [&](int b) { return lds + b * (TN_RK * (TN_BM + TN_BN)); };
     auto Bbuf = [&](int b) { return lds + b * (TN_RK * (TN_BM + TN_BN)) + TN_RK * TN_BM; };
 
-    Slot sa[TN_A_SLOTS], sb[TN_B_SLOTS];
-    make_slots<TN_A_SLOTS, TN_BM>(P.a, w.m0, sa, tid);
-    make_slots<TN_B_SLOTS, TN_BN>(P.b, w.n0, sb, tid);
+    Slot sa[A_SLOTS], sb[B_SLOTS];
+    make_slots<A_SLOTS, TN_BM, NTH>(P.a, w.m0, sa, tid);
+    make_slots<B_SLOTS, TN_BN, NTH>(P.b, w.n0, sb, tid);
     const int32_t* ga = any_gather(P.a);
     const int32_t* gb = any_gather(P.b);
     // the ones column (bias gradients) is written by hand; its position inside the tile, or -1
@@ -274,65 +396,82 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     const bool a_has_ones = a_ones >= 0 && a_ones < TN_BM, b_has_ones = b_ones >= 0 && b_ones < TN_BN;
     const int a_cols = max(0, min(TN_BM, a_data - w.m0)), b_cols = max(0, min(TN_BN, b_data - w.n0));
 
-    for (int i = tid; i < TN_DMA_LDS_FLOATS; i += 256) lds[i] = 0.f;  // columns no DMA piece covers stay zero
+    for (int i = tid; i < TN_DMA_LDS_FLOATS; i += NTH) lds[i] = 0.f;  // columns no DMA piece covers stay zero
     __syncthreads();
 
-    f32x16 acc[5];
+    f32x16 acc[MT][5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int j = 0; j < MT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
     const int r_last = w.r_end - 1;
-    const int nchunks = gcp_cdiv(w.r_end - w.r_begin, TN_RK);
-    int64_t ra[TN_A_SLOTS], rb[TN_B_SLOTS];
+    const int nchunks = w.nchunks;
+    auto row0 = [&](int chunk) { return w.r_first + chunk * w.r_step; };
+    int64_t ra[A_SLOTS], rb[B_SLOTS];
     auto stage = [&](int chunk, int b) {  // rows of `chunk` are in ra / rb
-        const int r0 = w.r_begin + chunk * TN_RK;
-        issue_dma<TN_A_SLOTS>(sa, ra, Abuf(b), tid);
-        issue_dma<TN_B_SLOTS>(sb, rb, Bbuf(b), tid);
+        const int r0 = row0(chunk);
+        issue_dma<A_SLOTS, NTH>(sa, ra, Abuf(b), tid);
+        issue_dma<B_SLOTS, NTH>(sb, rb, Bbuf(b), tid);
         if (tid < TN_RK) {
             const float one = (r0 + tid <= r_last) ? 1.f : 0.f;
             if (a_has_ones) Abuf(b)[tid * TN_BM + a_ones] = one;
             if (b_has_ones) Bbuf(b)[tid * TN_BN + b_ones] = one;
         }
     };
-    int va[TN_A_SLOTS], vb[TN_B_SLOTS];
-    fetch_issue<TN_A_SLOTS>(sa, va, w.r_begin, r_last, ga);
-    fetch_issue<TN_B_SLOTS>(sb, vb, w.r_begin, r_last, gb);
-    fetch_finish<TN_A_SLOTS>(sa, va, ra, w.r_begin, r_last, ga);
-    fetch_finish<TN_B_SLOTS>(sb, vb, rb, w.r_begin, r_last, gb);
+    int va[A_SLOTS], vb[B_SLOTS];
+    fetch_issue<A_SLOTS>(sa, va, row0(0), r_last, ga);
+    fetch_issue<B_SLOTS>(sb, vb, row0(0), r_last, gb);
+    fetch_finish<A_SLOTS>(sa, va, ra, row0(0), r_last, ga);
+    fetch_finish<B_SLOTS>(sb, vb, rb, row0(0), r_last, gb);
     // every source row resolved BEFORE the first piece goes out: hipcc otherwise sinks each select into the (conditional) issue
     // of its piece and drains vmcnt(0) -- the previous piece -- in front of every one
 #pragma unroll
-    for (int k = 0; k < TN_A_SLOTS; ++k) asm volatile("" : "+v"(ra[k]));
+    for (int k = 0; k < A_SLOTS; ++k) asm volatile("" : "+v"(ra[k]));
 #pragma unroll
-    for (int k = 0; k < TN_B_SLOTS; ++k) asm volatile("" : "+v"(rb[k]));
+    for (int k = 0; k < B_SLOTS; ++k) asm volatile("" : "+v"(rb[k]));
     stage(0, 0);
-    fetch_issue<TN_A_SLOTS>(sa, va, w.r_begin + TN_RK, r_last, ga);
-    fetch_issue<TN_B_SLOTS>(sb, vb, w.r_begin + TN_RK, r_last, gb);
-    fetch_finish<TN_A_SLOTS>(sa, va, ra, w.r_begin + TN_RK, r_last, ga);
-    fetch_finish<TN_B_SLOTS>(sb, vb, rb, w.r_begin + TN_RK, r_last, gb);
+    fetch_issue<A_SLOTS>(sa, va, row0(1), r_last, ga);
+    fetch_issue<B_SLOTS>(sb, vb, row0(1), r_last, gb);
+    fetch_finish<A_SLOTS>(sa, va, ra, row0(1), r_last, ga);
+    fetch_finish<B_SLOTS>(sb, vb, rb, row0(1), r_last, gb);
+    TN_T_DECL;
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
+        TN_T_MARK(3);
         __syncthreads();  // vmcnt(0) + barrier: this chunk has landed, and every wave is done with the other buffer
-        const int nvalid = min(TN_RK, w.r_end - (w.r_begin + c * TN_RK));
+        TN_T_MARK(0);
+        const int nvalid = min(TN_RK, w.r_end - row0(c));
         if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
-            for (int i = tid; i < (TN_RK - nvalid) * TN_BM; i += 256) Abuf(cur)[nvalid * TN_BM + i] = 0.f;
-            for (int i = tid; i < (TN_RK - nvalid) * TN_BN; i += 256) Bbuf(cur)[nvalid * TN_BN + i] = 0.f;
+            for (int i = tid; i < (TN_RK - nvalid) * TN_BM; i += NTH) Abuf(cur)[nvalid * TN_BM + i] = 0.f;
+            for (int i = tid; i < (TN_RK - nvalid) * TN_BN; i += NTH) Bbuf(cur)[nvalid * TN_BN + i] = 0.f;
             __syncthreads();
         }
         if (P.a.act || P.b.act) {
-            if (P.a.act) act_in_lds(Abuf(cur), TN_BM, a_cols, nvalid, P.a.act, P.a.slope, tid);
-            if (P.b.act) act_in_lds(Bbuf(cur), TN_BN, b_cols, nvalid, P.b.act, P.b.slope, tid);
+            if (P.a.act) act_in_lds(Abuf(cur), TN_BM, a_cols, nvalid, P.a.act, P.a.slope, tid, NTH);
+            if (P.b.act) act_in_lds(Bbuf(cur), TN_BN, b_cols, nvalid, P.b.act, P.b.slope, tid, NTH);
             __syncthreads();
         }
-        const int rn = w.r_begin + (c + 2) * TN_RK;  // gather indices of the chunk after next: requested now,
+        const int rn = row0(c + 2);  // gather indices of the chunk after next: requested now,
         if (c + 1 < nchunks) {                        // consumed after this chunk's MFMAs
-            stage(c + 1, cur ^ 1);
-            fetch_issue<TN_A_SLOTS>(sa, va, rn, r_last, ga);
-            fetch_issue<TN_B_SLOTS>(sb, vb, rn, r_last, gb);
+            if (!(a.debug & 2)) stage(c + 1, cur ^ 1);
+            fetch_issue<A_SLOTS>(sa, va, rn, r_last, ga);
+            fetch_issue<B_SLOTS>(sb, vb, rn, r_last, gb);
         }
-        if (wave_active) {
+        TN_T_MARK(1);
+        if (X3 && wave_active && !(a.debug & 1)) {
+            const float* As = Abuf(cur) + col + 8 * hi * TN_BM + aoff[0];
+            const float* Bs = Bbuf(cur) + col + 8 * hi * TN_BN;
+            if (MODE == 2) {
+                x3_step<MT, TN_BM, TN_BN>(As + 16 * kh * TN_BM, Bs + 16 * kh * TN_BN, boff, my_tiles, acc);
+            } else {
+#pragma unroll 1
+                for (int ks = 0; ks < TN_RK / 16; ++ks) x3_step<MT, TN_BM, TN_BN>(As + 16 * ks * TN_BM, Bs + 16 * ks * TN_BN, boff, my_tiles, acc);
+            }
+        }
+        if (!X3 && wave_active) {
             // fragments of step ss + 1 are read (unconditionally: the offsets are clamped to valid tiles) before the MFMAs of
             // step ss, so that an MFMA never waits for its own ds_read
             const float* As = Abuf(cur) + col + hi * TN_BM;
@@ -352,19 +491,48 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
                 }
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    if (i < my_tiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+                    if (i < my_tiles) acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[0][i], 0, 0, 0);
                 if (ss + 1 < TN_RK / 2) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
                 }
             }
         }
+        TN_T_MARK(2);
         if (c + 1 < nchunks) {
-            fetch_finish<TN_A_SLOTS>(sa, va, ra, rn, r_last, ga);
-            fetch_finish<TN_B_SLOTS>(sb, vb, rb, rn, r_last, gb);
+            fetch_finish<A_SLOTS>(sa, va, ra, rn, r_last, ga);
+            fetch_finish<B_SLOTS>(sb, vb, rb, rn, r_last, gb);
         }
     }
-    if (wave_active) store_partial(P, w, a.M[w.pi], a.N[w.pi], acc, wave, col, hi);
+    if (MODE == 2) {
+        // rows 16 .. 31 of every chunk (waves 4-7) onto rows 0 .. 15 (waves 0-3) through the staging buffers, free now: n-tiles 0-2,
+        // then 3-4 (five tiles of four waves would not fit)
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const int i0 = round ? 3 : 0, i1 = round ? 5 : 3;
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int i = i0; i < i1; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane] = acc[0][i][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int i = i0; i < i1; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][r] += lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (X3) {
+        if (wave_active && kh == 0) store_partial_x3(P, w, a.M[w.pi], a.N[w.pi], acc[0], xt, col, hi);
+        TN_T_MARK(3);
+        TN_T_STORE(P.partial + (int64_t)w.split * a.M[w.pi] * a.N[w.pi], wave + 4 * kh, lane);
+    } else if (wave_active) {
+        store_partial(P, w, a.M[w.pi], a.N[w.pi], acc[0], wave, col, hi);
+    }
 }
 
 // ---- big-block path: ONE workgroup owns the whole output of a problem with 128 < M <= 256 or 160 < N <= 320 -------------------
@@ -411,6 +579,7 @@ __device__ __forceinline__ void big_issue(const BigSlot* s, float* buf, int r0, 
     }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -420,8 +589,9 @@ __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
     const gcp_tn_problem_t& P = a.p[pi];
     const int M = a.M[pi], N = a.N[pi];
     const int split = blockIdx.x - a.block_start[pi];
-    const int rps = tn_rows_per_split(P.rows, P.splits);
-    const int r_begin = split * rps, r_end = min(P.rows, r_begin + rps), r_last = r_end - 1;
+    int r_first, r_step, r_end, nchunks;
+    split_rows(P.rows, P.splits, split, a.cyclic != 0, r_first, r_step, r_end, nchunks);
+    const int r_last = r_end - 1;
     const int mtiles = gcp_cdiv(M, 32), ntiles = gcp_cdiv(N, 32);
     const int mt0 = 2 * (wave & 3), nt0 = 5 * (wave >> 2);
     auto Abuf = [&](int b) { return lds + b * (TN_RK * (TB_BM + TB_BN)); };
@@ -443,9 +613,8 @@ __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    const int nchunks = gcp_cdiv(r_end - r_begin, TN_RK);
     auto stage = [&](int chunk, int b) {
-        const int r0 = r_begin + chunk * TN_RK;
+        const int r0 = r_first + chunk * r_step;
         big_issue<TB_A_SLOTS>(sa, Abuf(b), r0, r_last, tid);
         big_issue<TB_B_SLOTS>(sb, Bbuf(b), r0, r_last, tid);
         if (tid < TN_RK) {
@@ -456,17 +625,30 @@ __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
     };
     if (nchunks > 0) stage(0, 0);
     const bool m_on[2] = {mt0 < mtiles, mt0 + 1 < mtiles};
+    TN_T_DECL;
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
+        TN_T_MARK(3);
         __syncthreads();  // vmcnt(0) + barrier: this chunk has landed, and every wave is done with the other buffer
-        const int nvalid = min(TN_RK, r_end - (r_begin + c * TN_RK));
+        TN_T_MARK(0);
+        const int nvalid = min(TN_RK, r_end - (r_first + c * r_step));
         if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
             for (int i = tid; i < (TN_RK - nvalid) * TB_BM; i += TB_NTH) Abuf(cur)[nvalid * TB_BM + i] = 0.f;
             for (int i = tid; i < (TN_RK - nvalid) * TB_BN; i += TB_NTH) Bbuf(cur)[nvalid * TB_BN + i] = 0.f;
             __syncthreads();
         }
-        if (c + 1 < nchunks) stage(c + 1, cur ^ 1);
-        if (m_on[0] && nt0 < ntiles) {  // (wave-uniform: waves whose tiles lie outside a narrower problem only keep the barriers)
+        if (c + 1 < nchunks && !(a.debug & 2)) stage(c + 1, cur ^ 1);
+        TN_T_MARK(1);
+        if (X3 && m_on[0] && nt0 < ntiles && !(a.debug & 1)) {  // three-term bf16 products (x3_step); an absent second m-tile is computed and dropped
+            const float* As = Abuf(cur) + 8 * hi * TB_BM + 32 * mt0 + col;
+            const float* Bs = Bbuf(cur) + 8 * hi * TB_BN + 32 * nt0 + col;
+            const int boff[5] = {0, 32, 64, 96, 128};
+            const int nt = min(5, ntiles - nt0);
+#pragma unroll 1
+            for (int ks = 0; ks < TN_RK / 16; ++ks) x3_step<2, TB_BM, TB_BN>(As + 16 * ks * TB_BM, Bs + 16 * ks * TB_BN, boff, nt, acc);
+        }
+        TN_T_MARK(2);
+        if (!X3 && m_on[0] && nt0 < ntiles) {  // (wave-uniform: waves whose tiles lie outside a narrower problem only keep the barriers)
             const float* As = Abuf(cur) + hi * TB_BM + 32 * mt0 + col;
             const float* Bs = Bbuf(cur) + hi * TB_BN + 32 * nt0 + col;
             float fa[2], fb[5];
@@ -510,6 +692,8 @@ __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
                 if (m < M && n < N) part[(int64_t)m * N + n] = acc[j][i][r];
             }
         }
+    TN_T_MARK(3);
+    TN_T_STORE(part, wave, lane);
 }
 
 inline bool big_ok(const gcp_operand_t& o) {
@@ -600,8 +784,13 @@ extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
 
 extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream) {
     if (n_problems <= 0 || n_problems > GCP_TN_MAX_PROBLEMS || !problems) return GCPNET_E_BADARG;
+    // (GCPNET_DEBUG_SKIP_TN: measurement knob -- no launch, the gradients stay unwritten: "what would the step cost without these")
+    static const bool skip_env = getenv("GCPNET_DEBUG_SKIP_TN") != nullptr;
+    if (skip_env) return 0;
     TnArgs a;
     a.n = n_problems;
+    a.debug = getenv("GCPNET_TN_DEBUG") ? atoi(getenv("GCPNET_TN_DEBUG")) : 0;
+    a.cyclic = getenv("GCPNET_TN_BLOCKED") == nullptr;  // (GCPNET_TN_BLOCKED: contiguous row range per split, the earlier form, for A/B runs)
     int blocks = 0, max_mn = 0;
     bool dma = true;
     for (int i = 0; i < n_problems; ++i) {
@@ -627,9 +816,13 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     // problems whose output needs more than one 128 x 160 block (and fits 256 x 320) go through the big-block kernel, one
     // workgroup per split; the others keep the launch below
     static const bool big_env = getenv("GCPNET_TN_NO_BIG") == nullptr;
+    // (GCPNET_TN_FP32: the fp32-MFMA form of both DMA kernels, kept for A/B measurements and the tests that hold the two against each other)
+    const bool x3 = getenv("GCPNET_TN_FP32") == nullptr;
     if (dma && big_env) {
         TnArgs big, rest;
         big.n = rest.n = 0;
+        big.cyclic = rest.cyclic = a.cyclic;
+        big.debug = rest.debug = a.debug;
         int bblocks = 0, rblocks_ = 0, big_mn = 0, rest_mn = 0;
         for (int i = 0; i < n_problems; ++i) {
             const gcp_tn_problem_t& P = problems[i];
@@ -646,11 +839,14 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
             static bool big_configured = false;
             const size_t big_lds = (size_t)TB_LDS_FLOATS * sizeof(float);
             if (!big_configured) {
-                hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
+                hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
+                if (err == hipSuccess)
+                    err = hipFuncSetAttribute((const void*)tn_gemm_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
                 if (err != hipSuccess) return (int)err;
                 big_configured = true;
             }
-            hipLaunchKernelGGL(tn_gemm_big_kernel, dim3(bblocks), dim3(TB_NTH), big_lds, st, big);
+            if (x3) hipLaunchKernelGGL(tn_gemm_big_kernel<true>, dim3(bblocks), dim3(TB_NTH), big_lds, st, big);
+            else hipLaunchKernelGGL(tn_gemm_big_kernel<false>, dim3(bblocks), dim3(TB_NTH), big_lds, st, big);
             GCP_HIP_CHECK_LAUNCH();
             hipLaunchKernelGGL(tn_reduce_kernel, dim3(min(1024, gcp_cdiv(big_mn, 64)), big.n), dim3(256), 0, st, big);
             GCP_HIP_CHECK_LAUNCH();
@@ -668,12 +864,21 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         static const size_t pad = getenv("GCPNET_TN_LDS_PAD") ? (size_t)atoi(getenv("GCPNET_TN_LDS_PAD")) : 0;
         const size_t lds_bytes = (size_t)TN_DMA_LDS_FLOATS * sizeof(float) + pad;
         if (!configured) {
-            hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)lds_bytes);
+            hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (err == hipSuccess)
+                err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (err == hipSuccess)
+                err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (err != hipSuccess) return (int)err;
             configured = true;
         }
-        hipLaunchKernelGGL(tn_gemm_dma_kernel, dim3(blocks), dim3(256), lds_bytes, st, a);
+        // (GCPNET_TN_EIGHT_WAVES: the eight-wave form.  Alone it is the faster kernel -- 69 vs 86 us on the (128,16) weight gradient of
+        // 160 k rows --, inside the training step, where these launches share the chip with the caller's stream, it is the slower
+        // choice: 12.48 vs 12.01 ms per configs[1] step, profiles/r03_tn_bf16x3.txt.  Read per call: the tests switch it.)
+        const bool eight = getenv("GCPNET_TN_EIGHT_WAVES") != nullptr;
+        if (x3 && eight) hipLaunchKernelGGL(tn_gemm_dma_kernel<2>, dim3(blocks), dim3(512), lds_bytes, st, a);
+        else if (x3) hipLaunchKernelGGL(tn_gemm_dma_kernel<1>, dim3(blocks), dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL(tn_gemm_dma_kernel<0>, dim3(blocks), dim3(256), lds_bytes, st, a);
     } else {
         hipLaunchKernelGGL(tn_gemm_kernel, dim3(blocks), dim3(256), 0, st, a);
     }

@@ -14,9 +14,20 @@ pytestmark = pytest.mark.gpu
     (33, 256, 160),       # two chunks, the second with one valid row
     (50000, 128, 144),    # the (128,16) shape: the 128 x 160 kernel as before
     (777, 36, 12),        # tiny widths (still multiples of 4): 128 x 160 kernel
+    (5000, 64, 160),      # two m-tiles: waves laid out 2 along m x 2 along n (n-tiles 0,2,4 / 1,3)
+    (5000, 16, 144),      # one m-tile: four wave groups along n, the fifth n-tile back on group 0
+    (3000, 96, 100),      # three m-tiles (the fourth wave idles), last n-tile four columns wide
+    (2000, 128, 16),      # one n-tile
+    (2000, 160, 128),     # M over one block: two blocks along m in the 128 x 160 kernel when the big-block kernel is off
 ])
-def test_tn_weight_grad_vs_float64(rows, M, N):
+@pytest.mark.parametrize("form", ["default", "eight_waves", "fp32", "blocked_rows"])
+def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
+    """`form`: the switches of gcpnet_tn_gemm that select another kernel or row distribution for the same product."""
     from gcpnet_amd import ops
+
+    env = {"eight_waves": "GCPNET_TN_EIGHT_WAVES", "fp32": "GCPNET_TN_FP32", "blocked_rows": "GCPNET_TN_BLOCKED"}.get(form)
+    if env:
+        monkeypatch.setenv(env, "1")
 
     g = torch.Generator().manual_seed(rows + M)
     a = torch.randn(rows, M, generator=g)
@@ -46,3 +57,25 @@ def test_linear_weight_and_bias_gradient_wide():
     for got, want, name in ((xg.grad, xd.grad, "dx"), (wg.grad, wd.grad, "dW"), (bg.grad, bd.grad, "db")):
         err = (got.cpu().double() - want).abs().max().item()
         assert err <= 1e-5 * float(want.abs().max()) + 1e-5, f"{name}: {err:.3e}"
+
+
+@pytest.mark.parametrize("rows,M,N", [(40000, 128, 144), (20000, 256, 284)])
+def test_bf16_three_term_products_are_fp32_accurate(rows, M, N, monkeypatch):
+    """The default kernels multiply on the bf16 pipe with three-term operand splits (six MFMAs per product block); the fp32-MFMA
+    form of the same kernels stays behind GCPNET_TN_FP32.  Both against float64: the split form must not be less accurate than
+    fp32 arithmetic itself (bound: twice the fp32 form's own error + one ulp of the result scale)."""
+    from gcpnet_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(rows, M, generator=g) * torch.logspace(-3, 3, M)[None, :]   # columns of very different magnitude
+    b = torch.randn(rows, N, generator=g)
+    want = a.double().t() @ b.double()
+    scale = (a.double().abs().t() @ b.double().abs())                          # sum |a b| per output: the natural error scale
+    x3 = ops._tn_weight_grad(a.cuda(), b.cuda()).cpu().double()
+    monkeypatch.setenv("GCPNET_TN_FP32", "1")
+    f32 = ops._tn_weight_grad(a.cuda(), b.cuda()).cpu().double()
+    monkeypatch.delenv("GCPNET_TN_FP32")
+    e_x3 = ((x3 - want).abs() / scale).max().item()
+    e_f32 = ((f32 - want).abs() / scale).max().item()
+    assert not torch.equal(x3, f32), "the switch must select a different kernel"
+    assert e_x3 <= 2 * e_f32 + 2 ** -22, f"three-term {e_x3:.3e} vs fp32 {e_f32:.3e} (of sum |a b|)"
