@@ -98,8 +98,8 @@ struct GcpShape {
     int64_t offA, offB, offC, offD, offF, offVA, offVB, offVC, offVD, total;  // section offsets (floats) inside the packed image
     // B6: the backward-data weights once more as THREE bf16 terms (w = h + m + l exactly, by truncation) in the operand layout of
     // v_mfma_f32_32x32x16_bf16, for the chain backward kernel's fp32-exact product on the bf16 matrix pipe (gcp_bf16x3.h):
-    // [slab j < 2 NTG][tile uu < NKT of the merged axis][term][64 lanes][4 dwords of two bf16]; 0 floats when the block cannot
-    // run in that kernel
+    // [slab j < 2 NTG][tile uu < NKT of the (padded) merged axis][term][64 lanes][4 dwords of two bf16]; 0 floats when the block
+    // cannot run in that kernel
     int NKT;
     int64_t offB6;
     // F6 / C6: the same three-term bf16 images of the forward scalar_out weights over a register-resident state
@@ -142,8 +142,10 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     s.offVC = s.offVB + (s.vmm ? (int64_t)s.SVB * 64 : 0);
     s.offVD = s.offVC + (s.vmm ? (int64_t)s.SVC * 64 : 0);
     s.offB6 = s.offVD + (s.vmm ? (int64_t)s.CT * s.SVD * 64 : 0);
-    s.NKT = gcp_cdiv(s.K, 32);
-    const bool chainable = s.NG == 1 && si == so && vi == vo && vi > 0 && si == 32 * s.NTG && s.NKT == s.NTG + 1;
+    // (the merged axis of the B6 image is PADDED: scalars in tiles 0 .. NTS - 1 -- columns past si are zero --, norms / frame scalars
+    // in tile NTS, as the chain backward kernel walks it; identical to the raw axis when si is a multiple of 32)
+    s.NKT = s.NTS + gcp_cdiv(s.H + s.nf, 32);
+    const bool chainable = s.NG == 1 && si == so && vi == vo && vi > 0 && (si & 3) == 0 && s.NTS == s.NTG && s.NKT == s.NTG + 1;
     s.offF6 = s.offB6 + (chainable ? (int64_t)2 * s.NTG * s.NKT * 3 * 256 : 0);
     const bool fwd6 = s.NG == 1 && s.NTG >= 2 && s.NTS == s.NTG && s.GT == 1 && vi > 0 && vo > 0;
     s.offC6 = s.offF6 + (fwd6 ? (int64_t)2 * s.NTG * s.NTG * 3 * 256 : 0);

@@ -169,7 +169,9 @@ __device__ __forceinline__ void cb_vin_commit(const CbVin& b, float* vt, int VS,
 }
 
 // B6: W^T ds_pre on the bf16 matrix pipe, both operands as three bf16 terms, six products (gcp_bf16x3.h: exact to fp32 round-off)
-template <int NTG, int VQ, bool PWL, int HC, bool B6>
+// PAD: si == so is a multiple of 4 below 32 NTG (LBA: 100): the tile loads already return zeros past column so, the weight images
+// are zero-padded, so the padding columns of d(s) stay zero through the chain; only the two full-line stores need the column test.
+template <int NTG, int VQ, bool PWL, int HC, bool B6, bool PAD = false>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p_kernarg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 4 * VQ;  // registers per xyz component of a vector-channel quantity
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 }
             }
         }
-        gcp_store_acc_rows_half_dense<NTG>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG, 16-byte aligned: host checks)
+        gcp_store_acc_rows_half_dense<NTG, PAD>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG or PAD; 16-byte aligned: host checks)
         CB_LAUNDER();
 
         // ---- E. d(s) += W^T ds_pre: 16 * NTG k-pair steps whose B operands are the ds_pre registers; the weight
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         CB_LAUNDER();
 
-        if (k == 0) gcp_store_acc_rows_half_dense<NTG>(p.d_s_in, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
+        if (k == 0) gcp_store_acc_rows_half_dense<NTG, PAD>(p.d_s_in, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
 
         // ---- F. adjoint of the vector prologue: d[vh | vf] = Wu^T dvu + (norm and frame-scalar terms), d(V) += Wdf^T d[vh | vf] ---
@@ -650,15 +652,18 @@ int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
     // W^T ds_pre on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_BWD_FP32_MFMA / gcpnet_debug_set_fp32_mfma select the
     // fp32 MFMA form of the same product (A/B switch)
     static const bool b6_env = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
-    const bool b6 = g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0;
+    const bool pad = p.sh.so != 32 * NTG;  // (padded widths: bf16 form only)
+    const bool b6 = pad || (g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0);
     const dim3 grid((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS));
     if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4): hidden channel count known at compile time
-        if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+        if (pad) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+        else if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
         else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, false>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     }
-    if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+    if (pad) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0, true, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+    else if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
     else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 0, false>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
@@ -678,7 +683,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
                              const float* d_v_out, float* d_s_in, float* d_v_in, hipStream_t st) {
     const gcp2_weights_t& w0 = items[0].w;
     const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
-    if (S.NG != 1 || w0.si != w0.so || w0.vi != w0.vo || w0.vi <= 0 || w0.si != 32 * S.NTG || S.NTG < 2) return GCPNET_E_UNSUPPORTED;
+    if (S.NG != 1 || w0.si != w0.so || w0.vi != w0.vo || w0.vi <= 0 || (w0.si & 3) || S.NTG < 2 || S.NTS != S.NTG) return GCPNET_E_UNSUPPORTED;
     // register budget of the kernel: vi == vo <= 16 (two register quads per xyz component), H + 3 <= 16, H + 9 <= 32
     if ((w0.vi & 3) || w0.vi > 16 || !S.vmm || S.HF > 16 || S.H + S.nf > 32) return GCPNET_E_UNSUPPORTED;
     if (S.NUG < S.NTG) return GCPNET_E_UNSUPPORTED;

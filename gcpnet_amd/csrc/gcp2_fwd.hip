@@ -602,7 +602,8 @@ __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
         const int term = x % 3; x /= 3;
         const int uu = x % S.NKT;
         const int j = (int)(x / S.NKT);
-        const int k = 32 * uu + (lane & 31);
+        const int kp = 32 * uu + (lane & 31);  // padded merged axis -> column of w_scalar: scalars, then (from tile NTS on) the rest
+        const int k = uu < S.NTS ? (kp < S.si ? kp : S.K) : S.si + (kp - 32 * S.NTS);
         unsigned bits = 0;
         for (int h2 = 0; h2 < 2; ++h2) {
             const int r = 8 * (j & 1) + 2 * d + h2;  // accumulator register of tile j / 2 that is element 2 d + h2 of the slab

@@ -417,7 +417,8 @@ __device__ __forceinline__ void gcp_store_acc_rows_dense(float* __restrict__ dst
 // gcp_store_acc_rows_half for a destination the caller knows to be 16-byte aligned with ld % 4 == 0 and width == ld == 32 NT:
 // no per-piece column tests, and one wave-uniform test for a tile without rows past the end instead of a branch per store (the
 // general form compiles to ~8 branches per 32-column tile; inside an unrolled kernel body every one of them is a scheduling fence).
-template <int NT>
+// PAD: ld (a multiple of 4) may be less than 32 NT -- the 16-byte pieces past column ld are dropped (one lane test per piece).
+template <int NT, bool PAD = false>
 __device__ __forceinline__ void gcp_store_acc_rows_half_dense(float* __restrict__ dst, int ld, int r0, int rows, const f32x16 (&acc)[NT],
                                                               float* stage, int lane) {
     const int e = lane & 31, hi = lane >> 5;
@@ -440,8 +441,9 @@ __device__ __forceinline__ void gcp_store_acc_rows_half_dense(float* __restrict_
                 const float4 w0 = *reinterpret_cast<const float4*>(stage + sub * 20 + c4);
                 const float4 w1 = *reinterpret_cast<const float4*>(stage + (16 + sub) * 20 + c4);
                 const int c = 32 * t + 16 * h;
-                if (decltype(full_tag)::value || ok0) *reinterpret_cast<float4*>(p0 + c) = w0;
-                if (decltype(full_tag)::value || ok1) *reinterpret_cast<float4*>(p1 + c) = w1;
+                const bool in = !PAD || c + c4 + 3 < ld;
+                if ((decltype(full_tag)::value || ok0) && in) *reinterpret_cast<float4*>(p0 + c) = w0;
+                if ((decltype(full_tag)::value || ok1) && in) *reinterpret_cast<float4*>(p1 + c) = w1;
             }
     };
     if (full) pieces(std::true_type{});

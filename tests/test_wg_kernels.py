@@ -86,7 +86,9 @@ def test_single_block_vs_oracle(G, rows, din, dout, bott, acts, kw):
 @pytest.mark.parametrize("act", ["silu", "relu"])
 @pytest.mark.parametrize("n,e,dims,blocks", [(300, 2500, (128, 16), 8), (200, 1500, (256, 32), 8), (150, 1100, (64, 16), 4),
                                              (33, 64, (128, 32), 8),  # found by tests/sweep_layers.py: V = 32 at so <= 128
-                                             (90, 700, (100, 16), 3)], ids=["C2-dims", "C5-dims", "NMS-dims", "V32-dims", "LBA-dims"])
+                                             (90, 700, (100, 16), 3),   # scalar width not a multiple of 32: the padded form of
+                                             (120, 900, (36, 8), 3)],   # the chain backward (four / two 32-wide tiles)
+                         ids=["C2-dims", "C5-dims", "NMS-dims", "V32-dims", "LBA-dims", "pad36-dims"])
 def test_message_chain_vs_oracle(G, n, e, dims, blocks, act, wg_bwd):
     """GCPMessagePassing (first message GCP after project-then-gather + ResGCP chain + aggregation) through the workgroup
     kernels: chain in one launch at every hidden size, including (256, 32) where the wave-per-tile chain kernels do not apply."""
