@@ -815,7 +815,10 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     hipStream_t st = (hipStream_t)stream;
     // problems whose output needs more than one 128 x 160 block (and fits 256 x 320) go through the big-block kernel, one
     // workgroup per split; the others keep the launch below
-    static const bool big_env = getenv("GCPNET_TN_NO_BIG") == nullptr;
+    // (the big-block kernel is opt-in since the bf16 form: alone it is the faster one on 256 x 284 outputs, 0.98 against 1.2 ms, but
+    // in the configs[4] step the four-wave 128 x 160 kernel wins, 211 against 216 ms -- one 8-wave workgroup with 147 KB of LDS per CU
+    // leaves no room for the caller's stream.  Read per call: the tests switch it.)
+    const bool big_env = getenv("GCPNET_TN_BIG") != nullptr;
     // (GCPNET_TN_FP32: the fp32-MFMA form of both DMA kernels, kept for A/B measurements and the tests that hold the two against each other)
     const bool x3 = getenv("GCPNET_TN_FP32") == nullptr;
     if (dma && big_env) {

@@ -20,12 +20,13 @@ pytestmark = pytest.mark.gpu
     (2000, 128, 16),      # one n-tile
     (2000, 160, 128),     # M over one block: two blocks along m in the 128 x 160 kernel when the big-block kernel is off
 ])
-@pytest.mark.parametrize("form", ["default", "eight_waves", "fp32", "blocked_rows"])
+@pytest.mark.parametrize("form", ["default", "big_block", "eight_waves", "fp32", "blocked_rows"])
 def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
     """`form`: the switches of gcpnet_tn_gemm that select another kernel or row distribution for the same product."""
     from gcpnet_amd import ops
 
-    env = {"eight_waves": "GCPNET_TN_EIGHT_WAVES", "fp32": "GCPNET_TN_FP32", "blocked_rows": "GCPNET_TN_BLOCKED"}.get(form)
+    env = {"big_block": "GCPNET_TN_BIG", "eight_waves": "GCPNET_TN_EIGHT_WAVES", "fp32": "GCPNET_TN_FP32",
+           "blocked_rows": "GCPNET_TN_BLOCKED"}.get(form)
     if env:
         monkeypatch.setenv(env, "1")
 
@@ -59,13 +60,16 @@ def test_linear_weight_and_bias_gradient_wide():
         assert err <= 1e-5 * float(want.abs().max()) + 1e-5, f"{name}: {err:.3e}"
 
 
+@pytest.mark.parametrize("big", [False, True], ids=["128x160", "big-block"])
 @pytest.mark.parametrize("rows,M,N", [(40000, 128, 144), (20000, 256, 284)])
-def test_bf16_three_term_products_are_fp32_accurate(rows, M, N, monkeypatch):
+def test_bf16_three_term_products_are_fp32_accurate(rows, M, N, big, monkeypatch):
     """The default kernels multiply on the bf16 pipe with three-term operand splits (six MFMAs per product block); the fp32-MFMA
     form of the same kernels stays behind GCPNET_TN_FP32.  Both against float64: the split form must not be less accurate than
     fp32 arithmetic itself (bound: twice the fp32 form's own error + one ulp of the result scale)."""
     from gcpnet_amd import ops
 
+    if big:
+        monkeypatch.setenv("GCPNET_TN_BIG", "1")
     g = torch.Generator().manual_seed(11)
     a = torch.randn(rows, M, generator=g) * torch.logspace(-3, 3, M)[None, :]   # columns of very different magnitude
     b = torch.randn(rows, N, generator=g)
