@@ -34,7 +34,10 @@ namespace {
 #define TN_T_STORE(part, wave, lane)
 #endif
 
-constexpr int TN_BM = 128, TN_BN = 160, TN_RK = 32;
+#ifndef GCP_TN_RK
+#define GCP_TN_RK 32  // rows per staged chunk (16 or 32: -DGCP_TN_RK=16 halves the staging buffers; measured, see the header of x3_step)
+#endif
+constexpr int TN_BM = 128, TN_BN = 160, TN_RK = GCP_TN_RK;
 // Rows per split: about one split per CU for the big (edge-row) problems -- with one or two output blocks that is one
 // balanced wave of workgroups over the 256 CUs, two resident per CU -- and never fewer than 64 rows (node-row problems).
 constexpr int TN_TARGET_SPLITS = 256, TN_MIN_ROWS_PER_SPLIT = 64;
@@ -284,7 +287,9 @@ __device__ __forceinline__ void act_in_lds(float* buf, int LD, int data_cols, in
 // split costs ~1.6 cycles an instruction and hides under the MFMAs wherever it is placed; a v_mfma_f32_32x32x16_bf16 stream of
 // this shape runs at ~45 cycles a product (not 32) whether two or ten accumulators rotate; placing the split units, or the next
 // chunk's DMA pieces, BETWEEN the products by hand (sched_barrier) bought nothing, the DMA pieces there cost more than in a phase
-// of their own, and a (m half, row half) wave layout with 2 x 5 tiles per wave was slower in the step than this form.
+// of their own, and a (m half, row half) wave layout with 2 x 5 tiles per wave was slower in the step than this form.  16-row
+// chunks (-DGCP_TN_RK=16: half the staging LDS, up to four workgroups per CU): 0.093 against 0.082 ms alone, 11.97 against 11.74 ms
+// per configs[1] step, 213.7 against 210.0 ms per configs[4] step -- 32 rows stay.
 template <int MT, int LDA, int LDB>
 __device__ __forceinline__ void x3_step(const float* As, const float* Bs, const int (&boff)[5], int nt, f32x16 (&acc)[MT][5]) {
     gcp_u32x4 a3[MT][3];
@@ -543,9 +548,8 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : 256) void tn_gemm_dma_kernel(TnAr
 // fragment reads per ten MFMAs instead of ten per five.  Operands: plain segments (no row gather, no activation), DMA-able
 // (widths / strides multiples of four floats); everything else keeps the 128 x 160 kernel.
 constexpr int TB_BM = 256, TB_BN = 320, TB_NW = 8, TB_NTH = 64 * TB_NW;
-constexpr int TB_A_SLOTS = TN_RK * TB_BM / 4 / TB_NTH, TB_B_SLOTS = TN_RK * TB_BN / 4 / TB_NTH;  // 4 and 5 pieces per thread
+constexpr int TB_A_SLOTS = (TN_RK * TB_BM / 4 + TB_NTH - 1) / TB_NTH, TB_B_SLOTS = (TN_RK * TB_BN / 4 + TB_NTH - 1) / TB_NTH;  // 4 and 5 pieces per thread
 constexpr int TB_LDS_FLOATS = 2 * TN_RK * (TB_BM + TB_BN);
-static_assert(TN_RK * TB_BM / 4 % TB_NTH == 0 && TN_RK * TB_BN / 4 % TB_NTH == 0, "whole pieces per thread");
 
 struct BigSlot {
     const float* base;  // segment pointer + column offset of the 16-byte piece; nullptr: no column of the operand there
@@ -557,11 +561,12 @@ __device__ __forceinline__ void big_slots(const gcp_operand_t& op, BigSlot* s, i
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
         const int f = tid + TB_NTH * k;
-        const int row = f / (LD / 4), c = 4 * (f % (LD / 4));
+        const bool piece = f < TN_RK * LD / 4;
+        const int row = piece ? f / (LD / 4) : 0, c = 4 * (f % (LD / 4));
         s[k].row = row; s[k].base = nullptr; s[k].ld = 0;
         int cbase = 0;
         for (int sg = 0; sg < op.n; ++sg) {
-            if (c >= cbase && c < cbase + op.dim[sg]) { s[k].base = op.ptr[sg] + (c - cbase); s[k].ld = op.ld[sg]; }
+            if (piece && c >= cbase && c < cbase + op.dim[sg]) { s[k].base = op.ptr[sg] + (c - cbase); s[k].ld = op.ld[sg]; }
             cbase += op.dim[sg];
         }
     }
