@@ -1026,10 +1026,19 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 // out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].  A block sums 64 consecutive entries: its 256 threads are four
 // slices of the parts axis (16 loads in flight each), combined through LDS in a fixed order -- a few hundred parts of a small
 // matrix are otherwise one dependent load chain per thread.
-__global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ parts, int G, int R, int C, int CW,
-                                                        float* __restrict__ out_w, float* __restrict__ out_b) {
+struct WgReduceArgs {
+    gcp_wg_reduce_job_t j[GCP_WG_REDUCE_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void wg_reduce_kernel(WgReduceArgs a) {
     __shared__ float red[4][64];
+    const gcp_wg_reduce_job_t& J = a.j[blockIdx.y];
+    const float* __restrict__ parts = J.parts;
+    const int G = J.n_parts, R = J.R, C = J.C, CW = J.CW;
+    float* __restrict__ out_w = J.out_w;
+    float* __restrict__ out_b = J.out_b;
     const int64_t n = (int64_t)R * C;
+    if ((int64_t)blockIdx.x * 64 >= n) return;  // (the grid is sized for the largest job of the launch; uniform per block)
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + col;
     const int per = (G + 3) / 4, g0 = sl * per, g1 = min(G, g0 + per);
@@ -1090,12 +1099,25 @@ bool wg_bwd_is_shape(const WgBwdParams& p, const gcp2_weights_t& w, bool gated) 
 
 }  // namespace
 
-extern "C" int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, int CW, float* out_w, float* out_b, void* stream) {
-    if (!parts || n_parts <= 0 || R <= 0 || C <= 0 || CW < 0 || CW > C || !out_w) return GCPNET_E_BADARG;
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)gcp_cdiv(R * C, 64)), dim3(256), 0, (hipStream_t)stream, parts, n_parts, R, C,
-                       CW, out_w, out_b);
+extern "C" int gcpnet_wg_reduce_multi(int n_jobs, const gcp_wg_reduce_job_t* jobs, void* stream) {
+    if (n_jobs <= 0 || n_jobs > GCP_WG_REDUCE_MAX_JOBS || !jobs) return GCPNET_E_BADARG;
+    WgReduceArgs a;
+    int blocks = 1;
+    for (int k = 0; k < n_jobs; ++k) {
+        const gcp_wg_reduce_job_t& J = jobs[k];
+        if (!J.parts || J.n_parts <= 0 || J.R <= 0 || J.C <= 0 || J.CW < 0 || J.CW > J.C || !J.out_w) return GCPNET_E_BADARG;
+        a.j[k] = J;
+        blocks = max(blocks, gcp_cdiv(J.R * J.C, 64));
+    }
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)blocks, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, a);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, int CW, float* out_w, float* out_b, void* stream) {
+    gcp_wg_reduce_job_t J;
+    J.parts = parts; J.n_parts = n_parts; J.R = R; J.C = C; J.CW = CW; J.out_w = out_w; J.out_b = out_b;
+    return gcpnet_wg_reduce_multi(1, &J, stream);
 }
 
 // Plan of one backward launch: workgroup count (= rows of the partial buffers), fused or not, scratch widths.

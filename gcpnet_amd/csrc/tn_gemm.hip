@@ -910,6 +910,12 @@ extern "C" int gcpnet_reduce_partials(int n_jobs, const gcp_reduce_job_t* jobs, 
         max_groups = max(max_groups, gcp_cdiv(J.n_parts, RP_GROUP));
     }
     hipStream_t st = (hipStream_t)stream;
+    if (max_groups == 1) {  // every job fits one group (<= 64 parts: small graphs): the first level writes the result itself
+        for (int i = 0; i < n_jobs; ++i) a.j[i].tmp = a.j[i].out;
+        hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3(1, n_jobs), dim3(256), 0, st, a);
+        GCP_HIP_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3(max_groups, n_jobs), dim3(256), 0, st, a);
     GCP_HIP_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials_kernel<true>, dim3(1, n_jobs), dim3(256), 0, st, a);

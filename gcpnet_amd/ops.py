@@ -835,12 +835,15 @@ def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, 
         w_part = t["w_part"]
         n_small, kw = plan.n_small, plan.kw
 
-        def reduces():  # per-workgroup partial sums -> gradients, fixed order (three small HBM-bound launches)
-            st = _stream()
-            check(lib.gcpnet_wg_reduce(_p(dw_part), grid, so, kw, K, _p(g[0]), _p(g[1]), st), "wg_reduce")
+        def reduces():  # per-workgroup partial sums -> gradients, fixed order (one launch for the two or three buffers)
+            jobs = [(dw_part, so, kw, K, g[0], g[1])]
             if gated:
-                check(lib.gcpnet_wg_reduce(_p(dwg_part), grid, vo, so + 1, so, _p(g[5]), _p(g[6]), st), "wg_reduce")
-            check(lib.gcpnet_wg_reduce(_p(w_part), grid, 1, n_small, n_small, _p(wv), None, st), "wg_reduce")
+                jobs.append((dwg_part, vo, so + 1, so, g[5], g[6]))
+            jobs.append((w_part, 1, n_small, n_small, wv, None))
+            arr = (_lib.WgReduceJob * len(jobs))()
+            for j, (parts, R, Cc, CW, ow, ob) in zip(arr, jobs):
+                j.parts, j.n_parts, j.R, j.C, j.CW, j.out_w, j.out_b = _p(parts), grid, R, Cc, CW, _p(ow), _p(ob)
+            check(lib.gcpnet_wg_reduce_multi(len(jobs), arr, _stream()), "wg_reduce")
 
         if side_reduce and WEIGHT_GRADS_ON_SIDE_STREAM:
             # off the critical path, like the TN GEMMs of the unfused route: they run under the next block's kernel.  Only the

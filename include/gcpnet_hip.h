@@ -222,6 +222,16 @@ typedef struct {
 int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* args, void* stream);
 /* out_w[r, c] = sum_g parts[g, r, c] for c < CW, out_b[r] = sum_g parts[g, r, CW] when C == CW + 1; fixed summation order. */
 int gcpnet_wg_reduce(const float* parts, int n_parts, int R, int C, int CW, float* out_w, float* out_b, void* stream);
+/* The same for up to GCP_WG_REDUCE_MAX_JOBS partial buffers in ONE launch (the three of a fused backward: dw_part, dwg_part,
+ * wsm_part). */
+typedef struct {
+    const float* parts;
+    int n_parts, R, C, CW;
+    float* out_w;
+    float* out_b;  /* may be NULL */
+} gcp_wg_reduce_job_t;
+#define GCP_WG_REDUCE_MAX_JOBS 4
+int gcpnet_wg_reduce_multi(int n_jobs, const gcp_wg_reduce_job_t* jobs, void* stream);
 
 /* ---- GCP2 backward (data path) ----------------------------------------------------------------------------
  * Given d(s_out), d(v_out) and the saved s_pre/gate, writes d(s_in) [rows, si] and d(v_in) [rows, vi, 3] in the

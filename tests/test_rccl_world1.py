@@ -1,7 +1,8 @@
 """The RCCL branches of gcpnet_amd.parallel, executed for real: the GPU boxes of this build have ONE GPU, and RCCL refuses two
 ranks on one device, so the multi-rank tests run over gloo (tests/test_parallel_gloo.py, tests/test_sharded_gpu.py).  What those
 cannot cover is that the `backend == "nccl"` code paths exist in this stack at all -- `ReduceOp.AVG` on the flat gradient bucket,
-`all_gather_into_tensor` / `reduce_scatter_tensor` inside the all_gather_rows autograd Function, a device-bound process group.
+`all_gather_into_tensor` / `reduce_scatter_tensor` inside the all_gather_rows autograd Function, `all_to_all_single` of the halo
+mode, a device-bound process group.
 A process group of size 1 over RCCL runs exactly those calls (a subprocess, so that the suite's process keeps no group)."""
 import os
 import subprocess
@@ -64,6 +65,25 @@ red.all_reduce_mean()  # ReduceOp.AVG inside RCCL: the identity for one rank
 torch.cuda.synchronize()
 for p, w in zip(layer.parameters(), wref):
     close(p.grad, w, "weight gradient (bucket, AVG)")
+# the halo-exchange mode: all_to_all_single over RCCL (one rank: every split is empty, the call itself and its autograd pairing run)
+for v in ins.values():
+    v.grad = None
+for p in layer.parameters():
+    p.grad = None
+sgh = ShardedGraph(ei, n, 0, 1, halo=True).to("cuda")
+assert sgh.table_rows == n and sum(sgh.send_counts) == 0
+h3, chi3 = sharded_interactions_forward(layer, (ins["h"], ins["chi"]), (e_l, xi_l), sgh, fr_l, node_frames)
+((h3 * lw["h"]).sum() + (chi3 * lw["chi"]).sum()).backward()
+torch.cuda.synchronize()
+close(h3, ref["h"], "h (halo)"); close(chi3, ref["chi"], "chi (halo)")
+for k in ("h", "chi"):
+    close(ins[k].grad, ref["d" + k], "d" + k + " (halo)")
+# ... and with real traffic: one rank sending rows to itself through the same call
+send = torch.arange(12, dtype=torch.float32, device="cuda").reshape(4, 3)
+recv = torch.empty_like(send)
+dist.all_to_all_single(recv, send, output_split_sizes=[4], input_split_sizes=[4])
+torch.cuda.synchronize()
+assert torch.equal(recv, send)
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_WORLD1_OK")
