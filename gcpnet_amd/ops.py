@@ -1395,24 +1395,43 @@ def _rows_matmul_small(x2d: Tensor, w: Tensor) -> Tensor:
     return out
 
 
+def _tn_weight_grads_into(items) -> None:
+    """For every (a2d, b2d, out) of `items`: out[M, N] (any row stride, unit column stride) = a2d^T b2d, all in ONE gcpnet_tn_gemm
+    launch (+ one reduction) per GCP_TN_MAX_PROBLEMS problems."""
+    lib = _lib.load()
+    probs, parts = [], []
+    for a2d, b2d, out in items:
+        rows, M = a2d.shape
+        N = b2d.shape[1]
+        assert out.shape == (M, N) and out.stride(1) == 1
+        a, b = Operand(), Operand()
+        a.n, b.n = 1, 1
+        a.ptr[0], a.dim[0], a.ld[0] = a2d.data_ptr(), M, a2d.stride(0)
+        b.ptr[0], b.dim[0], b.ld[0] = b2d.data_ptr(), N, b2d.stride(0)
+        pr = TnProblem()
+        pr.rows, pr.a, pr.b = rows, a, b
+        pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = out.data_ptr(), out.stride(0), 1, M, N
+        pr.out2, pr.out2_n = None, 0
+        pr.splits = lib.gcpnet_tn_splits(rows, M, N)
+        part = torch.empty((pr.splits, M, N), dtype=torch.float32, device=a2d.device)
+        pr.partial = part.data_ptr()
+        probs.append(pr)
+        parts.append(part)  # (alive until the launches are enqueued; the caching allocator keeps them stream-ordered afterwards)
+    # (a launch takes the DMA kernels only if ALL its problems can -- widths / strides multiples of 4 floats, 16-byte aligned --: the
+    # others go in launches of their own)
+    def dma_ok(it):
+        return all(t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in it[:2])
+
+    for group in ([pr for pr, it in zip(probs, items) if dma_ok(it)], [pr for pr, it in zip(probs, items) if not dma_ok(it)]):
+        for i in range(0, len(group), _lib.TN_MAX_PROBLEMS):
+            chunk = group[i:i + _lib.TN_MAX_PROBLEMS]
+            arr = (TnProblem * len(chunk))(*chunk)
+            check(lib.gcpnet_tn_gemm(len(chunk), arr, _stream()), "tn_gemm")
+
+
 def _tn_weight_grad_into(a2d: Tensor, b2d: Tensor, out: Tensor) -> None:
     """out[M, N] (any row stride, unit column stride) = a2d^T b2d through gcpnet_tn_gemm."""
-    lib = _lib.load()
-    rows, M = a2d.shape
-    N = b2d.shape[1]
-    assert out.shape == (M, N) and out.stride(1) == 1
-    a, b = Operand(), Operand()
-    a.n, b.n = 1, 1
-    a.ptr[0], a.dim[0], a.ld[0] = a2d.data_ptr(), M, a2d.stride(0)
-    b.ptr[0], b.dim[0], b.ld[0] = b2d.data_ptr(), N, b2d.stride(0)
-    pr = TnProblem()
-    pr.rows, pr.a, pr.b = rows, a, b
-    pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = out.data_ptr(), out.stride(0), 1, M, N
-    pr.out2, pr.out2_n = None, 0
-    pr.splits = lib.gcpnet_tn_splits(rows, M, N)
-    part = torch.empty((pr.splits, M, N), dtype=torch.float32, device=a2d.device)
-    pr.partial = part.data_ptr()
-    check(lib.gcpnet_tn_gemm(1, C.byref(pr), _stream()), "tn_gemm")
+    _tn_weight_grads_into([(a2d, b2d, out)])
 
 
 class _Gcp2Projected(torch.autograd.Function):
@@ -1586,8 +1605,9 @@ class _Gcp2Projected(torch.autograd.Function):
                     g0[:, offs[k]:offs[k] + dims[k]].copy_(gj[0][:, c:c + dims[k]])
                     c += dims[k]
                 g0[:, spec.si:].copy_(gj[0][:, c:])
-                for k, g in zip(sg, dP):
-                    _tn_weight_grad_into(g, s_src[k], g0[:, offs[k]:offs[k] + dims[k]])
+                # the projected sources' weight gradients (row-split products over the SOURCE rows): one launch for all of them
+                items = [(g, s_src[k], g0[:, offs[k]:offs[k] + dims[k]]) for k, g in zip(sg, dP)]
+                tmps = []
                 if vg:
                     c = 0
                     for k in vr:
@@ -1596,9 +1616,13 @@ class _Gcp2Projected(torch.autograd.Function):
                         c += chans[k]
                     for k, g, vt in zip(vg, dQ, vts):
                         hfp = g.shape[1] // 3
-                        tmp = _tn_weight_grad(g.view(-1, hfp), vt.view(-1, chans[k]))  # [HF', V]
-                        gd[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[:H])
-                        gf[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[H:H + 3])
+                        tmp = torch.empty((hfp, chans[k]), **f32)  # [HF', V]
+                        tmps.append((k, tmp))
+                        items.append((g.view(-1, hfp), vt.view(-1, chans[k]), tmp))
+                _tn_weight_grads_into(items)
+                for k, tmp in tmps:
+                    gd[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[:H])
+                    gf[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[H:H + 3])
 
             keep = [job.keep, dP, dQ, list(s_src), list(vts), scr]
             if ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells):
