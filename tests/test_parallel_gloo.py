@@ -204,3 +204,49 @@ def test_sharded_graph_matches_unsharded(halo):
         for k, v in P.items():
             want = v.grad if v.grad is not None else torch.zeros_like(v)
             assert torch.allclose(o["w"][k], want, atol=2e-6 * max(1.0, float(want.abs().max())), rtol=1e-5), k
+
+
+# ---- data preparation of the halo mode: spatial order and node renaming (no process group) --------------------------------------
+def test_spatial_order_is_a_permutation_that_makes_ranges_compact():
+    from gcpnet_amd.parallel import ShardedGraph, spatial_order
+    from gcpnet_amd.synthetic import make_inputs, reorder_nodes
+
+    host = make_inputs(4000, 12, (8, 2), (4, 1), seed=3)
+    perm = spatial_order(host["x"])
+    assert sorted(perm.tolist()) == list(range(4000))
+    re = reorder_nodes(host, perm)
+    ei = re["edge_index"]
+    assert bool((ei[1][1:] >= ei[1][:-1]).all()), "edges stay sorted by target"
+    # the renamed graph is the same graph: identical multiset of (edge length, edge feature row sum), identical node features per position
+    d0 = (host["x"][host["edge_index"][0]] - host["x"][host["edge_index"][1]]).norm(dim=1) + host["e"].sum(1)
+    d1 = (re["x"][ei[0]] - re["x"][ei[1]]).norm(dim=1) + re["e"].sum(1)
+    assert torch.allclose(d0.sort().values, d1.sort().values)
+    assert torch.equal(re["h"], host["h"][perm]) and torch.equal(re["x"], host["x"][perm])
+    # ... and a contiguous node range now has a small halo: compare the remote sources of rank 1 of 4 before and after
+    before = ShardedGraph(host["edge_index"], 4000, 1, 4).halo_nodes().numel()
+    after = ShardedGraph(ei, 4000, 1, 4).halo_nodes().numel()
+    assert after < before // 2, (before, after)
+
+
+def test_halo_lists_are_consistent_across_ranks():
+    """Every rank derives all send / receive lists from the replicated edge list: what rank q sends to rank r must be what rank r
+    expects from rank q, row for row (no process group needed to check that)."""
+    from gcpnet_amd.parallel import ShardedGraph
+    from gcpnet_amd.synthetic import make_inputs
+
+    host = make_inputs(1500, 8, (8, 2), (4, 1), seed=5)
+    world = 3
+    sgs = [ShardedGraph(host["edge_index"], 1500, r, world, halo=True) for r in range(world)]
+    for r, sg in enumerate(sgs):
+        assert sg.table_rows == sg.n_local + sg.halo_ids.numel() and sum(sg.recv_counts) == sg.halo_ids.numel()
+        assert sg.recv_counts[r] == 0 and sg.send_counts[r] == 0
+        # table ids of the edge sources point at the right global node
+        table_gid = torch.cat((torch.arange(sg.n0, sg.n1), sg.halo_ids))
+        assert torch.equal(table_gid[sg.edge_index[0]], sg.edge_index_global[0])
+        ro = 0
+        for q in range(world):
+            want = sg.halo_ids[ro:ro + sg.recv_counts[q]]          # global ids rank r receives from rank q, in order
+            so = sum(sgs[q].send_counts[:r])
+            sent = sgs[q].send_index[so:so + sgs[q].send_counts[r]] + sgs[q].n0
+            assert torch.equal(want, sent), (r, q)
+            ro += sg.recv_counts[q]
