@@ -773,7 +773,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         if (hp + 1 < NP) WG_LAUNDER();
         }  // passes
 
+#ifndef GCP_WG_STAMP_TAIL  // (-DGCP_WG_STAMP_TAIL: stamps 5 and 6 move behind P7 and P8, to split the tail of the tile for tools/wg_phase_timing.py)
         stamp(5);
+#endif
         WG_LAUNDER();
         if constexpr (FUSED) {
             // ---- P5: dW[own 32 rows of so][K + 1] += ds_pre^T [s | norms | frame scalars | 1] (reduction over the 32 rows) ---
@@ -802,7 +804,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
             }
         }
 
+#ifndef GCP_WG_STAMP_TAIL
         stamp(6);
+#endif
         WG_LAUNDER();
         // the next tile's loads (this tile's again if it is the last: harmless).  Fused: requested after P8 instead -- next to
         // the 100+ persistent accumulator registers the 70 request registers do not fit alongside P7 / P8
@@ -817,21 +821,38 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 gpre[j][0] = g[0]; gpre[j][1] = g[1]; gpre[j][2] = g[2];
             }
         }
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL >= 2  // (variants 2, 3: stamp 5 behind the next tile's requests, stamp 6 behind P7)
+        stamp(5);
+#endif
         // ---- P7: adjoint of the vector prologue: d vh, d vf ---------------------------------------------------------------
         {
-            auto dext = [&](int x) -> float {  // d(extras column x) of this thread's row
-                const int c = si + x;
-                if (split && c >= 32 * (NKT - 1)) {
-                    const int cc = c - 32 * (NKT - 1);
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL == 3  // (variant 3: P7 without its arithmetic -- what the phase costs empty; results wrong)
+            for (int x = psub; x < 0; x += TPR) {
+#else
+            for (int x = psub; x < HF; x += TPR) {
+#endif
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                // d(extras) of this thread's entry (one column for a hidden channel, three for a frame row), REQUESTED here -- all
+                // partial sums of the split tile at once -- and used behind the vector_up^T loop: written as dext(x) calls at the
+                // point of use they compile to one LDS round trip per partial sum, 8 - 24 serial waits per thread (8 k cycles per
+                // tile at (256,32), tools/wg_phase_timing.py with -DGCP_WG_STAMP_TAIL=2)
+                float dxp[3][NW];
+                const int xcol0 = x < H ? x : H + 3 * (x - H), xn = x < H ? 1 : 3;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int xc = xcol0 + (a < xn ? a : 0);       // extras column (a >= xn: a duplicate, not used)
+                    const int cc = si + xc - 32 * (NKT - 1);        // its column inside the split tile, if it lies there
+                    const bool sp = split && cc >= 0;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww)
+                        dxp[a][ww] = sp ? EPART[(ww * 32 + prow) * EPS + cc] : (ww == 0 ? DEXT[prow * EXS + xc] : 0.f);
+                }
+                auto dsum = [&](int a) -> float {  // fixed order, as dext() had it
                     float sacc = 0.f;
 #pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) sacc += EPART[(ww * 32 + prow) * EPS + cc];
+                    for (int ww = 0; ww < NW; ++ww) sacc += dxp[a][ww];
                     return sacc;
-                }
-                return DEXT[prow * EXS + x];
-            };
-            for (int x = psub; x < HF; x += TPR) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                };
                 if (x < H) {
                     if (vo > 0) {
                         const float* wt = WUT + x * WTU;
@@ -854,14 +875,14 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                             }
                         }
                     }
-                    const float dn = dext(x) * RN[prow * (H | 1) + x];
+                    const float dn = dsum(0) * RN[prow * (H | 1) + x];
                     a0 += dn * VH[prow * HS + 3 * x + 0]; a1 += dn * VH[prow * HS + 3 * x + 1]; a2 += dn * VH[prow * HS + 3 * x + 2];
                 } else if (nf) {
                     const int k = x - H;
                     const float* f = FR + prow * 9;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        float ds = dext(H + 3 * k + a);
+                        float ds = dsum(a);
                         if (p.e3 && a == 1) ds *= SGN[prow * 3 + k];
                         a0 = fmaf(f[3 * a + 0], ds, a0); a1 = fmaf(f[3 * a + 1], ds, a1); a2 = fmaf(f[3 * a + 2], ds, a2);
                     }
@@ -881,6 +902,11 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
             }
         }
         wg_barrier();
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL >= 2
+        stamp(6);
+#elif defined(GCP_WG_STAMP_TAIL)
+        stamp(5);
+#endif
 
         WG_LAUNDER();
         // ---- P8: d(v_in) = [vector_down ; vector_down_frames]^T d[vh | vf] (+ pass-through terms) ----------------------------
@@ -924,6 +950,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 p.dvhf[(int64_t)r0 * wdt + i] = x < HF ? DVHF[r * FS + 3 * x + d] : 0.f;
             }
         }
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL < 2
+        stamp(6);
+#endif
         WG_LAUNDER();
         if constexpr (FUSED) request(min(tile + (int)gridDim.x, p.ntiles - 1));
         // ---- P9: small vector weight gradients on the matrix cores (v_mfma_f32_16x16x4_f32): 16 x 16 output tiles of
