@@ -329,6 +329,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         WG_LAUNDER();
         auto stamp = [&](int k) {  // (a tile from the middle of the workgroup's range: steady state, not the drained tail)
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL == 4
+            return;
+#endif
             if (w == 0 && (tile - (int)blockIdx.x) / (int)gridDim.x == p.ntiles / (int)gridDim.x / 2) gcp_stamp(p.stamps, p.stamp_cap, k, lane);
         };
         stamp(0);
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 gpre[j][0] = g[0]; gpre[j][1] = g[1]; gpre[j][2] = g[2];
             }
         }
-#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL >= 2  // (variants 2, 3: stamp 5 behind the next tile's requests, stamp 6 behind P7)
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL >= 2 && GCP_WG_STAMP_TAIL != 4  // (variants 2, 3: stamp 5 behind the next tile's requests, stamp 6 behind P7)
         stamp(5);
 #endif
         // ---- P7: adjoint of the vector prologue: d vh, d vf ---------------------------------------------------------------
@@ -901,10 +904,13 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 }
             }
         }
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL == 4  // (variant 4: slot w = arrival of wave w at the barrier behind P7; slot layout of the tool does not apply)
+        if ((tile - (int)blockIdx.x) / (int)gridDim.x == p.ntiles / (int)gridDim.x / 2) gcp_stamp(p.stamps, p.stamp_cap, w, lane);
+#endif
         wg_barrier();
-#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL >= 2
+#if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL >= 2 && GCP_WG_STAMP_TAIL != 4
         stamp(6);
-#elif defined(GCP_WG_STAMP_TAIL)
+#elif defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL == 1
         stamp(5);
 #endif
 

@@ -72,6 +72,11 @@ lib.gcpnet_debug_set_phase_timing(None, 0)
 print(f"one-block backward (incl. reduces) {a.elapsed_time(b) * 1e3:.0f} us; wg launches: {ops.WG_STATS}")
 t = buf.view(ntiles, 8).cpu().double()
 t = t[(t[:, 7] > 0) & (t[:, 0] > 0)][:512]
+if os.environ.get("WG_STAMPS_RAW"):  # (-DGCP_WG_STAMP_TAIL=4 builds: slot w = arrival of wave w at one barrier)
+    rel = t - t.min(dim=1, keepdim=True).values
+    print("arrival of wave w after the first wave (cycles), median over workgroups:", [round(float(x)) for x in rel.median(dim=0).values])
+    print("spread first -> last, median:", float((t.max(dim=1).values - t.min(dim=1).values).median()))
+    sys.exit(0)
 d = t[:, 1:8] - t[:, :7]
 print(f"workgroups with stamps: {t.shape[0]}, tile total median {(t[:, 7] - t[:, 0]).median().item():.0f} cycles")
 for i, lab in enumerate(BL):
