@@ -18,7 +18,7 @@ EXPORTS = [
     "gcpnet_abi_version", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
     "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_chain_forward_registers_ok", "gcpnet_gcp2_headchain_forward",
-    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
+    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
@@ -146,6 +146,7 @@ def load():
     lib.gcpnet_gcp2_backward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), vp, vp, vp,
                                          vp, vp, vp, P(BwdScratch), vp]
     lib.gcpnet_gcp2_chain_backward.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp]
+    lib.gcpnet_gcp2_chain_backward_gathered.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp, vp, vp]
     lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]
     lib.gcpnet_tn_splits.argtypes = [i32, i32, i32]
     lib.gcpnet_gcp2_bwd_tiles.argtypes = [i32]

@@ -31,7 +31,8 @@
 #endif
 
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
-                             const float* d_v_out, float* d_s_in, float* d_v_in, hipStream_t st);
+                             const float* d_v_out, const int32_t* out_idx, const float* out_scale, float* d_s_in, float* d_v_in,
+                             hipStream_t st);
 
 namespace {
 
@@ -55,6 +56,11 @@ struct ChainBwdParams {
     ChainItemB it[GCP_MAX_CHAIN];
     const float* d_s_out;
     const float* d_v_out;
+    // gathered form: the incoming gradient of row r is out_scale[j] * d_*_out[j], j = out_idx[r] -- the adjoint of a segment
+    // mean / sum over the chain's output (the aggregation, gcpnet.py:939-947) read straight from the node-level table instead of
+    // from a materialised [rows, .] copy; both NULL: d_*_out are per-row tensors
+    const int32_t* out_idx;
+    const float* out_scale;
     float* d_s_in;
     float* d_v_in;
     unsigned long long* stamps;
@@ -238,29 +244,43 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         cb_vin_issue(vb, it.v_in, vi, r0, rows, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
         gcp_load_gate<VQ>(scalar_gate ? it.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
+        int64_t orow0 = row;
+        float osc0 = 1.f;
+        if (p.out_idx) {  // (wave-uniform) gathered incoming gradient: source row and weight of this lane's row
+            orow0 = p.out_idx[row_ok ? row : rows - 1];
+            if (p.out_scale) osc0 = p.out_scale[orow0];
+        }
 #pragma unroll
         for (int t = 0; t < NTG; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j0 = 32 * t + 8 * q + 4 * hi;
-                const float4 b = gcp_load4(p.d_s_out, row, so, j0, row_ok, true);
-                dyr[t][4 * q] = b.x; dyr[t][4 * q + 1] = b.y; dyr[t][4 * q + 2] = b.z; dyr[t][4 * q + 3] = b.w;
+                const float4 b = gcp_load4(p.d_s_out, orow0, so, j0, row_ok, true);
+                dyr[t][4 * q] = osc0 * b.x; dyr[t][4 * q + 1] = osc0 * b.y; dyr[t][4 * q + 2] = osc0 * b.z; dyr[t][4 * q + 3] = osc0 * b.w;
             }
         cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
     }
     gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 
-    auto load_state = [&](const float* state_src, float(&out)[3][NV]) {
+    // (`gathered`: state_src is the node-level table of the incoming gradient, see ChainBwdParams::out_idx; the source row and its
+    // weight are looked up again where they are needed rather than carried in registers across the blocks)
+    auto load_state = [&](const float* state_src, float(&out)[3][NV], bool gathered) {
+        int64_t srow = row;
+        float sc = 1.f;
+        if (gathered) {  // (wave-uniform)
+            srow = p.out_idx[row_ok ? row : rows - 1];
+            if (p.out_scale) sc = p.out_scale[srow];
+        }
 #pragma unroll
         for (int q = 0; q < VQ; ++q) {
             const int o0 = 8 * q + 4 * hi;
             const bool on = row_ok && o0 < vi;
-            const float4* sp = reinterpret_cast<const float4*>(state_src + (on ? (int64_t)row * 3 * vi + 3 * o0 : 0));
+            const float4* sp = reinterpret_cast<const float4*>(state_src + (on ? srow * 3 * vi + 3 * o0 : 0));
             float t[12];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float4 x = sp[j];
-                t[4 * j] = on ? x.x : 0.f; t[4 * j + 1] = on ? x.y : 0.f; t[4 * j + 2] = on ? x.z : 0.f; t[4 * j + 3] = on ? x.w : 0.f;
+                t[4 * j] = on ? sc * x.x : 0.f; t[4 * j + 1] = on ? sc * x.y : 0.f; t[4 * j + 2] = on ? sc * x.z : 0.f; t[4 * j + 3] = on ? sc * x.w : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -269,7 +289,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         }
     };
     float dvs[3][NV];  // d(V) state entering the current block: channel crow(r, hi) of row e.  Loaded here for the last block;
-    load_state(p.d_v_out, dvs);  // afterwards carried over in registers from the end of the block before, where it is computed
+    load_state(p.d_v_out, dvs, p.out_idx != nullptr);  // afterwards carried over in registers from the end of the block before, where it is computed
     for (int k = p.n - 1; k >= 0; --k) {
         kcur = k;
         CB_LAUNDER();
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_xyz_zero(dv);
             gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
             float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
-            load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st);
+            load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st, k == p.n - 1 && p.out_idx != nullptr);
 #pragma unroll
             for (int q = 0; q < VQ; ++q) {
                 const int o0 = 8 * q + 4 * hi;
@@ -680,7 +700,8 @@ int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, hipStream_t 
 // Returns GCPNET_E_UNSUPPORTED when the chain does not fit this kernel; the caller then runs the blocks one by one
 // (gcpnet_gcp2_backward), passing the state through HBM.
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
-                             const float* d_v_out, float* d_s_in, float* d_v_in, hipStream_t st) {
+                             const float* d_v_out, const int32_t* out_idx, const float* out_scale, float* d_s_in, float* d_v_in,
+                             hipStream_t st) {
     const gcp2_weights_t& w0 = items[0].w;
     const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
     if (S.NG != 1 || w0.si != w0.so || w0.vi != w0.vo || w0.vi <= 0 || (w0.si & 3) || S.NTG < 2 || S.NTS != S.NTG) return GCPNET_E_UNSUPPORTED;
@@ -690,6 +711,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
     ChainBwdParams p;
     p.rows = rows; p.frames = frames; p.o = items[0].o; p.n = n;
     p.d_s_out = d_s_out; p.d_v_out = d_v_out; p.d_s_in = d_s_in; p.d_v_in = d_v_in;
+    p.out_idx = out_idx; p.out_scale = out_idx ? out_scale : nullptr;
     bool pwl = true;
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_bwd_item_t& c = items[k];
@@ -713,9 +735,9 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
     return launch_cb2<4>(p, lds_bytes, pwl, st);
 }
 
-extern "C" int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
-                                          const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in,
-                                          void* stream) {
+static int chain_backward_checked(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
+                                  const float* d_v_out, const int32_t* out_idx, const float* out_scale, float* d_s_in, float* d_v_in,
+                                  void* stream) {
     if (rows < 0 || n < 1 || n > GCP_MAX_CHAIN || !items || !d_s_out || !d_v_out || !d_s_in || !d_v_in) return GCPNET_E_BADARG;
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_bwd_item_t& c = items[k];
@@ -730,5 +752,18 @@ extern "C" int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, 
             misaligned(items[k].sc.dgate))
             return GCPNET_E_UNSUPPORTED;
     if (misaligned(d_s_out) || misaligned(d_v_out) || misaligned(d_s_in) || misaligned(d_v_in)) return GCPNET_E_UNSUPPORTED;
-    return gcp2_chain_bwd_registers(rows, frames, n, items, d_s_out, d_v_out, d_s_in, d_v_in, (hipStream_t)stream);
+    return gcp2_chain_bwd_registers(rows, frames, n, items, d_s_out, d_v_out, out_idx, out_scale, d_s_in, d_v_in, (hipStream_t)stream);
+}
+
+extern "C" int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
+                                          const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in,
+                                          void* stream) {
+    return chain_backward_checked(rows, frames, n, items, d_s_out, d_v_out, nullptr, nullptr, d_s_in, d_v_in, stream);
+}
+
+extern "C" int gcpnet_gcp2_chain_backward_gathered(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
+                                                   const float* d_s_tab, const float* d_v_tab, const int32_t* out_idx,
+                                                   const float* out_scale, float* d_s_in, float* d_v_in, void* stream) {
+    if (!out_idx) return GCPNET_E_BADARG;
+    return chain_backward_checked(rows, frames, n, items, d_s_tab, d_v_tab, out_idx, out_scale, d_s_in, d_v_in, stream);
 }

@@ -570,13 +570,15 @@ class GCPMessagePassing(nn.Module):
             self.scalar_message_attention = nn.Sequential(nn.Linear(output_dims.scalar, 1), nn.Sigmoid())
 
     def _messages(self, node_rep, edge_rep, edge_index, frames) -> ScalarVector:
-        m = self._fused_messages(node_rep, edge_rep, edge_index, frames)
+        m, _ = self._fused_messages(node_rep, edge_rep, edge_index, frames)
         if self.use_scalar_message_attention:  # :932-934, one fused kernel (dot product, sigmoid, scale)
             lin = self.scalar_message_attention[0]
             m = ScalarVector(ops.row_gate(m[0], lin.weight, lin.bias), m[1])
         return m
 
-    def _fused_messages(self, node_rep, edge_rep, edge_index, frames) -> ScalarVector:
+    def _fused_messages(self, node_rep, edge_rep, edge_index, frames, agg=None):
+        """-> (messages, False), or with `agg` = (GatherPlan, mean) and a chain that takes it (aggregated messages, True): the
+        ResGCP chain Function then returns the segment sum / mean itself (ops._Gcp2Chain)."""
         h, chi = node_rep
         e, xi = edge_rep
         plan = GraphPlan.get(edge_index, h.shape[0])
@@ -588,7 +590,9 @@ class GCPMessagePassing(nn.Module):
         if rest and self._chainable(rest):
             # ResGCP chain (:921-924) in one launch: the (s, V) state of each 32-edge tile never leaves the chip
             specs = [mod.make_spec([None], [None], residual=True) for mod in rest]
-            return ScalarVector(*ops.gcp2_chain(specs, m[0], m[1], frames, [mod._weights() for mod in rest]))
+            if agg is not None and not self.use_scalar_message_attention:
+                return ScalarVector(*ops.gcp2_chain(specs, m[0], m[1], frames, [mod._weights() for mod in rest], agg=agg)), True
+            return ScalarVector(*ops.gcp2_chain(specs, m[0], m[1], frames, [mod._weights() for mod in rest])), False
         for module in rest:
             same = (module.scalar_input_dim == module.scalar_output_dim
                     and module.vector_input_dim == module.vector_output_dim)
@@ -598,7 +602,7 @@ class GCPMessagePassing(nn.Module):
                 m = _sv_add(m, module.apply_rows([m[0]], [None], [m[1]], [None], frames))
             else:
                 m = ScalarVector(*module.apply_rows([m[0]], [None], [m[1]], [None], frames))
-        return m
+        return m, False
 
     def _chainable(self, mods) -> bool:
         if not self.use_residual_message_gcp or len(mods) > 8 or any(getattr(m, "feedforward_out", False) for m in mods):
@@ -626,11 +630,16 @@ class GCPMessagePassing(nn.Module):
     def forward(self, node_rep, edge_rep, edge_index, frames, node_mask=None) -> ScalarVector:
         frames = mask_frames(frames, edge_index, node_mask)
         node_rep, edge_rep = ScalarVector(*node_rep), ScalarVector(*edge_rep)
-        m = self._messages(node_rep, edge_rep, edge_index, frames)
         n = node_rep[0].shape[0]
         plan = GraphPlan.get(edge_index, n)
         side = plan.row if self.aggregate_with_row else plan.col
         mean = self.reduce_function == "mean"
+        if ops.FUSE_AGGREGATION and not self.use_scalar_message_attention:
+            m, done = self._fused_messages(node_rep, edge_rep, edge_index, frames, agg=(side, mean))
+            if done:
+                return m
+        else:
+            m = self._messages(node_rep, edge_rep, edge_index, frames)
         # scatter(message, col, reduce) (:939-947) as wavefront-segmented reductions over the CSR segments
         agg_s = ops.segment_reduce(m[0], side, mean)
         agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], 3 * self.vector_output_dim), side, mean).reshape(n, self.vector_output_dim, 3)

@@ -448,6 +448,9 @@ PREFER_WG_CHAIN_BACKWARD = True  # chains wider than 128 scalars: block by block
 # ResGCP chains with so <= 128: the register-resident wave-per-tile forward kernel (bf16 x 6 form; 0.62 ms per 7-block launch at
 # (128,16) on 160 k rows against 0.73 ms for the workgroup forward) where its shape test passes; GCPNET_CHAIN_FWD=wg switches back
 PREFER_WAVE_CHAIN_FORWARD = os.environ.get("GCPNET_CHAIN_FWD", "wave") == "wave"
+# The message aggregation inside the ResGCP chain's autograd Function (forward: the same two reductions; backward: the chain backward
+# kernel reads the node-level gradient tables through the edge -> node index, no [E, .] gradient copies).  GCPNET_FUSE_AGG=0: off.
+FUSE_AGGREGATION = os.environ.get("GCPNET_FUSE_AGG", "1") != "0"
 FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains the wave-per-tile chain kernel covers
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
@@ -1154,10 +1157,15 @@ def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t, in_backward_of
 
 class _Gcp2Chain(torch.autograd.Function):
     """x_k = x_{k-1} + GCP_k(x_{k-1}), k = 1..n, in ONE forward launch with the tile state kept on chip.
-    inputs: specs (one per block), frames, s0, v0, then 7 weights per block."""
+    inputs: specs (one per block), agg, frames, s0, v0, then 7 weights per block.
+    `agg` = None, or (GatherPlan, mean): the Function then returns the segment sum / mean of the chain's output over the plan's
+    segments (the message aggregation, components/gcpnet.py:939-947) instead of the per-row output, and its backward hands the
+    segment-level gradient tables to the chain backward kernel, which reads row r's incoming gradient from table row plan.idx[r]
+    (gcpnet_gcp2_chain_backward_gathered) -- the [rows, s] and [rows, V, 3] copies a separate aggregation's backward would write,
+    and the chain backward would read back, never exist."""
 
     @staticmethod
-    def forward(ctx, specs, frames, s0, v0, *weights):
+    def forward(ctx, specs, agg, frames, s0, v0, *weights):
         lib = _lib.load()
         n = len(specs)
         rows, dev = s0.shape[0], s0.device
@@ -1183,7 +1191,9 @@ class _Gcp2Chain(torch.autograd.Function):
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         if rows == 0:  # (an empty edge set: nothing to launch)
             if need_grad:
-                ctx.rows, ctx.n_weights = 0, len(weights)
+                ctx.rows, ctx.n_weights, ctx.agg = 0, len(weights), agg
+            if agg is not None:
+                return (torch.zeros((agg[0].n_src, specs[-1].so), **f32), torch.zeros((agg[0].n_src, specs[-1].vo, 3), **f32))
             return outs[-1][0], outs[-1][1]
         rc = _lib.E_UNSUPPORTED
         sp0 = specs[0]
@@ -1207,19 +1217,30 @@ class _Gcp2Chain(torch.autograd.Function):
             ctx.w_leaf = not any(sp.shared_weights for sp in specs)
             ctx.weights = weights
             ctx.use_cells = _note_uses(weights)
+            ctx.agg = agg
+        if agg is not None:
+            plan, mean = agg
+            m_s, m_v = outs[-1][0], outs[-1][1]
+            vo = specs[-1].vo
+            return (_segment_reduce_raw(m_s, 0, m_s.shape[1], m_s.shape[1], plan, mean),
+                    _segment_reduce_raw(m_v.view(rows, 3 * vo), 0, 3 * vo, 3 * vo, plan, mean).view(plan.n_src, vo, 3))
         return outs[-1][0], outs[-1][1]
 
     @staticmethod
     def backward(ctx, d_s, d_v):
+        agg = ctx.agg
         if ctx.rows == 0:  # no rows: the input gradients are empty, the weights receive none
-            return (None, None, d_s, d_v, *([None] * ctx.n_weights))
+            if agg is not None:  # (no row for the segment-level gradients to reach)
+                return (None, None, None, None, None, *([None] * ctx.n_weights))
+            return (None, None, None, d_s, d_v, *([None] * ctx.n_weights))
         specs, frames, rows = ctx.specs, ctx.frames, ctx.rows
         s0, v0, ws, packs, outs = ctx.state
         n = len(specs)
         f32 = dict(dtype=torch.float32, device=s0.device)
-        d_s = _req(d_s, "grad") if d_s is not None else torch.zeros((rows, specs[0].so), **f32)
-        d_v = _req(d_v, "grad") if d_v is not None else torch.zeros((rows, specs[0].vo, 3), **f32)
-        need_w = ctx.needs_input_grad[4:]
+        out_rows = agg[0].n_src if agg is not None else rows
+        d_s = _req(d_s, "grad") if d_s is not None else torch.zeros((out_rows, specs[0].so), **f32)
+        d_v = _req(d_v, "grad") if d_v is not None else torch.zeros((out_rows, specs[0].vo, 3), **f32)
+        need_w = ctx.needs_input_grad[5:]
         jobs: List[Optional[_WeightGradJob]] = [None] * n
         ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
         nws = [any(need_w[7 * k:7 * k + 7]) for k in range(n)]
@@ -1229,10 +1250,15 @@ class _Gcp2Chain(torch.autograd.Function):
         # (measured at (128,16): 1.2 ms + 0.76 ms of weight-gradient GEMMs per 7 blocks against 7 x 0.33 ms); wider chains --
         # (256,32) -- go block by block through the workgroup kernel; shapes outside both through the generic kernel.
         res = None
-        if not (USE_WG_KERNELS and USE_WG_BACKWARD and PREFER_WG_CHAIN_BACKWARD):
-            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
-        elif specs[0].so <= 128 and not FORCE_WG_CHAIN_BACKWARD:
-            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws)
+        wave_chain = (not (USE_WG_KERNELS and USE_WG_BACKWARD and PREFER_WG_CHAIN_BACKWARD)) or (specs[0].so <= 128 and not FORCE_WG_CHAIN_BACKWARD)
+        if wave_chain:  # (with `agg` the kernel reads the segment-level tables itself)
+            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg)
+        if res is None and agg is not None:
+            # block-by-block routes take per-row gradients: the adjoint of the aggregation as its own launches
+            plan, mean = agg
+            scale = plan.inv_count if mean else None
+            d_s = _gather_rows_raw(d_s, plan, scale)
+            d_v = _gather_rows_raw(d_v.reshape(plan.n_src, -1), plan, scale).view(rows, specs[0].vo, 3)
         if res is not None:
             d_s, d_v, scrs = res
             for k in range(n):
@@ -1261,13 +1287,15 @@ class _Gcp2Chain(torch.autograd.Function):
             g = jobs[k].grads() if jobs[k] is not None else [None] * 7
             wgrads += [gi if need else None for gi, need in zip(g, need_w[7 * k:7 * k + 7])]
         ctx.state = None
-        return (None, None, d_s, d_v, *wgrads)
+        return (None, None, None, d_s, d_v, *wgrads)
 
 
-def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s: Tensor, d_v: Tensor, need_w: Sequence[bool]):
+def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s: Tensor, d_v: Tensor, need_w: Sequence[bool],
+                             out_agg=None):
     """Backward data path of a whole ResGCP chain in one launch (gcpnet_gcp2_chain_backward).  ins[k] = (s, V) input of block
     k, outs[k] = (s_out, v_out, s_pre, gate) saved by the forward.  Returns (d_s_in, d_v_in, per-block scratch dicts), or None
-    when the shape is outside that kernel (the caller then goes block by block)."""
+    when the shape is outside that kernel (the caller then goes block by block).  `out_agg` = (GatherPlan, mean): d_s / d_v are
+    the gradients of the segment sum / mean of the chain's output, [n_seg, so] and [n_seg, vo, 3] (gcpnet_gcp2_chain_backward_gathered)."""
     lib = _lib.load()
     n = len(specs)
     items = (ChainBwdItem * n)()
@@ -1281,21 +1309,31 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
         items[k].s_pre = outs[k][2].data_ptr()
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
         items[k].sc = scr
-    d_s_in, d_v_in = torch.empty_like(d_s), torch.empty_like(d_v)
-    rc = lib.gcpnet_gcp2_chain_backward(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(d_s_in), _p(d_v_in), _stream())
+    d_s_in = torch.empty((rows, specs[0].si), dtype=torch.float32, device=d_s.device)
+    d_v_in = torch.empty((rows, specs[0].vi, 3), dtype=torch.float32, device=d_s.device)
+    if out_agg is not None:
+        plan, mean = out_agg
+        rc = lib.gcpnet_gcp2_chain_backward_gathered(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(plan.idx),
+                                                     _p(plan.inv_count) if mean else None, _p(d_s_in), _p(d_v_in), _stream())
+    else:
+        rc = lib.gcpnet_gcp2_chain_backward(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(d_s_in), _p(d_v_in), _stream())
     if rc == _lib.E_UNSUPPORTED:
         return None
     check(rc, "gcp2_chain_backward")
     return d_s_in, d_v_in, scrs
 
 
-def gcp2_chain(specs: Sequence[Gcp2Spec], s0: Tensor, v0: Tensor, frames: Optional[Tensor], weights: Sequence[tuple]):
-    """Chain of residual GCP2 blocks with identical dims (ResGCP).  `weights[k]` as for gcp2()."""
+def gcp2_chain(specs: Sequence[Gcp2Spec], s0: Tensor, v0: Tensor, frames: Optional[Tensor], weights: Sequence[tuple],
+               agg: Optional[Tuple[GatherPlan, bool]] = None):
+    """Chain of residual GCP2 blocks with identical dims (ResGCP).  `weights[k]` as for gcp2().  `agg` = (plan, mean): returns the
+    segment sum / mean of the chain's output over plan's segments ([n_seg, so], [n_seg, vo, 3]) instead of the per-row output."""
     s0, v0 = _req(s0, "scalar input"), _req(v0, "vector input")
     if frames is not None:
         frames = _req(frames.detach(), "frames")
     flat = [None if t is None else _req(t, "weight") for w in weights for t in w]
-    return _Gcp2Chain.apply(list(specs), frames, s0, v0, *flat)
+    if agg is not None:
+        assert agg[0].rows == s0.shape[0]
+    return _Gcp2Chain.apply(list(specs), agg, frames, s0, v0, *flat)
 
 
 def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor], frames: Optional[Tensor], weights,

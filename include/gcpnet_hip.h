@@ -273,6 +273,13 @@ typedef struct {
 } gcp2_chain_bwd_item_t;
 int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
                                const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in, void* stream);
+/* The same when the chain's output went into a segment sum / mean (the aggregation, components/gcpnet.py:939-947; the reference
+ * gets the adjoint -- d(message)[r] = d(aggregate)[col[r]] / count -- from autograd through torch_scatter): the incoming gradient of
+ * row r is out_scale[j] * d_*_tab[j] with j = out_idx[r] (d_s_tab [n_seg, so], d_v_tab [n_seg, vo, 3]; out_scale NULL = 1), read
+ * from the segment-level tables where the kernel needs it instead of from a materialised [rows, .] copy. */
+int gcpnet_gcp2_chain_backward_gathered(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
+                                        const float* d_s_tab, const float* d_v_tab, const int32_t* out_idx, const float* out_scale,
+                                        float* d_s_in, float* d_v_in, void* stream);
 
 /* ---- weight-gradient GEMM: out[m, n] (+)= sum_r A[r, m] * B[r, n] -------------------------------------------
  * A and B are row-wise concatenations (gcp_concat_t with per-segment leading dimension), optionally passed
