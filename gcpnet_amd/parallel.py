@@ -333,13 +333,21 @@ def sharded_interactions_forward(layer, node_rep, edge_rep, sg: ShardedGraph, fr
     full = sg.all_gather_rows(flat)
     h_full, chi_full = full[:, :s], full[:, s:].reshape(-1, v, 3)
     mp = layer.interaction
-    m = mp._messages(ScalarVector(h_full.contiguous(), chi_full.contiguous()), ScalarVector(*edge_rep), sg.edge_index, frames)
     plan = ops.GatherPlan(sg.col_local, n_loc) if not hasattr(sg, "_col_plan") else sg._col_plan
     sg._col_plan = plan
     mean = mp.reduce_function == "mean"
-    agg_s = ops.segment_reduce(m[0], plan, mean)
-    agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], 3 * v), plan, mean).reshape(n_loc, v, 3)
-    hidden = ScalarVector(agg_s, agg_v)
+    full_rep = ScalarVector(h_full.contiguous(), chi_full.contiguous())
+    done = False
+    if ops.FUSE_AGGREGATION and not mp.use_scalar_message_attention:  # (the aggregation inside the chain's Function, as unsharded)
+        m, done = mp._fused_messages(full_rep, ScalarVector(*edge_rep), sg.edge_index, frames, agg=(plan, mean))
+    else:
+        m = mp._messages(full_rep, ScalarVector(*edge_rep), sg.edge_index, frames)
+    if done:
+        hidden = m
+    else:
+        agg_s = ops.segment_reduce(m[0], plan, mean)
+        agg_v = ops.segment_reduce(m[1].reshape(m[1].shape[0], 3 * v), plan, mean).reshape(n_loc, v, 3)
+        hidden = ScalarVector(agg_s, agg_v)
     if layer.gcp_dropout[0].active:
         hidden = layer.gcp_dropout[0](hidden)
     node_rep = (layer.gcp_norm[1] if layer.pre_norm else layer.gcp_norm[0])(node_rep, residual=hidden)
