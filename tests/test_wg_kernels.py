@@ -185,3 +185,43 @@ def test_wg_and_wave_kernels_agree(G):
         ops.USE_WG_KERNELS = saved
     for k in ref:
         close(alt[k], ref[k], atol=2e-5 * max(1.0, float(ref[k].abs().max())), rtol=1e-4)
+
+
+@pytest.mark.parametrize("mean", [True, False], ids=["mean", "sum"])
+@pytest.mark.parametrize("dims", [(128, 16), (64, 8), (100, 16)], ids=["128x16", "64x8", "100x16-padded"])
+def test_aggregation_inside_the_chain_function_is_bit_identical(G, dims, mean):
+    """ops.gcp2_chain(..., agg=(plan, mean)) -- the chain's Function returns the segment mean / sum itself and its backward kernel reads
+    the node-level gradient tables through the edge -> node index (gcpnet_gcp2_chain_backward_gathered) -- against the same chain
+    followed by ops.segment_reduce as its own Function: same kernels forward, the same fp32 product scale x gradient backward, so
+    outputs, input gradients and weight gradients must agree BITWISE.  Rows not a multiple of 32, a node without in-edges."""
+    from gcpnet_amd import ops
+
+    torch.manual_seed(3)
+    n, e = 57, 1000 + 13
+    s, v = dims
+    mods = [G.GCP2((s, v), (s, v), nonlinearities=("silu", "silu"), bottleneck=4).cuda() for _ in range(3)]
+    g = torch.Generator().manual_seed(4)
+    col = torch.randint(0, n - 1, (e,), generator=g).sort().values  # (node n - 1 receives nothing)
+    plan = ops.GatherPlan(col.cuda(), n)
+    fr = torch.randn(e, 3, 3, generator=g).cuda()
+    s0, v0 = torch.randn(e, s, generator=g).cuda(), torch.randn(e, v, 3, generator=g).cuda()
+    ls, lv = torch.randn(n, s, generator=g).cuda(), torch.randn(n, v, 3, generator=g).cuda()
+    specs = [m.make_spec([None], [None], residual=True) for m in mods]
+    res = []
+    for fused in (True, False):
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        a, b = s0.clone().requires_grad_(), v0.clone().requires_grad_()
+        ws = [m._weights() for m in mods]
+        if fused:
+            o_s, o_v = ops.gcp2_chain(specs, a, b, fr, ws, agg=(plan, mean))
+        else:
+            m_s, m_v = ops.gcp2_chain(specs, a, b, fr, ws)
+            o_s = ops.segment_reduce(m_s, plan, mean)
+            o_v = ops.segment_reduce(m_v.reshape(e, 3 * v), plan, mean).reshape(n, v, 3)
+        ((o_s * ls).sum() + (o_v * lv).sum()).backward()
+        torch.cuda.synchronize()
+        res.append([o_s.detach(), o_v.detach(), a.grad, b.grad] + [p.grad for m in mods for p in m.parameters()])
+    assert float(res[0][0][n - 1].abs().max()) == 0.0 and float(res[0][2].abs().max()) > 0
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
