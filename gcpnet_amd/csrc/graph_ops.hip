@@ -2,6 +2,8 @@
 // GCPLayerNorm (+ residual) and a clamp/axpy.  Every kernel is a pure stream: the design goal is coalesced 16-byte
 // accesses and enough loads in flight per CU; reductions are wavefront-segmented (one 64-lane wave per node), so no
 // atomics are needed for scatter-add over variable-degree nodes.
+#include <cstdlib>
+
 #include "common.h"
 
 unsigned long long* g_gcp_phase_buf = nullptr;
@@ -12,18 +14,23 @@ namespace {
 
 // ---- segment reduce: replaces torch_scatter.scatter(sum|mean) on sorted segments --------------------------------
 // (reference call sites: components/gcpnet.py:946 aggregate, components/__init__.py:197 centroids, :316 node scalarize)
-template <bool VEC4>
+// LPS lanes per segment (VEC4 form): a wave holds 64 / LPS segments -- a 128-float row keeps 32 lanes busy, a 48-float row 12, and a
+// wave64 memory instruction costs the same whether 12 or 64 lanes take part.  Every output element is still summed by ONE lane in
+// the same order (four interleaved partial sums over the segment's rows), so the results do not depend on LPS.
+template <bool VEC4, int LPS = 64>
 __global__ __launch_bounds__(256) void segment_reduce_kernel(int n_seg, const int32_t* __restrict__ seg_ptr,
                                                              const int32_t* __restrict__ perm,
                                                              const float* __restrict__ x, int64_t ldx, int D, int mean,
                                                              float* __restrict__ out, int64_t ldo, int accumulate) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    constexpr int SPW = 64 / LPS;  // segments per wave
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wave = gw * SPW + (threadIdx.x & 63) / LPS;  // (this lane's segment)
+    const int lane = threadIdx.x & (LPS - 1);
     if (wave >= n_seg) return;
     const int beg = seg_ptr[wave], end = seg_ptr[wave + 1];
     const float scale = mean ? 1.0f / (float)max(end - beg, 1) : 1.0f;
     if (VEC4) {
-        for (int d0 = lane * 4; d0 < D; d0 += 256) {
+        for (int d0 = lane * 4; d0 < D; d0 += 4 * LPS) {
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
             int p = beg;
             for (; p + 3 < end; p += 4) {
@@ -308,7 +315,15 @@ extern "C" int gcpnet_segment_reduce(int n_seg, const int32_t* seg_ptr, const in
     if (n_seg == 0) return 0;
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
     const dim3 grid((unsigned)gcp_cdiv(n_seg, 4)), block(256);
-    if (vec)
+    // (GCPNET_SEGRED_LPS=64: one segment per wave whatever the width, the earlier form; A/B knob)
+    static const bool pack_env = !(getenv("GCPNET_SEGRED_LPS") && atoi(getenv("GCPNET_SEGRED_LPS")) == 64);
+    if (vec && pack_env && D <= 64)
+        hipLaunchKernelGGL((segment_reduce_kernel<true, 16>), dim3((unsigned)gcp_cdiv(n_seg, 16)), block, 0, (hipStream_t)stream, n_seg, seg_ptr,
+                           perm, x, ldx, D, mean, out, ldo, accumulate);
+    else if (vec && pack_env && D <= 128)
+        hipLaunchKernelGGL((segment_reduce_kernel<true, 32>), dim3((unsigned)gcp_cdiv(n_seg, 8)), block, 0, (hipStream_t)stream, n_seg, seg_ptr,
+                           perm, x, ldx, D, mean, out, ldo, accumulate);
+    else if (vec)
         hipLaunchKernelGGL(segment_reduce_kernel<true>, grid, block, 0, (hipStream_t)stream, n_seg, seg_ptr, perm, x, ldx,
                            D, mean, out, ldo, accumulate);
     else

@@ -33,6 +33,8 @@ for case in range(n_cases):
     ocfg = O.default_module_cfg(**dict(over, nonlinearities=(act_s, act_v)))
     olc = O.default_layer_cfg(**lover)
     n, e = rng.choice([(40, 300), (300, 4000), (33, 64)])
+    if os.environ.get("SWEEP_ONLY") and case != int(os.environ["SWEEP_ONLY"]):  # (re-run ONE case of a seed: the draws above still advance)
+        continue
     print(f"{case:3d} N={n} E={e} dims={dims} acts=({act_s},{act_v}) b={bott} {lover} upd={upd} force={force}: ", end="", flush=True)
     torch.manual_seed(case)
     layer = G.GCPInteractions(dims, (32, 4), cfg=cfg, layer_cfg=lc, dropout=0.0, updating_node_positions=upd).cuda().eval()
@@ -113,7 +115,10 @@ for case in range(n_cases):
         for k in ins:
             dif = (gi[k].grad.cpu().double() - c64[k].grad).flatten(1).abs().max(dim=1).values
             bad_rows[k] = int((dif > 1e-4 * float(c64[k].grad.abs().max())).sum())
-        few = all(v <= max(3, gi[k].shape[0] // 200) for k, v in bad_rows.items())
+        # ("handful": 0.5 % of the rows, and for the node tensors one node plus its in-neighbours -- a unit that flips in a NODE-level
+        # block, e.g. the first feed-forward GCP, reaches the source nodes of that node's in-edges through the aggregation)
+        fan_in = 2 + e // max(n, 1)
+        few = all(v <= max(3, gi[k].shape[0] // 200, fan_in if k in ("h", "chi") else 0) for k, v in bad_rows.items())
         note += f" [rows off by > 1e-4: {bad_rows}]"
         if not worse or few:
             worst = 0.0 if not worse else min(worst, 2.9e-3)
