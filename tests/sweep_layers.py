@@ -120,6 +120,11 @@ for case in range(n_cases):
         fan_in = 2 + e // max(n, 1)
         few = all(v <= max(3, gi[k].shape[0] // 200, fan_in if k in ("h", "chi") else 0) for k, v in bad_rows.items())
         note += f" [rows off by > 1e-4: {bad_rows}]"
+        if os.environ.get("SWEEP_VERBOSE") == str(case):  # which node rows, and are they one node + (some of) its in-neighbours?
+            dif = (gi["h"].grad.cpu().double() - c64["h"].grad).flatten(1).abs().max(dim=1).values
+            rows_h = torch.nonzero(dif > 1e-4 * float(c64["h"].grad.abs().max())).flatten().tolist()
+            expl = [i for i in rows_h if set(rows_h) <= ({i} | set(ei[0][ei[1] == i].tolist()))]
+            print(f"\n      h rows off: {rows_h}; nodes i with all of them inside {{i}} + sources of i's in-edges: {expl}")
         if not worse or few:
             worst = 0.0 if not worse else min(worst, 2.9e-3)
     if os.environ.get("SWEEP_VERBOSE") == str(case):
