@@ -78,18 +78,19 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int n_seg, const in
 }
 
 // ---- gather rows (adjoint of the segment reduce; also plain index_select) ---------------------------------------
-template <bool VEC4>
+template <bool VEC4, int LPS = 64>  // (LPS lanes per row, 64 / LPS rows per wave: as segment_reduce_kernel)
 __global__ __launch_bounds__(256) void gather_rows_kernel(int rows, const int32_t* __restrict__ idx,
                                                           const float* __restrict__ x, int64_t ldx, int D,
                                                           const float* __restrict__ scale, float* __restrict__ out,
                                                           int64_t ldo) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPS;
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (threadIdx.x & 63) / LPS;
+    const int lane = threadIdx.x & (LPS - 1);
     if (r >= rows) return;
     const int64_t src = idx ? idx[r] : r;
     const float s = scale ? scale[src] : 1.0f;
     if (VEC4) {
-        for (int d0 = lane * 4; d0 < D; d0 += 256) {
+        for (int d0 = lane * 4; d0 < D; d0 += 4 * LPS) {
             float4 v = *reinterpret_cast<const float4*>(x + src * ldx + d0);
             v.x *= s; v.y *= s; v.z *= s; v.w *= s;
             *reinterpret_cast<float4*>(out + (int64_t)r * ldo + d0) = v;
@@ -350,7 +351,13 @@ extern "C" int gcpnet_gather_rows(int rows, const int32_t* idx, const float* x, 
     if (rows == 0) return 0;
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
     const dim3 grid((unsigned)gcp_cdiv(rows, 4)), block(256);
-    if (vec)
+    if (vec && D <= 64)
+        hipLaunchKernelGGL((gather_rows_kernel<true, 16>), dim3((unsigned)gcp_cdiv(rows, 16)), block, 0, (hipStream_t)stream, rows, idx, x, ldx, D,
+                           scale, out, ldo);
+    else if (vec && D <= 128)
+        hipLaunchKernelGGL((gather_rows_kernel<true, 32>), dim3((unsigned)gcp_cdiv(rows, 8)), block, 0, (hipStream_t)stream, rows, idx, x, ldx, D,
+                           scale, out, ldo);
+    else if (vec)
         hipLaunchKernelGGL(gather_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, rows, idx, x, ldx, D, scale, out, ldo);
     else
         hipLaunchKernelGGL(gather_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, rows, idx, x, ldx, D, scale, out, ldo);
