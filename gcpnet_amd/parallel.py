@@ -280,8 +280,14 @@ class ShardedGraph:
         g_local = g_table[:n_loc].clone()
         back = g_table.new_zeros((int(self.send_index.numel()), g_table.shape[1]))
         self._all_to_all(back, g_table[n_loc:].contiguous(), self.send_counts, self.recv_counts)
-        if back.shape[0]:
-            g_local.index_add_(0, self.send_index, back)
+        # one index_add_ per consumer rank: inside a consumer's block the local rows are distinct (no colliding atomics), and the
+        # blocks are added in rank order -- the sum is the same in every run, like every other reduction of this package
+        off = 0
+        for k in range(self.world):
+            c = self.send_counts[k]
+            if c:
+                g_local.index_add_(0, self.send_index[off:off + c], back[off:off + c])
+            off += c
         return g_local
 
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
