@@ -1366,9 +1366,10 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
             dims = [t.shape[1] for t in s_sources]
             off = sum(dims[:k])
             src = s_sources[k]
-            add = _Project.apply(src[:, :cut], w_scalar[:, off:off + cut])
+            left, right = _SplitCols.apply(src, cut)
+            add = _Project.apply(left, w_scalar[:, off:off + cut])
             w_rest = torch.cat([w_scalar[:, :off], w_scalar[:, off + cut:]], dim=1)
-            s_sources = list(s_sources[:k]) + [src[:, cut:].contiguous()] + list(s_sources[k + 1:])
+            s_sources = list(s_sources[:k]) + [right] + list(s_sources[k + 1:])
             spec = replace(spec, si=spec.si - cut, pack_cache=None, add_plans=[spec.s_plans[k]])
             weights = (w_rest,) + tuple(weights[1:])
             vadds = []
@@ -1941,6 +1942,32 @@ class _ProjectV(torch.autograd.Function):
             else:
                 dw = torch.matmul(dq.reshape(3 * n, hfp).t(), vt.reshape(3 * n, V))
         return dv, dw
+
+
+class _SplitCols(torch.autograd.Function):
+    """x [n, w] -> (x[:, :cut] as a view, x[:, cut:] as a contiguous copy).  The backward writes the two gradient pieces into ONE
+    fresh [n, w] tensor.  Plain slicing leaves this to autograd, which builds a zero-filled [n, w] tensor per slice and adds them:
+    for the second feed-forward GCP of configs[4] ([100 000, 1 024], cut = 896) ~2.8 GB of traffic per layer instead of 0.8."""
+
+    @staticmethod
+    def forward(ctx, x, cut):
+        ctx.cut, ctx.shape = int(cut), tuple(x.shape)
+        return x[:, :cut], x[:, cut:].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_left, g_right):
+        cut = ctx.cut
+        ref = g_left if g_left is not None else g_right
+        g = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        if g_left is not None:
+            g[:, :cut].copy_(g_left)
+        else:
+            g[:, :cut].zero_()
+        if g_right is not None:
+            g[:, cut:].copy_(g_right)
+        else:
+            g[:, cut:].zero_()
+        return g, None
 
 
 class _Project(torch.autograd.Function):
