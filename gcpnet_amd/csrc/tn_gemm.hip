@@ -38,10 +38,13 @@ namespace {
 #define GCP_TN_RK 32  // rows per staged chunk (16 or 32: -DGCP_TN_RK=16 halves the staging buffers; measured, see the header of x3_step)
 #endif
 constexpr int TN_BM = 128, TN_BN = 160, TN_RK = GCP_TN_RK;
-// Rows per split: about one split per CU for the big (edge-row) problems -- with one or two output blocks that is one
-// balanced wave of workgroups over the 256 CUs, two resident per CU -- and never fewer than 64 rows (node-row problems).
-constexpr int TN_TARGET_SPLITS = 256, TN_MIN_ROWS_PER_SPLIT = 64;
-// host side: rows per split for the target split count (GCPNET_TN_SPLITS overrides the 256: a tuning knob)
+// Rows per split: 128 splits for the big (edge-row) problems, and never fewer than 64 rows (node-row problems).  Alone a launch is
+// fastest with 256 - 512 splits (every CU busy); inside the training step, where these launches share the chip with the caller's
+// stream, HALF of that wins -- fewer resident workgroups, half the partial sums: configs[1] 11.64 -> 11.37 ms, configs[4] 213.8 ->
+// 212.9 ms, c4 under hipGraph replay 4.37 -> 4.30 ms, configs[3] equal (64 and 96 splits: no further gain;
+// profiles/r03_tn_bf16x3.txt).
+constexpr int TN_TARGET_SPLITS = 128, TN_MIN_ROWS_PER_SPLIT = 64;
+// host side: rows per split for the target split count (GCPNET_TN_SPLITS overrides the 128: a tuning knob)
 inline int tn_rows_per_split_host(int rows) {
     static const int target = getenv("GCPNET_TN_SPLITS") && atoi(getenv("GCPNET_TN_SPLITS")) > 0 ? atoi(getenv("GCPNET_TN_SPLITS")) : TN_TARGET_SPLITS;
     const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, target), TN_RK);
