@@ -1186,7 +1186,8 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     plan->kt = KTn == 1 ? 1 : 4;
     plan->fused = fused;
     const int per_cu = (fused && NW == 4 && D.NNT <= 2 && getenv("GCPNET_WG_BWD_FN2")) ? 3 : 2;  // resident workgroups per CU of the instantiation that will run
-    plan->grid = ntiles <= 0 ? 1 : min(ntiles, per_cu * g_wg_cus);
+    static const int per_cu_env = getenv("GCPNET_WG_BWD_PER_CU") ? atoi(getenv("GCPNET_WG_BWD_PER_CU")) : 0;  // (tuning knob: persistent workgroups per CU)
+    plan->grid = ntiles <= 0 ? 1 : min(ntiles, (per_cu_env > 0 ? per_cu_env : per_cu) * g_wg_cus);
     plan->kw = KW;
     plan->n_small = n_sm;
     plan->ext_w = gcp_round_up(S.H + S.nf, 4);
