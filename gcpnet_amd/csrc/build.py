@@ -10,11 +10,30 @@ LIB = os.path.join(HERE, "libgcpnet_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def _extra():
+    return os.environ.get("GCPNET_HIPCC_EXTRA", "")
+
+
+def _stamp(obj):
+    """Per-object record of the flags the object was compiled with (written right after THAT compile succeeds, so a failed or
+    partial build with measurement flags cannot leave objects that a later plain build links)."""
+    return obj + ".flags"
+
+
+def _obj_fresh(src, obj, dep_t, flags):
+    st = _stamp(obj)
+    return (os.path.exists(obj) and os.path.exists(st) and open(st).read() == flags
+            and os.path.getmtime(obj) > max(dep_t, os.path.getmtime(os.path.join(HERE, src))))
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS + ["build.py"])
+    if any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS + ["build.py"]):
+        return True
+    flag_file = os.path.join(HERE, ".build_flags")  # flags of the last successful LINK
+    return not (os.path.exists(flag_file) and open(flag_file).read() == _extra())
 
 
 def build(force=False, verbose=False):
@@ -23,27 +42,34 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    extra = os.environ.get("GCPNET_HIPCC_EXTRA", "")
+    extra = _extra()
+    flags = " ".join(FLAGS) + " | " + extra
     flag_file = os.path.join(HERE, ".build_flags")
-    flags_same = os.path.exists(flag_file) and open(flag_file).read() == extra
     dep_t = max(os.path.getmtime(os.path.join(HERE, f)) for f in HEADERS + ["build.py"])
     for src in SOURCES:
         obj = os.path.join(HERE, src.replace(".hip", ".o"))
         objs.append(obj)
-        # incremental: an object newer than its source, every header and this script (built with the same extra flags) is kept
-        if (not force and flags_same and os.path.exists(obj)
-                and os.path.getmtime(obj) > max(dep_t, os.path.getmtime(os.path.join(HERE, src)))):
+        # incremental: an object newer than its source, every header and this script, stamped with the SAME flags, is kept
+        if not force and _obj_fresh(src, obj, dep_t, flags):
             continue
-        cmd = [hipcc] + FLAGS + os.environ.get("GCPNET_HIPCC_EXTRA", "").split() + ["-c", os.path.join(HERE, src), "-o", obj]
+        if os.path.exists(_stamp(obj)):
+            os.remove(_stamp(obj))
+        cmd = [hipcc] + FLAGS + extra.split() + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = []
+    for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+            failed.append(f"hipcc failed on {src}:\n{out.decode()}")
+            continue
+        with open(_stamp(obj), "w") as f:
+            f.write(flags)
         if verbose and out:
             print(out.decode())
+    if failed:
+        raise RuntimeError("\n".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
     with open(flag_file, "w") as f:

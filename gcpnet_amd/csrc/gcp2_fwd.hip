@@ -726,6 +726,13 @@ void fill_item(ChainItem& it, const gcp2_weights_t& w, const gcp2_opts_t& o, flo
 }  // namespace
 
 extern "C" int gcpnet_abi_version(void) { return GCPNET_ABI_VERSION; }
+extern "C" int gcpnet_debug_knobs_compiled(void) {
+#ifdef GCP_DEBUG_KNOBS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int64_t gcpnet_gcp2_pack_floats(int si, int vi, int so, int vo, int hidden, int use_frames) {
     return gcp_shape(si, vi, so, vo, hidden, use_frames).total;

@@ -792,12 +792,17 @@ extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
 
 extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream) {
     if (n_problems <= 0 || n_problems > GCP_TN_MAX_PROBLEMS || !problems) return GCPNET_E_BADARG;
-    // (GCPNET_DEBUG_SKIP_TN: measurement knob -- no launch, the gradients stay unwritten: "what would the step cost without these")
-    static const bool skip_env = getenv("GCPNET_DEBUG_SKIP_TN") != nullptr;
-    if (skip_env) return 0;
     TnArgs a;
     a.n = n_problems;
+    a.debug = 0;
+#ifdef GCP_DEBUG_KNOBS
+    // Measurement knobs that CHANGE RESULTS exist only in a -DGCP_DEBUG_KNOBS build (never shipped; gcpnet_debug_knobs_compiled()
+    // reports it and bench.py refuses such a library).  GCPNET_DEBUG_SKIP_TN: no launch, the gradients stay unwritten ("what would
+    // the step cost without these"); GCPNET_TN_DEBUG: bit 0 = no products, bit 1 = no DMA after the first chunk.
+    static const bool skip_env = getenv("GCPNET_DEBUG_SKIP_TN") != nullptr;
+    if (skip_env) return 0;
     a.debug = getenv("GCPNET_TN_DEBUG") ? atoi(getenv("GCPNET_TN_DEBUG")) : 0;
+#endif
     a.cyclic = getenv("GCPNET_TN_BLOCKED") == nullptr;  // (GCPNET_TN_BLOCKED: contiguous row range per split, the earlier form, for A/B runs)
     int blocks = 0, max_mn = 0;
     bool dma = true;

@@ -468,6 +468,10 @@ int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);
  * the previous setting (-1: never set). */
 int gcpnet_debug_set_fp32_mfma(int on);
 
+/* 1 when the library was built with -DGCP_DEBUG_KNOBS: only such a build honours the measurement knobs that change RESULTS
+ * (GCPNET_DEBUG_SKIP_TN, GCPNET_TN_DEBUG).  The shipped build returns 0; bench.py refuses to produce a line with a 1. */
+int gcpnet_debug_knobs_compiled(void);
+
 int gcpnet_abi_version(void);
 
 #ifdef __cplusplus

@@ -33,7 +33,9 @@ def test_host_only_entry_points():
     SV = 18 + 8 + 8 + 2 * 8
     assert n == (NG * KK * 64 * NTG + NGK * NS * 64 * NUG + 1 * NS * 64 + 8 * NG * 64 * NTG + NTS * 16 * 64 * NTG
                  + SV * 64)
-    assert lib.gcpnet_tn_splits(160000, 128, 142) == 250
+    # 128 row splits by default (csrc/tn_gemm.hip TN_TARGET_SPLITS): ceil(160000 / 128) rounded up to whole 32-row chunks = 1280 rows
+    assert lib.gcpnet_tn_splits(160000, 128, 142) == 125
+    assert lib.gcpnet_debug_knobs_compiled() == 0  # the shipped build carries no result-changing measurement knob
     assert lib.gcpnet_tn_splits(0, 1, 1) == 1
     # packed image of a chainable block: the fp32 sections + the three-term bf16 sections B6 / F6 / C6 (csrc/gcp_bf16x3.h):
     # (128,16,H=4): NTG = 4, NKT = 5 -> 2*4*5*768 + 2*4*4*768 + 2*4*768 floats on top
