@@ -217,7 +217,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         so = S.so; vi = S.vi; /* si == so, vo == vi */                                                                    \
         H = HC ? HC : S.H; HF = HC ? HC + 3 : S.HF; /* (frames are in use whenever HC is given) */                         \
         SVB = HC ? 4 * ((HC + 7) / 8) : S.SVB; SVD = HC ? 4 * ((HC + 3 + 7) / 8) : S.SVD;                                  \
-        EP = gcp_round_up(S.H + S.nf, 4); VOP = gcp_round_up(vi, 4);                                                      \
+        EP = HC ? gcp_round_up(HC + 9, 4) : gcp_round_up(S.H + S.nf, 4); VOP = gcp_round_up(vi, 4);                                                      \
         slope = p.o.slope;                                                                                                \
         scalar_gate = p.o.vmode == GCP_VMODE_SCALAR_GATE;                                                                 \
         NUG = S.NUG;                                                                                                      \
@@ -290,6 +290,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     };
     float dvs[3][NV];  // d(V) state entering the current block: channel crow(r, hi) of row e.  Loaded here for the last block;
     load_state(p.d_v_out, dvs, p.out_idx != nullptr);  // afterwards carried over in registers from the end of the block before, where it is computed
+    // sums of the second partial-sum pass of the block before and where they go: they leave with the NEXT block's small stores (end
+    // of its step C), so that the coming block's requests do not queue behind them
+    f32x4 tn2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* tn2_part = nullptr;
     for (int k = p.n - 1; k >= 0; --k) {
         kcur = k;
         CB_LAUNDER();
@@ -302,7 +306,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 2, lane);
 
         // ---- A. recompute [vh | vf] = [vector_down ; vector_down_frames] v on the matrix cores; norms and frame scalars
-        //         (element-wise) go to the weight-gradient GEMM's operand `ext`; 1/|vh| and the e3 signs stay in registers --
+        //         (element-wise) go to the weight-gradient GEMM's operand `ext` -- through the LDS tile `dext` (free until the end of
+        //         step E), from which they leave as full rows behind the s_pre requests at the end of step C: no store in step A -----
         float dgr[NV];
         {
             gcp_xyz_acc u;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 if (x < H) {
                     const float nr = sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + 1e-8f);
                     vht[e * L.HS + 3 * x + 0] = u0; vht[e * L.HS + 3 * x + 1] = u1; vht[e * L.HS + 3 * x + 2] = u2;
-                    if (row_ok) it.ext[(int64_t)row * EP + x] = nr + 1e-8f;
+                    dext[e * L.DS + x] = nr + 1e-8f;
                 } else if (x < HF) {
                     const int kk = x - H;
 #pragma unroll
@@ -327,16 +332,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                             e3t[e * 3 + kk] = pr < 0.f ? -1.f : 1.f;  // sign for the adjoint of |.|
                             pr = fabsf(pr);
                         }
-                        if (row_ok) it.ext[(int64_t)row * EP + H + 3 * kk + a] = pr;
+                        dext[e * L.DS + H + 3 * kk + a] = pr;
                     }
                 }
-            }
-            // (staging these rows in LDS and writing them as full lines was tried: same time, -1 % counter traffic, but the extra
-            // control flow cost the kernel 67 spilled registers)
-            if (row_ok && hi == 0) {  // zero the stride padding
-                for (int c = H + S.nf; c < EP; ++c) it.ext[(int64_t)row * EP + c] = 0.f;
-                if (scalar_gate)
-                    for (int c = vi; c < VOP; ++c) it.dgate[(int64_t)row * VOP + c] = 0.f;
             }
             // ---- B. vu = vector_up(vh), B fragments = the registers just produced ------------------------------------
             gcp_xyz_acc vu;
@@ -373,15 +371,58 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                     xt[e * L.VS + 3 * o + 0] = d0; xt[e * L.VS + 3 * o + 1] = d1; xt[e * L.VS + 3 * o + 2] = d2;
                 }
             }
-            if (scalar_gate) {
-#pragma unroll
-                for (int q = 0; q < VQ; ++q)
-                    if (row_ok && 8 * q + 4 * hi < VOP)  // (VOP % 4 == 0, dgate 16-byte aligned: one guarded 16-byte store)
-                        *reinterpret_cast<float4*>(it.dgate + (int64_t)row * VOP + 8 * q + 4 * hi) =
-                            make_float4(dgr[4 * q], dgr[4 * q + 1], dgr[4 * q + 2], dgr[4 * q + 3]);
-            }
         }
         gcp_wave_lds_sync();
+        // per-tile partial sums of the small vector weight gradients (v_mfma_f32_16x16x4_f32 over the tile's 96 (row, xyz)
+        // pairs, operands = the row-major LDS copies); reduced over tiles by gcpnet_reduce_partials
+        const int l16 = lane & 15, kq = lane >> 4;
+        // (step st = 3 u + v covers the reduction index 12 u + 4 v + kq: row 4 u + (4 v + kq) / 3, component (4 v + kq) % 3 -- three
+        // per-lane (row, component) pairs for the whole pass; the 24 operand pairs are read from LDS in batches of GCP_CB_TNB and
+        // accumulated in three independent chains: the pass is a latency chain, 6.6 k -> ~2 k cycles with this)
+        // One 16 x 16 output tile (M, N <= 16: vi <= 16 and H + 3 <= 16 in this kernel); the sums stay in registers and leave with
+        // the next batch of stores (small_tn_store)
+        auto small_tn = [&](const float* A, int ars, int ams, int ads, int M, const float* B, int brs, int bms, int bds, int N) -> f32x4 {
+            int aoff[3], boff[3], rv[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int kk = 4 * v + kq, rr = kk / 3, d = kk - 3 * rr;
+                rv[v] = rr; aoff[v] = rr * ars + d * ads; boff[v] = rr * brs + d * bds;
+            }
+            const bool mok = l16 < M, nok = l16 < N;
+            const float* ap = A + (mok ? l16 : 0) * ams;
+            const float* bp = B + (nok ? l16 : 0) * bms;
+            f32x4 acc[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int part4 = 0; part4 < 24 / GCP_CB_TNB; ++part4) {
+                constexpr int NB = GCP_CB_TNB, UB = NB / 3;
+                float av[NB], bv[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int u = UB * part4 + i / 3, v = i % 3;
+                    av[i] = ap[4 * u * ars + aoff[v]];
+                    bv[i] = bp[4 * u * brs + boff[v]];
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int u = UB * part4 + i / 3, v = i % 3;
+                    const float a = (mok && r0 + 4 * u + rv[v] < rows) ? av[i] : 0.f;
+                    acc[v % GCP_CB_TNC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, nok ? bv[i] : 0.f, acc[v % GCP_CB_TNC], 0, 0, 0);
+                }
+            }
+            f32x4 r4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r4[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+            return r4;
+        };
+        auto small_tn_store = [&](const f32x4& v, int M, int N, float* out, bool transposed) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * kq + r;
+                if (i < M && l16 < N) out[transposed ? l16 * M + i : i * N + l16] = v[r];
+            }
+        };
         // s_pre of this block: requested here, where few registers are live, and in flight under the first partial-sum pass
         f32x16 spr[NTG];
 #pragma unroll
@@ -392,58 +433,44 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 spr[t][4 * q] = a.x; spr[t][4 * q + 1] = a.y; spr[t][4 * q + 2] = a.z; spr[t][4 * q + 3] = a.w;
             }
         __builtin_amdgcn_sched_barrier(0);
-        // per-tile partial sums of the small vector weight gradients (v_mfma_f32_16x16x4_f32 over the tile's 96 (row, xyz)
-        // pairs, operands = the row-major LDS copies); reduced over tiles by gcpnet_reduce_partials
-        const int l16 = lane & 15, kq = lane >> 4;
-        // (step st = 3 u + v covers the reduction index 12 u + 4 v + kq: row 4 u + (4 v + kq) / 3, component (4 v + kq) % 3 -- three
-        // per-lane (row, component) pairs for the whole pass; the 24 operand pairs are read from LDS in batches of GCP_CB_TNB and
-        // accumulated in three independent chains: the pass is a latency chain, 6.6 k -> ~2 k cycles with this)
-        auto small_tn = [&](const float* A, int ars, int ams, int ads, int M, const float* B, int brs, int bms, int bds, int N,
-                            float* out, bool transposed) {
-            int aoff[3], boff[3], rv[3];
+        // ... and BEHIND the requests the block's small stores.  (vmcnt retires loads and stores in issue order, and a store is only
+        // retired once L2 has acknowledged it: a load requested behind a batch of stores cannot be used before all of them are
+        // through.  The per-element stores of the norms that sat inside step A cost a full acknowledgement round trip each -- hipcc
+        // waits vmcnt(0) at the merge points of that divergent code -- and another one in front of vector_up's fragments.)  The norms /
+        // frame scalars leave as whole rows of [rows, EP] (a tile is one contiguous piece of 32 EP floats; columns past H + nf are the
+        // stride padding: zeros), d(gate) from the registers, and the second partial-sum pass's sums of the block before
+        {
+            const int q4 = EP >> 2, n4 = min(rows - r0, GCP_TILE_ROWS) * q4, hn = H + S.nf;
+            const unsigned magic = (unsigned)(((1ull << 32) + (unsigned)q4 - 1) / (unsigned)q4);  // idx / q4 for idx < 2^16
+            float4* dst = reinterpret_cast<float4*>(it.ext + (int64_t)r0 * EP);
+            float4 xv[4];
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int kk = 4 * v + kq, rr = kk / 3, d = kk - 3 * rr;
-                rv[v] = rr; aoff[v] = rr * ars + d * ads; boff[v] = rr * brs + d * bds;
+            for (int j = 0; j < 4; ++j) {  // (EP <= 32: at most 256 pieces per tile)
+                xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (64 * j >= GCP_TILE_ROWS * q4) continue;  // (wave-uniform; a compile-time test in the HC instantiations)
+                const int idx = min(lane + 64 * j, GCP_TILE_ROWS * q4 - 1);
+                const int rr = (int)__umulhi((unsigned)idx, magic), c = 4 * (idx - rr * q4);
+                const float* s4 = dext + rr * L.DS;
+                const float a0 = s4[min(c, hn - 1)], a1 = s4[min(c + 1, hn - 1)], a2 = s4[min(c + 2, hn - 1)], a3 = s4[min(c + 3, hn - 1)];
+                xv[j] = make_float4(c < hn ? a0 : 0.f, c + 1 < hn ? a1 : 0.f, c + 2 < hn ? a2 : 0.f, c + 3 < hn ? a3 : 0.f);
             }
-            for (int mt = 0; mt < M; mt += 16)
-                for (int nt = 0; nt < N; nt += 16) {
-                    const int m = mt + l16, n = nt + l16;
-                    const bool mok = m < M, nok = n < N;
-                    const float* ap = A + (mok ? m : 0) * ams;
-                    const float* bp = B + (nok ? n : 0) * bms;
-                    f32x4 acc[3];
 #pragma unroll
-                    for (int v = 0; v < 3; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j)
+                if (64 * j < GCP_TILE_ROWS * q4 && lane + 64 * j < n4) dst[lane + 64 * j] = xv[j];
+            if (scalar_gate) {
 #pragma unroll
-                    for (int part4 = 0; part4 < 24 / GCP_CB_TNB; ++part4) {
-                        constexpr int NB = GCP_CB_TNB, UB = NB / 3;
-                        float av[NB], bv[NB];
-#pragma unroll
-                        for (int i = 0; i < NB; ++i) {
-                            const int u = UB * part4 + i / 3, v = i % 3;
-                            av[i] = ap[4 * u * ars + aoff[v]];
-                            bv[i] = bp[4 * u * brs + boff[v]];
-                        }
-#pragma unroll
-                        for (int i = 0; i < NB; ++i) {
-                            const int u = UB * part4 + i / 3, v = i % 3;
-                            const float a = (mok && r0 + 4 * u + rv[v] < rows) ? av[i] : 0.f;
-                            acc[v % GCP_CB_TNC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, nok ? bv[i] : 0.f, acc[v % GCP_CB_TNC], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = mt + 4 * kq + r;
-                        if (i < M && nok) out[transposed ? n * M + i : i * N + n] = (acc[0][r] + acc[1][r]) + acc[2][r];
-                    }
-                }
-        };
+                for (int q = 0; q < VQ; ++q)
+                    if (row_ok && 8 * q + 4 * hi < VOP)  // (VOP % 4 == 0, dgate 16-byte aligned: one guarded 16-byte store)
+                        *reinterpret_cast<float4*>(it.dgate + (int64_t)row * VOP + 8 * q + 4 * hi) =
+                            make_float4(dgr[4 * q], dgr[4 * q + 1], dgr[4 * q + 2], dgr[4 * q + 3]);
+            }
+        }
         float* part = it.w_part ? it.w_part + (int64_t)blockIdx.x * (vi * H + vi * HF) : nullptr;
 #ifdef GCP_CB_FINE2
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 #endif
-        if (part) small_tn(xt, L.VS, 3, 1, vi, vht, L.HS, 3, 1, H, part, false);  // d vector_up[o, h] = sum dvu[row, o, d] vh[row, h, d]
+        f32x4 tn1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (part) { tn1 = small_tn(xt, L.VS, 3, 1, vi, vht, L.HS, 3, 1, H); small_tn_store(tn1, vi, H, part, false); }  // d vector_up[o, h] = sum dvu[row, o, d] vh[row, h, d]
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
         CB_LAUNDER();
 
@@ -481,7 +508,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 }
             }
         }
+#ifdef GCP_CB_FINE3  // (measurement build: stamps 0 / 1 of block 0 = end of step D / end of the ds_pre store)
+        if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
+#endif
         gcp_store_acc_rows_half_dense<NTG, PAD>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG or PAD; 16-byte aligned: host checks)
+#ifdef GCP_CB_FINE3
+        if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
+#endif
         CB_LAUNDER();
 
         // ---- E. d(s) += W^T ds_pre: 16 * NTG k-pair steps whose B operands are the ds_pre registers; the weight
@@ -649,7 +682,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
 #endif
         // d [vector_down ; vector_down_frames][x, c] = sum v[row, c, d] [dvh | dvf][row, d, x], stored as [H + 3, vi]
-        if (part) small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF, part + vi * H, true);
+        if (part) { tn2 = small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF); small_tn_store(tn2, vi, HF, part + vi * H, true); }
         gcp_wave_lds_sync();
         CB_LAUNDER();
         if (k > 0) {
@@ -659,6 +692,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
+    }
+    if (tn2_part) {
+        const int l16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * kq + r;
+            if (i < vi && l16 < HF) tn2_part[l16 * vi + i] = tn2[r];
+        }
     }
     gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
 }

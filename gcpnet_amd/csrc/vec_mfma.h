@@ -102,3 +102,53 @@ __device__ __forceinline__ void gcp_vmm_arr(const float* __restrict__ w, int ste
                 for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
         }
 }
+
+// Forms of gcp_vmm_regs / gcp_vmm_arr whose weight fragments were requested earlier by the caller (gcp_vmm_frags): a kernel that has
+// stores in flight issues these requests BEFORE the stores -- vmcnt retires loads and stores in issue order, so a fragment
+// requested behind a batch of stores is only usable once every one of those stores has been acknowledged by L2.
+template <int NR>
+__device__ __forceinline__ void gcp_vmm_frags(const float* __restrict__ w, int steps, float (&a)[NR]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) a[r] = w[(int64_t)min(r, steps - 1) * 64];
+}
+template <int MAXR>
+__device__ __forceinline__ void gcp_vmm_regs_pre(const float (&a)[MAXR], int steps, const gcp_xyz_acc& in, gcp_xyz_acc& out) {
+    static_assert(MAXR % 4 == 0, "steps come in groups of four registers");
+#pragma unroll
+    for (int r0 = 0; r0 < MAXR; r0 += 4)
+        if (r0 < steps) {
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
+        }
+}
+template <int NR>
+__device__ __forceinline__ void gcp_vmm_arr_pre(const float (&a)[NR], int steps, const float (&in)[3][NR], gcp_xyz_acc& out) {
+    static_assert(NR % 4 == 0, "steps come in groups of four registers");
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += 4)
+        if (r0 < steps) {
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], in[d][r], out[d], 0, 0, 0);
+        }
+}
+
+// gcp_vmm_down with fragments requested earlier (gcp_vmm_frags<MAXS>(wa, steps, a)).
+template <int MAXS>
+__device__ __forceinline__ void gcp_vmm_down_pre(const float (&a)[MAXS], int steps, int vi, const float* vrow, int hi, gcp_xyz_acc& u) {
+    gcp_xyz_zero(u);
+#pragma unroll
+    for (int s0 = 0; s0 < MAXS; s0 += 2)
+        if (s0 < steps) {  // wave-uniform, one test per two steps (a step past the end multiplies by a zero weight)
+#pragma unroll
+            for (int s = s0; s < s0 + 2 && s < MAXS; ++s) {
+                const float* b = vrow + 3 * min(2 * s + hi, vi - 1);  // (an odd vi pads with a zero weight)
+                const float as = s < steps ? a[s] : 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) u[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b[d], u[d], 0, 0, 0);
+            }
+        }
+}
