@@ -18,7 +18,7 @@ EXPORTS = [
     "gcpnet_abi_version", "gcpnet_debug_knobs_compiled", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
     "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_chain_forward_registers_ok", "gcpnet_gcp2_headchain_forward",
-    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
+    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_chain_backward_ok", "gcpnet_tb_floats", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
@@ -48,7 +48,7 @@ class Gcp2Opts(C.Structure):
 
 class ChainItem(C.Structure):
     _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p),
-                ("gate", C.c_void_p)]
+                ("gate", C.c_void_p), ("s_out_tb", C.c_int), ("s_pre_tb", C.c_int)]
 
 
 class Head(C.Structure):
@@ -87,13 +87,13 @@ class BwdScratch(C.Structure):
 
 class ChainBwdItem(C.Structure):
     _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("v_in", C.c_void_p), ("s_pre", C.c_void_p), ("gate", C.c_void_p),
-                ("sc", BwdScratch)]
+                ("sc", BwdScratch), ("tb", C.c_int)]
 
 
 class Operand(C.Structure):
     _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * TN_MAX_SEG), ("idx", C.c_void_p * TN_MAX_SEG),
                 ("dim", C.c_int * TN_MAX_SEG), ("ld", C.c_int * TN_MAX_SEG), ("act", C.c_int), ("slope", C.c_float),
-                ("ones", C.c_int)]
+                ("ones", C.c_int), ("tb", C.c_int * TN_MAX_SEG)]
 
 
 class TnProblem(C.Structure):
@@ -170,6 +170,9 @@ def load():
     lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
     lib.gcpnet_debug_set_fp32_mfma.argtypes = [i32]
     lib.gcpnet_gcp2_chain_forward_registers_ok.argtypes = [i32] * 6
+    lib.gcpnet_gcp2_chain_backward_ok.argtypes = [i32] * 6
+    lib.gcpnet_tb_floats.argtypes = [i32, i32]
+    lib.gcpnet_tb_floats.restype = i64
     lib.gcpnet_wg_pack_floats.restype = i64
     lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
     lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]
@@ -193,9 +196,9 @@ def load():
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",
-                        "gcpnet_wg_pack_floats"):
+                        "gcpnet_wg_pack_floats", "gcpnet_tb_floats"):
             fn.restype = i32
-    if lib.gcpnet_abi_version() != 1:
+    if lib.gcpnet_abi_version() != 2:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -46,6 +46,7 @@ struct ChainItemB {
     float* ext;
     float* w_part;
     int act_s, act_v;
+    int tb;  // s_pre / ds_pre in the tile-blocked layout (include/gcpnet_hip.h, gcp2_chain_item_t)
 };
 
 struct ChainBwdParams {
@@ -425,13 +426,21 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         };
         // s_pre of this block: requested here, where few registers are live, and in flight under the first partial-sum pass
         f32x16 spr[NTG];
+        {
+            // (one address select per request instead of two code paths: a wave-uniform branch around loads makes hipcc wait for
+            // them where the sides merge.  Tile-blocked: piece (t, q) of this lane, 1 KB per instruction; rows of [rows, so] otherwise)
+            const int64_t off_rm = (int64_t)(row_ok ? row : 0) * so, off_tb = (int64_t)r0 * (32 * NTG) + 4 * lane;
+            const bool tb = it.tb != 0;
 #pragma unroll
-        for (int t = 0; t < NTG; ++t)
+            for (int t = 0; t < NTG; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a = gcp_load4(it.s_pre, row, so, 32 * t + 8 * q + 4 * hi, row_ok, true);
-                spr[t][4 * q] = a.x; spr[t][4 * q + 1] = a.y; spr[t][4 * q + 2] = a.z; spr[t][4 * q + 3] = a.w;
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int j0 = 32 * t + 8 * q + 4 * hi;
+                    const float4 a = *reinterpret_cast<const float4*>(it.s_pre + (tb ? off_tb + (t * 4 + q) * 256 : off_rm + min(j0, so - 4)));
+                    const bool in = row_ok && j0 + 3 < so;
+                    spr[t][4 * q] = in ? a.x : 0.f; spr[t][4 * q + 1] = in ? a.y : 0.f; spr[t][4 * q + 2] = in ? a.z : 0.f; spr[t][4 * q + 3] = in ? a.w : 0.f;
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ... and BEHIND the requests the block's small stores.  (vmcnt retires loads and stores in issue order, and a store is only
         // retired once L2 has acknowledged it: a load requested behind a batch of stores cannot be used before all of them are
@@ -511,7 +520,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #ifdef GCP_CB_FINE3  // (measurement build: stamps 0 / 1 of block 0 = end of step D / end of the ds_pre store)
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
 #endif
-        gcp_store_acc_rows_half_dense<NTG, PAD>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG or PAD; 16-byte aligned: host checks)
+        if (it.tb) {  // tile-blocked: sixteen 1 KB pieces straight from the registers (rows past the end are zeros, the buffer holds whole tiles)
+            float4* bp = reinterpret_cast<float4*>(it.ds_pre + (int64_t)r0 * (32 * NTG)) + lane;
+#pragma unroll
+            for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bp[(t * 4 + q) * 64] = make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]);
+        } else {
+            gcp_store_acc_rows_half_dense<NTG, PAD>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG or PAD; 16-byte aligned: host checks)
+        }
 #ifdef GCP_CB_FINE3
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 #endif
@@ -738,6 +755,14 @@ int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, hipStream_t 
 
 }  // namespace
 
+static bool chain_bwd_shape_ok(const gcp2_weights_t& w0, const GcpShape& S) {
+    if (S.NG != 1 || w0.si != w0.so || w0.vi != w0.vo || w0.vi <= 0 || (w0.si & 3) || S.NTG < 2 || S.NTS != S.NTG) return false;
+    // register budget of the kernel: vi == vo <= 16 (two register quads per xyz component), H + 3 <= 16, H + 9 <= 32
+    if ((w0.vi & 3) || w0.vi > 16 || !S.vmm || S.HF > 16 || S.H + S.nf > 32) return false;
+    if (S.NUG < S.NTG) return false;
+    return (size_t)cb_lds(S).total * sizeof(float) <= 64 * 1024;
+}
+
 // Returns GCPNET_E_UNSUPPORTED when the chain does not fit this kernel; the caller then runs the blocks one by one
 // (gcpnet_gcp2_backward), passing the state through HBM.
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
@@ -745,10 +770,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
                              hipStream_t st) {
     const gcp2_weights_t& w0 = items[0].w;
     const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
-    if (S.NG != 1 || w0.si != w0.so || w0.vi != w0.vo || w0.vi <= 0 || (w0.si & 3) || S.NTG < 2 || S.NTS != S.NTG) return GCPNET_E_UNSUPPORTED;
-    // register budget of the kernel: vi == vo <= 16 (two register quads per xyz component), H + 3 <= 16, H + 9 <= 32
-    if ((w0.vi & 3) || w0.vi > 16 || !S.vmm || S.HF > 16 || S.H + S.nf > 32) return GCPNET_E_UNSUPPORTED;
-    if (S.NUG < S.NTG) return GCPNET_E_UNSUPPORTED;
+    if (!chain_bwd_shape_ok(w0, S)) return GCPNET_E_UNSUPPORTED;
     ChainBwdParams p;
     p.rows = rows; p.frames = frames; p.o = items[0].o; p.n = n;
     p.d_s_out = d_s_out; p.d_v_out = d_v_out; p.d_s_in = d_s_in; p.d_v_in = d_v_in;
@@ -766,6 +788,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
         it.v_in = c.v_in; it.s_pre = c.s_pre; it.gate = c.gate;
         it.ds_pre = c.sc.ds_pre; it.dgate = c.sc.dgate; it.ext = c.sc.ext; it.w_part = c.sc.w_part;
         it.act_s = o.act_s; it.act_v = o.act_v;
+        it.tb = c.tb;
         pwl = pwl && gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
     }
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
@@ -774,6 +797,12 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
     if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
     if (S.NTG == 2) return launch_cb2<2>(p, lds_bytes, pwl, st);
     return launch_cb2<4>(p, lds_bytes, pwl, st);
+}
+
+extern "C" int gcpnet_gcp2_chain_backward_ok(int si, int vi, int so, int vo, int hidden, int use_frames) {
+    gcp2_weights_t w0{};
+    w0.si = si; w0.vi = vi; w0.so = so; w0.vo = vo; w0.hidden = hidden; w0.use_frames = use_frames;
+    return chain_bwd_shape_ok(w0, gcp_shape(si, vi, so, vo, hidden, use_frames)) ? 1 : 0;
 }
 
 static int chain_backward_checked(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
@@ -790,7 +819,7 @@ static int chain_backward_checked(int rows, const float* frames, int n, const gc
     auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
     for (int k = 0; k < n; ++k)  // the deferred tile loads and the accumulator-layout accesses are 16-byte accesses
         if (misaligned(items[k].v_in) || misaligned(items[k].s_pre) || misaligned(items[k].gate) || misaligned(items[k].sc.ds_pre) ||
-            misaligned(items[k].sc.dgate))
+            misaligned(items[k].sc.dgate) || misaligned(items[k].sc.ext))
             return GCPNET_E_UNSUPPORTED;
     if (misaligned(d_s_out) || misaligned(d_v_out) || misaligned(d_s_in) || misaligned(d_v_in)) return GCPNET_E_UNSUPPORTED;
     return gcp2_chain_bwd_registers(rows, frames, n, items, d_s_out, d_v_out, out_idx, out_scale, d_s_in, d_v_in, (hipStream_t)stream);

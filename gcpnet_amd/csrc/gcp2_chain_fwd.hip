@@ -30,6 +30,7 @@ struct ChainItemF {
     float* s_pre;
     float* gate;
     int act_s, act_v;
+    int s_out_tb, s_pre_tb;  // tile-blocked outputs (include/gcpnet_hip.h, gcp2_chain_item_t)
 };
 
 // Optional head block in front of the chain: the first message GCP after project-then-gather, (se, vi0) -> (s, V) with the
@@ -109,6 +110,18 @@ __device__ __forceinline__ void gcp_store_acc_rows_any(float* __restrict__ dst, 
                                                        float* stage, int lane) {
     if ((so & 3) == 0 && gcp_aligned16(dst)) gcp_store_acc_rows_dense<NT>(dst, so, so, r0, rows, acc, stage, lane);
     else gcp_store_acc_rows<NT>(dst, so, 0, so, r0, rows, acc, stage, lane);
+}
+
+// The same tile in the tile-blocked layout: register quad (t, q) of every lane is one 16-byte piece, the 64 pieces of a (t, q) are
+// 1 KB contiguous -- one store instruction = eight full lines, no LDS transposition, no row or column test (the buffer holds whole
+// tiles of padded width 32 NT).
+template <int NT>
+__device__ __forceinline__ void gcp_store_acc_tb(float* __restrict__ dst, int r0, const f32x16 (&acc)[NT], int lane) {
+    float4* bp = reinterpret_cast<float4*>(dst + (int64_t)r0 * (32 * NT)) + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bp[(t * 4 + q) * 64] = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
 }
 
 // NT = 32-wide tiles of the scalar state (so <= 32 * NT); PWL as in gcp2_fwd.hip.
@@ -482,7 +495,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
 #endif
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
-        if (it.s_pre) gcp_store_acc_rows_any<NT>(it.s_pre, so, r0, rows, acc, stage, lane);
+        if (it.s_pre) {
+            if (it.s_pre_tb) gcp_store_acc_tb<NT>(it.s_pre, r0, acc, lane);
+            else gcp_store_acc_rows_any<NT>(it.s_pre, so, r0, rows, acc, stage, lane);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -490,7 +506,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 const float y = gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][r]);
                 xs[t][r] = head ? y : xs[t][r] + y;
             }
-        if (it.s_out) gcp_store_acc_rows_any<NT>(it.s_out, so, r0, rows, xs, stage, lane);
+        if (it.s_out) {
+            if (it.s_out_tb) gcp_store_acc_tb<NT>(it.s_out, r0, xs, lane);
+            else gcp_store_acc_rows_any<NT>(it.s_out, so, r0, rows, xs, stage, lane);
+        }
 
 #ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
@@ -582,6 +601,7 @@ static int fill_chain(ChainParams& p, const GcpShape& S, int n, const gcp2_chain
         it.pack = c.w.pack; it.b_scalar = c.w.b_scalar;
         it.b_gate = c.w.b_gate; it.s_out = c.s_out; it.v_out = c.v_out; it.s_pre = c.s_pre;
         it.gate = c.gate; it.act_s = c.o.act_s; it.act_v = c.o.act_v;
+        it.s_out_tb = c.s_out_tb; it.s_pre_tb = c.s_pre_tb;
         pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
     }
     (void)S;
@@ -681,6 +701,7 @@ extern "C" int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, 
     it.pack = hw.pack; it.b_scalar = hw.b_scalar; it.b_gate = hw.b_gate;
     it.s_out = head->s_out; it.v_out = head->v_out; it.s_pre = head->s_pre; it.gate = head->gate;
     it.act_s = head->o.act_s; it.act_v = head->o.act_v;
+    it.s_out_tb = it.s_pre_tb = 0;
     const size_t lds_bytes = (size_t)chain_lds(S, &S0).total * sizeof(float);
     if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

@@ -74,6 +74,11 @@ __host__ __device__ inline int operand_width(const gcp_operand_t& o) {
     return w;
 }
 
+// Tile-blocked segments (include/gcpnet_hip.h, gcp2_chain_item_t): float offset of the 16-byte piece at column c (a multiple of 4)
+// of row 0 inside a tile, and the offset of row r's copy of that piece: (r / 32) tiles of 32 wp floats + (r % 32) pieces of 4.
+__host__ __device__ inline int tb_col_offset(int c) { return (((c >> 5) * 4 + ((c & 31) >> 3)) * 64 + ((c >> 2) & 1) * 32) * 4; }
+__host__ __device__ inline int64_t tb_row_offset(int64_t r, int wp) { return (r >> 5) * (int64_t)(32 * wp) + (r & 31) * 4; }
+
 struct BlockWork {
     int pi, split, m0, n0, mw, nw, ntiles;
     int r_first, r_step, r_end, nchunks;  // chunk c covers rows r_first + c * r_step .. + 31, cut at r_end
@@ -146,8 +151,13 @@ __device__ __forceinline__ void stage_operand(const gcp_operand_t& op, int c0, i
             if (lo < hi) {
                 if (valid) {
                     const int64_t src = op.idx[sg] ? (int64_t)op.idx[sg][r] : (int64_t)r;
+                    if (op.tb[sg]) {
+                        const float* tp = op.ptr[sg] + tb_row_offset(src, gcp_round_up(dim, 32));
+                        for (int c = lo + lane; c < hi; c += GCP_WAVE) dst[c - c0] = gcp_act(op.act, tp[tb_col_offset((c - cbase) & ~3) + ((c - cbase) & 3)], op.slope);
+                    } else {
                     const float* rowp = op.ptr[sg] + src * op.ld[sg] - cbase;
                     for (int c = lo + lane; c < hi; c += GCP_WAVE) dst[c - c0] = gcp_act(op.act, rowp[c], op.slope);
+                    }
                 } else {
                     for (int c = lo + lane; c < hi; c += GCP_WAVE) dst[c - c0] = 0.f;
                 }
@@ -210,7 +220,7 @@ struct Slot {
     int ld;
     int row;             // row inside the 32-row chunk
     bool on;             // piece belongs to a real column group of the operand
-};
+};  // (ld < 0: a tile-blocked segment of padded width -ld; base then includes the piece's column offset inside a tile)
 
 template <int NSLOT, int LD, int NTH = 256>
 __device__ __forceinline__ void make_slots(const gcp_operand_t& op, int c0, Slot* s, int tid) {
@@ -223,9 +233,9 @@ __device__ __forceinline__ void make_slots(const gcp_operand_t& op, int c0, Slot
         int cbase = 0;
         for (int sg = 0; sg < op.n; ++sg) {
             if (piece && c >= cbase && c < cbase + op.dim[sg]) {
-                s[k].base = op.ptr[sg] + (c - cbase);
+                s[k].base = op.ptr[sg] + (op.tb[sg] ? tb_col_offset(c - cbase) : (c - cbase));
                 s[k].idx = op.idx[sg];
-                s[k].ld = op.ld[sg];
+                s[k].ld = op.tb[sg] ? -gcp_round_up(op.dim[sg], 32) : op.ld[sg];
                 s[k].on = true;
             }
             cbase += op.dim[sg];
@@ -263,8 +273,9 @@ __device__ __forceinline__ void issue_dma(const Slot* s, const int64_t* src, flo
     for (int k = 0; k < NSLOT; ++k) {
         float* dst = buf + (NTH * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
         if (s[k].on)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s[k].base + src[k] * s[k].ld),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(s[k].base + (s[k].ld < 0 ? tb_row_offset(src[k], -s[k].ld) : src[k] * s[k].ld)),
+                (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 }
 
@@ -556,7 +567,7 @@ constexpr int TB_LDS_FLOATS = 2 * TN_RK * (TB_BM + TB_BN);
 
 struct BigSlot {
     const float* base;  // segment pointer + column offset of the 16-byte piece; nullptr: no column of the operand there
-    int ld, row;
+    int ld, row;  // (ld < 0: a tile-blocked segment of padded width -ld)
 };
 
 template <int NSLOT, int LD>
@@ -569,7 +580,10 @@ __device__ __forceinline__ void big_slots(const gcp_operand_t& op, BigSlot* s, i
         s[k].row = row; s[k].base = nullptr; s[k].ld = 0;
         int cbase = 0;
         for (int sg = 0; sg < op.n; ++sg) {
-            if (piece && c >= cbase && c < cbase + op.dim[sg]) { s[k].base = op.ptr[sg] + (c - cbase); s[k].ld = op.ld[sg]; }
+            if (piece && c >= cbase && c < cbase + op.dim[sg]) {
+                s[k].base = op.ptr[sg] + (op.tb[sg] ? tb_col_offset(c - cbase) : (c - cbase));
+                s[k].ld = op.tb[sg] ? -gcp_round_up(op.dim[sg], 32) : op.ld[sg];
+            }
             cbase += op.dim[sg];
         }
     }
@@ -582,7 +596,8 @@ __device__ __forceinline__ void big_issue(const BigSlot* s, float* buf, int r0, 
         float* dst = buf + (TB_NTH * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
         if (s[k].base)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(s[k].base + (int64_t)min(r0 + s[k].row, r_last) * s[k].ld),
+                (const __attribute__((address_space(1))) void*)(s[k].base + (s[k].ld < 0 ? tb_row_offset(min(r0 + s[k].row, r_last), -s[k].ld)
+                                                                                         : (int64_t)min(r0 + s[k].row, r_last) * s[k].ld)),
                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 }
@@ -779,7 +794,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
 
 inline bool dma_ok(const gcp_operand_t& o) {
     for (int k = 0; k < o.n; ++k)
-        if ((o.dim[k] & 3) || (o.ld[k] & 3) || (reinterpret_cast<uintptr_t>(o.ptr[k]) & 15)) return false;
+        if ((o.dim[k] & 3) || (!o.tb[k] && (o.ld[k] & 3)) || (reinterpret_cast<uintptr_t>(o.ptr[k]) & 15)) return false;
     return true;
 }
 
@@ -811,6 +826,10 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         if (P.rows < 0 || P.a.n < 0 || P.a.n > GCP_TN_MAX_SEG || P.b.n < 0 || P.b.n > GCP_TN_MAX_SEG || !P.out || !P.partial)
             return GCPNET_E_BADARG;
         if (P.splits != gcpnet_tn_splits(P.rows, 0, 0)) return GCPNET_E_BADARG;
+        for (int k = 0; k < P.a.n; ++k)
+            if (P.a.tb[k] && P.a.idx[k]) return GCPNET_E_BADARG;  // (a tile-blocked segment is addressed by its own row number)
+        for (int k = 0; k < P.b.n; ++k)
+            if (P.b.tb[k] && P.b.idx[k]) return GCPNET_E_BADARG;
         a.p[i] = P;
         a.M[i] = operand_width(P.a);
         a.N[i] = operand_width(P.b);

@@ -452,6 +452,32 @@ PREFER_WAVE_CHAIN_FORWARD = os.environ.get("GCPNET_CHAIN_FWD", "wave") == "wave"
 # kernel reads the node-level gradient tables through the edge -> node index, no [E, .] gradient copies).  GCPNET_FUSE_AGG=0: off.
 FUSE_AGGREGATION = os.environ.get("GCPNET_FUSE_AGG", "1") != "0"
 FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains the wave-per-tile chain kernel covers
+# Tensors that only the register-resident chain kernels and the weight-gradient GEMM exchange -- s_pre, ds_pre and the intermediate
+# scalar states of a ResGCP chain -- in the tile-blocked layout (include/gcpnet_hip.h, gcp2_chain_item_t): every wave instruction on
+# them moves 1 KB of whole lines, no LDS transposition.  GCPNET_CHAIN_TB=0: row-major as before (A/B measurements, tests).
+CHAIN_TILE_BLOCKED = os.environ.get("GCPNET_CHAIN_TB", "1") != "0"
+
+
+class TileBlocked:
+    """A [rows, width] fp32 matrix in the tile-blocked layout: `data` holds gcpnet_tb_floats(rows, width) floats."""
+    __slots__ = ("data", "rows", "width")
+
+    def __init__(self, rows: int, width: int, device):
+        self.rows, self.width = rows, width
+        self.data = torch.empty((_lib.load().gcpnet_tb_floats(rows, width),), dtype=torch.float32, device=device)
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def to_rows(self) -> Tensor:
+        """Row-major copy (tests, debugging)."""
+        wp = (self.width + 31) // 32 * 32
+        t = self.data.view(-1, wp // 32, 4, 2, 32, 4)  # [tile, t, q, hi, e, i]
+        return t.permute(0, 4, 1, 2, 3, 5).reshape(-1, wp)[:self.rows, :self.width].contiguous()
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
 
@@ -871,7 +897,7 @@ def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, 
     return d_s_in, d_v_in, t
 
 
-def _alloc_bwd_scratch(spec: Gcp2Spec, rows: int, need_w: bool, device):
+def _alloc_bwd_scratch(spec: Gcp2Spec, rows: int, need_w: bool, device, tb: bool = False):
     """The backward kernels' per-row / per-tile outputs for the weight gradients (include/gcpnet_hip.h, gcp2_bwd_scratch_t)."""
     lib = _lib.load()
     f32 = dict(dtype=torch.float32, device=device)
@@ -880,7 +906,7 @@ def _alloc_bwd_scratch(spec: Gcp2Spec, rows: int, need_w: bool, device):
     has_vec, has_vout = vi > 0, vi > 0 and vo > 0
     gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
     scr = BwdScratch()
-    t = dict(ds_pre=torch.empty((rows, so), **f32))
+    t = dict(ds_pre=TileBlocked(rows, so, device) if tb else torch.empty((rows, so), **f32))
     scr.ds_pre = t["ds_pre"].data_ptr()
     r4 = lambda x: (x + 3) // 4 * 4
     if has_vec:
@@ -900,7 +926,7 @@ class _WeightGradJob:
 
     def __init__(self, spec: Gcp2Spec, rows: int, s_src, s_pre, t):
         lib = _lib.load()
-        f32 = dict(dtype=torch.float32, device=s_pre.device)
+        f32 = dict(dtype=torch.float32, device=s_pre.device)  # (s_pre: a Tensor or a TileBlocked)
         H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
         nf = 9 if (spec.use_frames and vi > 0) else 0
         self.spec, self.nf = spec, nf
@@ -917,6 +943,8 @@ class _WeightGradJob:
             for k, (x, pl, dim, ld) in enumerate(segs):
                 op.ptr[k], op.dim[k], op.ld[k] = x.data_ptr(), dim, ld
                 op.idx[k] = pl.idx.data_ptr() if pl is not None else None
+                op.tb[k] = int(isinstance(x, TileBlocked))
+                assert not (op.tb[k] and pl is not None)
             op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
             return op
 
@@ -938,7 +966,8 @@ class _WeightGradJob:
         EP, VOP = r4(H + nf), r4(vo)
         self.EP = EP
         # d scalar_out.weight / bias: ds_pre^T [s sources | norms | frame scalars | 1]
-        bsegs = [(x, pl, x.shape[1], x.shape[1]) for x, pl in zip(s_src, spec.s_plans)]
+        bsegs = [(x, pl, x.width, x.width) if isinstance(x, TileBlocked) else (x, pl, x.shape[1], x.shape[1])
+                 for x, pl in zip(s_src, spec.s_plans)]
         n1 = si + 1
         if self.has_vec:
             bsegs.append((t["ext"], None, EP, EP))
@@ -1173,13 +1202,27 @@ class _Gcp2Chain(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         items = (ChainItem * n)()
         ws, packs, outs = [], [], []
+        sp0 = specs[0]
+        wave_first = (PREFER_WAVE_CHAIN_FORWARD and sp0.so <= 128 and n <= _lib.MAX_CHAIN and
+                      lib.gcpnet_gcp2_chain_forward_registers_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
+        # what only the chain kernels and the weight-gradient GEMM read -- s_pre, the intermediate scalar states -- is saved
+        # tile-blocked when both the forward and the backward will run in the register-resident chain kernels (decided HERE: the
+        # backward of this graph then takes that route whatever the module switches say by then)
+        tb = (CHAIN_TILE_BLOCKED and need_grad and wave_first and rows > 0 and _wave_chain_backward(sp0) and
+              lib.gcpnet_gcp2_chain_backward_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
         for k, spec in enumerate(specs):
             w = tuple(weights[7 * k:7 * k + 7])
             pack = _pack(spec, w)
             last = k == n - 1  # intermediate states are only materialised when the backward will need them
-            s_out = torch.empty((rows, spec.so), **f32) if (need_grad or last) else None
+            if tb and not last:
+                s_out = TileBlocked(rows, spec.so, dev)
+            else:
+                s_out = torch.empty((rows, spec.so), **f32) if (need_grad or last) else None
             v_out = torch.empty((rows, spec.vo, 3), **f32) if (need_grad or last) else None
-            s_pre = torch.empty((rows, spec.so), **f32) if need_grad else None
+            if tb:
+                s_pre = TileBlocked(rows, spec.so, dev)
+            else:
+                s_pre = torch.empty((rows, spec.so), **f32) if need_grad else None
             gated = spec.vmode == VMODE_SCALAR_GATE
             gate = torch.empty((rows, spec.vo), **f32) if (need_grad and gated) else None
             items[k].w = _weights_struct(spec, w, pack)
@@ -1188,17 +1231,15 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].v_out = v_out.data_ptr() if v_out is not None else None
             items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
             items[k].gate = gate.data_ptr() if gate is not None else None
+            items[k].s_out_tb, items[k].s_pre_tb = int(isinstance(s_out, TileBlocked)), int(isinstance(s_pre, TileBlocked))
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         if rows == 0:  # (an empty edge set: nothing to launch)
             if need_grad:
-                ctx.rows, ctx.n_weights, ctx.agg = 0, len(weights), agg
+                ctx.rows, ctx.n_weights, ctx.agg, ctx.weights = 0, len(weights), agg, weights
             if agg is not None:
                 return (torch.zeros((agg[0].n_src, specs[-1].so), **f32), torch.zeros((agg[0].n_src, specs[-1].vo, 3), **f32))
             return outs[-1][0], outs[-1][1]
         rc = _lib.E_UNSUPPORTED
-        sp0 = specs[0]
-        wave_first = (PREFER_WAVE_CHAIN_FORWARD and sp0.so <= 128 and n <= _lib.MAX_CHAIN and
-                      lib.gcpnet_gcp2_chain_forward_registers_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
         if USE_WG_KERNELS and n <= _lib.WG_MAX_BLOCKS and not wave_first:
             keep: list = []
             blks = (WgBlock * n)(*[_wg_block(spec, w, *outs[k], True, keep) for k, (spec, w) in enumerate(zip(specs, ws))])
@@ -1218,6 +1259,7 @@ class _Gcp2Chain(torch.autograd.Function):
             ctx.weights = weights
             ctx.use_cells = _note_uses(weights)
             ctx.agg = agg
+            ctx.tb = tb
         if agg is not None:
             plan, mean = agg
             m_s, m_v = outs[-1][0], outs[-1][1]
@@ -1229,10 +1271,12 @@ class _Gcp2Chain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_s, d_v):
         agg = ctx.agg
-        if ctx.rows == 0:  # no rows: the input gradients are empty, the weights receive none
+        if ctx.rows == 0:  # no rows: the input gradients are empty, the weight gradients zero (as the single-block path returns them)
+            wz = [torch.zeros_like(w) if (w is not None and need) else None for w, need in zip(ctx.weights, ctx.needs_input_grad[5:])]
+            ctx.weights = None
             if agg is not None:  # (no row for the segment-level gradients to reach)
-                return (None, None, None, None, None, *([None] * ctx.n_weights))
-            return (None, None, None, d_s, d_v, *([None] * ctx.n_weights))
+                return (None, None, None, None, None, *wz)
+            return (None, None, None, d_s, d_v, *wz)
         specs, frames, rows = ctx.specs, ctx.frames, ctx.rows
         s0, v0, ws, packs, outs = ctx.state
         n = len(specs)
@@ -1250,9 +1294,10 @@ class _Gcp2Chain(torch.autograd.Function):
         # (measured at (128,16): 1.2 ms + 0.76 ms of weight-gradient GEMMs per 7 blocks against 7 x 0.33 ms); wider chains --
         # (256,32) -- go block by block through the workgroup kernel; shapes outside both through the generic kernel.
         res = None
-        wave_chain = (not (USE_WG_KERNELS and USE_WG_BACKWARD and PREFER_WG_CHAIN_BACKWARD)) or (specs[0].so <= 128 and not FORCE_WG_CHAIN_BACKWARD)
+        wave_chain = ctx.tb or _wave_chain_backward(specs[0])
         if wave_chain:  # (with `agg` the kernel reads the segment-level tables itself)
             res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg)
+            assert res is not None or not ctx.tb, "tile-blocked activations were saved for a chain the backward kernel refuses"
         if res is None and agg is not None:
             # block-by-block routes take per-row gradients: the adjoint of the aggregation as its own launches
             plan, mean = agg
@@ -1290,6 +1335,12 @@ class _Gcp2Chain(torch.autograd.Function):
         return (None, None, None, d_s, d_v, *wgrads)
 
 
+def _wave_chain_backward(sp0: Gcp2Spec) -> bool:
+    """The module switches' choice for the backward of a ResGCP chain: one launch of the wave-per-tile chain kernel (True) or
+    block by block through the workgroup backward kernel."""
+    return (not (USE_WG_KERNELS and USE_WG_BACKWARD and PREFER_WG_CHAIN_BACKWARD)) or (sp0.so <= 128 and not FORCE_WG_CHAIN_BACKWARD)
+
+
 def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s: Tensor, d_v: Tensor, need_w: Sequence[bool],
                              out_agg=None):
     """Backward data path of a whole ResGCP chain in one launch (gcpnet_gcp2_chain_backward).  ins[k] = (s, V) input of block
@@ -1301,11 +1352,13 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
     items = (ChainBwdItem * n)()
     scrs = []
     for k in range(n):
-        scr, t = _alloc_bwd_scratch(specs[k], rows, need_w[k], d_s.device)
+        tb = isinstance(outs[k][2], TileBlocked)  # (s_pre saved tile-blocked: ds_pre leaves the same way)
+        scr, t = _alloc_bwd_scratch(specs[k], rows, need_w[k], d_s.device, tb=tb)
         scrs.append(t)
         items[k].w = _weights_struct(specs[k], ws[k], packs[k])
         items[k].o = _opts_struct(specs[k], fused_residual=True)
         items[k].v_in = ins[k][1].data_ptr()
+        items[k].tb = int(tb)
         items[k].s_pre = outs[k][2].data_ptr()
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
         items[k].sc = scr

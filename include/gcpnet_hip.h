@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GCPNET_ABI_VERSION 1
+#define GCPNET_ABI_VERSION 2
 
 #define GCPNET_E_BADARG (-1)
 #define GCPNET_E_UNSUPPORTED (-2)
@@ -106,6 +106,14 @@ int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* 
  * One launch; the (s, V) state of a 32-row tile stays on chip between the blocks.  All blocks share the dims
  * (si == so <= 128, vi == vo), frames and gating mode; each item carries its own weights, activations and outputs
  * (s_out/v_out = x_k, s_pre/gate saved for the backward when non-NULL). */
+/* Tile-blocked layout ("tb") of a [rows, W] fp32 matrix that only the chain kernels and gcpnet_tn_gemm exchange (s_pre, ds_pre, the
+ * intermediate scalar states of a chain): rows in tiles of 32, columns padded to Wp = 32 ceil(W / 32); element (r, c) sits at float
+ *     (r / 32) * 32 Wp + (((c / 32) * 4 + (c % 32) / 8) * 64 + ((c / 4) % 2) * 32 + r % 32) * 4 + c % 4,
+ * i.e. register quad q of accumulator tile t of lane (r % 32, half) of the 32-row wave-tile is one 16-byte piece and the 64 pieces
+ * of a (t, q) are 1 KB contiguous: a wave's store / load instruction of such a tensor moves eight full 128-byte lines instead of
+ * touching 32 rows (row-major, each lane pair owns 32 bytes of a row), and needs no LDS transposition.  A tb buffer holds
+ * gcpnet_tb_floats(rows, W) floats (whole tiles); rows past the end hold unspecified finite values. */
+int64_t gcpnet_tb_floats(int rows, int width);
 typedef struct {
     gcp2_weights_t w;
     gcp2_opts_t o;
@@ -113,6 +121,8 @@ typedef struct {
     float* v_out;
     float* s_pre;
     float* gate;
+    int s_out_tb;  /* s_out is written tile-blocked (register-resident kernel only: E_UNSUPPORTED elsewhere) */
+    int s_pre_tb;  /* s_pre is written tile-blocked */
 } gcp2_chain_item_t;
 #define GCP_MAX_CHAIN 8
 int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const float* frames, int n,
@@ -270,7 +280,11 @@ typedef struct {
     const float* s_pre;
     const float* gate;
     gcp2_bwd_scratch_t sc;
+    int tb;  /* s_pre is read and sc.ds_pre written in the tile-blocked layout (see gcp2_chain_item_t) */
 } gcp2_chain_bwd_item_t;
+/* 1 if gcpnet_gcp2_chain_backward takes a chain of residual blocks of this shape (callers that save tile-blocked tensors in the
+ * forward ask first: there is no other consumer of that layout) */
+int gcpnet_gcp2_chain_backward_ok(int si, int vi, int so, int vo, int hidden, int use_frames);
 int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
                                const float* d_s_out, const float* d_v_out, float* d_s_in, float* d_v_in, void* stream);
 /* The same when the chain's output went into a segment sum / mean (the aggregation, components/gcpnet.py:939-947; the reference
@@ -296,6 +310,7 @@ typedef struct {
     int act;       /* activation applied on load */
     float slope;
     int ones;      /* append a column of ones */
+    int tb[GCP_TN_MAX_SEG];  /* 0: rows of ld floats; 1: the segment is tile-blocked (see gcp2_chain_item_t; its width is dim, no gather) */
 } gcp_operand_t;
 
 typedef struct {
