@@ -168,7 +168,7 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     return dict(times=times, bytes=kbytes, flops=kflops, n_blocks=n)
 
 
-PMC_FILE = "profiles/r03_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
+PMC_FILE = "profiles/r04_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
 
 
 def _pmc_file():
@@ -246,7 +246,8 @@ def aggregate_product_path(G, ops, n_nodes, n_edges, sdim, vdim, iters=30):
 def other_configs_block(G, ops, args):
     """The BASELINE configurations that are model steps -- c1 (NMS 5-body), c4 (NMS 20-body), c3 (LBA) -- on this one GPU, eager
     and as a hipGraph replay of the captured step (these are launch-bound: ~700 launches for 2 000 .. 250 000 edges): median
-    ms/step of HIP-event pairs, edges/s = edges x layers / step."""
+    ms/step of HIP-event pairs, edges/s = edges x layers / step.  A step here is the reference's whole training step: forward +
+    loss + backward + Adam update, all of it inside the captured graph."""
     import copy
     from gcpnet_amd.graphs import GraphedStep
 
@@ -260,7 +261,7 @@ def other_configs_block(G, ops, args):
         rec = {"workload": wl["label"], "n_edges": wl["n_edges"], "layers": wl["n_layers"], "steps": steps, "warmup": 5,
                "eager_ms_per_step_median": med, "eager_edges_per_s": wl["n_edges"] * wl["n_layers"] / (med * 1e-3)}
         try:
-            graphed = GraphedStep(wl["step"], warmup=3)
+            graphed = GraphedStep(wl["fwd_bwd"], warmup=3, optimizer=wl["optimizer"])  # forward + backward + Adam in ONE graph
             _, gmed = timed_steps(graphed, steps, 3, 1, None)
             rec.update({"hipgraph_ms_per_step_median": gmed, "hipgraph_edges_per_s": wl["n_edges"] * wl["n_layers"] / (gmed * 1e-3)})
             del graphed
@@ -405,8 +406,11 @@ def build_model_workload(args, rank, world, G, ops):
     reducer = GradAllReducer(params) if world > 1 else None
     dev = {k: v.cuda() for k, v in batch.items()}
     n_edges = batch["edge_index"].shape[1]
+    # the reference's training step ends in Adam (configs/model/gcpnet_nms.yaml:8-12, gcpnet_lba.yaml): one fused launch, step count
+    # on the device, so that the whole step -- optimizer included -- can be captured
+    opt = G.FusedAdam(params, lr=1e-4, capturable=True)
 
-    def step():
+    def fwd_bwd():
         for p in params:
             p.grad = None
         b = G.Batch(**dev)
@@ -416,7 +420,13 @@ def build_model_workload(args, rank, world, G, ops):
             reducer.all_reduce_mean()
         return loss
 
-    return dict(step=step, n_edges=n_edges, total_edges=world * n_edges, n_layers=model_cfg["num_encoder_layers"], label=label,
+    def step():
+        loss = fwd_bwd()
+        opt.step()
+        return loss
+
+    return dict(step=step, fwd_bwd=fwd_bwd, optimizer=opt, n_edges=n_edges, total_edges=world * n_edges,
+                n_layers=model_cfg["num_encoder_layers"], label=label + " + Adam update (FusedAdam, one launch)",
                 sharded=False, scaling="weak", model=model)
 
 
@@ -447,6 +457,18 @@ def timed_steps(step, steps, warmup, world, dist):
     return elapsed, per[len(per) // 2]
 
 
+def saved_activation_bytes(wl):
+    """Device memory one training-mode forward of the stack keeps for its backward (allocator bytes held while the outputs live),
+    per layer."""
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    out = wl["forward"]()
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - before
+    del out
+    return held / wl["n_layers"]
+
+
 def c5_block(G, ops, args):
     """A short measurement at BASELINE configs[4] size on this one GPU (100 000 nodes / 1 000 000 edges, (256,32), 4 layers),
     reported inside the default line: the configuration north_star's target sentence is written on."""
@@ -460,14 +482,70 @@ def c5_block(G, ops, args):
     k = 10
     elapsed, med = timed_steps(wl["step"], k, 2, 1, None)
     fl = layer_flops(a.nodes, wl["n_edges"], (256, 32), (32, 4))["fwd_bwd"] * a.layers
-    out = {"workload": wl["label"], "n_edges": wl["n_edges"], "steps": k, "warmup": 2, "ms_per_step": elapsed / k * 1e3,
+    saved = saved_activation_bytes(wl)
+    out = {"saved_activation_bytes_per_layer": saved, "workload": wl["label"], "n_edges": wl["n_edges"], "steps": k, "warmup": 2, "ms_per_step": elapsed / k * 1e3,
            "ms_per_step_median": med, "edges_per_s": wl["n_edges"] * a.layers * k / elapsed,
            "algorithmic_tflops_per_s": fl * k / elapsed / 1e12,
            "frac_of_fp32_mfma_peak": fl * k / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            "frac_of_fp32_mfma_peak_median_step": fl / (med * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     del wl
     torch.cuda.empty_cache()
+    try:
+        out["roofline"] = c5_kernel_roofline(G, ops, 1000000, 256, 32)
+    except Exception as exc:  # noqa: BLE001 -- must not cost the run its headline line
+        out["roofline_error"] = f"{type(exc).__name__}: {exc}"[:300]
+    torch.cuda.empty_cache()
     return out
+
+
+def c5_kernel_roofline(G, ops, rows, sdim, vdim, iters=10):
+    """The dominant kernel of the configs[4] step -- the backward (data path) of ONE residual message GCP (256,32)->(256,32) on
+    10^6 edge rows, `gcp_wg_bwd_kernel`, 28 launches per 4-layer step -- alone, HIP events on the launch stream: 2 * rows *
+    gcp_macs FLOP per launch against the fp32 MFMA peak; counter traffic / MFMA-busy share from the committed PMC passes."""
+    from gcpnet_amd.synthetic import gcp_macs
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    block = G.GCP2((sdim, vdim), (sdim, vdim), nonlinearities=("relu", None), bottleneck=4).cuda()
+    spec = block.make_spec([None], [None], residual=True)
+    w = tuple(None if t is None else t.detach() for t in block._weights())
+    s = torch.randn(rows, sdim, device="cuda", generator=g).requires_grad_()
+    v = torch.randn(rows, vdim, 3, device="cuda", generator=g)
+    fr = torch.randn(rows, 3, 3, device="cuda", generator=g)
+    ds = torch.randn(rows, sdim, device="cuda", generator=g)
+    dv = torch.randn(rows, vdim, 3, device="cuda", generator=g)
+    out_s, _ = ops.gcp2(spec, [s], [v], fr, w)
+    saved = out_s.grad_fn.saved_tensors
+    pack, s_pre, gate = saved[-3], saved[-2], saved[-1]
+    keep = {}
+
+    def bwd():
+        keep["r"] = ops.gcp2_backward_data(spec, rows, [s.detach()], [v], fr, w, pack, s_pre, gate, ds, dv, need_w=True)
+
+    with torch.no_grad():
+        for _ in range(3):
+            bwd()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        torch.cuda.synchronize()
+        for a, b in ev:
+            a.record()
+            bwd()
+            b.record()
+        torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    t = ts[len(ts) // 2] * 1e-3
+    flops = 2.0 * rows * gcp_macs(sdim, vdim, sdim, vdim)
+    H = block.hidden_dim
+    # algorithmic bytes per row: reads s_pre, d(s_out), d(v_out), v_in, gate, frames; writes d(s_in), d(v_in), ds_pre, dgate, ext
+    nbytes = rows * (4.0 * (2 * sdim + 2 * 3 * vdim + vdim + 9) + 4.0 * (2 * sdim + 3 * vdim + vdim + (H + 9 + 3) // 4 * 4))
+    name = "gcp_wg_bwd_kernel (256,32)"
+    achieved = flops / t / 1e12
+    return {"kernel": f"gcp_wg_bwd_kernel: backward (data path) of one residual message GCP ({sdim},{vdim})->({sdim},{vdim}) on {rows} rows, "
+                      "28 launches per 4-layer configs[4] step",
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "median_launch_ms": t * 1e3, "flop_per_launch": flops,
+            "algorithmic_bytes_per_launch": nbytes, "algorithmic_hbm_gbs": nbytes / t / 1e9,
+            "traffic": pmc_traffic(name), "traffic_source": PMC_FILE if pmc_traffic(name) is not None else None,
+            "mfma_busy_frac_pmc": pmc_mfma_busy(name)}
 
 
 def main():
@@ -484,16 +562,45 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
+    # what the process group actually is goes into the line (`rccl`): world size, backend and the (rank, device) pairs collected
+    # with an all_gather -- i.e. a collective over every rank has run before anything is timed.  If the group cannot be set up
+    # or that collective raises, the run falls back to independent replicas (no collective, rank 0 reports N x its own rate)
+    # and says so.
+    rccl_info = {"world": world, "backend": None, "ranks_seen": [[0, local_rank]], "fallback": None}
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            seen = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(seen, torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int64, device="cuda"))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            assert int(probe.item()) == world
+            rccl_info.update(backend=dist.get_backend(), world=dist.get_world_size(), ranks_seen=[[int(t[0]), int(t[1])] for t in seen])
+        except Exception as exc:  # noqa: BLE001 -- any failure of the collective layer ends up in the JSON line, not in a dead run
+            rccl_info["fallback"] = f"independent replicas, no collective ({type(exc).__name__}: {str(exc)[:200]})"
+            sys.stderr.write(f"[bench rank {rank}] process group unusable, falling back to replicas: {exc}\n")
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            world_job, world = world, 1  # this process now behaves like a single-GPU run; rank 0 scales its own rate
+            args.shard = "batch"
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            world_job = world
+    else:
+        world_job = 1
 
     import gcpnet_amd as G
     from gcpnet_amd import ops
     from gcpnet_amd.synthetic import layer_flops
 
+    from gcpnet_amd import _lib as _glib
+    if _glib.load().gcpnet_debug_knobs_compiled():
+        raise SystemExit("libgcpnet_hip.so was built with -DGCP_DEBUG_KNOBS (measurement knobs that change results): no bench line from it")
     is_stack = args.config in ("c2", "c5")
     if args.dry_run_world:
         assert is_stack and world == 1, "--dry-run-world: c2 / c5, one process"
@@ -505,7 +612,8 @@ def main():
         from gcpnet_amd.graphs import GraphedStep
 
         assert world == 1, "--hip-graph: single-GPU runs (collectives are not captured here)"
-        step_fn = GraphedStep(wl["step"], warmup=max(args.warmup, 3))
+        step_fn = (GraphedStep(wl["fwd_bwd"], warmup=max(args.warmup, 3), optimizer=wl["optimizer"]) if "optimizer" in wl else
+                   GraphedStep(wl["step"], warmup=max(args.warmup, 3)))
     elapsed, median_ms = timed_steps(step_fn, args.steps, args.warmup, world, dist)
 
     if rank == 0 and args.step_only:
@@ -513,11 +621,16 @@ def main():
                           "warmup": args.warmup, "config": args.config}))
     elif rank == 0:
         value = wl["total_edges"] * wl["n_layers"] * args.steps / elapsed
+        if rccl_info["fallback"]:  # (replicas: every rank runs this same step on its own GPU; no barrier was possible)
+            value *= world_job
         out = {
-            "metric": "processed edges/sec (GCP fwd+bwd)", "value": value, "unit": "edges/s", "n_gpus": world,
+            "metric": "processed edges/sec (GCP fwd+bwd)", "value": value, "unit": "edges/s", "n_gpus": world_job,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_median": median_ms,
             "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # every switch of this package that the environment sets (the shipped library honours none that changes results)
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("GCPNET_", "BENCH_"))},
+            "rccl": rccl_info,
             "config": {
                 "workload": f"{args.config}: {wl['label']}", "n_edges": wl["n_edges"], "layers": wl["n_layers"],
                 "launch": "hipGraph replay of the captured step" if args.hip_graph else "eager launches",
@@ -533,6 +646,7 @@ def main():
             node_dims = (args.sdim, args.vdim)
             fl = layer_flops(args.nodes, wl["n_edges"], node_dims, (32, 4))["fwd_bwd"] * args.layers
             per_job = fl * (1 if wl["sharded"] else world)
+            out["saved_activation_bytes_per_layer"] = saved_activation_bytes(wl)
             out["whole_step"] = {"algorithmic_tflops_per_s": per_job * args.steps / elapsed / 1e12,
                                  "frac_of_fp32_mfma_peak": per_job * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS / world}
         if is_stack and not wl["sharded"]:
@@ -619,6 +733,8 @@ def cpu_baseline(wl, args):
     def one():
         for t in ins.values():
             t.grad = None
+        for t in P.values():
+            t.grad = None
         h, chi = ins["h"], ins["chi"]
         for i in range(n_layers):
             h, chi = O.gcp_interactions(P, f"{i}.", h, chi, ins["e"], ins["xi"], ei, fr, cfg, lcfg)
@@ -641,16 +757,31 @@ def cpu_baseline(wl, args):
     gi = {k: sample[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
     gfr = G.localize(sample["x"].cuda(), ei.cuda())
     h, chi = gi["h"], gi["chi"]
+    for p_ in layers.parameters():
+        p_.grad = None
     for i in range(n_layers):
         h, chi = layers[i]((h, chi), (gi["e"], gi["xi"]), ei.cuda(), gfr)
     ((h * lw["h"].cuda()).sum() + (chi * lw["chi"].cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    # weight gradients of the FIRST layer (it sees the gradient of everything behind it): every parameter tensor against the oracle's,
+    # relative L2 (a step that skipped or corrupted a weight-gradient GEMM cannot pass)
+    wg_err = {}
+    for name, p_ in layers[0].named_parameters():
+        ref = P["0." + name].grad
+        if ref is None or p_.grad is None:
+            wg_err[name] = float("inf") if (ref is None) != (p_.grad is None) else 0.0
+            continue
+        wg_err[name] = float((p_.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp(min=1e-30))
+    worst_w = max(wg_err, key=wg_err.get)
     fwd_err = max(float((h.detach().cpu() - ch).abs().max() / ch.abs().max().clamp(min=1.0)),
                   float((chi.detach().cpu() - cchi).abs().max() / cchi.abs().max().clamp(min=1.0)))
     grad_err = {k: float((gi[k].grad.cpu().double() - ins[k].grad.double()).norm() / ins[k].grad.double().norm().clamp(min=1e-30))
                 for k in gi}
     parity = {"against": "the cpu_baseline run above (oracle, fp32)", "forward_max_abs_err_over_scale": fwd_err,
               "forward_tol": 1e-5, "input_grad_rel_l2_err": grad_err, "input_grad_tol": 1e-3,
-              "ok": bool(fwd_err <= 1e-5 and max(grad_err.values()) <= 1e-3)}
+              "layer0_weight_grad_rel_l2_err_max": wg_err[worst_w], "layer0_weight_grad_worst": worst_w,
+              "layer0_weight_grads_checked": len(wg_err), "weight_grad_tol": 2e-3,
+              "ok": bool(fwd_err <= 1e-5 and max(grad_err.values()) <= 1e-3 and wg_err[worst_w] <= 2e-3)}
     assert parity["ok"], f"GPU path disagrees with the CPU oracle: {parity}"
     return base, parity
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing", "gcpnet_debug_set_fp32_mfma",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
-    "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
+    "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
     "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
 ]
 
@@ -184,6 +184,7 @@ def load():
     lib.gcpnet_wg_reduce_multi.argtypes = [i32, vp, vp]
     lib.gcpnet_dropout.argtypes = [i64, i32, vp, f32, C.c_uint64, vp, vp]
     lib.gcpnet_adam_step.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, i32, vp]
+    lib.gcpnet_adam_step_dev.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, vp, vp]
     lib.gcpnet_nms_edge_features.argtypes = [i64, vp, vp, vp, vp, i32, f32, i32, vp, vp, vp]
     lib.gcpnet_nms_node_features.argtypes = [i64, vp, vp, vp, vp, vp, vp]
     lib.gcpnet_orientations.argtypes = [i64, vp, vp, vp, vp]

@@ -48,6 +48,27 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 }
 
+// The same with the step count in DEVICE memory (a captured step: hipGraph replays would freeze a host-side count and its bias
+// corrections): every thread reads *step, which adam_step_inc_kernel -- launched behind the last adam launch of the call -- advances.
+__global__ __launch_bounds__(256) void adam_dev_kernel(AdamArgs a, const int64_t* __restrict__ step) {
+    const gcp_adam_tensor_t& T = a.t[blockIdx.y];
+    const double st = (double)(*step + 1);
+    const float bias1 = (float)(1.0 - pow((double)a.beta1, st)), bias2 = (float)(1.0 - pow((double)a.beta2, st));
+    const float rs2 = 1.f / sqrtf(bias2), lr1 = a.lr / bias1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < T.n; i += (int64_t)gridDim.x * 256) {
+        float g = T.grad[i];
+        const float p = T.param[i];
+        if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
+        const float m = a.beta1 * T.exp_avg[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * T.exp_avg_sq[i] + (1.f - a.beta2) * g * g;
+        T.exp_avg[i] = m;
+        T.exp_avg_sq[i] = v;
+        const float denom = sqrtf(v) * rs2 + a.eps;
+        T.param[i] = p - lr1 * (m / denom);
+    }
+}
+__global__ void adam_step_inc_kernel(int64_t* step) { *step += 1; }
+
 // y = act(x) / dx = g * act'(x), element-wise (models/__init__.py:42-57); used where an activation sits between separately launched
 // pieces (the frame-gate path of GCP2, components/gcpnet.py:369-384).
 __global__ __launch_bounds__(256) void act_kernel(int64_t n, const float* __restrict__ x, const float* __restrict__ g, int act, float slope,
@@ -189,9 +210,27 @@ extern "C" int gcpnet_dropout(int64_t n_groups, int group, const float* x, float
     return 0;
 }
 
+static int adam_launch(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int step, int64_t* step_dev, void* stream);
+
 extern "C" int gcpnet_adam_step(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, void* stream) {
-    if (n < 0 || (n > 0 && !tensors) || step < 1) return GCPNET_E_BADARG;
+    if (step < 1) return GCPNET_E_BADARG;
+    return adam_launch(n, tensors, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream);
+}
+
+extern "C" int gcpnet_adam_step_dev(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int64_t* step_dev, void* stream) {
+    if (!step_dev) return GCPNET_E_BADARG;
+    if (int rc = adam_launch(n, tensors, lr, beta1, beta2, eps, weight_decay, 1, step_dev, stream)) return rc;
+    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+static int adam_launch(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int step, int64_t* step_dev, void* stream) {
+    if (n < 0 || (n > 0 && !tensors)) return GCPNET_E_BADARG;
     for (int i0 = 0; i0 < n; i0 += GCP_ADAM_MAX_TENSORS) {
         AdamArgs a;
         a.n = n - i0 < GCP_ADAM_MAX_TENSORS ? n - i0 : GCP_ADAM_MAX_TENSORS;
@@ -207,7 +246,8 @@ extern "C" int gcpnet_adam_step(int n, const gcp_adam_tensor_t* tensors, float l
         a.bias2 = (float)(1.0 - pow((double)beta2, (double)step));
         if (nmax == 0) continue;
         const int64_t nb = (nmax + 255) / 256;
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb < 64 ? nb : 64), a.n), dim3(256), 0, (hipStream_t)stream, a);
+        if (step_dev) hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)(nb < 64 ? nb : 64), a.n), dim3(256), 0, (hipStream_t)stream, a, step_dev);
+        else hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb < 64 ? nb : 64), a.n), dim3(256), 0, (hipStream_t)stream, a);
         GCP_HIP_CHECK_LAUNCH();
     }
     return 0;

@@ -1,5 +1,6 @@
-"""hipGraph capture of a whole training step (forward + loss + backward) for launch-bound configurations.  The optimizer stays
-outside the capture: FusedAdam.step() takes the step count as a host value and refuses to run under capture.
+"""hipGraph capture of a whole training step (forward + loss + backward [+ optimizer]) for launch-bound configurations.  With
+`optimizer=FusedAdam(..., capturable=True)` the Adam update is part of the capture (its step count lives in device memory and is
+advanced by the update itself); an optimizer with a host-side step count stays outside (its step() refuses to run under capture).
 
 A GCPNet step on the n-body batches of the NMS task is ~700 kernel launches for 2 000 - 38 000 edges: the GPU idles between launches
 while Python and the HIP runtime enqueue them.  Captured once into a hipGraph (torch.cuda.CUDAGraph; the ctypes launches of this
@@ -18,7 +19,16 @@ from . import ops
 
 
 class GraphedStep:
-    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3):
+    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3, optimizer=None):
+        """step_fn: zeroes the gradients, runs forward + loss + backward, returns the loss.  optimizer (optional, capturable):
+        optimizer.step() runs behind step_fn in every warm-up step and inside the capture -- the `warmup` eager steps DO update the
+        parameters, the capture pass itself executes nothing."""
+        def full_step():
+            loss = step_fn()
+            if optimizer is not None:
+                optimizer.step()
+            return loss
+
         self._saved_side = ops.WEIGHT_GRADS_ON_SIDE_STREAM
         ops.WEIGHT_GRADS_ON_SIDE_STREAM = False  # (one stream inside the capture; the end-of-backward join is a host callback)
         try:
@@ -26,13 +36,13 @@ class GraphedStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    step_fn()
+                    full_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             ops.invalidate_packs()  # every packed-weight image is rebuilt INSIDE the graph, i.e. at every replay
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.loss = step_fn()
+                self.loss = full_step()
         finally:
             ops.WEIGHT_GRADS_ON_SIDE_STREAM = self._saved_side
         ops.invalidate_packs()  # (eager calls after this must not trust images that live in the graph's private pool)

@@ -16,8 +16,13 @@ class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) semantics (amsgrad=False, maximize=False, L2 weight decay added to
     the gradient), state keys `step`, `exp_avg`, `exp_avg_sq` as in torch (state_dicts interchange).  fp32 CUDA parameters."""
 
-    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 capturable: bool = False):
+        """capturable: the step count lives in device memory (one int64 per parameter group, advanced by the update itself:
+        gcpnet_adam_step_dev), state["step"] is that tensor as in torch.optim.Adam(capturable=True), and step() may be captured
+        into a hipGraph (gcpnet_amd.graphs.GraphedStep(step_fn, optimizer=...)).  lr / betas / eps / weight_decay are frozen into
+        a capture; every parameter of a group must take part from the first step on."""
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -25,12 +30,17 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            # the step count and the bias corrections derived from it are host values passed as kernel arguments: a captured
-            # step() would replay the capture-time corrections for ever and state["step"] would stop advancing
-            raise RuntimeError("FusedAdam.step() cannot be captured into a hipGraph: call it eagerly after GraphedStep's replay")
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         lib = _lib.load()
         for group in self.param_groups:
+            if group.get("capturable"):
+                self._step_capturable(lib, group)
+                continue
+            if capturing:
+                # the step count and the bias corrections derived from it are host values passed as kernel arguments: a captured
+                # step() would replay the capture-time corrections for ever and state["step"] would stop advancing
+                raise RuntimeError("FusedAdam.step() with a host-side step count cannot be captured into a hipGraph: construct the "
+                                   "optimizer with capturable=True, or call it eagerly after GraphedStep's replay")
             items, step = [], None
             for p in group["params"]:
                 if p.grad is None:
@@ -53,6 +63,48 @@ class FusedAdam(torch.optim.Optimizer):
                 self._launch(lib, group, items, step)
         ops.invalidate_packs()  # (p.data was written through a raw pointer: the packed-weight caches must not outlive it)
         return loss
+
+    def _step_capturable(self, lib, group):
+        """One update of a capturable group: the step count is read and advanced on the device."""
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return
+        dev_step = group.get("_step_dev")
+        if dev_step is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdam(capturable=True): run at least one eager step before capturing (state is created there)")
+            known = [self.state[p]["step"] for p in group["params"] if self.state.get(p)]  # (a loaded state_dict: per-parameter tensors)
+            start = int(known[0].item() if torch.is_tensor(known[0]) else known[0]) if known else 0
+            dev_step = group["_step_dev"] = torch.full((1,), start, dtype=torch.int64, device=ps[0].device)
+        items = []
+        for p in ps:
+            if not p.is_cuda or p.dtype != torch.float32:
+                raise _lib.GcpnetHipError("FusedAdam: fp32 parameters on the GPU only (gcpnet_amd has no CPU path)")
+            st = self.state[p]
+            if "exp_avg" not in st:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FusedAdam(capturable=True): a parameter without state inside a capture")
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["step"] = dev_step  # (one counter per group: every parameter takes part in every step)
+            items.append((p, st))
+        arr, keep = self._tensors(items)
+        b1, b2 = group["betas"]
+        check(lib.gcpnet_adam_step_dev(len(items), arr, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                       float(group["weight_decay"]), C.c_void_p(dev_step.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam_step_dev")
+        del keep
+
+    @staticmethod
+    def _tensors(items):
+        arr = (AdamTensor * len(items))()
+        keep = []
+        for k, (p, st) in enumerate(items):
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            keep.append(g)
+            arr[k].param, arr[k].grad = p.data_ptr(), g.data_ptr()
+            arr[k].exp_avg, arr[k].exp_avg_sq, arr[k].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+        return arr, keep
 
     @staticmethod
     def _launch(lib, group, items, step):

@@ -444,6 +444,11 @@ typedef struct {
 #define GCP_ADAM_MAX_TENSORS 96
 int gcpnet_adam_step(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, void* stream);
+/* The same with the step count in device memory (*step_dev = steps taken so far; the call uses *step_dev + 1 for the bias corrections
+ * and advances it behind the update): nothing of the call depends on a host value that changes from step to step, so a training step
+ * that ends in it can be captured into a hipGraph and replayed (torch.optim.Adam(capturable=True) semantics). */
+int gcpnet_adam_step_dev(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int64_t* step_dev, void* stream);
 
 /* ---- input side ---------------------------------------------------------------------------------
  * NMS featuriser, src/datamodules/components/nms_dataset.py:23-61 + helper.py:16-59:

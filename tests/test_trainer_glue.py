@@ -200,6 +200,66 @@ def test_hip_graph_replay_matches_eager_step(G):
         assert torch.equal(p.grad, g)
 
 
+def test_captured_training_steps_with_adam_match_torch_adam_on_the_oracle(G):
+    """forward + MSE loss + backward + Adam as ONE hipGraph (GraphedStep(step, optimizer=FusedAdam(capturable=True))): 2 eager
+    warm-up steps + 8 replays must leave the parameters where 10 steps of torch.optim.Adam on the CPU oracle leave them
+    (gcpnet_nms_module.py:153-178: the reference's step is forward + loss + backward + Adam, configs/model/gcpnet_nms.yaml:8-12).
+    eps = 1e-4 for both optimizers: with the default 1e-8 Adam turns a gradient that is round-off (1e-12 in one implementation, 0 or
+    -1e-12 in the other) into a full +-lr update, which compares the signs of noise, not the optimizers."""
+    from gcpnet_amd.graphs import GraphedStep
+    from oracle import gcp_oracle as O
+    from tests.golden.gen_helpers import nms_like_batch
+
+    torch.manual_seed(5)
+    model_cfg = dict(h_input_dim=1, chi_input_dim=3, e_input_dim=17, xi_input_dim=1, h_hidden_dim=64, chi_hidden_dim=16,
+                     e_hidden_dim=32, xi_hidden_dim=4, num_encoder_layers=2, dropout=0.0)
+    mcfg = G.default_module_cfg()
+    mcfg["nonlinearities"] = ["silu", None]
+    model = G.GCPNetNMS(model_cfg=model_cfg, module_cfg=mcfg, layer_cfg=G.default_layer_cfg()).cuda().train()
+    b = nms_like_batch(12, 5, 77)
+    b["label"] = b["x"] + 0.3 * torch.randn(b["x"].shape, generator=torch.Generator().manual_seed(78))
+    # ---- the oracle: 10 steps of torch.optim.Adam on the CPU
+    P = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    ocfg = O.default_module_cfg()
+    ocfg["nonlinearities"] = ("silu", None)
+    opt_ref = torch.optim.Adam(list(P.values()), lr=1e-3, eps=1e-4)
+    ref_losses = []
+    for _ in range(10):
+        opt_ref.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(O.nms_forward(P, b, ocfg, O.default_layer_cfg(), 2)["x"], b["label"])
+        loss.backward()
+        opt_ref.step()
+        ref_losses.append(float(loss))
+    # ---- the product path: 2 eager steps (GraphedStep's warm-up) + 8 replays of the captured step
+    dev = {k: v.cuda() for k, v in b.items()}
+    params = list(model.parameters())
+    opt = G.FusedAdam(params, lr=1e-3, eps=1e-4, capturable=True)
+    losses = []
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss, _, _ = model.step(G.Batch(**dev))
+        loss.backward()
+        return loss
+
+    graphed = GraphedStep(step, warmup=2, optimizer=opt)
+    for _ in range(8):
+        losses.append(float(graphed()))
+    torch.cuda.synchronize()
+    assert int(opt.state[params[0]]["step"].item()) == 10
+    for a, r in zip(losses, ref_losses[2:]):  # (replay k computes the loss of step k + 2)
+        assert abs(a - r) <= 1e-5 * max(1.0, abs(r)), (losses, ref_losses)
+    worst = 0.0
+    for k, v in model.state_dict().items():
+        worst = max(worst, float((v.cpu() - P[k].detach()).abs().max()))
+    assert worst <= 1e-5, worst
+    # an optimizer with a host-side step count still refuses capture
+    opt2 = G.FusedAdam(params, lr=1e-3)
+    with pytest.raises(RuntimeError):
+        GraphedStep(step, warmup=1, optimizer=opt2)
+
+
 def test_forward_without_backward_frees_saved_activations(G):
     """A training-mode forward whose backward never runs (validation without no_grad, an aborted step) must give its saved
     activations back once the outputs are dropped: nothing may hang off the autograd context in a cycle."""
