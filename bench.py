@@ -56,9 +56,11 @@ def parse():
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--shard", choices=["batch", "graph"], default="batch",
                     help="N > 1: 'batch' = one graph per rank (weak scaling); 'graph' = one graph split by node ranges (strong scaling)")
-    ap.add_argument("--halo", action="store_true",
-                    help="--shard graph: renumber the nodes along a Morton curve and exchange only the halo rows (all-to-all) instead of "
-                         "all-gathering the whole feature table")
+    ap.add_argument("--halo", dest="halo", action="store_true", default=True,
+                    help="--shard graph (the default there): nodes renumbered along a Morton curve, only the halo rows exchanged "
+                         "(all-to-all): 30 - 45x fewer bytes than the all-gather at configs[4] size (profiles/r03_c5_dry_run_world8.json)")
+    ap.add_argument("--allgather", dest="halo", action="store_false",
+                    help="--shard graph: all-gather the whole node-feature table per layer (reduce-scatter of its gradient) instead")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--neighbors", type=int, default=None)

@@ -106,8 +106,10 @@ def test_shard_graph_batch_single_process():
 
 # ---- ONE graph split by target-node ranges: per-layer all-gather of node features forward,
 #      reduce-scatter of their gradients backward; the oracle plays the per-rank kernels -----------------------------------
-def _sharded_case():
-    """Seeded graph (not col-sorted: the sharding sorts), two GCPInteractions layers' parameters, inputs, loss weights."""
+def _sharded_case(skew=False):
+    """Seeded graph (not col-sorted: the sharding sorts), two GCPInteractions layers' parameters, inputs, loss weights.
+    skew: a third of the edges point at six hub nodes and a stretch of nodes has no in-edge at all -- the equal-EDGE cut then gives
+    the ranks very different node counts (one of them a handful of hubs), i.e. uneven table slots and empty peers in the halo lists."""
     import gcpnet_amd as G
     from oracle import gcp_oracle as O
     from tests.helpers import rand_graph
@@ -118,6 +120,15 @@ def _sharded_case():
                                                    layer_cfg=G.default_layer_cfg(num_message_layers=3), dropout=0.0) for _ in range(2))
     P = {k: v.detach().clone() for k, v in layers.state_dict().items()}
     ei, x = rand_graph(n, e, 6)
+    if skew:
+        gs = torch.Generator().manual_seed(8)
+        col = ei[1].clone()
+        hub = torch.randperm(e, generator=gs)[: e // 3]
+        col[hub] = torch.randint(40, 46, (hub.numel(),), generator=gs)
+        quiet = (col >= 60) & (col < 75)  # nodes 60..74 keep no in-edge
+        col[quiet] = torch.randint(0, 40, (int(quiet.sum()),), generator=gs)
+        col = torch.where(col == ei[0], (col + 1) % 40, col)
+        ei = torch.stack((ei[0], col))
     g = torch.Generator().manual_seed(7)
     ins = dict(h=torch.randn(n, dims[0], generator=g), chi=torch.randn(n, dims[1], 3, generator=g),
                e=torch.randn(e, 32, generator=g), xi=torch.randn(e, 4, 3, generator=g))
@@ -148,10 +159,18 @@ def _sharded_job_halo(rank, world):
     return _sharded_job(rank, world, halo=True)
 
 
-def _sharded_job(rank, world, halo=False):
+def _sharded_job_skew(rank, world):
+    return _sharded_job(rank, world, halo=False, skew=True)
+
+
+def _sharded_job_halo_skew(rank, world):
+    return _sharded_job(rank, world, halo=True, skew=True)
+
+
+def _sharded_job(rank, world, halo=False, skew=False):
     from oracle import gcp_oracle as O
 
-    P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
+    P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case(skew)
     P = {k: v.clone().requires_grad_() for k, v in P.items()}
     sg = ShardedGraph(ei, n, rank, world, halo=halo)
     frames_loc = O.localize(x, sg.edge_index_global)  # (positions are replicated, by global id)
@@ -176,12 +195,14 @@ def _sharded_job(rank, world, halo=False):
                 w={k: v.grad.clone() for k, v in P.items()})
 
 
-@pytest.mark.parametrize("halo", [False, True])
-def test_sharded_graph_matches_unsharded(halo):
-    """halo=False: all-gather of the whole feature table; halo=True: all-to-all of the rows the peers' in-edges reference."""
+@pytest.mark.parametrize("halo,world,skew", [(False, 2, False), (True, 2, False), (False, 4, False), (True, 4, False),
+                                             (False, 4, True), (True, 4, True)])
+def test_sharded_graph_matches_unsharded(halo, world, skew):
+    """halo=False: all-gather of the whole feature table; halo=True: all-to-all of the rows the peers' in-edges reference.  2 and 4
+    ranks; `skew`: hub nodes and nodes without in-edges, so that the equal-edge cut leaves the ranks with very uneven node ranges."""
     from oracle import gcp_oracle as O
 
-    P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case()
+    P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case(skew)
     P = {k: v.clone().requires_grad_() for k, v in P.items()}
     ci = {k: v.clone().requires_grad_() for k, v in ins.items()}
     fr = O.localize(x, ei)
@@ -189,13 +210,20 @@ def test_sharded_graph_matches_unsharded(halo):
     for i in range(2):
         hh, cc = O.gcp_interactions(P, f"{i}.", hh, cc, ci["e"], ci["xi"], ei, fr, cfg, lcfg)
     ((hh * lw["h"]).sum() + (cc * lw["chi"]).sum()).backward()
-    out = _run(_sharded_job_halo if halo else _sharded_job)
-    assert out[0]["n0"] == 0 and out[0]["n1"] == out[1]["n0"] and out[1]["n1"] == n
-    assert sum(out[0]["edges"]) == ei.shape[1] and abs(out[0]["edges"][0] - out[0]["edges"][1]) <= 40  # equal-edge cut
+    job = {(False, False): _sharded_job, (True, False): _sharded_job_halo, (False, True): _sharded_job_skew,
+           (True, True): _sharded_job_halo_skew}[(halo, skew)]
+    out = _run(job, world)
+    assert out[0]["n0"] == 0 and out[world - 1]["n1"] == n and all(out[r]["n1"] == out[r + 1]["n0"] for r in range(world - 1))
+    assert sum(out[0]["edges"]) == ei.shape[1]
+    if skew:  # the node ranges really are uneven (a rank of hubs next to ranks of ordinary nodes)
+        sizes = [out[r]["n1"] - out[r]["n0"] for r in range(world)]
+        assert max(sizes) >= 4 * max(1, min(sizes)), sizes
+    else:
+        assert max(out[0]["edges"]) - min(out[0]["edges"]) <= 40  # equal-edge cut
     perm = out[0]["perm"]
     de, dxi = ci["e"].grad[perm], ci["xi"].grad[perm]  # (the shards hold their edges in col-sorted order)
     tol = dict(atol=2e-6, rtol=1e-5)
-    for r in (0, 1):
+    for r in range(world):
         o = out[r]
         sl, es = slice(o["n0"], o["n1"]), slice(o["e0"], o["e1"])
         assert torch.allclose(o["h"], hh.detach()[sl], **tol) and torch.allclose(o["chi"], cc.detach()[sl], **tol)
