@@ -24,7 +24,7 @@ EXPORTS = [
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing", "gcpnet_debug_set_fp32_mfma",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
-    "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
+    "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_radius_graph_first", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
     "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
 ]
 
@@ -194,6 +194,7 @@ def load():
     lib.gcpnet_frame_gate_bwd_parts.argtypes = [i64]
     lib.gcpnet_node_scalarize.argtypes = [i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.gcpnet_radius_graph.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]
+    lib.gcpnet_radius_graph_first.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",

@@ -87,6 +87,13 @@ constexpr int RG_MAX_K = 64;
 // One thread per target node (in cell-sorted order).  cell_start[c] .. cell_start[c + 1] are the sorted positions of the nodes
 // of cell c (cells of all graphs concatenated: graph g owns cells [g * ncell, (g + 1) * ncell)).  Distances in double from the
 // float coordinates: the same exact values, hence the same order, as scipy's cKDTree on the float32 array.
+// FIRST: torch_cluster 1.6.0's selection instead of the nearest K (its CUDA kernel `radius_kernel`, csrc/cuda/radius_cuda.cu: for each
+// target the candidates of its graph are visited in ascending INDEX order, a candidate with dist^2 < r^2 -- strict -- is taken, the
+// walk stops at the cap; `radius_graph(loop=False)`, torch_cluster/radius.py, calls it with cap K + 1 WITH the node itself among the
+// candidates and removes the self loop afterwards): the K lowest ids of {nodes within r, self included}, self dropped -- a node
+// whose K + 1 lowest in-range ids are all below its own keeps K + 1 neighbours, as upstream does.  Here K is that cap (K + 1 of the
+// caller) and the list is kept ascending by id.
+template <bool FIRST>
 __global__ __launch_bounds__(128) void radius_graph_kernel(int N, const float* __restrict__ xs /* sorted coordinates */,
                                                            const int32_t* __restrict__ order /* sorted position -> node id */,
                                                            const int32_t* __restrict__ cell_of /* sorted position -> global cell */,
@@ -113,11 +120,12 @@ __global__ __launch_bounds__(128) void radius_graph_kernel(int N, const float* _
                 if (xq < 0 || xq >= nx) continue;
                 const int c = g * ncell + (z * ny + y) * nx + xq;
                 for (int q = cell_start[c]; q < cell_start[c + 1]; ++q) {
-                    if (q == p) continue;
+                    if (!FIRST && q == p) continue;
                     const double ex = xs[3 * q] - px, ey = xs[3 * q + 1] - py, ez = xs[3 * q + 2] - pz;
-                    const double d2 = ex * ex + ey * ey + ez * ez;
-                    if (d2 > r2) continue;
+                    double d2 = ex * ex + ey * ey + ez * ez;
+                    if (FIRST ? !(d2 < r2) : d2 > r2) continue;
                     const int id = order[q];
+                    if (FIRST) d2 = (double)id;  // the sort key of this mode
                     // insertion into the ascending list (ties: lower node id first), keeping at most K
                     int pos = n < K ? n : K;
                     while (pos > 0 && (bd[pos - 1] > d2 || (bd[pos - 1] == d2 && bi[pos - 1] > id))) --pos;
@@ -131,6 +139,12 @@ __global__ __launch_bounds__(128) void radius_graph_kernel(int N, const float* _
         }
     }
     const int me = order[p];
+    if (FIRST) {  // drop the self loop (if it made the list), keep the order
+        int m = 0;
+        for (int t = 0; t < n; ++t)
+            if (bi[t] != me) bi[m++] = bi[t];
+        n = m;
+    }
     cnt[me] = n;
     for (int t = 0; t < K; ++t) nbr[(int64_t)me * K + t] = t < n ? bi[t] : -1;
 }
@@ -175,8 +189,21 @@ extern "C" int gcpnet_radius_graph(int N, const float* x_sorted, const int32_t* 
         max_neighbors > RG_MAX_K || !nbr || !count)
         return GCPNET_E_BADARG;
     if (N == 0) return 0;
-    hipLaunchKernelGGL(radius_graph_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, x_sorted, order,
+    hipLaunchKernelGGL(radius_graph_kernel<false>, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, x_sorted, order,
                        cell_of, cell_start, nx, ny, nz, (double)radius * (double)radius, max_neighbors, nbr, count);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_radius_graph_first(int N, const float* x_sorted, const int32_t* order, const int32_t* cell_of,
+                                         const int32_t* cell_start, int nx, int ny, int nz, float radius, int max_neighbors, int32_t* nbr,
+                                         int32_t* count, void* stream) {
+    if (N < 0 || !x_sorted || !order || !cell_of || !cell_start || nx < 1 || ny < 1 || nz < 1 || !(radius > 0.f) || max_neighbors < 1 ||
+        max_neighbors + 1 > RG_MAX_K || !nbr || !count)
+        return GCPNET_E_BADARG;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, x_sorted, order,
+                       cell_of, cell_start, nx, ny, nz, (double)radius * (double)radius, max_neighbors + 1, nbr, count);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

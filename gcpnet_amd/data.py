@@ -36,18 +36,28 @@ def nms_featurize(x: Tensor, vel: Tensor, edge_attr: Tensor, edge_index: Tensor,
     return dict(h=h, chi=chi, e=e, xi=xi)
 
 
-def radius_graph(x: Tensor, r: float = 4.5, max_num_neighbors: int = 32, batch: Optional[Tensor] = None) -> Tensor:
+def radius_graph(x: Tensor, r: float = 4.5, max_num_neighbors: int = 32, batch: Optional[Tensor] = None, select: str = "nearest") -> Tensor:
     """edge_index [2, E] (int64; row = neighbour, col = node; sorted by col, neighbours of a node in ascending distance): for
     every node its `max_num_neighbors` nearest other nodes of the same graph within `r`, no self loops -- the edge list
-    gcpnet_amd.synthetic.radius_graph builds with scipy's cKDTree, bit for bit.  Cell list with cell edge r."""
+    gcpnet_amd.synthetic.radius_graph builds with scipy's cKDTree, bit for bit.  Cell list with cell edge r.
+
+    select="first": torch_cluster 1.6.0's choice when a node has more than `max_num_neighbors` nodes in range (the reference's
+    `radius_graph(..., max_num_neighbors=32)`, atom3d_dataset.py:110-112) as its CUDA kernel makes it -- the LOWEST node ids instead
+    of the nearest, distance test strict, the self loop removed after the cap was applied (a node whose own id is not among its
+    first max_num_neighbors + 1 in-range ids keeps max_num_neighbors + 1 edges: upstream's behaviour, kept); a node's neighbours
+    ascending by id.  (torch_cluster's CPU path walks a nanoflann k-d tree unsorted: that order is implementation-defined and not
+    restated.)  Below the cap both modes give the same edge SET."""
     lib = _lib.load()
     x = _req(x, "x")
     n = x.shape[0]
     dev = x.device
     if n == 0:
         return torch.zeros((2, 0), dtype=torch.int64, device=dev)
-    if max_num_neighbors > 64:
-        raise ValueError("radius_graph: at most 64 neighbours per node")
+    if select not in ("nearest", "first"):
+        raise ValueError("radius_graph: select is 'nearest' or 'first'")
+    first = select == "first"
+    if max_num_neighbors + int(first) > 64:
+        raise ValueError("radius_graph: at most 64 neighbours per node (63 with select='first')")
     b = batch.long() if batch is not None else torch.zeros(n, dtype=torch.long, device=dev)
     n_graphs = int(b.max()) + 1
     lo = torch.full((n_graphs, 3), float("inf"), device=dev).scatter_reduce(0, b.unsqueeze(1).expand(n, 3), x, "amin")
@@ -60,14 +70,16 @@ def radius_graph(x: Tensor, r: float = 4.5, max_num_neighbors: int = 32, batch: 
     start = torch.zeros(n_graphs * ncell + 1, dtype=torch.int64, device=dev)
     start[1:] = torch.cumsum(counts, 0)
     xs = x[order].contiguous()
-    nbr = torch.empty((n, max_num_neighbors), dtype=torch.int32, device=dev)
+    width = max_num_neighbors + int(first)
+    nbr = torch.empty((n, width), dtype=torch.int32, device=dev)
     cnt = torch.empty((n,), dtype=torch.int32, device=dev)
     # (held in variables until the launch is enqueued: a temporary's memory goes back to the caching allocator at once)
     order32, cell32, start32 = order.to(torch.int32), key_sorted.to(torch.int32), start.to(torch.int32)
-    check(lib.gcpnet_radius_graph(n, _p(xs), _p(order32), _p(cell32), _p(start32), nx, ny, nz, float(r), int(max_num_neighbors),
-                                  _p(nbr), _p(cnt), _stream()), "radius_graph")
+    fn = lib.gcpnet_radius_graph_first if first else lib.gcpnet_radius_graph
+    check(fn(n, _p(xs), _p(order32), _p(cell32), _p(start32), nx, ny, nz, float(r), int(max_num_neighbors), _p(nbr), _p(cnt), _stream()),
+          "radius_graph")
     keep = nbr >= 0
-    col = torch.arange(n, device=dev).unsqueeze(1).expand(n, max_num_neighbors)[keep]
+    col = torch.arange(n, device=dev).unsqueeze(1).expand(n, width)[keep]
     return torch.stack((nbr[keep].long(), col))
 
 
@@ -82,24 +94,26 @@ def element_mapping(elements: Sequence[str]) -> Tensor:
 
 
 def lba_featurize(coords: Tensor, atom_types: Tensor, n_ligand: Optional[int] = None, edge_cutoff: float = 4.5, num_rbf: int = 16,
-                  max_num_neighbors: int = 32, batch: Optional[Tensor] = None, edge_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                  max_num_neighbors: int = 32, batch: Optional[Tensor] = None, edge_index: Optional[Tensor] = None,
+                  select: str = "nearest") -> Dict[str, Tensor]:
     """`BaseTransform.__call__` / `LBATransform.__call__` (atom3d_dataset.py:101-149) for one structure -- or, with `batch`, for
     the concatenated atoms of several -- on the GPU: radius graph (r = edge_cutoff, <= max_num_neighbors in-edges per atom, no
     self loops), e = 16 RBFs of the edge length with D_max = edge_cutoff (`_edge_features`, :42-62; `_rbf`, helper.py:29-49), xi =
     unit(x_row - x_col) [E, 1, 3], h = atom types (int64), chi = forward / backward orientations along the atom order [N, 2, 3]
     (`_node_features`, :65-84; `_orientations`, helper.py:52-59); `lig_flag` marks the last `n_ligand` atoms (:146-148).
 
-    Neighbour selection when an atom has MORE than `max_num_neighbors` atoms within the cutoff: this builder keeps the nearest
-    ones (deterministic, order-independent); torch_cluster 1.6.0's `radius_graph` keeps whichever it meets first (an unsorted
-    nanoflann radius search on the CPU, index order on the GPU) -- unpinned by the reference's tests and not
-    reproducible without that library.  Below the cap the edge SETS are identical; the edge order here is col-sorted with each
-    atom's neighbours by ascending distance.  Pass `edge_index` to featurise a given graph instead."""
+    Neighbour selection when an atom has MORE than `max_num_neighbors` atoms within the cutoff: by default this builder keeps the
+    nearest ones (deterministic, order-independent); `select="first"` keeps what torch_cluster 1.6.0's `radius_graph` keeps when it
+    walks a structure's atoms in index order (its CUDA kernel; pinned by the fixture `lba_features_capped`, whose stub restates that
+    walk) -- see radius_graph.  torch_cluster's CPU path (an unsorted nanoflann search) is not reproducible without that library.
+    Below the cap the edge SETS are identical; the edge order here is col-sorted with each atom's neighbours by ascending distance
+    ("nearest") or id ("first").  Pass `edge_index` to featurise a given graph instead."""
     lib = _lib.load()
     coords = _req(coords, "coords")
     n = coords.shape[0]
     dev = coords.device
     if edge_index is None:
-        edge_index = radius_graph(coords, r=edge_cutoff, max_num_neighbors=max_num_neighbors, batch=batch)
+        edge_index = radius_graph(coords, r=edge_cutoff, max_num_neighbors=max_num_neighbors, batch=batch, select=select)
     e_cnt = edge_index.shape[1]
     row, col = edge_index[0].to(torch.int32).contiguous(), edge_index[1].to(torch.int32).contiguous()
     f32 = dict(dtype=torch.float32, device=dev)

@@ -849,10 +849,22 @@ def collate(graphs: Sequence[Mapping[str, Tensor]]) -> Dict[str, Tensor]:
     return out
 
 
-def radius_graph(x: Tensor, batch: Tensor, radius: float = 4.5, max_neighbors: int = 32) -> Tensor:
+def radius_graph(x: Tensor, batch: Tensor, radius: float = 4.5, max_neighbors: int = 32, select: str = "nearest") -> Tensor:
     """K nearest other nodes of the same graph within `radius`, ascending by distance; edges (row = neighbour, col = node),
-    col-sorted.  Brute force in float64 (small inputs only)."""
+    col-sorted.  Brute force in float64 (small inputs only).
+    select="first": torch_cluster 1.6.0's selection as its CUDA kernel makes it (torch_cluster/radius.py `radius_graph` ->
+    csrc/cuda/radius_cuda.cu `radius_kernel`, the call of src/datamodules/components/atom3d_dataset.py:110-112): per target the
+    nodes of its graph in ascending index order, taken when dist^2 < r^2, at most max_neighbors + 1 with the node itself among the
+    candidates, the self loop removed afterwards."""
     xd = x.double()
+    if select == "first":
+        d2 = ((xd.unsqueeze(1) - xd.unsqueeze(0)) ** 2).sum(-1)
+        ok = (batch.unsqueeze(1) == batch.unsqueeze(0)) & (d2 < radius * radius)
+        rank = torch.cumsum(ok.long(), dim=1)  # position of every in-range node in the target's index-order walk (1-based)
+        keep = ok & (rank <= max_neighbors + 1)
+        keep.fill_diagonal_(False)
+        col, row = torch.nonzero(keep, as_tuple=True)
+        return torch.stack((row, col))
     d2 = ((xd.unsqueeze(1) - xd.unsqueeze(0)) ** 2).sum(-1)
     ok = (batch.unsqueeze(1) == batch.unsqueeze(0)) & (d2 <= radius * radius)
     ok.fill_diagonal_(False)

@@ -634,6 +634,33 @@ def fx_lba_features():
     save("lba_features", inputs=ins, outputs=outs, meta=dict(edge_cutoff=4.5, num_rbf=16, max_num_neighbors=32))
 
 
+def fx_lba_features_capped():
+    """The neighbour cap of the reference's graph recipe (atom3d_dataset.py:110-112, `radius_graph(..., max_num_neighbors=32)`):
+    the reference's REAL `LBATransform` on a DENSE pocket + ligand structure -- most atoms have 40 - 70 atoms within 4.5 A -- with
+    `torch_cluster.radius_graph` = the restatement of torch_cluster 1.6.0's index-order walk (ref_stubs._radius_graph_first).  Pins
+    which neighbours survive the cap (the lowest ids, the self loop removed after the cap) and the features of those edges."""
+    import pandas as pd
+    from src.datamodules.components import atom3d_dataset as A
+
+    rng = np.random.default_rng(123)
+    elements = ["C", "N", "O", "S", "H"]
+    ref_stubs.RADIUS_GRAPH_SELECT = "first"
+    try:
+        tf = A.LBATransform()
+
+        def frame(n, lo, side):
+            xyz = rng.uniform(lo, lo + side, size=(n, 3)).astype(np.float32)
+            return pd.DataFrame(dict(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2], element=rng.choice(elements, size=n)))
+        d = tf(dict(atoms_pocket=frame(110, 0.0, 7.0), atoms_ligand=frame(14, 2.0, 4.0), scores=dict(neglog_aff=6.25)))
+    finally:
+        ref_stubs.RADIUS_GRAPH_SELECT = "refuse"
+    deg = torch.bincount(d.edge_index[1], minlength=d.x.shape[0])
+    assert int(deg.max()) == 33 and int((deg >= 32).sum()) > 50, (int(deg.max()), int((deg >= 32).sum()))  # the cap binds, incl. the 33 case
+    save("lba_features_capped", inputs=dict(x=d.x, n_ligand=torch.tensor(14)),
+         outputs={k: getattr(d, k) for k in ("h", "chi", "e", "xi", "edge_index", "lig_flag")},
+         meta=dict(edge_cutoff=4.5, num_rbf=16, max_num_neighbors=32))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:  # only the named groups, e.g. `gen_fixtures.py fx_gcp_original`
@@ -652,4 +679,5 @@ if __name__ == "__main__":
     fx_models()
     fx_input_side()
     fx_lba_features()
+    fx_lba_features_capped()
     fx_cpd()

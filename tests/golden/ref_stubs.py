@@ -101,6 +101,32 @@ def _subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes
     return ei, (edge_attr[keep] if edge_attr is not None else None)
 
 
+RADIUS_GRAPH_SELECT = "refuse"  # "first": torch_cluster's index-order walk for inputs that exceed the cap (fx_lba_features_capped)
+
+
+def _radius_graph_first(x, r, batch, max_num_neighbors):
+    """torch_cluster 1.6.0, `radius_graph(x, r, batch, loop=False, max_num_neighbors)` as its CUDA kernel computes it, restated:
+    torch_cluster/radius.py calls `radius(x, x, r, batch, batch, max_num_neighbors + 1)` and removes the self loops afterwards;
+    csrc/cuda/radius_cuda.cu's `radius_kernel` visits, for every target, the nodes of its graph in ascending index order, takes a
+    node when dist^2 < r^2 (strict; fp32 arithmetic there, float64 here: generators keep every pair away from the boundary) and
+    stops at the cap.  edge_index = [source; target], grouped by target, sources ascending."""
+    import torch
+
+    n = x.shape[0]
+    d2 = torch.cdist(x.double(), x.double()) ** 2
+    ok = d2 < float(r) * float(r)
+    assert bool(((d2 - float(r) ** 2).abs() > 1e-6).all()), "a pair on the cutoff sphere"
+    if batch is not None:
+        ok &= batch.view(-1, 1) == batch.view(1, -1)
+    rows, cols = [], []
+    for i in range(n):
+        cand = torch.nonzero(ok[i]).flatten()[: max_num_neighbors + 1]  # ascending ids, self included, cap + 1
+        cand = cand[cand != i]
+        rows.append(cand)
+        cols.append(torch.full_like(cand, i))
+    return torch.stack((torch.cat(rows), torch.cat(cols)))
+
+
 def _radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", num_workers=1):
     """torch_cluster.radius_graph (1.6.0), documented semantics restated by brute force: edge (j -> i) for every pair of the same
     graph with |x_j - x_i| <= r, j != i (loop=False), at most `max_num_neighbors` per target i; edge_index = [source j; target i],
@@ -109,6 +135,8 @@ def _radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="sour
     import torch
 
     assert flow == "source_to_target" and not loop
+    if RADIUS_GRAPH_SELECT == "first":
+        return _radius_graph_first(x, r, batch, max_num_neighbors)
     n = x.shape[0]
     d = torch.cdist(x.double(), x.double())
     ok = d <= float(r)

@@ -374,6 +374,23 @@ def _by_col_row(ei):
     return torch.argsort(key)
 
 
+def test_lba_features_capped_golden():
+    """The neighbour cap (atom3d_dataset.py:110-112): the oracle's restatement of torch_cluster's index-order selection against the
+    fixture the reference's real LBATransform produced on a dense structure (edge lists identical, order included)."""
+    f = Fixture("lba_features_capped")
+    x = f.i["x"]
+    ei = O.radius_graph(x, torch.zeros(x.shape[0], dtype=torch.long), 4.5, 32, select="first")
+    assert torch.equal(ei, f.o["edge_index"])
+    deg = torch.bincount(ei[1], minlength=x.shape[0])
+    assert int(deg.max()) == 33 and int((deg >= 32).sum()) > 50  # the cap binds, incl. upstream's 33-neighbour case
+    near = O.radius_graph(x, torch.zeros(x.shape[0], dtype=torch.long), 4.5, 32)
+    assert near.shape[1] != ei.shape[1] or not torch.equal(near[:, _by_col_row(near)], ei)  # "nearest" is another graph here
+    out = O.lba_features(x, ei)
+    close(out["e"], f.o["e"], atol=1e-6, rtol=1e-6)
+    close(out["xi"], f.o["xi"], atol=1e-6, rtol=1e-6)
+    close(out["chi"], f.o["chi"], atol=1e-6, rtol=1e-6)
+
+
 def test_lba_features_golden():
     """Oracle restatement of the ATOM3D / LBA featuriser and of PyG collation against the fixture built by the reference's real
     LBATransform (atom3d_dataset.py:134-149) on two pocket + ligand structures."""

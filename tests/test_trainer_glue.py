@@ -145,6 +145,30 @@ def test_lba_featurize_and_collate_golden(G):
     assert G.element_mapping(["C", "Cl", "CL", "Zn", "H"]).tolist() == [1, 6, 6, 8, 0]
 
 
+def test_lba_featurize_neighbour_cap_first_found(G):
+    """select="first": torch_cluster's choice among more than 32 in-range atoms (lowest ids, self loop removed after the cap), against
+    the fixture of the reference's real LBATransform on a dense structure: identical edge list, features of those edges."""
+    from tests.helpers import Fixture, close
+
+    f = Fixture("lba_features_capped")
+    x = f.i["x"].cuda()
+    out = G.lba_featurize(x, f.o["h"], n_ligand=int(f.i["n_ligand"]), select="first")
+    assert torch.equal(out["edge_index"].cpu(), f.o["edge_index"])
+    close(out["e"].cpu(), f.o["e"], atol=2e-6, rtol=1e-5)
+    close(out["xi"].cpu(), f.o["xi"], atol=2e-6, rtol=1e-5)
+    close(out["chi"].cpu(), f.o["chi"], atol=2e-6, rtol=1e-5)
+    assert torch.equal(out["lig_flag"].cpu(), f.o["lig_flag"])
+    # the default keeps the NEAREST 32 instead: same targets, another (smaller or equal) edge list
+    near = G.radius_graph(x, max_num_neighbors=32)
+    assert int(torch.bincount(near[1]).max()) == 32 and not torch.equal(near.cpu(), f.o["edge_index"])
+    # two copies of the structure as a batch: the walk stays inside each graph
+    xb = torch.cat((x, x))
+    bb = torch.cat((torch.zeros(x.shape[0], dtype=torch.long), torch.ones(x.shape[0], dtype=torch.long))).cuda()
+    eb = G.radius_graph(xb, batch=bb, select="first").cpu()
+    n = x.shape[0]
+    assert torch.equal(eb, torch.cat((f.o["edge_index"], f.o["edge_index"] + n), dim=1))
+
+
 def test_radius_graph_matches_scipy_bit_for_bit(G):
     """GPU cell-list radius graph: the committed scipy fixture (3 graphs: dense, sparse, fewer nodes than K) and a fresh 20 000-node
     cloud against gcpnet_amd.synthetic.radius_graph -- identical edge_index arrays, col-sorted."""
