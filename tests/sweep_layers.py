@@ -62,6 +62,18 @@ for case in range(n_cases):
     lw = [torch.randn(t.shape, generator=g) for t in flat(ro)]
     sum((t * w).sum() for t, w in zip(flat(ro), lw)).backward()
     runs = []
+    hip_pre = []  # SWEEP_VERBOSE: (rows, so, s_pre) of every single-block launch of the HIP forward, in launch order
+    if os.environ.get("SWEEP_VERBOSE") == str(case):
+        from gcpnet_amd import ops as _ops
+
+        _orig_launch = _ops._gcp2_forward_launch
+
+        def _spy(spec, *a, **kw):
+            r = _orig_launch(spec, *a, **kw)
+            if r[4] is not None:
+                hip_pre.append((r[0], spec.so, r[4]))
+            return r
+        _ops._gcp2_forward_launch = _spy
     ei_d, fr_d, x_d = ei.cuda(), fr.cuda(), x.cuda()
     for rep in range(REPEAT):
         for p in layer.parameters():
@@ -73,6 +85,8 @@ for case in range(n_cases):
         runs.append(dict(**{f"out{i}": t.detach() for i, t in enumerate(flat(go))}, **{"d" + k: gi[k].grad for k in ins},
                          **{"w." + k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}))
     unstable = bit_identical(runs)
+    if os.environ.get("SWEEP_VERBOSE") == str(case):
+        _ops._gcp2_forward_launch = _orig_launch
 
     # smooth activations: element-wise (max error over max magnitude).  relu / leakyrelu: a pre-activation within round-off of
     # zero takes the other branch in one of the two fp32 implementations (expected for ~1 of the ~1e6 units of the larger cases)
@@ -125,6 +139,35 @@ for case in range(n_cases):
             rows_h = torch.nonzero(dif > 1e-4 * float(c64["h"].grad.abs().max())).flatten().tolist()
             expl = [i for i in rows_h if set(rows_h) <= ({i} | set(ei[0][ei[1] == i].tolist()))]
             print(f"\n      h rows off: {rows_h}; nodes i with all of them inside {{i}} + sources of i's in-edges: {expl}")
+            # The decisive look: the pre-activations themselves.  For every node-row block, the units of the
+            # suspected node(s) whose float64 pre-activation is closest to zero: HIP-side s_pre (what the kernel SAVED for its
+            # backward), the fp32 CPU oracle's and the float64 oracle's value.  A flip = HIP and float64 on opposite sides of zero.
+            O.TRACE_PRE = []
+            try:
+                O.gcp_interactions({k: t.detach().double() for k, t in P.items()}, "", ins["h"].double(), ins["chi"].double(),
+                                   ins["e"].double(), ins["xi"].double(), ei, fr.double(), ocfg, olc, node_pos=x.double() if upd else None)
+                t64 = O.TRACE_PRE
+                O.TRACE_PRE = []
+                O.gcp_interactions({k: t.detach() for k, t in P.items()}, "", ins["h"], ins["chi"], ins["e"], ins["xi"], ei, fr, ocfg, olc,
+                                   node_pos=x if upd else None)
+                t32 = O.TRACE_PRE
+            finally:
+                O.TRACE_PRE = None
+            node_hip = [(so_, sp) for r_, so_, sp in hip_pre[-len(hip_pre) // max(REPEAT, 1):] if r_ == n]
+            node_64 = [(name, sp) for name, sp in t64 if sp.shape[0] == n and n != e]
+            node_32 = [sp for name, sp in t32 if sp.shape[0] == n and n != e]
+            print(f"      node-row blocks: oracle {[(nm, tuple(sp.shape)) for nm, sp in node_64]}, HIP launches {[(so_, tuple(sp.shape)) for so_, sp in node_hip]}")
+            for (nm, p64), p32 in zip(node_64, node_32):
+                cand = [(so_, sp) for so_, sp in node_hip if so_ == p64.shape[1]]
+                for i in (expl or rows_h[:1]):
+                    scale = float(p64.abs().mean())
+                    u = int(p64[i].abs().argmin())
+                    line = f"      {nm:40s} node {i} unit {u}: f64 {float(p64[i, u]):+.3e}  cpu32 {float(p32[i, u]):+.3e}  (block scale {scale:.2e})"
+                    for so_, sp in cand:
+                        hv = float(sp[i, u])
+                        flip = " <-- OPPOSITE SIDE OF THE KINK" if hv * float(p64[i, u]) < 0 else ""
+                        line += f"  hip {hv:+.3e}{flip}"
+                    print(line)
         if not worse or few:
             worst = 0.0 if not worse else min(worst, 2.9e-3)
     if os.environ.get("SWEEP_VERBOSE") == str(case):
