@@ -15,7 +15,7 @@ VMODE_NONE, VMODE_SCALAR_GATE, VMODE_SELF_GATE = 0, 1, 2
 MAX_SEG, TN_MAX_SEG, TN_MAX_PROBLEMS = 3, 4, 8
 
 EXPORTS = [
-    "gcpnet_abi_version", "gcpnet_debug_knobs_compiled", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_gcp2_forward",
+    "gcpnet_abi_version", "gcpnet_debug_knobs_compiled", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_pack_gcp2_weights_multi", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
     "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_chain_forward_registers_ok", "gcpnet_gcp2_headchain_forward",
     "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_chain_backward_ok", "gcpnet_tb_floats", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
@@ -24,7 +24,7 @@ EXPORTS = [
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
     "gcpnet_debug_set_phase_timing", "gcpnet_debug_set_fp32_mfma",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
-    "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_radius_graph_first", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
+    "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_copy2d_multi", "gcpnet_axpy_clamp_backward", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_radius_graph_first", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
     "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
 ]
 
@@ -63,6 +63,11 @@ class WgBlock(C.Structure):
 
 WG_MAX_BLOCKS = 9
 MAX_CHAIN = 8  # GCP_MAX_CHAIN: blocks per launch of the wave-per-tile chain kernels
+
+
+class Copy2dJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("src_rs", C.c_int64),
+                ("src_cs", C.c_int64), ("dst_rs", C.c_int64), ("dst_cs", C.c_int64)]
 
 
 class AdamTensor(C.Structure):
@@ -139,6 +144,7 @@ def load():
     lib.gcpnet_gcp2_forward_lds_bytes.restype = i64
     lib.gcpnet_gcp2_forward_lds_bytes.argtypes = [i32] * 6
     lib.gcpnet_pack_gcp2_weights.argtypes = [P(Gcp2Weights), vp, vp]
+    lib.gcpnet_pack_gcp2_weights_multi.argtypes = [i32, P(Gcp2Weights), P(vp), vp]
     lib.gcpnet_gcp2_forward.argtypes = [i32, P(Concat), P(Concat), vp, P(Gcp2Weights), P(Gcp2Opts), P(Concat), P(Concat), vp,
                                         vp, vp, vp, vp, vp, vp]
     lib.gcpnet_gcp2_chain_forward.argtypes = [i32, vp, vp, vp, i32, P(ChainItem), vp]
@@ -184,6 +190,8 @@ def load():
     lib.gcpnet_wg_reduce_multi.argtypes = [i32, vp, vp]
     lib.gcpnet_dropout.argtypes = [i64, i32, vp, f32, C.c_uint64, vp, vp]
     lib.gcpnet_adam_step.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, i32, vp]
+    lib.gcpnet_copy2d_multi.argtypes = [i32, P(Copy2dJob), vp]
+    lib.gcpnet_axpy_clamp_backward.argtypes = [i64, vp, vp, f32, i32, f32, f32, vp, vp]
     lib.gcpnet_adam_step_dev.argtypes = [i32, P(AdamTensor), f32, f32, f32, f32, f32, vp, vp]
     lib.gcpnet_nms_edge_features.argtypes = [i64, vp, vp, vp, vp, i32, f32, i32, vp, vp, vp]
     lib.gcpnet_nms_node_features.argtypes = [i64, vp, vp, vp, vp, vp, vp]

@@ -548,9 +548,26 @@ __global__ __launch_bounds__(GCP_WAVE, 1) void gcp2_fwd_kernel(FwdParams p) {
     }
 }
 
+__device__ __forceinline__ void pack_gcp2_element(const gcp2_weights_t& w, const GcpShape& S, float* out, int64_t i);
+
 __global__ void pack_gcp2_kernel(gcp2_weights_t w, GcpShape S, float* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S.total) return;
+    pack_gcp2_element(w, S, out, i);
+}
+
+// the blocks of a ResGCP chain (one shape) in ONE launch: blockIdx.y = block
+struct PackMultiArgs {
+    gcp2_weights_t w[GCP_MAX_CHAIN];
+    float* out[GCP_MAX_CHAIN];
+};
+__global__ void pack_gcp2_multi_kernel(PackMultiArgs a, GcpShape S) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.total) return;
+    pack_gcp2_element(a.w[blockIdx.y], S, a.out[blockIdx.y], i);
+}
+
+__device__ __forceinline__ void pack_gcp2_element(const gcp2_weights_t& w, const GcpShape& S, float* out, int64_t i) {
     float val = 0.f;
     if (i < S.offB) {  // A: forward fragments [NG][KK][64][NTG] = W[j, k]
         int64_t x = i - S.offA;
@@ -747,6 +764,25 @@ extern "C" int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out
     const int threads = 256;
     const int64_t blocks = (S.total + threads - 1) / threads;
     hipLaunchKernelGGL(pack_gcp2_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, *w, S, pack_out);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_pack_gcp2_weights_multi(int n, const gcp2_weights_t* w, float* const* pack_out, void* stream) {
+    if (n < 1 || n > GCP_MAX_CHAIN || !w || !pack_out) return GCPNET_E_BADARG;
+    PackMultiArgs a;
+    for (int k = 0; k < n; ++k) {
+        if (!pack_out[k] || !w[k].w_scalar) return GCPNET_E_BADARG;
+        if (w[k].si != w[0].si || w[k].vi != w[0].vi || w[k].so != w[0].so || w[k].vo != w[0].vo || w[k].hidden != w[0].hidden ||
+            w[k].use_frames != w[0].use_frames)
+            return GCPNET_E_BADARG;  // (one shape: the blocks of a chain)
+        a.w[k] = w[k];
+        a.out[k] = pack_out[k];
+    }
+    const GcpShape S = gcp_shape(w[0].si, w[0].vi, w[0].so, w[0].vo, w[0].hidden, w[0].use_frames);
+    const int threads = 256;
+    const int64_t blocks = (S.total + threads - 1) / threads;
+    hipLaunchKernelGGL(pack_gcp2_multi_kernel, dim3((unsigned)blocks, n), dim3(threads), 0, (hipStream_t)stream, a, S);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

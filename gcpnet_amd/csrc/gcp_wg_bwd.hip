@@ -641,7 +641,11 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)ktc[0] * NSL * 192 + lane;
                     const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(DS) + lane;
                     auto lda = [&](gcp_u32x4(&a)[3], int sj) {
+#ifdef GCP_WG_EXP1  // (measurement build, wrong results: every slab's fragments from slabs 0 / 1 of tile 0 -- 6 KB, L1-resident)
+                        const gcp_u32x4* q = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + lane + (int64_t)(sj & 1) * 192;
+#else
                         const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSL - 1) * 192;
+#endif
                         a[0] = q[0]; a[1] = q[64]; a[2] = q[128];
                     };
                     gcp_u32x4 a0[3], a1[3], a2[3], a3[3];

@@ -210,6 +210,61 @@ extern "C" int gcpnet_dropout(int64_t n_groups, int group, const float* x, float
     return 0;
 }
 
+// ---- many small strided 2-D copies / fills in ONE launch: the glue around the kernels of a block -- column slices and padded /
+// transposed forms of the small vector weights, the pieces of an assembled weight gradient -- is a dozen ~4 us launches per block as
+// ATen cat / pad / clone / copy_; blockIdx.y = job ------------------------------------------------------------------------------
+struct Copy2dArgs {
+    gcp_copy2d_job_t j[GCP_COPY2D_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void copy2d_multi_kernel(Copy2dArgs a) {
+    const gcp_copy2d_job_t& J = a.j[blockIdx.y];
+    const int64_t n = (int64_t)J.rows * J.cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / J.cols, c = i - r * J.cols;
+        J.dst[r * J.dst_rs + c * J.dst_cs] = J.src ? J.src[r * J.src_rs + c * J.src_cs] : 0.f;
+    }
+}
+
+extern "C" int gcpnet_copy2d_multi(int n, const gcp_copy2d_job_t* jobs, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return GCPNET_E_BADARG;
+    for (int i0 = 0; i0 < n; i0 += GCP_COPY2D_MAX_JOBS) {
+        Copy2dArgs a;
+        const int m = n - i0 < GCP_COPY2D_MAX_JOBS ? n - i0 : GCP_COPY2D_MAX_JOBS;
+        int64_t nmax = 0;
+        for (int k = 0; k < m; ++k) {
+            a.j[k] = jobs[i0 + k];
+            if (!a.j[k].dst || a.j[k].rows < 0 || a.j[k].cols < 0) return GCPNET_E_BADARG;
+            const int64_t e = (int64_t)a.j[k].rows * a.j[k].cols;
+            nmax = e > nmax ? e : nmax;
+        }
+        if (nmax == 0) continue;
+        const int64_t nb = (nmax + 255) / 256;
+        hipLaunchKernelGGL(copy2d_multi_kernel, dim3((unsigned)(nb < 256 ? nb : 256), m), dim3(256), 0, (hipStream_t)stream, a);
+        GCP_HIP_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// adjoint of y = a + clamp(alpha b, lo, hi) w.r.t. b (the position update, components/gcpnet.py:1156-1158): alpha g inside the clamp
+__global__ __launch_bounds__(256) void axpy_clamp_bwd_kernel(int64_t n, const float* __restrict__ g, const float* __restrict__ b, float alpha,
+                                                             int clamp, float lo, float hi, float* __restrict__ gb) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float u = b[i] * alpha;
+        gb[i] = (!clamp || (u >= lo && u <= hi)) ? g[i] * alpha : 0.f;
+    }
+}
+
+extern "C" int gcpnet_axpy_clamp_backward(int64_t n, const float* g, const float* b, float alpha, int clamp, float lo, float hi, float* gb,
+                                          void* stream) {
+    if (n < 0 || (n > 0 && (!g || !b || !gb))) return GCPNET_E_BADARG;
+    if (n == 0) return 0;
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(axpy_clamp_bwd_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, n, g, b, alpha, clamp,
+                       lo, hi, gb);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 static int adam_launch(int n, const gcp_adam_tensor_t* tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int step, int64_t* step_dev, void* stream);
 

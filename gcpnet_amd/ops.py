@@ -282,10 +282,10 @@ class _AxpyClamp(torch.autograd.Function):
     def backward(ctx, g):
         (b,) = ctx.saved_tensors
         alpha, clamp, lo, hi = ctx.cfg
-        gb = g * alpha
-        if clamp:  # tiny [N, 3] host-glue mask for the clamp's adjoint
-            u = b * alpha
-            gb = gb * ((u >= lo) & (u <= hi)).to(g.dtype)
+        g = _req(g, "grad")
+        gb = torch.empty_like(b)
+        check(_lib.load().gcpnet_axpy_clamp_backward(b.numel(), _p(g), _p(b), float(alpha), int(clamp), float(lo), float(hi), _p(gb),
+                                                     _stream()), "axpy_clamp_backward")
         return g, gb, None, None, None, None
 
 
@@ -442,6 +442,38 @@ def _pack(spec: Gcp2Spec, w) -> Tensor:
     return pack
 
 
+def _pack_many(specs, ws) -> List[Tensor]:
+    """_pack for the blocks of a chain (one shape): the images that are not cached are built by ONE launch."""
+    lib = _lib.load()
+    out: List[Optional[Tensor]] = [None] * len(specs)
+    todo = []
+    for k, (spec, w) in enumerate(zip(specs, ws)):
+        w = _dense_weights(spec, w)
+        key = (_PACK_EPOCH,) + tuple(None if t is None else (t.data_ptr(), t._version) for t in (w[0], w[5], w[2], w[3], w[4]))
+        cache = spec.pack_cache
+        if cache is not None and cache.get("key") == key:
+            out[k] = cache["pack"]
+        else:
+            todo.append((k, spec, w, key))
+    if len(todo) == 1:
+        out[todo[0][0]] = _pack(todo[0][1], ws[todo[0][0]])
+    elif todo:
+        sp0 = todo[0][1]
+        n = int(lib.gcpnet_gcp2_pack_floats(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)))
+        structs = (Gcp2Weights * len(todo))()
+        ptrs = (C.c_void_p * len(todo))()
+        for j, (k, spec, w, key) in enumerate(todo):
+            assert (spec.si, spec.vi, spec.so, spec.vo, spec.hidden, spec.use_frames) == (sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, sp0.use_frames)
+            pack = torch.empty(n, dtype=torch.float32, device=w[0].device)
+            structs[j] = _weights_struct(spec, w, pack)
+            ptrs[j] = pack.data_ptr()
+            out[k] = pack
+            if spec.pack_cache is not None:
+                spec.pack_cache["key"], spec.pack_cache["pack"] = key, pack
+        check(lib.gcpnet_pack_gcp2_weights_multi(len(todo), structs, ptrs, _stream()), "pack_gcp2_weights_multi")
+    return out
+
+
 USE_WG_KERNELS = True  # module switch: multi-wave workgroup kernels (gcp_wg_*.hip) where the shape fits, else the wave-per-tile ones
 USE_WG_BACKWARD = True  # (separately for the backward; both need USE_WG_KERNELS)
 PREFER_WG_CHAIN_BACKWARD = True  # chains wider than 128 scalars: block by block through the workgroup backward kernel
@@ -456,6 +488,26 @@ FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains
 # scalar states of a ResGCP chain -- in the tile-blocked layout (include/gcpnet_hip.h, gcp2_chain_item_t): every wave instruction on
 # them moves 1 KB of whole lines, no LDS transposition.  GCPNET_CHAIN_TB=0: row-major as before (A/B measurements, tests).
 CHAIN_TILE_BLOCKED = os.environ.get("GCPNET_CHAIN_TB", "1") != "0"
+
+
+def copy2d_multi(jobs) -> None:
+    """jobs: (dst, src) pairs of <= 2-D fp32 views on the current device (any strides; src None = zero fill; shapes equal): ONE launch
+    (gcpnet_copy2d_multi) instead of one ATen cat / pad / clone / copy_ each."""
+    jobs = [(d, s_) for d, s_ in jobs if d.numel() > 0]
+    if not jobs:
+        return
+    arr = (_lib.Copy2dJob * len(jobs))()
+    for k, (d, s_) in enumerate(jobs):
+        if d.dim() == 1:
+            d = d.unsqueeze(0)
+        if s_ is not None and s_.dim() == 1:
+            s_ = s_.unsqueeze(0)
+        assert d.dim() == 2 and d.dtype == torch.float32 and d.is_cuda and (s_ is None or (s_.shape == d.shape and s_.dtype == torch.float32))
+        arr[k].dst, arr[k].rows, arr[k].cols = d.data_ptr(), d.shape[0], d.shape[1]
+        arr[k].dst_rs, arr[k].dst_cs = d.stride(0), d.stride(1)
+        if s_ is not None:
+            arr[k].src, arr[k].src_rs, arr[k].src_cs = s_.data_ptr(), s_.stride(0), s_.stride(1)
+    check(_lib.load().gcpnet_copy2d_multi(len(jobs), arr, _stream()), "copy2d_multi")
 
 
 class TileBlocked:
@@ -1210,9 +1262,11 @@ class _Gcp2Chain(torch.autograd.Function):
         # backward of this graph then takes that route whatever the module switches say by then)
         tb = (CHAIN_TILE_BLOCKED and need_grad and wave_first and rows > 0 and _wave_chain_backward(sp0) and
               lib.gcpnet_gcp2_chain_backward_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
+        all_w = [tuple(weights[7 * k:7 * k + 7]) for k in range(n)]
+        all_packs = _pack_many(specs, all_w) if n <= _lib.MAX_CHAIN else [_pack(sp, w_) for sp, w_ in zip(specs, all_w)]
         for k, spec in enumerate(specs):
-            w = tuple(weights[7 * k:7 * k + 7])
-            pack = _pack(spec, w)
+            w = all_w[k]
+            pack = all_packs[k]
             last = k == n - 1  # intermediate states are only materialised when the backward will need them
             if tb and not last:
                 s_out = TileBlocked(rows, spec.so, dev)
@@ -1571,12 +1625,23 @@ class _Gcp2Projected(torch.autograd.Function):
             vc = spec.pack_cache.get("vproj") if spec.pack_cache is not None else None
             if vc is None or vc["key"] != vkey:
                 vc = dict(key=vkey, wk=[], wkt=[])
-                for k in vg:
-                    wk = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]], w_frames[:, voffs[k]:voffs[k] + chans[k]]], dim=0).detach()
-                    wk = torch.nn.functional.pad(wk, (0, 0, 0, hfp - (H + 3)))  # [HF', V], zero rows past H + 3
-                    vc["wk"].append(wk); vc["wkt"].append(wk.t().contiguous())
-                vc["wd_rest"] = torch.cat([w_down[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1).detach()
-                vc["wf_rest"] = torch.cat([w_frames[:, voffs[k]:voffs[k] + chans[k]] for k in vr], dim=1).detach()
+                f32v = dict(dtype=torch.float32, device=w_down.device)
+                wd_, wf_ = w_down.detach(), w_frames.detach()
+                jobs = []
+                for k in vg:  # [HF', V] = [vector_down ; vector_down_frames ; zero rows] of the source's channels, and its transpose
+                    wk, wkt = torch.empty((hfp, chans[k]), **f32v), torch.empty((chans[k], hfp), **f32v)
+                    for dst in (wk, wkt.t()):
+                        jobs += [(dst[:H], wd_[:, voffs[k]:voffs[k] + chans[k]]), (dst[H:H + 3], wf_[:, voffs[k]:voffs[k] + chans[k]]),
+                                 (dst[H + 3:], None)]
+                    vc["wk"].append(wk); vc["wkt"].append(wkt)
+                nrest = sum(chans[k] for k in vr)
+                vc["wd_rest"], vc["wf_rest"] = torch.empty((H, nrest), **f32v), torch.empty((3, nrest), **f32v)
+                c = 0
+                for k in vr:
+                    jobs += [(vc["wd_rest"][:, c:c + chans[k]], wd_[:, voffs[k]:voffs[k] + chans[k]]),
+                             (vc["wf_rest"][:, c:c + chans[k]], wf_[:, voffs[k]:voffs[k] + chans[k]])]
+                    c += chans[k]
+                copy2d_multi(jobs)  # (one launch; as ATen cat / pad / clone: a dozen)
                 if spec.pack_cache is not None:
                     spec.pack_cache["vproj"] = vc
             for j, k in enumerate(vg):
@@ -1693,18 +1758,19 @@ class _Gcp2Projected(torch.autograd.Function):
             def assemble():
                 run_weight_grad_jobs([job])
                 c = 0
+                cjobs = []
                 for k in rest:
-                    g0[:, offs[k]:offs[k] + dims[k]].copy_(gj[0][:, c:c + dims[k]])
+                    cjobs.append((g0[:, offs[k]:offs[k] + dims[k]], gj[0][:, c:c + dims[k]]))
                     c += dims[k]
-                g0[:, spec.si:].copy_(gj[0][:, c:])
+                cjobs.append((g0[:, spec.si:], gj[0][:, c:]))
                 # the projected sources' weight gradients (row-split products over the SOURCE rows): one launch for all of them
                 items = [(g, s_src[k], g0[:, offs[k]:offs[k] + dims[k]]) for k, g in zip(sg, dP)]
                 tmps = []
                 if vg:
                     c = 0
                     for k in vr:
-                        gd[:, voffs[k]:voffs[k] + chans[k]].copy_(gj[2][:, c:c + chans[k]])
-                        gf[:, voffs[k]:voffs[k] + chans[k]].copy_(gj[3][:, c:c + chans[k]])
+                        cjobs += [(gd[:, voffs[k]:voffs[k] + chans[k]], gj[2][:, c:c + chans[k]]),
+                                  (gf[:, voffs[k]:voffs[k] + chans[k]], gj[3][:, c:c + chans[k]])]
                         c += chans[k]
                     for k, g, vt in zip(vg, dQ, vts):
                         hfp = g.shape[1] // 3
@@ -1713,8 +1779,8 @@ class _Gcp2Projected(torch.autograd.Function):
                         items.append((g.view(-1, hfp), vt.view(-1, chans[k]), tmp))
                 _tn_weight_grads_into(items)
                 for k, tmp in tmps:
-                    gd[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[:H])
-                    gf[:, voffs[k]:voffs[k] + chans[k]].copy_(tmp[H:H + 3])
+                    cjobs += [(gd[:, voffs[k]:voffs[k] + chans[k]], tmp[:H]), (gf[:, voffs[k]:voffs[k] + chans[k]], tmp[H:H + 3])]
+                copy2d_multi(cjobs)  # (every piece of the assembled gradients in one launch)
 
             keep = [job.keep, dP, dQ, list(s_src), list(vts), scr]
             if ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells):

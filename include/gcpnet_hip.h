@@ -79,6 +79,8 @@ typedef struct {
 int64_t gcpnet_gcp2_pack_floats(int si, int vi, int so, int vo, int hidden, int use_frames);
 /* Packs scalar_out / vector_out_scale into MFMA operand order (forward, backward-data, gate, gate-backward). */
 int gcpnet_pack_gcp2_weights(const gcp2_weights_t* w, float* pack_out, void* stream);
+/* the same for n <= GCP_MAX_CHAIN blocks of ONE shape (the blocks of a ResGCP chain) in one launch */
+int gcpnet_pack_gcp2_weights_multi(int n, const gcp2_weights_t* w, float* const* pack_out, void* stream);
 
 /* ---- GCP2 forward: replaces GCP2.forward (components/gcpnet.py:394-468) on `rows` rows --------------------
  * s_in/v_in: concatenated inputs; frames: per-row frames [rows,3,3] (per-edge frames for edge rows; the
@@ -431,6 +433,23 @@ int gcpnet_node_scalarize(int n_nodes, const int32_t* seg_ptr, const int32_t* pe
  * y[g * group + j] = keep(g) ? x[g * group + j] / keep_prob : 0 with keep(g) = uniform(seed, g) < keep_prob, a counter-based
  * hash: the backward is the same call on the gradient with the same seed (no mask is stored).  group = 1 or 3. */
 int gcpnet_dropout(int64_t n_groups, int group, const float* x, float keep_prob, uint64_t seed, float* y, void* stream);
+
+/* ---- host-glue helpers of the small-graph regime (a step of the NMS model is ~600 launches of a few microseconds each) -------------
+ * gcpnet_copy2d_multi: n strided 2-D copies dst[r, c] = src[r, c] (strides in floats; src NULL = zero fill) in one launch -- the
+ * column slices, zero-padded and transposed forms of the small vector weights that project-then-gather wants, and the pieces of an
+ * assembled weight gradient (ATen: one cat / pad / clone / copy_ launch each). */
+typedef struct {
+    const float* src;
+    float* dst;
+    int rows, cols;
+    int64_t src_rs, src_cs, dst_rs, dst_cs;
+} gcp_copy2d_job_t;
+#define GCP_COPY2D_MAX_JOBS 48
+int gcpnet_copy2d_multi(int n, const gcp_copy2d_job_t* jobs, void* stream);
+/* gb = alpha g where lo <= alpha b <= hi (everywhere without `clamp`), else 0: the adjoint of gcpnet_axpy_clamp w.r.t. b
+ * (components/gcpnet.py:1156-1158: x + clamp(weight * update, -100, 100)) */
+int gcpnet_axpy_clamp_backward(int64_t n, const float* g, const float* b, float alpha, int clamp, float lo, float hi, float* gb,
+                               void* stream);
 
 /* ---- fused Adam over many small parameter tensors (the reference's optimizer: torch.optim.Adam, configs/model/gcpnet_*.yaml;
  * amsgrad = False): one launch per GCP_ADAM_MAX_TENSORS tensors instead of ~10 launches per tensor.  `step` counts from 1. */
