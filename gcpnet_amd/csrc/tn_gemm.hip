@@ -44,6 +44,7 @@ constexpr int TN_BM = 128, TN_BN = 160, TN_RK = GCP_TN_RK;
 // 212.9 ms, c4 under hipGraph replay 4.37 -> 4.30 ms, configs[3] equal (64 and 96 splits: no further gain;
 // profiles/r03_tn_bf16x3.txt).
 constexpr int TN_TARGET_SPLITS = 128, TN_MIN_ROWS_PER_SPLIT = 64;
+constexpr bool TN_PLANES_DEFAULT = false;  // (tn_gemm_planes_kernel: measured before it becomes the default)
 // host side: rows per split for the target split count (GCPNET_TN_SPLITS overrides the 128: a tuning knob)
 inline int tn_rows_per_split_host(int rows) {
     static const int target = getenv("GCPNET_TN_SPLITS") && atoi(getenv("GCPNET_TN_SPLITS")) > 0 ? atoi(getenv("GCPNET_TN_SPLITS")) : TN_TARGET_SPLITS;
@@ -554,6 +555,175 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : 256) void tn_gemm_dma_kernel(TnAr
     }
 }
 
+// ---- "planes" form: every operand element is split into its three bf16 terms ONCE per chunk -----------------------------------------
+// In the form above each wave splits its own fragments where it reads them: the five B fragments of a 16-row step are split by all
+// four waves of a workgroup (they share the n-tiles), 12 splits = 528 VALU instructions and 96 ds_read_b32 per wave and chunk for 60
+// MFMAs -- the products phase ran at 2.4 x its MFMA time and the pipe was 20 % busy (profiles/r03_g_pmc_summary.txt).  Here the
+// landed fp32 chunk (32 rows x [128 | 160] columns) is converted by ALL threads, one fragment-lane (eight rows of one column) per
+// thread and pass, into operand-ordered bf16 planes in LDS -- [16-row step][tile][term][64 lanes][16 bytes] -- and the products read
+// whole fragments with three ds_read_b128 each: 1152 splits per chunk instead of 3 072, no redundant LDS reads.  Eight waves: waves
+// 0-3 take rows 0-15 of every chunk, waves 4-7 rows 16-31 (one 16-row step each: 30 MFMAs), the halves are added through LDS at the
+// end.  LDS: two fp32 staging buffers (the next chunk's DMA flies under the split pass and the products) + 54 KB of planes = 126 KB,
+// one workgroup per CU.
+constexpr int TP_NTH = 512;
+constexpr int TP_F32 = TN_RK * (TN_BM + TN_BN);
+constexpr int TP_STEPS = TN_RK / 16;
+constexpr int TP_APL = TP_STEPS * (TN_BM / 32) * 3 * 256, TP_BPL = TP_STEPS * (TN_BN / 32) * 3 * 256;  // floats
+constexpr int TP_LDS_FLOATS = 2 * TP_F32 + TP_APL + TP_BPL;
+
+__global__ __launch_bounds__(TP_NTH) void tn_gemm_planes_kernel(TnArgs a) {
+    constexpr int NTH = TP_NTH;
+    constexpr int A_SLOTS = (TN_RK * TN_BM / 4 + NTH - 1) / NTH, B_SLOTS = (TN_RK * TN_BN / 4 + NTH - 1) / NTH;
+    constexpr int MTA = TN_BM / 32, NTB = TN_BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    const BlockWork w = locate(a);
+    const gcp_tn_problem_t& P = a.p[w.pi];
+    X3Tiles xt = x3_tiles(w, wave);
+    xt.my_n = __builtin_amdgcn_readfirstlane(xt.my_n);
+    const bool wave_active = xt.my_n > 0;
+    auto Abuf = [&](int b) { return lds + b * TP_F32; };
+    auto Bbuf = [&](int b) { return lds + b * TP_F32 + TN_RK * TN_BM; };
+    gcp_u32x4* const Apl = reinterpret_cast<gcp_u32x4*>(lds + 2 * TP_F32);
+    gcp_u32x4* const Bpl = reinterpret_cast<gcp_u32x4*>(lds + 2 * TP_F32 + TP_APL);
+    const int mtiles = gcp_cdiv(w.mw, 32);
+
+    Slot sa[A_SLOTS], sb[B_SLOTS];
+    make_slots<A_SLOTS, TN_BM, NTH>(P.a, w.m0, sa, tid);
+    make_slots<B_SLOTS, TN_BN, NTH>(P.b, w.n0, sb, tid);
+    const int32_t* ga = any_gather(P.a);
+    const int32_t* gb = any_gather(P.b);
+    const int a_data = operand_width(P.a) - (P.a.ones ? 1 : 0), b_data = operand_width(P.b) - (P.b.ones ? 1 : 0);
+    const int a_ones = P.a.ones ? (a_data - w.m0) : -1, b_ones = P.b.ones ? (b_data - w.n0) : -1;
+    const bool a_has_ones = a_ones >= 0 && a_ones < TN_BM, b_has_ones = b_ones >= 0 && b_ones < TN_BN;
+    const int a_cols = max(0, min(TN_BM, a_data - w.m0)), b_cols = max(0, min(TN_BN, b_data - w.n0));
+
+    for (int i = tid; i < 2 * TP_F32; i += NTH) lds[i] = 0.f;  // columns no DMA piece covers stay zero
+    __syncthreads();
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int r_last = w.r_end - 1;
+    const int nchunks = w.nchunks;
+    auto row0 = [&](int chunk) { return w.r_first + chunk * w.r_step; };
+    int64_t ra[A_SLOTS], rb[B_SLOTS];
+    auto stage = [&](int chunk, int b) {  // rows of `chunk` are in ra / rb
+        const int r0 = row0(chunk);
+        issue_dma<A_SLOTS, NTH>(sa, ra, Abuf(b), tid);
+        issue_dma<B_SLOTS, NTH>(sb, rb, Bbuf(b), tid);
+        if (tid < TN_RK) {
+            const float one = (r0 + tid <= r_last) ? 1.f : 0.f;
+            if (a_has_ones) Abuf(b)[tid * TN_BM + a_ones] = one;
+            if (b_has_ones) Bbuf(b)[tid * TN_BN + b_ones] = one;
+        }
+    };
+    int va[A_SLOTS], vb[B_SLOTS];
+    fetch_issue<A_SLOTS>(sa, va, row0(0), r_last, ga);
+    fetch_issue<B_SLOTS>(sb, vb, row0(0), r_last, gb);
+    fetch_finish<A_SLOTS>(sa, va, ra, row0(0), r_last, ga);
+    fetch_finish<B_SLOTS>(sb, vb, rb, row0(0), r_last, gb);
+#pragma unroll
+    for (int k = 0; k < A_SLOTS; ++k) asm volatile("" : "+v"(ra[k]));
+#pragma unroll
+    for (int k = 0; k < B_SLOTS; ++k) asm volatile("" : "+v"(rb[k]));
+    stage(0, 0);
+    fetch_issue<A_SLOTS>(sa, va, row0(1), r_last, ga);
+    fetch_issue<B_SLOTS>(sb, vb, row0(1), r_last, gb);
+    fetch_finish<A_SLOTS>(sa, va, ra, row0(1), r_last, ga);
+    fetch_finish<B_SLOTS>(sb, vb, rb, row0(1), r_last, gb);
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        __syncthreads();  // vmcnt(0) + barrier: this chunk has landed; every wave is done with the planes and with the other buffer
+        const int nvalid = min(TN_RK, w.r_end - row0(c));
+        if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
+            for (int i = tid; i < (TN_RK - nvalid) * TN_BM; i += NTH) Abuf(cur)[nvalid * TN_BM + i] = 0.f;
+            for (int i = tid; i < (TN_RK - nvalid) * TN_BN; i += NTH) Bbuf(cur)[nvalid * TN_BN + i] = 0.f;
+            __syncthreads();
+        }
+        if (P.a.act || P.b.act) {
+            if (P.a.act) act_in_lds(Abuf(cur), TN_BM, a_cols, nvalid, P.a.act, P.a.slope, tid, NTH);
+            if (P.b.act) act_in_lds(Bbuf(cur), TN_BN, b_cols, nvalid, P.b.act, P.b.slope, tid, NTH);
+            __syncthreads();
+        }
+        const int rn = row0(c + 2);
+        if (c + 1 < nchunks) {  // the next chunk's DMA: in flight under the split pass and the products (the barrier between them is
+            stage(c + 1, cur ^ 1);  // a raw s_barrier: it does not drain vmcnt)
+            fetch_issue<A_SLOTS>(sa, va, rn, r_last, ga);
+            fetch_issue<B_SLOTS>(sb, vb, rn, r_last, gb);
+        }
+        // ---- split pass: one fragment-lane per thread and pass: eight rows of one column -> three 16-byte plane entries ------------
+#pragma unroll
+        for (int k = 0; k < (TP_STEPS * (MTA + NTB) * 64 + NTH - 1) / NTH; ++k) {
+            const int u = tid + NTH * k, t = u >> 6;  // (t: wave-uniform)
+            if (t < TP_STEPS * (MTA + NTB)) {
+                const int ks = t / (MTA + NTB), tile = t - ks * (MTA + NTB);
+                const bool isA = tile < MTA;
+                const int tl = isA ? tile : tile - MTA;
+                if (isA ? tl < mtiles : tl < w.ntiles) {
+                    const float* src = (isA ? Abuf(cur) + 32 * tl : Bbuf(cur) + 32 * tl) + col + (16 * ks + 8 * hi) * (isA ? TN_BM : TN_BN);
+                    const int LD = isA ? TN_BM : TN_BN;
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = src[q * LD];
+                    gcp_u32x4 th, tm, tl3;
+                    gcp_bf16x3_split8(x, th, tm, tl3);
+                    gcp_u32x4* dst = (isA ? Apl + (ks * MTA + tl) * 192 : Bpl + (ks * NTB + tl) * 192) + lane;
+                    dst[0] = th; dst[64] = tm; dst[128] = tl3;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes complete (LDS only: the DMA stays in flight)
+        // ---- products: this wave's m-tile x its n-tiles, rows 16 kh .. 16 kh + 15 of the chunk ------------------------------------
+        if (wave_active && !(a.debug & 1)) {
+            const gcp_u32x4* pa = Apl + (kh * MTA + xt.mi) * 192 + lane;
+            const gcp_u32x4 a3[3] = {pa[0], pa[64], pa[128]};
+            const gcp_u32x4* pb0 = Bpl + kh * NTB * 192 + lane;
+            gcp_u32x4 b0[3], b1[3];
+            auto ldb = [&](gcp_u32x4(&b)[3], int i) {
+                const gcp_u32x4* q = pb0 + min(xt.g + xt.G * i, w.ntiles - 1) * 192;
+                b[0] = q[0]; b[1] = q[64]; b[2] = q[128];
+            };
+            ldb(b0, 0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                gcp_u32x4(&bc)[3] = (i & 1) ? b1 : b0;
+                gcp_u32x4(&bn)[3] = (i & 1) ? b0 : b1;
+                if (i + 1 < 5) ldb(bn, i + 1);
+                if (i < xt.my_n) acc[i] = gcp_mfma_bf16x6(a3, bc[0], bc[1], bc[2], acc[i]);
+            }
+        }
+        if (c + 1 < nchunks) {
+            fetch_finish<A_SLOTS>(sa, va, ra, rn, r_last, ga);
+            fetch_finish<B_SLOTS>(sb, vb, rb, rn, r_last, gb);
+        }
+    }
+    // rows 16 .. 31 of every chunk (waves 4-7) onto rows 0 .. 15 (waves 0-3) through the staging buffers, free now
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int i0 = round ? 3 : 0, i1 = round ? 5 : 3;
+        __syncthreads();
+        if (kh == 1) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane] = acc[i][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] += lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane];
+        }
+    }
+    if (wave_active && kh == 0) store_partial_x3(P, w, a.M[w.pi], a.N[w.pi], acc, xt, col, hi);
+}
+
 // ---- big-block path: ONE workgroup owns the whole output of a problem with 128 < M <= 256 or 160 < N <= 320 -------------------
 // The weight gradients of the (256,32) message GCPs of BASELINE configs[4] are 256 x 285 products: cut into 128 x 160 blocks every
 // operand row is fetched by two workgroups (4.3 KB per row for 2.2 KB of operands), and the kernel is bound by its DMA pipeline.
@@ -911,7 +1081,37 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         // 160 k rows --, inside the training step, where these launches share the chip with the caller's stream, it is the slower
         // choice: 12.48 vs 12.01 ms per configs[1] step, profiles/r03_tn_bf16x3.txt.  Read per call: the tests switch it.)
         const bool eight = getenv("GCPNET_TN_EIGHT_WAVES") != nullptr;
-        if (x3 && eight) hipLaunchKernelGGL(tn_gemm_dma_kernel<2>, dim3(blocks), dim3(512), lds_bytes, st, a);
+        // (the planes form, see tn_gemm_planes_kernel; GCPNET_TN_PLANES=0 / 1 switches per call: A/B measurements, tests)
+        static bool planes_configured = false;
+        const char* pl_env = getenv("GCPNET_TN_PLANES");
+        const bool planes = x3 && !eight && (pl_env ? pl_env[0] == '1' : TN_PLANES_DEFAULT);
+        if (planes) {
+            const size_t pl_bytes = (size_t)TP_LDS_FLOATS * sizeof(float);
+            if (!planes_configured) {
+                const hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_bytes);
+                if (err != hipSuccess) return (int)err;
+                planes_configured = true;
+            }
+            // problems with more than one m-tile go to the planes kernel; the skinny ones (the gate weight gradient: M = vo <= 32, one
+            // m-tile, bound by their DMA latency) keep the four-wave kernel, two of whose workgroups share a CU
+            TnArgs wide, thin;
+            wide.n = thin.n = 0;
+            wide.cyclic = thin.cyclic = a.cyclic;
+            wide.debug = thin.debug = a.debug;
+            int wblocks = 0, tblocks = 0;
+            for (int i = 0; i < n_problems; ++i) {
+                TnArgs& d = a.M[i] > 32 ? wide : thin;
+                int& nb = a.M[i] > 32 ? wblocks : tblocks;
+                const int k = d.n++;
+                d.p[k] = a.p[i]; d.M[k] = a.M[i]; d.N[k] = a.N[i]; d.mb[k] = a.mb[i]; d.nb[k] = a.nb[i];
+                d.block_start[k] = nb;
+                nb += a.mb[i] * a.nb[i] * a.p[i].splits;
+            }
+            wide.block_start[wide.n] = wblocks;
+            thin.block_start[thin.n] = tblocks;
+            if (wide.n) hipLaunchKernelGGL(tn_gemm_planes_kernel, dim3(wblocks), dim3(TP_NTH), pl_bytes, st, wide);
+            if (thin.n) hipLaunchKernelGGL(tn_gemm_dma_kernel<1>, dim3(tblocks), dim3(256), lds_bytes, st, thin);
+        } else if (x3 && eight) hipLaunchKernelGGL(tn_gemm_dma_kernel<2>, dim3(blocks), dim3(512), lds_bytes, st, a);
         else if (x3) hipLaunchKernelGGL(tn_gemm_dma_kernel<1>, dim3(blocks), dim3(256), lds_bytes, st, a);
         else hipLaunchKernelGGL(tn_gemm_dma_kernel<0>, dim3(blocks), dim3(256), lds_bytes, st, a);
     } else {

@@ -20,15 +20,15 @@ pytestmark = pytest.mark.gpu
     (2000, 128, 16),      # one n-tile
     (2000, 160, 128),     # M over one block: two blocks along m in the 128 x 160 kernel when the big-block kernel is off
 ])
-@pytest.mark.parametrize("form", ["default", "big_block", "eight_waves", "fp32", "blocked_rows"])
+@pytest.mark.parametrize("form", ["default", "planes", "planes_off", "big_block", "eight_waves", "fp32", "blocked_rows"])
 def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
     """`form`: the switches of gcpnet_tn_gemm that select another kernel or row distribution for the same product."""
     from gcpnet_amd import ops
 
     env = {"big_block": "GCPNET_TN_BIG", "eight_waves": "GCPNET_TN_EIGHT_WAVES", "fp32": "GCPNET_TN_FP32",
-           "blocked_rows": "GCPNET_TN_BLOCKED"}.get(form)
+           "blocked_rows": "GCPNET_TN_BLOCKED", "planes": "GCPNET_TN_PLANES", "planes_off": "GCPNET_TN_PLANES"}.get(form)
     if env:
-        monkeypatch.setenv(env, "1")
+        monkeypatch.setenv(env, "0" if form == "planes_off" else "1")
 
     g = torch.Generator().manual_seed(rows + M)
     a = torch.randn(rows, M, generator=g)
