@@ -339,3 +339,31 @@ def test_lba_step_realistic_pocket_size(G):
     assert 2800 < n < 3200 and e > 60000, (n, e)
     fwd = lambda P, i: O.lba_forward(P, i, O.default_module_cfg(), O.default_layer_cfg(), 8)
     _step_case(G, model, fwd, {k: b[k] for k in ("h", "chi", "e", "xi", "x", "edge_index", "batch", "label")}, ("chi", "e", "xi"), "pred")
+
+
+def test_eight_layer_stack_at_c5_size_fits_one_gpu(G):
+    """The saved activations of the message chains are 20.8 GB per layer at configs[4] size (bench.py, saved_activation_bytes_per_layer):
+    an 8-layer (256,32) stack on the 10^6-edge graph -- LBA depth at configs[4] width -- must run forward + backward on ONE 288 GB
+    MI355X without a recompute route.  (Finite outputs and gradients; parity at this width is the sub-problem test above.)"""
+    from gcpnet_amd.synthetic import make_inputs
+
+    dims, n_nodes = (256, 32), 100000
+    ins = make_inputs(n_nodes, 10, node_dims=dims, seed=0)
+    ei, x = ins.pop("edge_index").cuda(), ins.pop("x").cuda()
+    torch.manual_seed(13)
+    layers = torch.nn.ModuleList(G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0)
+                                 for _ in range(8)).cuda().train()
+    gi = {k_: t.cuda().requires_grad_() for k_, t in ins.items()}
+    fr = G.localize(x, ei)
+    torch.cuda.reset_peak_memory_stats()
+    h, chi = gi["h"], gi["chi"]
+    for layer in layers:
+        h, chi = layer((h, chi), (gi["e"], gi["xi"]), ei, fr)
+    held = torch.cuda.memory_allocated()
+    (h.sum() + chi.sum()).backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated()
+    print(f"8 layers at configs[4] size: {held / 2**30:.1f} GiB held after the forward, peak {peak / 2**30:.1f} GiB")
+    assert peak < 280 * 2**30
+    assert bool(torch.isfinite(h).all()) and all(bool(torch.isfinite(t.grad).all()) for t in gi.values())
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in layers.parameters())
