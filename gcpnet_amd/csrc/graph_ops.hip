@@ -33,6 +33,25 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int n_seg, const in
         for (int d0 = lane * 4; d0 < D; d0 += 4 * LPS) {
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
             int p = beg;
+            // eight rows in flight (two steps of the four interleaved sums: the order of every addition is that of the 4-row loop
+            // below, so the result is bit-identical) -- at 10 - 16 rows per segment the 4-row loop is two or three dependent
+            // index -> row round trips per segment, and the small-graph launches are bound by exactly that latency
+            for (; p + 7 < end; p += 8) {
+                int64_t ix[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ix[k] = perm ? perm[p + k] : p + k;
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(x + ix[k] * ldx + d0);
+                a0.x += v[0].x; a0.y += v[0].y; a0.z += v[0].z; a0.w += v[0].w;
+                a1.x += v[1].x; a1.y += v[1].y; a1.z += v[1].z; a1.w += v[1].w;
+                a2.x += v[2].x; a2.y += v[2].y; a2.z += v[2].z; a2.w += v[2].w;
+                a3.x += v[3].x; a3.y += v[3].y; a3.z += v[3].z; a3.w += v[3].w;
+                a0.x += v[4].x; a0.y += v[4].y; a0.z += v[4].z; a0.w += v[4].w;
+                a1.x += v[5].x; a1.y += v[5].y; a1.z += v[5].z; a1.w += v[5].w;
+                a2.x += v[6].x; a2.y += v[6].y; a2.z += v[6].z; a2.w += v[6].w;
+                a3.x += v[7].x; a3.y += v[7].y; a3.z += v[7].z; a3.w += v[7].w;
+            }
             for (; p + 3 < end; p += 4) {
                 const int64_t i0 = perm ? perm[p] : p, i1 = perm ? perm[p + 1] : p + 1;
                 const int64_t i2 = perm ? perm[p + 2] : p + 2, i3 = perm ? perm[p + 3] : p + 3;

@@ -672,7 +672,7 @@ class _Gcp2(torch.autograd.Function):
             d_v_out = _req(d_v_out, "grad") if d_v_out is not None else torch.zeros((rows, spec.vo, 3), **f32)
         si, vi = spec.si, spec.vi
         need_w = ctx.needs_input_grad[2 + n_s + n_v + 2:2 + n_s + n_v + 9]
-        side = ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells)
+        side = ctx.w_leaf and _side_stream_ok(ctx.weights, _take_use_cells(ctx))
         d_s_in, d_v_in, scr = gcp2_backward_data(spec, rows, s_src, v_src, ctx.frames, w, pack, s_pre, gate, d_s_out,
                                                  d_v_out, need_w=any(need_w), vadds=vadds, side_reduce=side)
         wgrads = [None] * 7
@@ -1073,7 +1073,21 @@ _side_streams: dict = {}
 _side_pending: list = []
 
 
-_weight_uses: dict = {}  # id(weight) -> [the weight, number of autograd Functions of the graph being built that take it]
+class _UseCell:
+    """[the weight, number of autograd Functions of live graphs that take it]; list-like for its readers (c[0], c[1])."""
+    __slots__ = ("t", "n", "__weakref__")
+
+    def __init__(self, t):
+        self.t, self.n = t, 0
+
+    def __getitem__(self, i):
+        return self.t if i == 0 else self.n
+
+
+# id(weight) -> its cell, held WEAKLY: the autograd contexts that counted a use own the cell, so it lives exactly as long as a graph
+# that uses the weight does and nothing ever has to clear the table (a clear that landed between two uses of one weight in one graph
+# -- an auxiliary backward in the middle of a forward -- made both Functions see a count of 1: ADVICE round 3)
+_weight_uses = weakref.WeakValueDictionary()
 
 
 def _note_uses(weights) -> list:
@@ -1082,20 +1096,18 @@ def _note_uses(weights) -> list:
     `interaction` twice; any module called twice per step) receives two gradients that the autograd engine SUMS on the caller's
     stream as soon as the second arrives -- inside the backward pass, before the end-of-backward join -- so both must be complete
     on the caller's stream.  Returns the shared counter cells; the backward reads them through _side_stream_ok.
-    The table is dropped at the end of every backward pass (the cells live on in the contexts that hold them: a second backward
-    over a retained graph still sees its counts); forwards whose graphs are never differentiated only make the next step's
-    answer conservative."""
+    A cell dies with the last context that holds it (the graph is freed); a graph that is kept alive makes later answers about its
+    weights conservative (count > 1: caller's stream), never wrong."""
     cells = []
     for t in weights:
         if t is None:
             continue
         cell = _weight_uses.get(id(t))
-        if cell is None or cell[0] is not t:
-            cell = _weight_uses[id(t)] = [t, 0]
-        cell[1] += 1
+        if cell is None or cell.t is not t:
+            cell = _UseCell(t)
+            _weight_uses[id(t)] = cell
+        cell.n += 1
         cells.append(cell)
-    if len(_weight_uses) > 4096:  # (forward-only loops with grad enabled: bounded)
-        _weight_uses.clear()
     return cells
 
 
@@ -1115,9 +1127,20 @@ def _side_stream_ok(weights, use_cells=None) -> bool:
             continue
         if not t.is_leaf or t.grad is not None or t._backward_hooks or getattr(t, "_post_accumulate_grad_hooks", None):
             return False
+    if use_cells is False:  # (a context whose cells were released by an earlier backward over the same graph: stay on the caller's stream)
+        return False
     if use_cells is not None and any(c[1] > 1 for c in use_cells):
         return False
     return True
+
+
+def _take_use_cells(ctx):
+    """The context's use cells, released: the cells must die with the backward pass, not with the graph object (a `loss` tensor that
+    the caller still holds while the next step's forward runs keeps every context of the old graph alive -- its cells would make the
+    next step count every weight twice).  A second backward over a retained graph finds False: no side stream."""
+    cells = getattr(ctx, "use_cells", None)
+    ctx.use_cells = False
+    return cells
 
 
 SIDE_STREAM_UNDER_DISTRIBUTED = False  # set by gcpnet_amd.parallel.GradAllReducer (it reduces after the backward pass)
@@ -1154,7 +1177,6 @@ def _end_of_backward():
     weight uses of the graph that was just differentiated is dropped."""
     global _end_callback_task
     _end_callback_task = -1
-    _weight_uses.clear()
     _flush_deferred_weight_grads()
     _join_side_stream()
 
@@ -1309,6 +1331,7 @@ class _Gcp2Chain(torch.autograd.Function):
             # garbage collector cannot see, i.e. every forward whose backward never runs would leak its saved activations)
             saved = outs[:-1] + [(None, None, outs[-1][2], outs[-1][3])]
             ctx.state = (s0, v0, ws, packs, saved)
+            ctx.in_versions = (s0._version, v0._version)  # (plain attributes bypass autograd's saved-tensor check: do it by hand)
             ctx.w_leaf = not any(sp.shared_weights for sp in specs)
             ctx.weights = weights
             ctx.use_cells = _note_uses(weights)
@@ -1333,6 +1356,9 @@ class _Gcp2Chain(torch.autograd.Function):
             return (None, None, None, d_s, d_v, *wz)
         specs, frames, rows = ctx.specs, ctx.frames, ctx.rows
         s0, v0, ws, packs, outs = ctx.state
+        if (s0._version, v0._version) != ctx.in_versions:  # (e.g. a masked layer's in-place row update, gcpnet.py:1248-1251, on a tensor
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation "  # this
+                               "(the input state of a ResGCP chain)")                                                             # chain read)
         n = len(specs)
         f32 = dict(dtype=torch.float32, device=s0.device)
         out_rows = agg[0].n_src if agg is not None else rows
@@ -1348,6 +1374,7 @@ class _Gcp2Chain(torch.autograd.Function):
         # (measured at (128,16): 1.2 ms + 0.76 ms of weight-gradient GEMMs per 7 blocks against 7 x 0.33 ms); wider chains --
         # (256,32) -- go block by block through the workgroup kernel; shapes outside both through the generic kernel.
         res = None
+        side_ok = ctx.w_leaf and _side_stream_ok(ctx.weights, _take_use_cells(ctx))  # (asked once: the cells are released by the question)
         wave_chain = ctx.tb or _wave_chain_backward(specs[0])
         if wave_chain:  # (with `agg` the kernel reads the segment-level tables itself)
             res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg)
@@ -1364,7 +1391,7 @@ class _Gcp2Chain(torch.autograd.Function):
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k])
         else:
-            side = ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells)
+            side = side_ok
             for k in range(n - 1, -1, -1):
                 s_in, v_in = ins[k]
                 _, _, s_pre, gate = outs[k]
@@ -1374,7 +1401,7 @@ class _Gcp2Chain(torch.autograd.Function):
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]
         if live:
-            side = ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells)
+            side = side_ok
             if side and DEFER_CHAIN_WEIGHT_GRADS:
                 # (experiment, DESIGN.md 6b: the chain's TN GEMMs are handed to the side stream only after the first message GCP's
                 # backward and its HBM-bound input-gradient reductions have been enqueued -- _flush_deferred_weight_grads)
@@ -1783,7 +1810,7 @@ class _Gcp2Projected(torch.autograd.Function):
                 copy2d_multi(cjobs)  # (every piece of the assembled gradients in one launch)
 
             keep = [job.keep, dP, dQ, list(s_src), list(vts), scr]
-            if ctx.w_leaf and _side_stream_ok(ctx.weights, ctx.use_cells):
+            if ctx.w_leaf and _side_stream_ok(ctx.weights, _take_use_cells(ctx)):
                 _side_submit(assemble, keep)
             else:
                 assemble()
