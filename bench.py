@@ -30,6 +30,7 @@ roofline.peak_bf16x6_equiv = the ceiling of the bf16 matrix pipe for fp32 produc
 --dry-run-world N = no timing: the N-rank bookkeeping of `--shard graph` on one GPU (nodes / edges / halo per rank, MB per layer).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -441,15 +442,25 @@ def timed_steps(step, steps, warmup, world, dist):
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        loss = step()
-        b.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # (the eager step is as much host work as GPU work -- tools/host_enqueue_time.py: 10.6 ms of Python per 11.2 ms configs[1] step --
+    # so a generation-2 garbage collection inside the loop shows up as a 10 - 30 ms outlier step: collect before, none inside, as
+    # `timeit` does)
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record()
+            loss = step()
+            b.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

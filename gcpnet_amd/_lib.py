@@ -26,6 +26,7 @@ EXPORTS = [
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
     "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_copy2d_multi", "gcpnet_axpy_clamp_backward", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_radius_graph_first", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
     "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
+    "gcpnet_gcp2_weight_grads", "gcpnet_gcp2_weight_grads_workspace", "gcpnet_stream_wait_stream",
 ]
 
 
@@ -114,6 +115,14 @@ class ReduceJob(C.Structure):
 REDUCE_MAX_JOBS = 8
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("rows", C.c_int), ("so", C.c_int), ("vo", C.c_int), ("vi", C.c_int), ("hidden", C.c_int), ("use_frames", C.c_int),
+                ("gated", C.c_int), ("act_v", C.c_int), ("slope", C.c_float), ("s_in", Operand), ("ds_pre", C.c_void_p),
+                ("ds_pre_tb", C.c_int), ("s_pre", C.c_void_p), ("s_pre_tb", C.c_int), ("ext", C.c_void_p), ("dgate", C.c_void_p),
+                ("w_part", C.c_void_p), ("n_parts", C.c_int), ("w_width", C.c_int), ("d_w_scalar", C.c_void_p),
+                ("d_b_scalar", C.c_void_p), ("d_w_small", C.c_void_p), ("d_w_gate", C.c_void_p), ("d_b_gate", C.c_void_p)]
+
+
 class WgReduceJob(C.Structure):
     _fields_ = [("parts", C.c_void_p), ("n_parts", C.c_int), ("R", C.c_int), ("C", C.c_int), ("CW", C.c_int), ("out_w", C.c_void_p),
                 ("out_b", C.c_void_p)]
@@ -158,6 +167,10 @@ def load():
     lib.gcpnet_gcp2_bwd_tiles.argtypes = [i32]
     lib.gcpnet_reduce_partials.argtypes = [i32, P(ReduceJob), vp]
     lib.gcpnet_reduce_partials_groups.argtypes = [i32]
+    lib.gcpnet_gcp2_weight_grads.argtypes = [i32, P(WgradJob), vp, vp]
+    lib.gcpnet_gcp2_weight_grads_workspace.argtypes = [i32, P(WgradJob)]
+    lib.gcpnet_gcp2_weight_grads_workspace.restype = i64
+    lib.gcpnet_stream_wait_stream.argtypes = [vp, vp]
     lib.gcpnet_segment_reduce.argtypes = [i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp]
     lib.gcpnet_gather_rows.argtypes = [i32, vp, vp, i64, i32, vp, vp, i64, vp]
     lib.gcpnet_localize.argtypes = [i32, vp, vp, vp, i32, vp, vp]
@@ -206,7 +219,7 @@ def load():
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",
-                        "gcpnet_wg_pack_floats", "gcpnet_tb_floats"):
+                        "gcpnet_wg_pack_floats", "gcpnet_tb_floats", "gcpnet_gcp2_weight_grads_workspace"):
             fn.restype = i32
     if lib.gcpnet_abi_version() != 2:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")

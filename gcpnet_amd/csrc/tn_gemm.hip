@@ -14,6 +14,7 @@
 // be passed through an activation (applied at fragment read) and carry a column of ones (bias gradients).
 // the row axis is split across workgroups (see tn_rows_per_split).
 // Per-split partial sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
+#include <mutex>
 #include <cstdlib>
 
 #include "common.h"
@@ -1148,4 +1149,146 @@ extern "C" int gcpnet_reduce_partials(int n_jobs, const gcp_reduce_job_t* jobs, 
     hipLaunchKernelGGL(reduce_partials_kernel<true>, dim3(1, n_jobs), dim3(256), 0, st, a);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- weight gradients of n GCP2 blocks in one call (include/gcpnet_hip.h, gcp2_wgrad_job_t) ------------------------------------------
+namespace {
+
+struct WgradDims {
+    int nf, EP, VOP, si, n1;
+    bool has_vec, gated;
+};
+
+inline WgradDims wgrad_dims(const gcp2_wgrad_job_t& J) {
+    WgradDims d;
+    d.has_vec = J.vi > 0;
+    d.nf = (J.use_frames && J.vi > 0) ? 9 : 0;
+    d.EP = gcp_round_up(J.hidden + d.nf, 4);
+    d.VOP = gcp_round_up(J.vo, 4);
+    d.si = 0;
+    for (int k = 0; k < J.s_in.n; ++k) d.si += J.s_in.dim[k];
+    d.n1 = d.si + (d.has_vec ? d.EP : 0) + 1;
+    d.gated = J.gated && J.vi > 0 && J.vo > 0;
+    return d;
+}
+
+inline bool wgrad_job_ok(const gcp2_wgrad_job_t& J) {
+    if (J.rows <= 0 || J.so <= 0 || J.s_in.n < 0 || J.s_in.n + (J.vi > 0 ? 1 : 0) > GCP_TN_MAX_SEG || !J.ds_pre || !J.d_w_scalar || !J.d_b_scalar) return false;
+    if (J.vi > 0 && (!J.ext || (J.w_part && (J.n_parts <= 0 || J.w_width <= 0 || !J.d_w_small)))) return false;
+    if (J.gated && J.vi > 0 && J.vo > 0 && (!J.dgate || !J.s_pre || !J.d_w_gate || !J.d_b_gate)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t gcpnet_gcp2_weight_grads_workspace(int n, const gcp2_wgrad_job_t* jobs) {
+    if (n <= 0 || !jobs) return 0;
+    int64_t fl = 0;
+    for (int i = 0; i < n; ++i) {
+        const gcp2_wgrad_job_t& J = jobs[i];
+        const WgradDims d = wgrad_dims(J);
+        const int64_t splits = gcpnet_tn_splits(J.rows, 0, 0);
+        fl += splits * J.so * d.n1;
+        if (d.gated) fl += splits * d.VOP * (J.so + 1);
+        if (d.has_vec && J.w_part) fl += (int64_t)gcpnet_reduce_partials_groups(J.n_parts) * J.w_width;
+    }
+    return fl;
+}
+
+extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, float* workspace, void* stream) {
+    if (n <= 0 || !jobs || !workspace) return GCPNET_E_BADARG;
+    for (int i = 0; i < n; ++i)
+        if (!wgrad_job_ok(jobs[i])) return GCPNET_E_BADARG;
+    gcp_tn_problem_t probs[GCP_TN_MAX_PROBLEMS];
+    gcp_reduce_job_t reds[GCP_REDUCE_MAX_JOBS];
+    int np = 0, nr = 0;
+    float* ws = workspace;
+    auto flush_p = [&]() -> int {
+        const int rc = np ? gcpnet_tn_gemm(np, probs, stream) : 0;
+        np = 0;
+        return rc;
+    };
+    auto flush_r = [&]() -> int {
+        const int rc = nr ? gcpnet_reduce_partials(nr, reds, stream) : 0;
+        nr = 0;
+        return rc;
+    };
+    auto plain = [](gcp_operand_t& o, const float* ptr, int width, int tb) {
+        o = gcp_operand_t{};
+        o.n = 1;
+        o.ptr[0] = ptr; o.dim[0] = width; o.ld[0] = width; o.tb[0] = tb;
+    };
+    // every GEMM problem first (the reductions' launches follow, as the block-by-block host code ordered them)
+    for (int i = 0; i < n; ++i) {
+        const gcp2_wgrad_job_t& J = jobs[i];
+        const WgradDims d = wgrad_dims(J);
+        const int splits = gcpnet_tn_splits(J.rows, 0, 0);
+        {   // d scalar_out.weight | bias: ds_pre^T [s segments | ext | 1]
+            gcp_tn_problem_t& P = probs[np++];
+            P = gcp_tn_problem_t{};
+            P.rows = J.rows;
+            plain(P.a, J.ds_pre, J.so, J.ds_pre_tb);
+            P.b = J.s_in;
+            P.b.act = 0; P.b.slope = J.slope; P.b.ones = 1;
+            if (d.has_vec) {
+                const int k = P.b.n++;
+                P.b.ptr[k] = J.ext; P.b.idx[k] = nullptr; P.b.dim[k] = d.EP; P.b.ld[k] = d.EP; P.b.tb[k] = 0;
+            }
+            const int K = d.si + (d.has_vec ? J.hidden + d.nf : 0);
+            P.out = J.d_w_scalar; P.out_sm = K; P.out_sn = 1; P.out_m = J.so; P.out_n = K;
+            P.out2 = J.d_b_scalar; P.out2_n = d.n1 - 1;
+            P.splits = splits;
+            P.partial = ws;
+            ws += (int64_t)splits * J.so * d.n1;
+            if (np == GCP_TN_MAX_PROBLEMS) { const int rc = flush_p(); if (rc) return rc; }
+        }
+        if (d.gated) {  // d vector_out_scale.weight | bias: dgate^T [act_v(s_pre) | 1]
+            gcp_tn_problem_t& P = probs[np++];
+            P = gcp_tn_problem_t{};
+            P.rows = J.rows;
+            plain(P.a, J.dgate, d.VOP, 0);
+            plain(P.b, J.s_pre, J.so, J.s_pre_tb);
+            P.a.slope = P.b.slope = J.slope;
+            P.b.act = J.act_v; P.b.ones = 1;
+            P.out = J.d_w_gate; P.out_sm = J.so; P.out_sn = 1; P.out_m = J.vo; P.out_n = J.so;
+            P.out2 = J.d_b_gate; P.out2_n = J.so;
+            P.splits = splits;
+            P.partial = ws;
+            ws += (int64_t)splits * d.VOP * (J.so + 1);
+            if (np == GCP_TN_MAX_PROBLEMS) { const int rc = flush_p(); if (rc) return rc; }
+        }
+    }
+    { const int rc = flush_p(); if (rc) return rc; }
+    for (int i = 0; i < n; ++i) {
+        const gcp2_wgrad_job_t& J = jobs[i];
+        if (!(J.vi > 0 && J.w_part)) continue;
+        gcp_reduce_job_t& R = reds[nr++];
+        R.parts = J.w_part; R.n_parts = J.n_parts; R.width = J.w_width; R.tmp = ws; R.out = J.d_w_small;
+        ws += (int64_t)gcpnet_reduce_partials_groups(J.n_parts) * J.w_width;
+        if (nr == GCP_REDUCE_MAX_JOBS) { const int rc = flush_r(); if (rc) return rc; }
+    }
+    return flush_r();
+}
+
+extern "C" int gcpnet_stream_wait_stream(void* to, void* from) {
+    // a ring of events: a wait enqueued on `to` refers to the record that preceded it, so an event may be recorded again as soon as
+    // that wait has been enqueued; 256 slots keep re-use far from any call still being processed by the runtime
+    constexpr int RING = 256, MAX_DEV = 16;
+    static hipEvent_t ring[MAX_DEV][RING];
+    static int made_[MAX_DEV] = {0}, next_[MAX_DEV] = {0};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return GCPNET_E_BADARG;  // (events belong to the current device)
+    std::lock_guard<std::mutex> lock(mu);
+    int &made = made_[dev], &next = next_[dev];
+    if (made < RING && next == made) {
+        const hipError_t err = hipEventCreateWithFlags(&ring[dev][made], hipEventDisableTiming);
+        if (err != hipSuccess) return (int)err;
+        ++made;
+    }
+    hipEvent_t ev = ring[dev][next];
+    next = (next + 1) % RING;
+    hipError_t err = hipEventRecord(ev, (hipStream_t)from);
+    if (err == hipSuccess) err = hipStreamWaitEvent((hipStream_t)to, ev, 0);
+    return (int)err;
 }

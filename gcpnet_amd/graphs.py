@@ -11,7 +11,8 @@ synchronisation inside the step (index plans are cached on their tensors: GraphP
 steps first, which `GraphedStep` does), dropout masks would be frozen (capture with dropout 0 / eval dropout)."""
 from __future__ import annotations
 
-from typing import Callable
+import os
+from typing import Callable, Optional
 
 import torch
 
@@ -19,10 +20,15 @@ from . import ops
 
 
 class GraphedStep:
-    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3, optimizer=None):
+    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3, optimizer=None, side_stream: Optional[bool] = None):
         """step_fn: zeroes the gradients, runs forward + loss + backward, returns the loss.  optimizer (optional, capturable):
         optimizer.step() runs behind step_fn in every warm-up step and inside the capture -- the `warmup` eager steps DO update the
-        parameters, the capture pass itself executes nothing."""
+        parameters, the capture pass itself executes nothing.
+        side_stream: keep the weight-gradient stream inside the capture -- its launches fork from the capturing stream
+        (`side.wait_stream(main)`) and rejoin it in the end-of-backward callback, i.e. they become a parallel branch of the graph.
+        None = the GCPNET_GRAPH_SIDE_STREAM environment variable (default off: one stream inside the capture)."""
+        if side_stream is None:
+            side_stream = os.environ.get("GCPNET_GRAPH_SIDE_STREAM", "0") == "1"
         def full_step():
             loss = step_fn()
             if optimizer is not None:
@@ -30,7 +36,8 @@ class GraphedStep:
             return loss
 
         self._saved_side = ops.WEIGHT_GRADS_ON_SIDE_STREAM
-        ops.WEIGHT_GRADS_ON_SIDE_STREAM = False  # (one stream inside the capture; the end-of-backward join is a host callback)
+        if not side_stream:
+            ops.WEIGHT_GRADS_ON_SIDE_STREAM = False  # one stream inside the capture
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT, WgBwdArgs, WgBwdPlan, BwdScratch, ChainBwdItem, ChainItem, Head, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, VMODE_NONE, VMODE_SCALAR_GATE,
+from ._lib import (ACT, WgBwdArgs, WgBwdPlan, BwdScratch, ChainBwdItem, ChainItem, Head, Concat, Gcp2Opts, Gcp2Weights, Operand, ReduceJob, TnProblem, WgradJob, VMODE_NONE, VMODE_SCALAR_GATE,
                    VMODE_SELF_GATE, WgBlock, check)
 
 Tensor = torch.Tensor
@@ -981,73 +981,49 @@ class _WeightGradJob:
         f32 = dict(dtype=torch.float32, device=s_pre.device)  # (s_pre: a Tensor or a TileBlocked)
         H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
         nf = 9 if (spec.use_frames and vi > 0) else 0
-        self.spec, self.nf = spec, nf
+        self.spec, self.nf, self.device = spec, nf, s_pre.device
         if "fused" in t:  # the workgroup backward kernel has produced the gradients itself
-            self.probs, self.keep, self.reduce, self.g = [], [t], None, t.pop("fused")
+            self.job, self.keep, self.g = None, [t], t.pop("fused")
             return
-        self.has_vec, self.has_vout = vi > 0, vi > 0 and vo > 0
-        self.gated = spec.vmode == VMODE_SCALAR_GATE and self.has_vout
-        self.probs, self.keep = [], [t, s_pre, list(s_src)]
-
-        def operand(segs, act=None, ones=False):
-            op = Operand()
-            op.n = len(segs)
-            for k, (x, pl, dim, ld) in enumerate(segs):
-                op.ptr[k], op.dim[k], op.ld[k] = x.data_ptr(), dim, ld
-                op.idx[k] = pl.idx.data_ptr() if pl is not None else None
-                op.tb[k] = int(isinstance(x, TileBlocked))
-                assert not (op.tb[k] and pl is not None)
-            op.act, op.slope, op.ones = ACT[act], float(spec.slope), int(ones)
-            return op
-
-        def problem(a, M, b, N, out, out2, out2_n):
-            # the reduction writes the gradients in their final layouts: out = [weight block], out2 = bias column
-            pr = TnProblem()
-            pr.rows, pr.a, pr.b = rows, a, b
-            pr.out, pr.out_sm, pr.out_sn = out.data_ptr(), out.shape[1], 1
-            pr.out_m, pr.out_n = out.shape
-            pr.out2, pr.out2_n = out2.data_ptr(), out2_n
-            pr.splits = lib.gcpnet_tn_splits(rows, M, N)
-            part = torch.empty((pr.splits, M, N), **f32)
-            self.keep.append(part)
-            pr.partial = part.data_ptr()
-            self.probs.append(pr)
-
-        r4 = lambda x: (x + 3) // 4 * 4
-        si = spec.si
-        EP, VOP = r4(H + nf), r4(vo)
-        self.EP = EP
-        # d scalar_out.weight / bias: ds_pre^T [s sources | norms | frame scalars | 1]
-        bsegs = [(x, pl, x.width, x.width) if isinstance(x, TileBlocked) else (x, pl, x.shape[1], x.shape[1])
-                 for x, pl in zip(s_src, spec.s_plans)]
-        n1 = si + 1
-        if self.has_vec:
-            bsegs.append((t["ext"], None, EP, EP))
-            n1 = si + EP + 1
+        has_vec, has_vout = vi > 0, vi > 0 and vo > 0
+        gated = spec.vmode == VMODE_SCALAR_GATE and has_vout
+        self.keep = [t, s_pre, list(s_src)]
+        # one record per block (include/gcpnet_hip.h, gcp2_wgrad_job_t): gcpnet_gcp2_weight_grads derives the two GEMM problems
+        #     d scalar_out.weight | bias = ds_pre^T [s sources | norms | frame scalars | 1],  d gate.weight | bias = dgate^T [act_v(s_pre) | 1]
+        # and the column sums of the per-tile partials from it, and carves their scratch out of ONE workspace per call
+        j = WgradJob()
+        j.rows, j.so, j.vo, j.vi, j.hidden, j.use_frames = rows, so, vo, vi, H, int(bool(spec.use_frames))
+        j.gated, j.act_v, j.slope = int(gated), ACT[spec.act_v], float(spec.slope)
+        op = j.s_in
+        op.n = len(s_src)
+        for k, (x, pl) in enumerate(zip(s_src, spec.s_plans)):
+            tb = isinstance(x, TileBlocked)
+            width = x.width if tb else x.shape[1]
+            op.ptr[k], op.dim[k], op.ld[k], op.tb[k] = x.data_ptr(), width, width, int(tb)
+            op.idx[k] = pl.idx.data_ptr() if pl is not None else None
+            assert not (tb and pl is not None)
+        ds = t["ds_pre"]
+        j.ds_pre, j.ds_pre_tb = ds.data_ptr(), int(isinstance(ds, TileBlocked))
         g: List[Optional[Tensor]] = [None] * 7
         self.g = g
         g[0], g[1] = torch.empty((so, spec.K), **f32), torch.empty((so,), **f32)
-        # (columns of the product: [s sources | norms, frame scalars, stride padding | 1]; K = si + H + nf of them are weights)
-        problem(operand([(t["ds_pre"], None, so, so)]), so, operand(bsegs, ones=True), n1, g[0], g[1], n1 - 1)
-        if self.gated:  # d vector_out_scale.weight / bias: dgate^T [act_v(s_pre) | 1]  (the wide side carries the ones)
+        j.d_w_scalar, j.d_b_scalar = g[0].data_ptr(), g[1].data_ptr()
+        if gated:  # d vector_out_scale.weight / bias
             g[5], g[6] = torch.empty((vo, so), **f32), torch.empty((vo,), **f32)
-            problem(operand([(t["dgate"], None, VOP, VOP)]), VOP,
-                    operand([(s_pre, None, so, so)], act=spec.act_v, ones=True), so + 1, g[5], g[6], so)
-        self.reduce = None
-        if self.has_vec:  # d vector_up / vector_down(.frames): the backward kernel left one partial sum per tile
+            j.dgate, j.s_pre, j.s_pre_tb = t["dgate"].data_ptr(), s_pre.data_ptr(), int(isinstance(s_pre, TileBlocked))
+            j.d_w_gate, j.d_b_gate = g[5].data_ptr(), g[6].data_ptr()
+        if has_vec:  # d vector_up / vector_down(.frames): the backward kernel left one partial sum per tile
+            j.ext = t["ext"].data_ptr()
             part = t["w_part"]
             wv = torch.empty((part.shape[1],), **f32)
-            tmp = torch.empty((lib.gcpnet_reduce_partials_groups(part.shape[0]), part.shape[1]), **f32)
-            self.keep.append(tmp)
-            job = ReduceJob()
-            job.parts, job.n_parts, job.width, job.tmp, job.out = part.data_ptr(), part.shape[0], part.shape[1], tmp.data_ptr(), wv.data_ptr()
-            self.reduce = job
+            j.w_part, j.n_parts, j.w_width, j.d_w_small = part.data_ptr(), part.shape[0], part.shape[1], wv.data_ptr()
             o1, o2 = vo * H, vo * H + H * vi
-            if self.has_vout:
+            if has_vout:
                 g[4] = wv[:o1].view(vo, H)
             g[2] = wv[o1:o2].view(H, vi)
             if nf:
                 g[3] = wv[o2:].view(3, vi)
+        self.job = j
 
     def grads(self) -> List[Optional[Tensor]]:
         """(scalar_out.weight, scalar_out.bias, vector_down, vector_down_frames, vector_up, gate.weight, gate.bias).
@@ -1070,6 +1046,7 @@ def set_weight_grad_stream(enabled: bool) -> None:
     global WEIGHT_GRADS_ON_SIDE_STREAM
     WEIGHT_GRADS_ON_SIDE_STREAM = bool(enabled)
 _side_streams: dict = {}
+_main_streams: dict = {}
 _side_pending: list = []
 
 
@@ -1214,16 +1191,27 @@ def _side_submit(fn, keep) -> None:
     if torch._C._current_graph_task_id() < 0:  # not inside a backward pass: nothing would join the side stream
         fn()
         return
+    main, side = _fork_side_stream(keep)
+    with torch.cuda.stream(side):
+        fn()
+
+
+def _fork_side_stream(keep):
+    """(caller's stream, weight-gradient stream) with the latter ordered behind everything enqueued on the former so far; `keep` is
+    registered for the end-of-backward join.  The fork is one library call on the raw handles (gcpnet_stream_wait_stream: event
+    record + stream wait, ~3 us) instead of torch's Event / Stream objects (~20 us, 16 forks per configs[1] step)."""
     dev = torch.cuda.current_device()
-    main = torch.cuda.current_stream()
+    raw = _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+    main = _main_streams.get((dev, raw))
+    if main is None:  # (the Stream object of the caller's stream, for the join: built once per stream, not per fork)
+        main = _main_streams[(dev, raw)] = torch.cuda.current_stream()
     side = _side_streams.get(dev)
     if side is None:
         side = _side_streams[dev] = _make_side_stream(dev)
-    side.wait_stream(main)
+    check(_lib.load().gcpnet_stream_wait_stream(C.c_void_p(side.cuda_stream), C.c_void_p(raw)), "stream_wait_stream")
     _ensure_end_of_backward_callback()
     _side_pending.append((main, side, keep))
-    with torch.cuda.stream(side):
-        fn()
+    return main, side
 
 
 def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: bool = False) -> None:
@@ -1233,23 +1221,19 @@ def run_weight_grad_jobs(jobs: Sequence[_WeightGradJob], in_backward_of_leaves: 
     parameters), so from inside autograd they are enqueued on a second HIP stream: they then run concurrently with the data-path
     kernels of the following blocks, which on their own leave most CUs idle for node-row launches.  The caller's stream
     joins that stream in a callback at the end of the backward pass (before any optimizer / all-reduce can touch .grad)."""
-    jobs = [j for j in jobs if j.probs or j.reduce is not None]  # (fused blocks have produced their gradients already)
+    jobs = [j for j in jobs if j.job is not None]  # (fused blocks have produced their gradients already)
     if not jobs:
         return
-    if in_backward_of_leaves and WEIGHT_GRADS_ON_SIDE_STREAM:
-        _side_submit(lambda: run_weight_grad_jobs(jobs), [j.keep for j in jobs])  # operands / partials alive until the join
-        return
     lib = _lib.load()
-    probs = [pr for j in jobs for pr in j.probs]
-    for i in range(0, len(probs), _lib.TN_MAX_PROBLEMS):
-        chunk = probs[i:i + _lib.TN_MAX_PROBLEMS]
-        arr = (TnProblem * len(chunk))(*chunk)
-        check(lib.gcpnet_tn_gemm(len(chunk), arr, _stream()), "tn_gemm")
-    reds = [j.reduce for j in jobs if j.reduce is not None]
-    for i in range(0, len(reds), _lib.REDUCE_MAX_JOBS):
-        chunk = reds[i:i + _lib.REDUCE_MAX_JOBS]
-        arr = (ReduceJob * len(chunk))(*chunk)
-        check(lib.gcpnet_reduce_partials(len(chunk), arr, _stream()), "reduce_partials")
+    arr = (WgradJob * len(jobs))(*[j.job for j in jobs])
+    ws = torch.empty((max(int(lib.gcpnet_gcp2_weight_grads_workspace(len(jobs), arr)), 1),), dtype=torch.float32, device=jobs[0].device)
+    stream = _stream()
+    if in_backward_of_leaves and WEIGHT_GRADS_ON_SIDE_STREAM and torch._C._current_graph_task_id() >= 0:
+        # operands, partials and the workspace (allocated on the caller's stream, used on the other one) stay referenced until the
+        # end-of-backward join; the launches take the weight-gradient stream's raw handle -- no stream context to enter and leave
+        _, side = _fork_side_stream([j.keep for j in jobs] + [ws])
+        stream = C.c_void_p(side.cuda_stream)
+    check(lib.gcpnet_gcp2_weight_grads(len(jobs), arr, _p(ws), stream), "gcp2_weight_grads")
 
 
 def gcp2_weight_grads(spec: Gcp2Spec, rows: int, s_src, s_pre, t, in_backward_of_leaves: bool = False) -> List[Optional[Tensor]]:

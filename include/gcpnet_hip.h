@@ -346,6 +346,44 @@ typedef struct {
 int gcpnet_reduce_partials(int n_jobs, const gcp_reduce_job_t* jobs, void* stream);
 int gcpnet_reduce_partials_groups(int n_parts);
 
+/* ---- the weight gradients of n GCP2 blocks from their backward kernels' scratch, in ONE call -----------------------------------
+ * (autograd through GCP2.forward, components/gcpnet.py:394-468, gives per block d scalar_out.weight / bias, d vector_down[_frames],
+ * d vector_up and d vector_out_scale.weight / bias.)  For each job the call builds
+ *     d scalar_out.weight | bias        = ds_pre^T [scalar input segments | norms, frame scalars (ext) | 1]
+ *     d vector_out_scale.weight | bias  = dgate^T [act_v(s_pre) | 1]                                   (gated blocks)
+ *     d [vector_up | vector_down | vector_down_frames] = column sums of the per-tile partial sums w_part
+ * as gcp_tn_problem_t / gcp_reduce_job_t records and launches them GCP_TN_MAX_PROBLEMS / GCP_REDUCE_MAX_JOBS at a time -- what the
+ * host mirror otherwise assembles block by block in its own language (40 small records and 24 scratch allocations per 7-block chain).
+ * `workspace`: gcpnet_gcp2_weight_grads_workspace(n, jobs) floats (the GEMMs' per-split partial sums, the reductions' group sums);
+ * it must stay allocated until the launches have run. */
+typedef struct {
+    int rows;
+    int so, vo, vi, hidden, use_frames;  /* the block's dimensions, as in gcp2_weights_t */
+    int gated;                           /* vector_out_scale in use (d_w_gate / d_b_gate wanted) */
+    int act_v;
+    float slope;
+    gcp_operand_t s_in;   /* the block's scalar input as the GEMM reads it: n, ptr, idx, dim, ld, tb of its segments (act / ones unused) */
+    const float* ds_pre;  /* [rows, so], or tile-blocked */
+    int ds_pre_tb;
+    const float* s_pre;   /* [rows, so], or tile-blocked (gated blocks) */
+    int s_pre_tb;
+    const float* ext;     /* [rows, (hidden + 9 use_frames)'], NULL when vi == 0 */
+    const float* dgate;   /* [rows, vo'] (gated blocks) */
+    const float* w_part;  /* [n_parts, w_width] per-tile partial sums of the small vector weights, NULL when vi == 0 */
+    int n_parts, w_width;
+    float* d_w_scalar;    /* [so, si + hidden + 9 use_frames] */
+    float* d_b_scalar;    /* [so] */
+    float* d_w_small;     /* [w_width] */
+    float* d_w_gate;      /* [vo, so] */
+    float* d_b_gate;      /* [vo] */
+} gcp2_wgrad_job_t;
+int64_t gcpnet_gcp2_weight_grads_workspace(int n, const gcp2_wgrad_job_t* jobs);
+int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, float* workspace, void* stream);
+
+/* `to` waits for everything enqueued on `from` so far (hipEventRecord + hipStreamWaitEvent on an event of a library-owned ring): the
+ * fork of the weight-gradient stream off the caller's stream, and its join back, without the host language's stream / event objects. */
+int gcpnet_stream_wait_stream(void* to, void* from);
+
 /* ---- segment reductions: torch_scatter.scatter(reduce=sum|mean) over sorted segments ------------------------
  * out[s, 0:D] = reduce_{p in [seg_ptr[s], seg_ptr[s+1])} x[(perm ? perm[p] : p) * ldx + 0:D]
  * (components/gcpnet.py:939-947 aggregate; components/__init__.py:195-198 centroids; :314-323 node scalarize). */

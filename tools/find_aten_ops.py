@@ -31,10 +31,12 @@ class Mode(TorchDispatchMode):
         if not name.startswith(SKIP):
             dev = any(torch.is_tensor(a) and a.is_cuda for a in args) or any(
                 isinstance(a, (list, tuple)) and any(torch.is_tensor(b) and b.is_cuda for b in a) for a in args)
+            kd = (kwargs or {}).get("device")
+            dev = dev or (kd is not None and "cuda" in str(kd))  # (factories: zeros / full / arange on the device have no tensor argument)
             if dev:
                 st = [f"{os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in traceback.extract_stack()[:-1]
                       if "gcpnet_amd" in f.filename or f.filename.endswith("bench.py")][-2:]
-                shp = next((tuple(a.shape) for a in args if torch.is_tensor(a)), None)
+                shp = next((tuple(a.shape) for a in args if torch.is_tensor(a)), args[0] if args and isinstance(args[0], (list, tuple)) else None)
                 seen[(name, " <- ".join(reversed(st)) or "(autograd engine)", str(shp))] += 1
         return func(*args, **(kwargs or {}))
 

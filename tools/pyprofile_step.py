@@ -1,5 +1,5 @@
 """Host-side profile of one model step (launch-bound configurations): cProfile over K eager steps, top functions by own time.
-usage: pyprofile_step.py [c1|c4|c3] [steps]"""
+usage: pyprofile_step.py [c1|c4|c3|c2|c5] [steps] [extra bench.py flags, e.g. --nodes 200]"""
 import cProfile
 import os
 import pstats
@@ -14,9 +14,9 @@ from gcpnet_amd import ops  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c1"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-sys.argv = [sys.argv[0], "--config", cfg]
+sys.argv = [sys.argv[0], "--config", cfg] + sys.argv[3:]
 args = bench.parse()
-wl = bench.build_model_workload(args, 0, 1, G, ops)
+wl = (bench.build_layer_workload if cfg in ("c2", "c5") else bench.build_model_workload)(args, 0, 1, G, ops)
 for _ in range(5):
     wl["step"]()
 torch.cuda.synchronize()

@@ -1,6 +1,8 @@
 """Timeline of the last bench step in a rocprofv3 kernel_trace CSV: every launch with its start offset, duration and queue, the busy /
 idle time of the busiest queue (the caller's stream) and the launches that run beside it.
-usage: step_timeline.py <kernel_trace.csv> <steps incl. warmup> [min_us to print]"""
+usage: step_timeline.py <kernel_trace.csv> <steps incl. warmup> [min_us to print] [anchor:K]
+anchor:K = instead of cutting the trace into equal parts, print the launches between the 2K-th and the K-th launch from the end whose
+kernel name contains `anchor` (K launches of it per step: one step, rotated to start at that kernel) -- robust against set-up launches."""
 import collections
 import csv
 import re
@@ -12,6 +14,11 @@ min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 per = len(rows) // steps
 last = rows[-per:]
+if len(sys.argv) > 4:
+    name, k = sys.argv[4].rsplit(":", 1)
+    hits = [i for i, r in enumerate(rows) if name in r["Kernel_Name"]]
+    last = rows[hits[-2 * int(k)]:hits[-int(k)]]
+    per = len(last)
 t0 = int(last[0]["Start_Timestamp"])
 byq = collections.defaultdict(float)
 for r in last:
