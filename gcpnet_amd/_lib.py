@@ -26,7 +26,7 @@ EXPORTS = [
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
     "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_copy2d_multi", "gcpnet_axpy_clamp_backward", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_radius_graph_first", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
     "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
-    "gcpnet_gcp2_weight_grads", "gcpnet_gcp2_weight_grads_workspace", "gcpnet_stream_wait_stream",
+    "gcpnet_gcp2_weight_grads", "gcpnet_gcp2_weight_grads_workspace", "gcpnet_stream_wait_stream", "gcpnet_wg_pack_multi",
 ]
 
 
@@ -40,6 +40,11 @@ class Gcp2Weights(C.Structure):
         ("w_down", C.c_void_p), ("w_frames", C.c_void_p), ("w_up", C.c_void_p), ("w_scalar", C.c_void_p),
         ("b_scalar", C.c_void_p), ("w_gate", C.c_void_p), ("b_gate", C.c_void_p), ("pack", C.c_void_p),
     ]
+
+
+class WgPackJob(C.Structure):
+    _fields_ = [("w", Gcp2Weights), ("gated", C.c_int), ("W", C.c_void_p), ("ld", C.c_int), ("trans", C.c_int), ("nseg", C.c_int),
+                ("start", C.c_int * 3), ("len", C.c_int * 3), ("out", C.c_void_p)]
 
 
 class Gcp2Opts(C.Structure):
@@ -195,6 +200,7 @@ def load():
     lib.gcpnet_wg_pack_floats.restype = i64
     lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
     lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]
+    lib.gcpnet_wg_pack_multi.argtypes = [i32, P(WgPackJob), vp]
     lib.gcpnet_wg_pack_view.argtypes = [P(Gcp2Weights), i32, vp, i32, i32, i32, P(i32), P(i32), vp, vp]
     lib.gcpnet_wg_forward.argtypes = [i32, vp, vp, vp, P(Concat), P(Concat), i32, P(WgBlock), vp]
     lib.gcpnet_wg_backward_plan.argtypes = [i32, P(Gcp2Weights), P(Gcp2Opts), i32, P(WgBwdPlan)]

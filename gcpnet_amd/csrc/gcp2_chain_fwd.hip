@@ -200,6 +200,19 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
     for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
 
     const int n_blocks = ONLY ? 0 : p.n;
+    // PRE (the compile-time-hidden-width instantiations of the chain blocks): the weight fragments of the two small vector products
+    // are requested AHEAD of the block's s_pre / s_out / v_out stores -- vector_up's before this block's stores, the next block's
+    // vector_down ones with them -- because vmcnt retires loads and stores in issue order: a fragment requested behind a batch of
+    // stores is usable only once L2 has acknowledged every one of them (the same reordering of the backward
+    // kernel was worth 3 %)
+#ifdef GCP_CF_NO_PRE  // (measurement build: the requests where they were, behind the stores)
+    constexpr bool PRE = false;
+#else
+    constexpr bool PRE = HC > 0 && !HEAD;
+#endif
+    constexpr int NVA = PRE ? 8 : 4, NVB = PRE ? 4 * ((HC + 7) / 8) : 4;  // k-pair steps of vector_down (vi <= 16), registers of vector_up's input
+    float va_pre[NVA], vb_pre[NVB];
+    if constexpr (PRE) gcp_vmm_frags<NVA>(p.it[0].pack + S.offVA + lane, S.SVA, va_pre);
     for (int ci = HEAD ? -1 : 0; ci < n_blocks; ++ci) {
         asm volatile("" : "+v"(lane), "+v"(e), "+v"(hi), "+s"(kp));  // keep per-lane addresses AND the uniform parameters from being hoisted and spilled
         CF_RELOAD();
@@ -264,7 +277,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         //      in registers) the norms of vh and the projections of vf onto the row's frame -> the 32 x XS extras tile ------
         {
             gcp_xyz_acc u;
-            gcp_vmm_down<16>(it.pack + B.offVA + lane, B.SVA, vib, vt + e * L.VS, hi, u);
+            if constexpr (PRE) gcp_vmm_down_pre<NVA>(va_pre, B.SVA, vib, vt + e * L.VS, hi, u);
+            else gcp_vmm_down<16>(it.pack + B.offVA + lane, B.SVA, vib, vt + e * L.VS, hi, u);
             if (head) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -494,6 +508,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 5, lane);
 #endif
+        if constexpr (PRE) {  // (clamped index, no branch around the requests: a divergent merge point would cost a vmcnt(0))
+            gcp_vmm_frags<NVB>(it.pack + B.offVB + lane, SVBb, vb_pre);
+            gcp_vmm_frags<NVA>(p.it[min(ci + 1, n_blocks - 1)].pack + S.offVA + lane, S.SVA, va_pre);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
         if (it.s_pre) {
             if (it.s_pre_tb) gcp_store_acc_tb<NT>(it.s_pre, r0, acc, lane);
@@ -523,7 +542,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #pragma unroll
                 for (int d = 0; d < 3; ++d) uin[d][r] = r < SVBb ? ust[(r * 3 + d) * 64 + lane] : 0.f;
             gcp_xyz_zero(vu);
-            gcp_vmm_regs<16>(it.pack + B.offVB + lane, SVBb, uin, vu);
+            if constexpr (PRE) gcp_vmm_regs_pre<NVB>(vb_pre, SVBb, uin, vu);
+            else gcp_vmm_regs<16>(it.pack + B.offVB + lane, SVBb, uin, vu);
             float sg[NVR], x[NVR][3];
 #pragma unroll
             for (int r = 0; r < NVR; ++r) {

@@ -708,9 +708,8 @@ __device__ __forceinline__ float wg_view_at(const WgPackView& v, int r, int c) {
     return v.trans ? v.W[(int64_t)pc * v.ld + r] : v.W[(int64_t)r * v.ld + pc];
 }
 
-__global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view, const float* __restrict__ Wg,
-                                                      float* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wg_pack_element(const WgShape& S, const WgPackView& view, const float* __restrict__ Wg,
+                                                float* __restrict__ out, int64_t idx) {
     if (idx >= S.total) return;
     const int i = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     const int m = lane & 31, hi = lane >> 5;
@@ -764,6 +763,30 @@ __global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view
         if (r < S.vo && c < S.so) v = Wg[(int64_t)r * S.so + c];
     }
     out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void wg_pack_kernel(WgShape S, WgPackView view, const float* __restrict__ Wg,
+                                                      float* __restrict__ out) {
+    wg_pack_element(S, view, Wg, out, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Several images in one launch (gcpnet_wg_pack_multi): the 256-element blocks of all jobs in one 1-D grid; a block finds its job in
+// the prefix sums of the block counts and re-derives the job's shape from its seven dimensions.
+constexpr int WG_PACK_MULTI_MAX = 24;
+struct WgPackMultiArgs {
+    int n;
+    int block_start[WG_PACK_MULTI_MAX + 1];
+    int dims[WG_PACK_MULTI_MAX][7];  // si, vi, so, vo, hidden, use_frames, gated
+    WgPackView view[WG_PACK_MULTI_MAX];
+    const float* Wg[WG_PACK_MULTI_MAX];
+    float* out[WG_PACK_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void wg_pack_multi_kernel(WgPackMultiArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && (int)blockIdx.x >= a.block_start[j + 1]) ++j;
+    const int* d = a.dims[j];
+    const WgShape S = wg_shape(d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
+    wg_pack_element(S, a.view[j], a.Wg[j], a.out[j], (int64_t)((int)blockIdx.x - a.block_start[j]) * 256 + threadIdx.x);
 }
 
 template <int SHP, int NW, int MT, bool B6 = false>
@@ -821,6 +844,42 @@ extern "C" int gcpnet_wg_pack_view(const gcp2_weights_t* w, int gated, const flo
     hipLaunchKernelGGL(wg_pack_kernel, dim3((unsigned)gcp_cdiv((int)S.total, 256)), dim3(256), 0, (hipStream_t)stream, S, v, w->w_gate,
                        out);
     GCP_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gcpnet_wg_pack_multi(int n, const gcp_wg_pack_job_t* jobs, void* stream) {
+    if (n <= 0 || !jobs) return GCPNET_E_BADARG;
+    for (int i0 = 0; i0 < n; i0 += WG_PACK_MULTI_MAX) {
+        WgPackMultiArgs a;
+        a.n = min(WG_PACK_MULTI_MAX, n - i0);
+        int blocks = 0;
+        for (int j = 0; j < a.n; ++j) {
+            const gcp_wg_pack_job_t& J = jobs[i0 + j];
+            const gcp2_weights_t& w = J.w;
+            if (!J.out || !J.W || J.nseg < 1 || J.nseg > 3 || J.ld < 1) return GCPNET_E_BADARG;
+            const WgShape S = wg_shape(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, J.gated);
+            if (S.gated && !w.w_gate) return GCPNET_E_BADARG;
+            WgPackView& v = a.view[j];
+            v.W = J.W; v.ld = J.ld; v.trans = J.trans; v.nseg = J.nseg;
+            int tot = 0;
+            for (int k = 0; k < 3; ++k) {
+                v.start[k] = k < J.nseg ? J.start[k] : 0;
+                v.len[k] = k < J.nseg ? J.len[k] : 0;
+                if (v.start[k] < 0 || v.len[k] < 0) return GCPNET_E_BADARG;
+                tot += v.len[k];
+            }
+            if (tot != S.K) return GCPNET_E_BADARG;
+            const int dims[7] = {w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, J.gated};
+            for (int k = 0; k < 7; ++k) a.dims[j][k] = dims[k];
+            a.Wg[j] = w.w_gate;
+            a.out[j] = J.out;
+            a.block_start[j] = blocks;
+            blocks += gcp_cdiv((int)S.total, 256);
+        }
+        a.block_start[a.n] = blocks;
+        hipLaunchKernelGGL(wg_pack_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        GCP_HIP_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -537,30 +537,75 @@ def _gated(spec: Gcp2Spec) -> bool:
     return spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
 
 
+# Every pack cache (one per GCP module) that has asked for a workgroup-kernel image is known through a weakly held handle that lives
+# IN that cache: when one image turns out stale -- the first block of a step after the optimizer has updated the weights -- the images
+# of ALL known blocks whose weights have moved on are rebuilt by the same launch (gcpnet_wg_pack_multi; 34 single-image launches per
+# NMS model step otherwise).  An image built ahead of its use is keyed on the weights' (address, version) like any other: a weight
+# changed again before the block runs, or a block that asks with another column view, just misses again.
+class _WgPackUser:
+    __slots__ = ("cache", "dims", "gated", "segs", "w_scalar", "w_gate", "__weakref__")
+
+
+_WG_PACK_USERS = weakref.WeakSet()
+BATCH_WG_PACKS = os.environ.get("GCPNET_BATCH_WG_PACKS", "1") != "0"
+
+
+def _wg_pack_key(segs, w_scalar, w_gate):
+    return (_PACK_EPOCH, segs) + tuple(None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
+
+
 def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
     """Packed image of scalar_out / vector_out_scale for the workgroup kernels (gcpnet_wg_pack[_view]), cached per weight version."""
-    lib = _lib.load()
     view = spec.w_view
     w_scalar, w_gate = (view[0] if view is not None else w[0]), w[5]
-    key = (_PACK_EPOCH, None if view is None else tuple(view[1])) + tuple(
-        None if t is None else (t.data_ptr(), t._version) for t in (w_scalar, w_gate))
+    segs = None if view is None else tuple(view[1])
+    key = _wg_pack_key(segs, w_scalar, w_gate)
     cache = spec.pack_cache
     if cache is not None and cache.get("wg_key") == key:
         return cache["wg_pack"]
-    gated = int(_gated(spec))
-    n = lib.gcpnet_wg_pack_floats(spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames), gated)
-    pack = torch.empty(int(n), dtype=torch.float32, device=w_scalar.device)
-    ws = _weights_struct(spec, w, pack)
-    if view is None:
-        check(lib.gcpnet_wg_pack(C.byref(ws), gated, _p(pack), _stream()), "wg_pack")
-    else:
-        segs = view[1]
-        starts, lens = (C.c_int * len(segs))(*[a for a, _ in segs]), (C.c_int * len(segs))(*[m for _, m in segs])
-        check(lib.gcpnet_wg_pack_view(C.byref(ws), gated, _p(w_scalar), w_scalar.stride(0), 0, len(segs), starts, lens, _p(pack),
-                                      _stream()), "wg_pack_view")
-    if cache is not None:
-        cache["wg_key"], cache["wg_pack"] = key, pack
-    return pack
+    dims = (spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames))
+    # (cache, dims, gated, column view, scalar weight matrix, gate weight, key) of every image this launch builds; the asked one first
+    todo = [(cache, dims, int(_gated(spec)), segs, w_scalar, w_gate, key)]
+    if cache is not None and BATCH_WG_PACKS:
+        me = cache.get("wg_user")
+        if me is None:
+            me = cache["wg_user"] = _WgPackUser()
+            me.cache = cache
+            _WG_PACK_USERS.add(me)
+        me.dims, me.gated, me.segs = dims, todo[0][2], segs
+        me.w_scalar, me.w_gate = weakref.ref(w_scalar), (None if w_gate is None else weakref.ref(w_gate))
+        for u in list(_WG_PACK_USERS):
+            if u is me or "wg_key" not in u.cache:
+                continue
+            ws2, wg2 = u.w_scalar(), (None if u.w_gate is None else u.w_gate())
+            if ws2 is None or (u.w_gate is not None and wg2 is None) or ws2.device != w_scalar.device:
+                continue  # (weights that were temporaries of one call: that block packs on its own miss)
+            key2 = _wg_pack_key(u.segs, ws2, wg2)
+            if u.cache["wg_key"] != key2:
+                todo.append((u.cache, u.dims, u.gated, u.segs, ws2, wg2, key2))
+    lib = _lib.load()
+    jobs = (_lib.WgPackJob * len(todo))()
+    packs = []
+    for j, (_, d, gated, sg, ws_, wg_, _) in zip(jobs, todo):
+        pack = torch.empty(int(lib.gcpnet_wg_pack_floats(*d, gated)), dtype=torch.float32, device=ws_.device)
+        packs.append(pack)
+        jw = j.w
+        jw.si, jw.vi, jw.so, jw.vo, jw.hidden, jw.use_frames = d
+        jw.w_scalar, jw.w_gate = ws_.data_ptr(), (None if wg_ is None else wg_.data_ptr())
+        j.gated, j.W, j.out = gated, ws_.data_ptr(), pack.data_ptr()
+        if sg is None:
+            K = d[0] + (d[4] + (9 if d[5] else 0) if d[1] > 0 else 0)
+            j.ld, j.trans, j.nseg = K, 0, 1
+            j.start[0], j.len[0] = 0, K
+        else:
+            j.ld, j.trans, j.nseg = ws_.stride(0), 0, len(sg)
+            for k, (a, m) in enumerate(sg):
+                j.start[k], j.len[k] = a, m
+    check(lib.gcpnet_wg_pack_multi(len(todo), jobs, _stream()), "wg_pack_multi")
+    for (c, _, _, _, _, _, key_), pack in zip(todo, packs):
+        if c is not None:
+            c["wg_key"], c["wg_pack"] = key_, pack
+    return packs[0]
 
 
 _ZERO_BIAS: dict = {}

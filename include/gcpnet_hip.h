@@ -169,6 +169,17 @@ int gcpnet_wg_pack(const gcp2_weights_t* w, int gated, float* pack_out, void* st
  * With vi == 0, vo == 0 a block is a plain Linear + activation: gcpnet_wg_forward then replaces nn.Linear on [rows, si]. */
 int gcpnet_wg_pack_view(const gcp2_weights_t* w, int gated, const float* W, int ld, int trans, int nseg, const int* start,
                         const int* len, float* pack_out, void* stream);
+/* Several images in ONE launch (a training step re-packs every block's weights after the optimizer has updated them: 34 images per
+ * NMS model step): job j = the arguments of gcpnet_wg_pack_view (W = w.w_scalar, ld = K, one segment (0, K) for a plain pack). */
+typedef struct {
+    gcp2_weights_t w;
+    int gated;
+    const float* W;
+    int ld, trans, nseg;
+    int start[3], len[3];
+    float* out;
+} gcp_wg_pack_job_t;
+int gcpnet_wg_pack_multi(int n, const gcp_wg_pack_job_t* jobs, void* stream);
 
 typedef struct {
     gcp2_weights_t w;   /* dims of THIS block, reference-layout weights, w.pack = image of gcpnet_wg_pack */
