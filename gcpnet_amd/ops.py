@@ -511,25 +511,55 @@ def copy2d_multi(jobs) -> None:
 
 
 class TileBlocked:
-    """A [rows, width] fp32 matrix in the tile-blocked layout: `data` holds gcpnet_tb_floats(rows, width) floats."""
-    __slots__ = ("data", "rows", "width")
+    """A [rows, width] fp32 matrix in the tile-blocked layout: gcpnet_tb_floats(rows, width) floats, its own allocation or (`owner`,
+    `offset` in floats) a region of a flat one."""
+    __slots__ = ("rows", "width", "ptr", "_n", "_data", "_owner", "_off")
 
-    def __init__(self, rows: int, width: int, device):
+    def __init__(self, rows: int, width: int, device, owner: Optional[Tensor] = None, offset: int = 0, n: Optional[int] = None):
         self.rows, self.width = rows, width
-        self.data = torch.empty((_lib.load().gcpnet_tb_floats(rows, width),), dtype=torch.float32, device=device)
+        self._n = int(n) if n is not None else int(_lib.load().gcpnet_tb_floats(rows, width))
+        if owner is None:
+            self._data = torch.empty((self._n,), dtype=torch.float32, device=device)
+            self._owner, self._off, self.ptr = None, 0, self._data.data_ptr()
+        else:
+            self._data, self._owner, self._off, self.ptr = None, owner, offset, owner.data_ptr() + 4 * offset
 
     def data_ptr(self) -> int:
-        return self.data.data_ptr()
+        return self.ptr
+
+    @property
+    def data(self) -> Tensor:
+        if self._data is None:
+            self._data = self._owner[self._off:self._off + self._n]
+        return self._data
 
     @property
     def device(self):
-        return self.data.device
+        return (self._data if self._data is not None else self._owner).device
 
     def to_rows(self) -> Tensor:
         """Row-major copy (tests, debugging)."""
         wp = (self.width + 31) // 32 * 32
         t = self.data.view(-1, wp // 32, 4, 2, 32, 4)  # [tile, t, q, hi, e, i]
         return t.permute(0, 4, 1, 2, 3, 5).reshape(-1, wp)[:self.rows, :self.width].contiguous()
+
+
+class _Region:
+    """A row-major [rows, width] fp32 region of a flat allocation, for consumers that only need its address and shape (the backward
+    kernels' scratch: one allocation per chain instead of four per block)."""
+    __slots__ = ("owner", "ptr", "shape")
+
+    def __init__(self, owner: Tensor, offset: int, rows: int, width: int):
+        self.owner, self.ptr, self.shape = owner, owner.data_ptr() + 4 * offset, (rows, width)
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    @property
+    def device(self):
+        return self.owner.device
+
+
 WG_STATS = {"fwd": 0, "fwd_chain": 0, "bwd": 0}  # launches that went through them (tests assert the path under test ran)
 
 
@@ -1315,21 +1345,38 @@ class _Gcp2Chain(torch.autograd.Function):
               lib.gcpnet_gcp2_chain_backward_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
         all_w = [tuple(weights[7 * k:7 * k + 7]) for k in range(n)]
         all_packs = _pack_many(specs, all_w) if n <= _lib.MAX_CHAIN else [_pack(sp, w_) for sp, w_ in zip(specs, all_w)]
+        if tb:
+            # everything this route saves for its backward -- intermediate states, s_pre, gates: read back only by address -- comes
+            # out of ONE allocation (the blocks of a chain share their dimensions)
+            so, vo = sp0.so, sp0.vo
+            r64 = lambda x: (x + 63) // 64 * 64
+            n_tb = int(lib.gcpnet_tb_floats(rows, so))
+            gated0 = sp0.vmode == VMODE_SCALAR_GATE
+            o_gate = r64(n_tb)
+            o_sout = o_gate + (r64(rows * vo) if gated0 else 0)
+            o_vout = o_sout + r64(n_tb)
+            per = o_vout + r64(rows * 3 * vo)
+            flat = torch.empty((per * n,), **f32)
         for k, spec in enumerate(specs):
             w = all_w[k]
             pack = all_packs[k]
             last = k == n - 1  # intermediate states are only materialised when the backward will need them
-            if tb and not last:
-                s_out = TileBlocked(rows, spec.so, dev)
+            gated = spec.vmode == VMODE_SCALAR_GATE
+            if tb:
+                assert (spec.so, spec.vo, gated) == (so, vo, gated0)
+                base = per * k
+                s_pre = TileBlocked(rows, so, dev, owner=flat, offset=base, n=n_tb)
+                gate = _Region(flat, base + o_gate, rows, vo) if gated else None
+                if last:
+                    s_out, v_out = torch.empty((rows, so), **f32), torch.empty((rows, vo, 3), **f32)
+                else:
+                    s_out = TileBlocked(rows, so, dev, owner=flat, offset=base + o_sout, n=n_tb)
+                    v_out = _Region(flat, base + o_vout, rows, 3 * vo)
             else:
                 s_out = torch.empty((rows, spec.so), **f32) if (need_grad or last) else None
-            v_out = torch.empty((rows, spec.vo, 3), **f32) if (need_grad or last) else None
-            if tb:
-                s_pre = TileBlocked(rows, spec.so, dev)
-            else:
+                v_out = torch.empty((rows, spec.vo, 3), **f32) if (need_grad or last) else None
                 s_pre = torch.empty((rows, spec.so), **f32) if need_grad else None
-            gated = spec.vmode == VMODE_SCALAR_GATE
-            gate = torch.empty((rows, spec.vo), **f32) if (need_grad and gated) else None
+                gate = torch.empty((rows, spec.vo), **f32) if (need_grad and gated) else None
             items[k].w = _weights_struct(spec, w, pack)
             items[k].o = _opts_struct(spec)
             items[k].s_out = s_out.data_ptr() if s_out is not None else None
@@ -1366,6 +1413,7 @@ class _Gcp2Chain(torch.autograd.Function):
             ctx.use_cells = _note_uses(weights)
             ctx.agg = agg
             ctx.tb = tb
+            ctx.fwd_items = items  # (the backward's records start from these: same weights, packs, options)
         if agg is not None:
             plan, mean = agg
             m_s, m_v = outs[-1][0], outs[-1][1]
@@ -1406,7 +1454,8 @@ class _Gcp2Chain(torch.autograd.Function):
         side_ok = ctx.w_leaf and _side_stream_ok(ctx.weights, _take_use_cells(ctx))  # (asked once: the cells are released by the question)
         wave_chain = ctx.tb or _wave_chain_backward(specs[0])
         if wave_chain:  # (with `agg` the kernel reads the segment-level tables itself)
-            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg)
+            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg,
+                                           fwd_items=getattr(ctx, "fwd_items", None))
             assert res is not None or not ctx.tb, "tile-blocked activations were saved for a chain the backward kernel refuses"
         if res is None and agg is not None:
             # block-by-block routes take per-row gradients: the adjoint of the aggregation as its own launches
@@ -1452,7 +1501,7 @@ def _wave_chain_backward(sp0: Gcp2Spec) -> bool:
 
 
 def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s: Tensor, d_v: Tensor, need_w: Sequence[bool],
-                             out_agg=None):
+                             out_agg=None, fwd_items=None):
     """Backward data path of a whole ResGCP chain in one launch (gcpnet_gcp2_chain_backward).  ins[k] = (s, V) input of block
     k, outs[k] = (s_out, v_out, s_pre, gate) saved by the forward.  Returns (d_s_in, d_v_in, per-block scratch dicts), or None
     when the shape is outside that kernel (the caller then goes block by block).  `out_agg` = (GatherPlan, mean): d_s / d_v are
@@ -1461,14 +1510,49 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
     n = len(specs)
     items = (ChainBwdItem * n)()
     scrs = []
+    # the blocks of a chain share their dimensions: the four scratch regions of every block come out of ONE allocation
+    sp0 = specs[0]
+    H, vi, vo, so = sp0.hidden, sp0.vi, sp0.vo, sp0.so
+    nf = 9 if (sp0.use_frames and vi > 0) else 0
+    has_vec = vi > 0
+    gated = sp0.vmode == VMODE_SCALAR_GATE and vi > 0 and vo > 0
+    r4 = lambda x: (x + 3) // 4 * 4
+    r64 = lambda x: (x + 63) // 64 * 64
+    tb_all = isinstance(outs[0][2], TileBlocked)
+    n_ds = int(lib.gcpnet_tb_floats(rows, so)) if tb_all else rows * so
+    EP, VOP = r4(H + nf), r4(vo)
+    tiles = int(lib.gcpnet_gcp2_bwd_tiles(rows)) if has_vec else 0
+    w_width = vo * H + vi * (H + 3)
+    o_ext = r64(n_ds)
+    o_dg = o_ext + (r64(rows * EP) if has_vec else 0)
+    o_wp = o_dg + (r64(rows * VOP) if gated else 0)
+    per = o_wp + (r64(tiles * w_width) if has_vec else 0)
+    flat = torch.empty((per * n,), dtype=torch.float32, device=d_s.device)
     for k in range(n):
-        tb = isinstance(outs[k][2], TileBlocked)  # (s_pre saved tile-blocked: ds_pre leaves the same way)
-        scr, t = _alloc_bwd_scratch(specs[k], rows, need_w[k], d_s.device, tb=tb)
+        assert isinstance(outs[k][2], TileBlocked) == tb_all
+        base = per * k
+        scr = BwdScratch()
+        ds = TileBlocked(rows, so, d_s.device, owner=flat, offset=base, n=n_ds) if tb_all else _Region(flat, base, rows, so)
+        t = dict(ds_pre=ds)
+        scr.ds_pre = ds.ptr
+        if has_vec:
+            t["ext"] = _Region(flat, base + o_ext, rows, EP)
+            scr.ext = t["ext"].ptr
+            if need_w[k]:
+                t["w_part"] = _Region(flat, base + o_wp, tiles, w_width)
+                scr.w_part = t["w_part"].ptr
+            if gated:
+                t["dgate"] = _Region(flat, base + o_dg, rows, VOP)
+                scr.dgate = t["dgate"].ptr
         scrs.append(t)
-        items[k].w = _weights_struct(specs[k], ws[k], packs[k])
-        items[k].o = _opts_struct(specs[k], fused_residual=True)
+        if fwd_items is not None:  # (the forward's records of the same weights, packs and options)
+            items[k].w, items[k].o = fwd_items[k].w, fwd_items[k].o
+            items[k].o.fused_residual = 1
+        else:
+            items[k].w = _weights_struct(specs[k], ws[k], packs[k])
+            items[k].o = _opts_struct(specs[k], fused_residual=True)
         items[k].v_in = ins[k][1].data_ptr()
-        items[k].tb = int(tb)
+        items[k].tb = int(tb_all)
         items[k].s_pre = outs[k][2].data_ptr()
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
         items[k].sc = scr
