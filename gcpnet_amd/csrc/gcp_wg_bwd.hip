@@ -1062,15 +1062,18 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 #undef WG_LAUNDER
 
 // out[...] = sum over parts, fixed order.  parts[g][r * C + c] for r < R, c < C; columns c < CW of row r go to
-// out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].  A block sums 64 consecutive entries: its 256 threads are four
-// slices of the parts axis (16 loads in flight each), combined through LDS in a fixed order -- a few hundred parts of a small
-// matrix are otherwise one dependent load chain per thread.
+// out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].  A block sums 64 consecutive entries: its 64 x WR_SL threads are
+// WR_SL slices of the parts axis (16 loads in flight each), combined through LDS in a fixed order -- a few hundred parts of a small
+// matrix are otherwise one dependent load chain per thread.  (16 slices since round 4: the 768 partial sets of a fused first
+// message GCP backward were twelve dependent 16-load batches per thread with four slices -- 92 us per launch in the LBA step,
+// where this kernel sits on the caller's stream between the backward kernel and the input-gradient reductions.)
 struct WgReduceArgs {
     gcp_wg_reduce_job_t j[GCP_WG_REDUCE_MAX_JOBS];
 };
+constexpr int WR_SL = 16;
 
-__global__ __launch_bounds__(256) void wg_reduce_kernel(WgReduceArgs a) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(64 * WR_SL) void wg_reduce_kernel(WgReduceArgs a) {
+    __shared__ float red[WR_SL][64];
     const gcp_wg_reduce_job_t& J = a.j[blockIdx.y];
     const float* __restrict__ parts = J.parts;
     const int G = J.n_parts, R = J.R, C = J.C, CW = J.CW;
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(WgReduceArgs a) {
     if ((int64_t)blockIdx.x * 64 >= n) return;  // (the grid is sized for the largest job of the launch; uniform per block)
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + col;
-    const int per = (G + 3) / 4, g0 = sl * per, g1 = min(G, g0 + per);
+    const int per = (G + WR_SL - 1) / WR_SL, g0 = min(G, sl * per), g1 = min(G, g0 + per);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < n) {
         int g = g0;
@@ -1091,12 +1094,21 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(WgReduceArgs a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k & 7] += v[k];
         }
+        for (; g + 3 < g1; g += 4) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = parts[(int64_t)(g + k) * n + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += v[k];
+        }
         for (; g < g1; ++g) acc[0] += parts[(int64_t)g * n + i];
     }
     red[sl][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (sl == 0 && i < n) {
-        const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WR_SL; k += 4) v += (red[k][col] + red[k + 1][col]) + (red[k + 2][col] + red[k + 3][col]);
         const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
         if (c < CW) out_w[(int64_t)r * CW + c] = v;
         else if (out_b) out_b[r] = v;
@@ -1148,7 +1160,7 @@ extern "C" int gcpnet_wg_reduce_multi(int n_jobs, const gcp_wg_reduce_job_t* job
         a.j[k] = J;
         blocks = max(blocks, gcp_cdiv(J.R * J.C, 64));
     }
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)blocks, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)blocks, (unsigned)n_jobs), dim3(64 * WR_SL), 0, (hipStream_t)stream, a);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }
