@@ -64,7 +64,7 @@ class Head(C.Structure):
 
 class WgBlock(C.Structure):
     _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p),
-                ("gate", C.c_void_p), ("residual", C.c_int)]
+                ("gate", C.c_void_p), ("residual", C.c_int), ("s_out_tb", C.c_int), ("s_pre_tb", C.c_int)]
 
 
 WG_MAX_BLOCKS = 9
@@ -89,7 +89,7 @@ class WgBwdArgs(C.Structure):
                 ("frames", C.c_void_p), ("v_add", C.POINTER(Concat)), ("s_pre", C.c_void_p), ("gate", C.c_void_p),
                 ("d_s_out", C.c_void_p), ("d_v_out", C.c_void_p), ("d_s_in", C.c_void_p), ("d_v_in", C.c_void_p),
                 ("ds_pre", C.c_void_p), ("dvhf", C.c_void_p), ("ext", C.c_void_p), ("dgate", C.c_void_p),
-                ("dw_part", C.c_void_p), ("dwg_part", C.c_void_p), ("wsm_part", C.c_void_p)]
+                ("dw_part", C.c_void_p), ("dwg_part", C.c_void_p), ("wsm_part", C.c_void_p), ("tb", C.c_int)]
 
 
 class BwdScratch(C.Structure):
@@ -227,7 +227,7 @@ def load():
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",
                         "gcpnet_wg_pack_floats", "gcpnet_tb_floats", "gcpnet_gcp2_weight_grads_workspace"):
             fn.restype = i32
-    if lib.gcpnet_abi_version() != 2:
+    if lib.gcpnet_abi_version() != 3:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

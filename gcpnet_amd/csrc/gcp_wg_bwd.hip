@@ -174,6 +174,7 @@ struct WgBwdParams {
     unsigned mg_v, mg_o, mg_g, mg_x, mg_xpad, mg_epad, mg_ns, mg_wdt, mg_hfp, mg_ep, mg_vop;  // wg_magic of the tile-copy divisors
     int sm_tiles, sm_up_tiles, sm_nu, sm_nd;  // their 16 x 16 tiles: all, those of vector_up, tiles along N (up / down)
     int npass;                                // passes of P3 -> P4 over the output tiles (MP instantiations)
+    int tb;  // tile-blocked layouts (include/gcpnet_hip.h, gcp_wg_bwd_args_t.tb): bit 0 s_pre, 1 d_s_out, 2 d_s_in, 3 ds_pre
     unsigned long long* stamps;  // profiling hook: s_memtime stamps of wave 0 at the phase boundaries (last tile of the workgroup)
     long long stamp_cap;
 };
@@ -296,11 +297,13 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         const int tr0 = t * 32, tnv = min(32, rows - tr0);
         const int64_t trow = min(tr0 + e, rows - 1);
         const int ot = min(w, NT - 1);
+        // (tile-blocked: the lanes' 16-byte pieces of one register quad are 1 KB of whole lines; an address select, no branch)
+        const int64_t tbo = (int64_t)t * 32 * so + (int64_t)ot * 1024 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = min(32 * ot + 8 * q + 4 * hi, so - 4);
-            spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + trow * so + c);
-            dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + trow * so + c);
+            spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + ((p.tb & 1) ? tbo + q * 256 : trow * so + c));
+            dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + ((p.tb & 2) ? tbo + q * 256 : trow * so + c));
         }
         // A tile that is absent (no output vectors, no gate, no frames) or not in the 16-byte form (its commit loads it itself)
         // still issues its requests -- no branches around loads -- but from `safe`, one row of s_pre (so >= 4: 16 valid bytes),
@@ -505,11 +508,12 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         for (int t = t_lo; t < t_lo + tpp && w + NW * t < NT; ++t) {
             const int ot = w + NW * t;
             if (t > 0) {
+                const int64_t tbo = (int64_t)tile * 32 * so + (int64_t)ot * 1024 + lane * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = min(32 * ot + 8 * q + 4 * hi, so - 4);
-                    spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + rowc * so + c);
-                    dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + c);
+                    spq[q] = *reinterpret_cast<const f32x4*>(p.s_pre + ((p.tb & 1) ? tbo + q * 256 : rowc * so + c));
+                    dyq[q] = *reinterpret_cast<const f32x4*>(p.d_s_out + ((p.tb & 2) ? tbo + q * 256 : rowc * so + c));
                 }
             }
             f32x16 gacc;
@@ -553,7 +557,14 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     pl[jh * 192] = th; pl[jh * 192 + 64] = tm; pl[jh * 192 + 128] = tl;
                 }
             }
-            if (p.ds_pre) {  // (head block: summed per source node afterwards; not fused: operand of gcpnet_tn_gemm)
+            if (p.ds_pre && (p.tb & 8)) {  // tile-blocked operand of gcpnet_tn_gemm: straight from the registers (zeros in the rows past the end)
+                float* dst = p.ds_pre + (int64_t)tile * 32 * so + (int64_t)ot * 1024 + lane * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {dsp[4 * q], dsp[4 * q + 1], dsp[4 * q + 2], dsp[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(dst + q * 256) = v;
+                }
+            } else if (p.ds_pre) {  // (head block: summed per source node afterwards; not fused: operand of gcpnet_tn_gemm)
                 const int sub = lane >> 2, c4 = 4 * (lane & 3);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -634,7 +645,9 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     for (int j = 0; j < KT; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            res[j][q] = *reinterpret_cast<const f32x4*>(p.d_s_out + rowc * so + min(32 * ktc[j] + 8 * q + 4 * hi, so - 4));
+                            res[j][q] = *reinterpret_cast<const f32x4*>(
+                                p.d_s_out + ((p.tb & 2) ? (int64_t)tile * 32 * so + (int64_t)min(ktc[j], NT - 1) * 1024 + q * 256 + lane * 4
+                                                        : rowc * so + min(32 * ktc[j] + 8 * q + 4 * hi, so - 4)));
                 }
                 if constexpr (B6) {
                     const int NSL = 2 * NT;  // slabs of the reduction over so
@@ -711,7 +724,10 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                             const int c = 32 * kt + 8 * q + 4 * hi;
                             f32x4 v = {acc2[j][4 * q], acc2[j][4 * q + 1], acc2[j][4 * q + 2], acc2[j][4 * q + 3]};
                             if (p.residual && c + 3 < so) { v[0] += res[j][q][0]; v[1] += res[j][q][1]; v[2] += res[j][q][2]; v[3] += res[j][q][3]; }
-                            if (c + 3 < si) {
+                            if (c + 3 < si && (p.tb & 4)) {  // (si % 32 == 0: whole tiles; zeros in the rows past the end)
+                                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                                *reinterpret_cast<f32x4*>(p.d_s_in + (int64_t)tile * 32 * si + (int64_t)kt * 1024 + q * 256 + lane * 4) = row_ok ? v : z;
+                            } else if (c + 3 < si) {
                                 if (row_ok) *reinterpret_cast<f32x4*>(p.d_s_in + (int64_t)(r0 + e) * si + c) = v;
                             } else {
 #pragma unroll
@@ -1230,6 +1246,9 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     if (misaligned(a->s_pre) || misaligned(a->d_s_out) || misaligned(a->d_s_in) || misaligned(w.pack) || misaligned(a->ds_pre))
         return WG_UNSUPPORTED("a scalar tensor is not 16-byte aligned");
     if (a->residual && (w.si & 3)) return WG_UNSUPPORTED("residual block with si not a multiple of 4");
+    if (a->tb & ~15) return GCPNET_E_BADARG;
+    if (((a->tb & 11) && (w.so & 31)) || ((a->tb & 4) && (w.si & 31)) || ((a->tb & 8) && !a->ds_pre))
+        return GCPNET_E_BADARG;  // tile-blocked tensors: whole 32-column tiles
     const WgShape S = wg_shape(w.si, w.vi, w.so, w.vo, w.hidden, w.use_frames, gated);
     if (S.nf && (!a->frames || !w.w_frames)) return GCPNET_E_BADARG;
     if (pl.fused && (!a->s_in || (gated && !a->dwg_part))) return GCPNET_E_BADARG;
@@ -1242,6 +1261,7 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     if (a->v_add) p.v_add = *a->v_add;
     if (p.v_add.n < 0 || p.v_add.n > GCP_MAX_SEG) return GCPNET_E_BADARG;
     p.d_s_in = a->d_s_in; p.d_v_in = a->d_v_in;
+    p.tb = a->tb;
     p.pk = w.pack; p.offA2 = S.offA2; p.offG2 = S.offG2; p.offA2b = S.offA2b;
     p.w_down = w.w_down; p.w_frames = w.w_frames; p.w_up = w.w_up;
     p.ds_pre = a->ds_pre; p.dvhf = a->dvhf; p.ext = a->ext; p.dgate = a->dgate;

@@ -32,6 +32,7 @@ struct WgBlk {
     int act_s, act_v;
     int si, vi, H, K, KG;
     int residual;
+    int tb;  // bit 0: s_out, bit 1: s_pre written tile-blocked (so % 32 == 0)
 };
 
 struct WgFwdParams {
@@ -540,10 +541,22 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
             __builtin_amdgcn_sched_barrier(0);
             // full 128-byte row pieces through the wave-private staging tile (wg_store_acc)
             auto store_acc = [&](float* dst, const f32x16& av, int otile) { wg_store_acc(dst, so, 32 * otile, so, r0, nvalid, av, ST, lane); };
+            // tile-blocked (gcp2_chain_item_t's layout): a register quad of the wave is 1 KB of whole lines, no staging tile
+            auto store_tb = [&](float* dst, const f32x16& av, int otile) {
+                float* d = dst + (int64_t)r0 * so + (int64_t)otile * 1024 + lane * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(d + q * 256) = v;
+                }
+            };
             if (B.s_pre) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    if (tv[t]) store_acc(B.s_pre, acc[t], otc[t]);
+                    if (tv[t]) {
+                        if (B.tb & 2) store_tb(B.s_pre, acc[t], otc[t]);
+                        else store_acc(B.s_pre, acc[t], otc[t]);
+                    }
             }
 #pragma unroll
             for (int t = 0; t < MT; ++t)
@@ -558,7 +571,10 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
             if (B.s_out) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    if (tv[t]) store_acc(B.s_out, ynew[t], otc[t]);
+                    if (tv[t]) {
+                        if (B.tb & 1) store_tb(B.s_out, ynew[t], otc[t]);
+                        else store_acc(B.s_out, ynew[t], otc[t]);
+                    }
             }
         }
         stamp(4);
@@ -955,6 +971,8 @@ extern "C" int gcpnet_wg_forward(int rows, const float* s_in, const float* v_in,
         k.act_s = c.o.act_s; k.act_v = c.o.act_v;
         k.si = w.si; k.vi = w.vi; k.H = S.H; k.K = S.K; k.KG = S.KG;
         k.residual = c.residual;
+        k.tb = (c.s_out_tb ? 1 : 0) | (c.s_pre_tb ? 2 : 0);
+        if (k.tb && (so & 31)) return GCPNET_E_BADARG;  // tile-blocked tensors: whole 32-column tiles
         pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
         kmax = max(kmax, S.KP);
         vmax = max(vmax, w.vi);

@@ -699,6 +699,7 @@ def _wg_block(spec: Gcp2Spec, w, s_out, v_out, s_pre, gate, residual: bool, keep
     blk.s_out, blk.v_out = _p(s_out), _p(v_out)
     blk.s_pre, blk.gate = _p(s_pre), _p(gate)
     blk.residual = int(residual)
+    blk.s_out_tb, blk.s_pre_tb = int(isinstance(s_out, TileBlocked)), int(isinstance(s_pre, TileBlocked))
     return blk
 
 
@@ -862,7 +863,7 @@ def _vadd_concat(tables: Sequence[Tensor], plans: Sequence[Optional[GatherPlan]]
 
 
 def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack, s_pre, gate, d_s_out, d_v_out,
-                       need_w: bool = True, vadds: Sequence[Tensor] = (), side_reduce: bool = False):
+                       need_w: bool = True, vadds: Sequence[Tensor] = (), side_reduce: bool = False, tb_out: bool = False):
     """Launches the backward data-path kernel.  Returns (d_s_in, d_v_in, scratch dict for the weight-gradient GEMMs).
     `side_reduce`: the weights are leaves whose gradients nothing reads before the end of the backward pass (_side_stream_ok): the
     fused kernel's partial-sum reductions may then run on the weight-gradient stream."""
@@ -887,9 +888,12 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
         return torch.zeros((0, si), **f32), (torch.zeros((0, vi, 3), **f32) if vi > 0 else None), t
     if (USE_WG_KERNELS and USE_WG_BACKWARD and len(s_src) == 1 and spec.s_plans[0] is None and len(v_src) == 1
             and spec.v_plans[0] is None and vi > 0 and rows > 0):
-        res = _wg_backward(spec, rows, s_src[0], v_src[0], frames, w, s_pre, gate, d_s_out, d_v_out, need_w, vadds, side_reduce)
+        res = _wg_backward(spec, rows, s_src[0], v_src[0], frames, w, s_pre, gate, d_s_out, d_v_out, need_w, vadds, side_reduce,
+                           tb_out=tb_out)
         if res is not None:
             return res
+    if tb_out or any(isinstance(t_, TileBlocked) for t_ in (s_pre, d_s_out, *s_src)):
+        raise _lib.GcpnetHipError("tile-blocked tensors reached a block the workgroup backward kernel refuses")
     d_s_in = torch.empty((rows, si), **f32)
     d_v_in = torch.empty((rows, vi, 3), **f32) if vi > 0 else None
     scr, t = _alloc_bwd_scratch(spec, rows, need_w, s_pre.device)
@@ -923,7 +927,7 @@ def _wg_backward_supported(spec: Gcp2Spec, rows: int, w) -> bool:
 
 
 def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, d_s_out, d_v_out, need_w: bool, vadds,
-                 side_reduce: bool = False):
+                 side_reduce: bool = False, tb_out: bool = False):
     """Backward of one block through the workgroup kernel (gcp_wg_bwd.hip).  Returns (d_s_in, d_v_in, scratch dict) like
     gcp2_backward_data, or None when the shape is outside that kernel.  In fused mode the scratch dict carries the finished
     weight gradients under "fused" (summed over the persistent workgroups' partials in a fixed order); otherwise the per-row
@@ -947,16 +951,26 @@ def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, 
     vac = _vadd_concat(vadds, spec.vadd_plans) if len(vadds) else None
     a.v_add = C.pointer(vac) if vac is not None else None
     a.s_pre, a.gate, a.d_s_out, a.d_v_out = _p(s_pre), _p(gate), _p(d_s_out), _p(d_v_out) if vo else None
-    d_s_in = torch.empty((rows, si), **f32)
+    # tile-blocked tensors (a ResGCP chain walked block by block: s_pre from the workgroup forward, the state gradient between
+    # the blocks, ds_pre for the weight-gradient GEMM -- nothing else reads them)
+    tb = int(isinstance(s_pre, TileBlocked)) | (int(isinstance(d_s_out, TileBlocked)) << 1) | (int(tb_out) << 2)
+    fused = bool(plan.fused)
+    if tb and fused:  # (the fused form reads s_in and keeps ds_pre on chip: row-major tensors only)
+        return None
+    d_s_in = TileBlocked(rows, si, s_pre.device) if tb_out else torch.empty((rows, si), **f32)
     d_v_in = torch.empty((rows, vi, 3), **f32)
     a.d_s_in, a.d_v_in = _p(d_s_in), _p(d_v_in)
     t = {}
-    fused = bool(plan.fused)
     if (not fused and need_w) or spec.add_plans:
-        t["ds_pre"] = torch.empty((rows, so), **f32)
+        if tb and not spec.add_plans and so % 32 == 0:
+            t["ds_pre"] = TileBlocked(rows, so, s_pre.device)
+            tb |= 8
+        else:
+            t["ds_pre"] = torch.empty((rows, so), **f32)
         a.ds_pre = _p(t["ds_pre"])
     else:
         t["ds_pre"] = None
+    a.tb = tb
     if len(vadds):
         t["dvhf"] = torch.empty((rows, 3 * vadds[0].shape[2]), **f32)
         a.dvhf = _p(t["dvhf"])
@@ -1344,6 +1358,16 @@ class _Gcp2Chain(torch.autograd.Function):
         tb = (CHAIN_TILE_BLOCKED and need_grad and wave_first and rows > 0 and _wave_chain_backward(sp0) and
               lib.gcpnet_gcp2_chain_backward_ok(sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden, int(sp0.use_frames)) == 1)
         all_w = [tuple(weights[7 * k:7 * k + 7]) for k in range(n)]
+        # the same for chains that run in the workgroup kernels both ways (wider than 128: (256,32)): s_pre and the intermediate
+        # states tile-blocked when the backward will walk the chain block by block through gcpnet_wg_backward's plain form
+        wtb = False
+        if (CHAIN_TILE_BLOCKED and need_grad and not tb and not wave_first and rows > 0 and USE_WG_KERNELS and USE_WG_BACKWARD
+                and n <= _lib.WG_MAX_BLOCKS and sp0.so % 32 == 0 and sp0.si == sp0.so and sp0.vi > 0 and not _wave_chain_backward(sp0)
+                and all((sp.si, sp.vi, sp.so, sp.vo, sp.hidden) == (sp0.si, sp0.vi, sp0.so, sp0.vo, sp0.hidden) and not sp.add_plans
+                        for sp in specs)):
+            plan = WgBwdPlan()
+            wtb = (lib.gcpnet_wg_backward_plan(rows, C.byref(_weights_struct(sp0, all_w[0], None)), C.byref(_opts_struct(sp0)), 1,
+                                               C.byref(plan)) == 0 and not plan.fused)
         all_packs = _pack_many(specs, all_w) if n <= _lib.MAX_CHAIN else [_pack(sp, w_) for sp, w_ in zip(specs, all_w)]
         if tb:
             # everything this route saves for its backward -- intermediate states, s_pre, gates: read back only by address -- comes
@@ -1373,9 +1397,15 @@ class _Gcp2Chain(torch.autograd.Function):
                     s_out = TileBlocked(rows, so, dev, owner=flat, offset=base + o_sout, n=n_tb)
                     v_out = _Region(flat, base + o_vout, rows, 3 * vo)
             else:
-                s_out = torch.empty((rows, spec.so), **f32) if (need_grad or last) else None
+                if wtb and not last:
+                    s_out = TileBlocked(rows, spec.so, dev)
+                else:
+                    s_out = torch.empty((rows, spec.so), **f32) if (need_grad or last) else None
                 v_out = torch.empty((rows, spec.vo, 3), **f32) if (need_grad or last) else None
-                s_pre = torch.empty((rows, spec.so), **f32) if need_grad else None
+                if wtb:
+                    s_pre = TileBlocked(rows, spec.so, dev)
+                else:
+                    s_pre = torch.empty((rows, spec.so), **f32) if need_grad else None
                 gate = torch.empty((rows, spec.vo), **f32) if (need_grad and gated) else None
             items[k].w = _weights_struct(spec, w, pack)
             items[k].o = _opts_struct(spec)
@@ -1399,6 +1429,8 @@ class _Gcp2Chain(torch.autograd.Function):
             if rc != _lib.E_UNSUPPORTED:
                 check(rc, "wg_forward")
                 WG_STATS["fwd_chain"] += 1
+            elif wtb:
+                raise _lib.GcpnetHipError("gcpnet_wg_forward refused a chain whose backward plan it accepted (tile-blocked activations)")
         if rc == _lib.E_UNSUPPORTED:
             check(lib.gcpnet_gcp2_chain_forward(rows, _p(s0), _p(v0), _p(frames), n, items, _stream()), "gcp2_chain_forward")
         if need_grad:
@@ -1413,6 +1445,7 @@ class _Gcp2Chain(torch.autograd.Function):
             ctx.use_cells = _note_uses(weights)
             ctx.agg = agg
             ctx.tb = tb
+            ctx.wtb = wtb
             ctx.fwd_items = items  # (the backward's records start from these: same weights, packs, options)
         if agg is not None:
             plan, mean = agg
@@ -1452,7 +1485,7 @@ class _Gcp2Chain(torch.autograd.Function):
         # (256,32) -- go block by block through the workgroup kernel; shapes outside both through the generic kernel.
         res = None
         side_ok = ctx.w_leaf and _side_stream_ok(ctx.weights, _take_use_cells(ctx))  # (asked once: the cells are released by the question)
-        wave_chain = ctx.tb or _wave_chain_backward(specs[0])
+        wave_chain = ctx.tb or (not getattr(ctx, "wtb", False) and _wave_chain_backward(specs[0]))
         if wave_chain:  # (with `agg` the kernel reads the segment-level tables itself)
             res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg,
                                            fwd_items=getattr(ctx, "fwd_items", None))
@@ -1474,7 +1507,7 @@ class _Gcp2Chain(torch.autograd.Function):
                 s_in, v_in = ins[k]
                 _, _, s_pre, gate = outs[k]
                 d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s,
-                                                   d_v, need_w=nws[k], side_reduce=side)
+                                                   d_v, need_w=nws[k], side_reduce=side, tb_out=bool(getattr(ctx, "wtb", False)) and k > 0)
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GCPNET_ABI_VERSION 2
+#define GCPNET_ABI_VERSION 3
 
 #define GCPNET_E_BADARG (-1)
 #define GCPNET_E_UNSUPPORTED (-2)
@@ -189,6 +189,7 @@ typedef struct {
     float* s_pre;       /* [rows, so]     saved for the backward (NULL in inference) */
     float* gate;        /* [rows, vo]     sigmoid of the vector gate, saved for the backward */
     int residual;       /* out = in + GCP(in) (needs si == so, vi == vo) */
+    int s_out_tb, s_pre_tb;  /* the tensor is written tile-blocked (so a multiple of 32; see gcp2_chain_item_t) */
 } gcp_wg_block_t;
 
 /* Forward of n blocks on `rows` rows in one launch: block 0 reads s_in [rows, w.si] / v_in [rows, w.vi, 3] (plus the
@@ -241,6 +242,8 @@ typedef struct {
     float* dw_part;       /* fused mode */
     float* dwg_part;      /* fused mode, scalar-gated blocks */
     float* wsm_part;
+    int tb;               /* tile-blocked tensors (the layout of gcp2_chain_item_t; so resp. si a multiple of 32): bit 0 s_pre, bit 1 d_s_out,
+                             bit 2 d_s_in, bit 3 ds_pre -- what only these kernels and gcpnet_tn_gemm exchange inside one backward pass */
 } gcp_wg_bwd_args_t;
 int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* args, void* stream);
 /* out_w[r, c] = sum_g parts[g, r, c] for c < CW, out_b[r] = sum_g parts[g, r, CW] when C == CW + 1; fixed summation order. */

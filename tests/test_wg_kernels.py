@@ -225,3 +225,42 @@ def test_aggregation_inside_the_chain_function_is_bit_identical(G, dims, mean):
     assert float(res[0][0][n - 1].abs().max()) == 0.0 and float(res[0][2].abs().max()) > 0
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1000 + 13, 64], ids=["ragged", "two-tiles"])
+def test_wide_chain_tile_blocked_route_is_bit_identical(G, rows):
+    """A (256,32) ResGCP chain runs in the workgroup kernels both ways (forward: one launch, backward: block by block, weight gradients
+    through gcpnet_tn_gemm).  With ops.CHAIN_TILE_BLOCKED its s_pre, its intermediate states, the state gradient between the blocks and
+    ds_pre travel tile-blocked (gcp_wg_block_t.s_*_tb, gcp_wg_bwd_args_t.tb); the arithmetic is the same, so outputs, input gradients
+    and weight gradients must agree BITWISE with the row-major route.  Rows not a multiple of 32: the padding rows of the last tile."""
+    from gcpnet_amd import ops
+
+    torch.manual_seed(5)
+    s, v = 256, 32
+    mods = [G.GCP2((s, v), (s, v), nonlinearities=("silu", "silu"), bottleneck=4).cuda() for _ in range(3)]
+    g = torch.Generator().manual_seed(6)
+    fr = torch.randn(rows, 3, 3, generator=g).cuda()
+    s0, v0 = torch.randn(rows, s, generator=g).cuda(), torch.randn(rows, v, 3, generator=g).cuda()
+    ls, lv = torch.randn(rows, s, generator=g).cuda(), torch.randn(rows, v, 3, generator=g).cuda()
+    specs = [m.make_spec([None], [None], residual=True) for m in mods]
+    res, routes = [], []
+    saved = ops.CHAIN_TILE_BLOCKED
+    try:
+        for tb in (True, False):
+            ops.CHAIN_TILE_BLOCKED = tb
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            a, b = s0.clone().requires_grad_(), v0.clone().requires_grad_()
+            before = dict(ops.WG_STATS)
+            o_s, o_v = ops.gcp2_chain(specs, a, b, fr, [m._weights() for m in mods])
+            routes.append(bool(getattr(o_s.grad_fn, "wtb", False)))
+            ((o_s * ls).sum() + (o_v * lv).sum()).backward()
+            torch.cuda.synchronize()
+            assert ops.WG_STATS["fwd_chain"] == before["fwd_chain"] + 1 and ops.WG_STATS["bwd"] == before["bwd"] + 3
+            res.append([o_s.detach(), o_v.detach(), a.grad, b.grad] + [p.grad for m in mods for p in m.parameters()])
+    finally:
+        ops.CHAIN_TILE_BLOCKED = saved
+    assert routes == [True, False], routes
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
