@@ -530,22 +530,34 @@ def c5_kernel_roofline(G, ops, rows, sdim, vdim, iters=10):
     saved = out_s.grad_fn.saved_tensors
     pack, s_pre, gate = saved[-3], saved[-2], saved[-1]
     keep = {}
+    # as the step launches it for a block inside the chain: s_pre, the state gradient on both sides, ds_pre and the block's input
+    # scalars (an operand of the weight-gradient GEMM only) in the tile-blocked layout; and with row-major tensors for comparison
+    tb = ops.CHAIN_TILE_BLOCKED
+    if tb:
+        s_tb, s_pre_tb, ds_tb = (ops.TileBlocked.from_rows(t_) for t_ in (s.detach(), s_pre, ds))
 
-    def bwd():
+    def bwd_rows():
         keep["r"] = ops.gcp2_backward_data(spec, rows, [s.detach()], [v], fr, w, pack, s_pre, gate, ds, dv, need_w=True)
 
-    with torch.no_grad():
-        for _ in range(3):
-            bwd()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        torch.cuda.synchronize()
-        for a, b in ev:
-            a.record()
-            bwd()
-            b.record()
-        torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in ev)
-    t = ts[len(ts) // 2] * 1e-3
+    def bwd_tb():
+        keep["r"] = ops.gcp2_backward_data(spec, rows, [s_tb], [v], fr, w, pack, s_pre_tb, gate, ds_tb, dv, need_w=True, tb_out=True)
+
+    def median_ms(fn):
+        with torch.no_grad():
+            for _ in range(3):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            torch.cuda.synchronize()
+            for a, b in ev:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in ev)
+        return ts[len(ts) // 2]
+
+    t_rows = median_ms(bwd_rows)
+    t = (median_ms(bwd_tb) if tb else t_rows) * 1e-3
     flops = 2.0 * rows * gcp_macs(sdim, vdim, sdim, vdim)
     H = block.hidden_dim
     # algorithmic bytes per row: reads s_pre, d(s_out), d(v_out), v_in, gate, frames; writes d(s_in), d(v_in), ds_pre, dgate, ext
@@ -555,7 +567,9 @@ def c5_kernel_roofline(G, ops, rows, sdim, vdim, iters=10):
     return {"kernel": f"gcp_wg_bwd_kernel: backward (data path) of one residual message GCP ({sdim},{vdim})->({sdim},{vdim}) on {rows} rows, "
                       "28 launches per 4-layer configs[4] step",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-            "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "median_launch_ms": t * 1e3, "flop_per_launch": flops,
+            "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "median_launch_ms": t * 1e3,
+            "layout": "tile-blocked s_pre / state gradient / ds_pre, as inside the chain" if tb else "row-major",
+            "row_major_launch_ms": t_rows, "flop_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes, "algorithmic_hbm_gbs": nbytes / t / 1e9,
             "traffic": pmc_traffic(name), "traffic_source": PMC_FILE if pmc_traffic(name) is not None else None,
             "mfma_busy_frac_pmc": pmc_mfma_busy(name)}

@@ -1080,13 +1080,13 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 // out[...] = sum over parts, fixed order.  parts[g][r * C + c] for r < R, c < C; columns c < CW of row r go to
 // out_w[r * CW + c], column CW (when C == CW + 1) to out_b[r].  A block sums 64 consecutive entries: its 64 x WR_SL threads are
 // WR_SL slices of the parts axis (16 loads in flight each), combined through LDS in a fixed order -- a few hundred parts of a small
-// matrix are otherwise one dependent load chain per thread.  (16 slices since round 4: the 768 partial sets of a fused first
-// message GCP backward were twelve dependent 16-load batches per thread with four slices -- 92 us per launch in the LBA step,
-// where this kernel sits on the caller's stream between the backward kernel and the input-gradient reductions.)
+// matrix are otherwise one dependent load chain per thread.  (Four slices = 256 threads: a 16-slice form, 1 024 threads per block,
+// was tried in round 4 -- faster alone, but this kernel runs on the caller's stream beside the weight-gradient GEMMs, and a block
+// that needs sixteen free wave slots of one CU waits for them: 1.16 ms instead of 0.40 ms per launch inside the configs[4] step.)
 struct WgReduceArgs {
     gcp_wg_reduce_job_t j[GCP_WG_REDUCE_MAX_JOBS];
 };
-constexpr int WR_SL = 16;
+constexpr int WR_SL = 4;
 
 __global__ __launch_bounds__(64 * WR_SL) void wg_reduce_kernel(WgReduceArgs a) {
     __shared__ float red[WR_SL][64];

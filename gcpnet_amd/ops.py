@@ -537,6 +537,17 @@ class TileBlocked:
     def device(self):
         return (self._data if self._data is not None else self._owner).device
 
+    @classmethod
+    def from_rows(cls, x: Tensor) -> "TileBlocked":
+        """Tile-blocked copy of a row-major [rows, width] matrix (tests, measurements); padding rows / columns are zero."""
+        rows, width = x.shape
+        wp, rp = (width + 31) // 32 * 32, (rows + 31) // 32 * 32
+        t = cls(rows, width, x.device)
+        pad = torch.zeros((rp, wp), dtype=torch.float32, device=x.device)
+        pad[:rows, :width] = x
+        t.data.copy_(pad.view(rp // 32, 32, wp // 32, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).reshape(-1))  # [tile, e, t, q, hi, i] -> [tile, t, q, hi, e, i]
+        return t
+
     def to_rows(self) -> Tensor:
         """Row-major copy (tests, debugging)."""
         wp = (self.width + 31) // 32 * 32

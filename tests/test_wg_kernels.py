@@ -264,3 +264,33 @@ def test_wide_chain_tile_blocked_route_is_bit_identical(G, rows):
     assert routes == [True, False], routes
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_block_backward_with_tile_blocked_tensors_matches_row_major(G):
+    """gcpnet_wg_backward with gcp_wg_bwd_args_t.tb = s_pre | d_s_out | d_s_in | ds_pre on tensors converted by TileBlocked.from_rows:
+    the input gradients (converted back by to_rows) and every scratch operand equal the row-major launch bit for bit -- the layout
+    of include/gcpnet_hip.h as the host writes it is the layout the kernel addresses.  1000 + 13 rows: a partial last tile."""
+    from gcpnet_amd import ops
+
+    torch.manual_seed(7)
+    rows, s, v = 1013, 256, 32
+    blk = G.GCP2((s, v), (s, v), nonlinearities=("silu", "silu"), bottleneck=4).cuda()
+    spec = blk.make_spec([None], [None], residual=True)
+    w = tuple(None if t is None else t.detach() for t in blk._weights())
+    g = torch.Generator().manual_seed(8)
+    x, vv = torch.randn(rows, s, generator=g).cuda().requires_grad_(), torch.randn(rows, v, 3, generator=g).cuda()
+    fr, ds, dv = torch.randn(rows, 3, 3, generator=g).cuda(), torch.randn(rows, s, generator=g).cuda(), torch.randn(rows, v, 3, generator=g).cuda()
+    out_s, _ = ops.gcp2(spec, [x], [vv], fr, w)
+    pack, s_pre, gate = out_s.grad_fn.saved_tensors[-3:]
+    with torch.no_grad():
+        a_s, a_v, a_t = ops.gcp2_backward_data(spec, rows, [x.detach()], [vv], fr, w, pack, s_pre, gate, ds, dv, need_w=True)
+        tbs = [ops.TileBlocked.from_rows(t) for t in (x.detach(), s_pre, ds)]
+        assert torch.equal(tbs[1].to_rows(), s_pre)
+        b_s, b_v, b_t = ops.gcp2_backward_data(spec, rows, [tbs[0]], [vv], fr, w, pack, tbs[1], gate, tbs[2], dv, need_w=True, tb_out=True)
+    torch.cuda.synchronize()
+    assert isinstance(b_s, ops.TileBlocked) and isinstance(b_t["ds_pre"], ops.TileBlocked) and "fused" not in b_t
+    assert torch.equal(b_s.to_rows(), a_s) and torch.equal(b_v, a_v)
+    assert torch.equal(b_t["ds_pre"].to_rows(), a_t["ds_pre"])
+    for k in ("ext", "dgate", "w_part"):
+        assert torch.equal(b_t[k], a_t[k])
