@@ -577,6 +577,9 @@ def c5_kernel_roofline(G, ops, rows, sdim, vdim, iters=10):
 
 def main():
     args = parse()
+    if os.environ.get("BENCH_WATCHDOG_S"):  # diagnosis of a hung multi-rank run: every thread's Python stack on stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG_S"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -673,7 +676,9 @@ def main():
             node_dims = (args.sdim, args.vdim)
             fl = layer_flops(args.nodes, wl["n_edges"], node_dims, (32, 4))["fwd_bwd"] * args.layers
             per_job = fl * (1 if wl["sharded"] else world)
-            out["saved_activation_bytes_per_layer"] = saved_activation_bytes(wl)
+            # (a forward of the one-graph sharding holds collectives: rank 0 alone must not run one -- every other rank is already
+            # at the closing barrier.  Found by the two-rank rehearsal: BENCH_SHARE_GPU=1 BENCH_DIST_BACKEND=gloo, BENCH_WATCHDOG_S)
+            out["saved_activation_bytes_per_layer"] = None if wl["sharded"] else saved_activation_bytes(wl)
             out["whole_step"] = {"algorithmic_tflops_per_s": per_job * args.steps / elapsed / 1e12,
                                  "frac_of_fp32_mfma_peak": per_job * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS / world}
         if is_stack and not wl["sharded"]:

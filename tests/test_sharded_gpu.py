@@ -173,3 +173,29 @@ def test_sharded_position_update_with_force_term_matches_unsharded():
         ok(o["d"]["e"], ref["d"]["e"][perm][es], "de"); ok(o["d"]["xi"], ref["d"]["xi"][perm][es], "dxi")
         for k, want in ref["w"].items():
             ok(o["w"][k], want, k)
+
+
+@pytest.mark.parametrize("extra", [[], ["--shard", "graph"], ["--shard", "graph", "--allgather"]], ids=["batch", "graph-halo", "graph-allgather"])
+def test_bench_two_ranks_on_one_gpu_prints_its_line(extra):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU over gloo:
+    every rank must reach the closing barrier -- a collective that only rank 0 executes (round 4: the saved-activation measurement
+    ran a sharded forward on rank 0 alone) hangs the job.  BENCH_WATCHDOG_S turns a hang into a stack dump and a non-zero exit."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", BENCH_WATCHDOG_S="150")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "2000",
+           "--no-cpu-baseline", "--no-c5-block", "--no-other-configs"] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["scaling"] == ("strong" if extra else "weak")
+    assert line["rccl"]["world"] == 2 and line["rccl"]["fallback"] is None
