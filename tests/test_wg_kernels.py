@@ -294,3 +294,39 @@ def test_block_backward_with_tile_blocked_tensors_matches_row_major(G):
     assert torch.equal(b_t["ds_pre"].to_rows(), a_t["ds_pre"])
     for k in ("ext", "dgate", "w_part"):
         assert torch.equal(b_t[k], a_t[k])
+
+
+@pytest.mark.gpu
+def test_stale_workgroup_images_are_rebuilt_together_and_equal_single_packs(G):
+    """ops._pack_wg: when one block's packed image is stale, the images of every other known block whose weights have moved on are
+    rebuilt by the same gcpnet_wg_pack_multi launch (a training step after the optimizer update).  The batched images must be the
+    single-launch images bit for bit, a block whose weights did NOT change must keep its image, and a weight changed again after the
+    batch must miss again."""
+    from gcpnet_amd import ops
+
+    torch.manual_seed(9)
+    mods = [G.GCP2((64, 16), (64, 16), nonlinearities=("silu", "silu"), bottleneck=4).cuda() for _ in range(3)]
+    specs = [m.make_spec([None], [None]) for m in mods]
+    first = [ops._pack_wg(sp, m._weights()) for sp, m in zip(specs, mods)]
+    assert all(ops._pack_wg(sp, m._weights()) is p for sp, m, p in zip(specs, mods, first))  # cached
+    with torch.no_grad():
+        for m in mods[:2]:  # (module 2 keeps its weights)
+            m.scalar_out.weight.add_(0.25)
+    p0 = ops._pack_wg(specs[0], mods[0]._weights())  # miss: rebuilds 0 and, in the same launch, 1
+    assert p0 is not first[0]
+    c1 = mods[1]._pack_cache
+    assert c1["wg_pack"] is not first[1] and c1["wg_key"] == ops._wg_pack_key(None, mods[1].scalar_out.weight, mods[1].vector_out_scale.weight)
+    assert ops._pack_wg(specs[1], mods[1]._weights()) is c1["wg_pack"]  # a hit now
+    assert ops._pack_wg(specs[2], mods[2]._weights()) is first[2]
+    saved = ops.BATCH_WG_PACKS
+    try:
+        ops.BATCH_WG_PACKS = False
+        ops.invalidate_packs()
+        single = [ops._pack_wg(sp, m._weights()) for sp, m in zip(specs, mods)]
+    finally:
+        ops.BATCH_WG_PACKS = saved
+    torch.cuda.synchronize()
+    assert torch.equal(single[0], p0) and torch.equal(single[1], c1["wg_pack"]) and torch.equal(single[2], first[2])
+    with torch.no_grad():
+        mods[1].scalar_out.weight.mul_(2.0)
+    assert ops._pack_wg(specs[1], mods[1]._weights()) is not single[1]
