@@ -185,9 +185,12 @@ def test_radius_graph_matches_scipy_bit_for_bit(G):
     assert bool((got[1, 1:] >= got[1, :-1]).all())
 
 
-def test_hip_graph_replay_matches_eager_step(G):
+@pytest.mark.parametrize("side_stream", [False, True], ids=["one-stream", "weight-grad-branch"])
+def test_hip_graph_replay_matches_eager_step(G, side_stream):
     """A whole NMS `step()` + backward captured in a hipGraph (gcpnet_amd.graphs.GraphedStep): replays reproduce the eager step's
-    loss and gradients bit for bit, and follow new data copied into the static input tensors."""
+    loss and gradients bit for bit, and follow new data copied into the static input tensors.  side_stream: the weight-gradient
+    stream stays inside the capture (forked by gcpnet_stream_wait_stream, joined by the end-of-backward callback) as a parallel
+    branch of the graph."""
     from gcpnet_amd.graphs import GraphedStep
     from gcpnet_amd.synthetic import model_batch
 
@@ -206,7 +209,7 @@ def test_hip_graph_replay_matches_eager_step(G):
 
     eager_loss = step().detach().clone()
     eager = [p.grad.clone() for p in params]
-    graphed = GraphedStep(step)
+    graphed = GraphedStep(step, side_stream=side_stream)
     loss = graphed()
     torch.cuda.synchronize()
     assert torch.equal(loss.detach(), eager_loss)
