@@ -1197,6 +1197,23 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     int NW = (w->so > 160 || S.K > 160) ? 8 : 4;
     // (experiment: few reduction columns and 128 < so <= 256 -- the first message GCP of configs[4] -- with four waves, plain form)
     if (getenv("GCPNET_WG_BWD_HEAD4") && w->so > 128 && w->so <= 256 && S.K <= 96) NW = 4;
+    if (!g_wg_cus) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g_wg_cus = cus;
+    }
+    // About one tile per CU (node rows of configs[1] / configs[3]: 313 / 238 tiles on 256 CUs): an eight-wave workgroup holds a CU
+    // alone, tiles past the first round cost a whole second one and a round leaves half of every CU's wave slots to latency; four-wave
+    // workgroups start two per CU.  Measured (same box, GCPNET_WG_BWD_SMALL_NW8 = the old choice): configs[1] 11.36 -> 11.20 ms,
+    // configs[3] 26.23 -> 26.01 ms.  NOT for a handful of tiles (the 16 / 63 node tiles of configs[0] / configs[3]'s NMS batches: most
+    // CUs idle, a tile's latency is what counts and eight waves per tile shorten it: captured c1 2.53 vs 2.60 ms, c4 4.02 vs 4.12).
+    static const bool small_nw4 = getenv("GCPNET_WG_BWD_SMALL_NW8") == nullptr;
+    if (NW == 8 && small_nw4 && 2 * gcp_cdiv(rows, 32) > g_wg_cus && gcp_cdiv(rows, 32) <= 2 * g_wg_cus && gcp_cdiv(S.NT, 4) <= 4) {
+        const WgBwdDims D4 = wg_bwd_dims(w->si, w->vi, w->so, w->vo, w->hidden, w->use_frames, gated,
+                                         want_fused && !getenv("GCPNET_WG_BWD_NOFUSE"), 4);
+        if (D4.KTn <= 4 && D4.sm_tiles <= NSW * 4 && D4.npass == 1 && (size_t)D4.lds_floats * sizeof(float) <= 160 * 1024) NW = 4;
+    }
     if (const char* ev = getenv("GCPNET_WG_BWD_NW")) {  // (tuning knob: 4 or 8 waves per workgroup)
         if (ev[0] == '4') NW = 4;
         if (ev[0] == '8') NW = 8;
@@ -1207,12 +1224,6 @@ extern "C" int gcpnet_wg_backward_plan(int rows, const gcp2_weights_t* w, const 
     if (D.KTn > 4) return WG_UNSUPPORTED("more than four K tiles per wave");
     if (D.sm_tiles > NSW * NW) return WG_UNSUPPORTED("small vector weight gradients: more 16 x 16 tiles than the waves hold");
     const int KTn = D.KTn, fused = D.fused, KW = D.KW, n_sm = D.n_sm, split = D.split;
-    if (!g_wg_cus) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        g_wg_cus = cus;
-    }
     const int ntiles = gcp_cdiv(rows, 32);
     plan->nw = NW;
     plan->kt = KTn == 1 ? 1 : 4;
