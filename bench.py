@@ -529,6 +529,8 @@ def c5_kernel_roofline(G, ops, rows, sdim, vdim, iters=10):
     out_s, _ = ops.gcp2(spec, [s], [v], fr, w)
     saved = out_s.grad_fn.saved_tensors
     pack, s_pre, gate = saved[-3], saved[-2], saved[-1]
+    if getattr(out_s.grad_fn, "s_pre_tb", False):  # (a single block through the workgroup kernels saves s_pre tile-blocked: rows for this probe)
+        s_pre = ops.TileBlocked(rows, sdim, s_pre.device, owner=s_pre, offset=0, n=s_pre.numel()).to_rows()
     keep = {}
     # as the step launches it for a block inside the chain: s_pre, the state gradient on both sides, ds_pre and the block's input
     # scalars (an operand of the weight-gradient GEMM only) in the tile-blocked layout; and with row-major tensors for comparison

@@ -488,6 +488,8 @@ FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains
 # scalar states of a ResGCP chain -- in the tile-blocked layout (include/gcpnet_hip.h, gcp2_chain_item_t): every wave instruction on
 # them moves 1 KB of whole lines, no LDS transposition.  GCPNET_CHAIN_TB=0: row-major as before (A/B measurements, tests).
 CHAIN_TILE_BLOCKED = os.environ.get("GCPNET_CHAIN_TB", "1") != "0"
+# (the same for the s_pre of a SINGLE block that runs in the workgroup kernels both ways: first message GCP, feed-forward GCPs)
+BLOCK_TILE_BLOCKED = os.environ.get("GCPNET_BLOCK_TB", "1") != "0"
 
 
 def copy2d_multi(jobs) -> None:
@@ -740,7 +742,8 @@ class _Gcp2(torch.autograd.Function):
             ctx.w_leaf = not spec.shared_weights  # (checked again, against the live tensors, in the backward: _side_stream_ok)
             ctx.weights = w
             ctx.use_cells = _note_uses(w)
-            ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre, gate, *vadds)
+            ctx.s_pre_tb = isinstance(s_pre, TileBlocked)  # (saved as its flat tensor, wrapped again in the backward)
+            ctx.save_for_backward(*s_src, *v_src, *[t for t in w], pack, s_pre.data if ctx.s_pre_tb else s_pre, gate, *vadds)
         if spec.vo:
             return s_out, v_out
         return s_out
@@ -752,6 +755,8 @@ class _Gcp2(torch.autograd.Function):
         s_src, v_src = list(saved[:n_s]), list(saved[n_s:n_s + n_v])
         w = tuple(saved[n_s + n_v:n_s + n_v + 7])
         pack, s_pre, gate = saved[n_s + n_v + 7:n_s + n_v + 10]
+        if getattr(ctx, "s_pre_tb", False):
+            s_pre = TileBlocked(rows, spec.so, s_pre.device, owner=s_pre, offset=0, n=s_pre.numel())
         vadds = list(saved[n_s + n_v + 10:])
         f32 = dict(dtype=torch.float32, device=s_pre.device)
         d_s_out = _req(d_s_out, "grad") if d_s_out is not None else torch.zeros((rows, spec.so), **f32)
@@ -818,13 +823,21 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
         res_s, res_v = s_src[0], (v_src[0] if n_v else None)
     s_out = torch.empty((rows, spec.so), dtype=torch.float32, device=dev)
     v_out = torch.empty((rows, spec.vo, 3), dtype=torch.float32, device=dev) if spec.vo else None
-    s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
+    plain = len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
+    wg_route = USE_WG_KERNELS and plain and (spec.residual or (res_s is None and res_v is None)) and spec.vi > 0
+    # s_pre is read back only by this block's backward and its weight-gradient GEMM: tile-blocked (include/gcpnet_hip.h,
+    # gcp2_chain_item_t) when the workgroup kernels will run both ways -- 16-byte pieces of whole lines instead of 32 lines per
+    # wave instruction on the way in, no staging tile on the way out
+    tbp = bool(CHAIN_TILE_BLOCKED and BLOCK_TILE_BLOCKED and need_grad and rows > 0 and wg_route and USE_WG_BACKWARD and spec.so % 32 == 0)
+    if tbp:
+        s_pre = TileBlocked(rows, spec.so, dev)
+    else:
+        s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev) if need_grad else None
     gated = spec.vmode == VMODE_SCALAR_GATE and spec.vo > 0 and spec.vi > 0
     gate = torch.empty((rows, spec.vo), dtype=torch.float32, device=dev) if (need_grad and gated) else None
     if rows == 0:  # (an empty edge set: one half of autoregressive_forward's edge split, a node without in-edges in the CPD
         return rows, s_out, v_out, pack, s_pre, gate  # sampling loop) -- nothing to launch, empty tensors have no address
-    plain = len(s_src) == 1 and spec.s_plans[0] is None and n_v == 1 and spec.v_plans[0] is None
-    if USE_WG_KERNELS and plain and (spec.residual or (res_s is None and res_v is None)) and spec.vi > 0:
+    if wg_route:
         # one workgroup per 32-row tile, output columns split over its waves (gcp_wg_fwd.hip)
         keep: list = []
         blk = _wg_block(spec, w, s_out, v_out, s_pre, gate, spec.residual, keep)
@@ -834,6 +847,8 @@ def _gcp2_forward_launch(spec: Gcp2Spec, frames, s_src, v_src, res_s, res_v, w, 
             check(rc, "wg_forward")
             WG_STATS["fwd"] += 1
             return rows, s_out, v_out, pack, s_pre, gate
+        if tbp:  # (the other kernels write rows)
+            s_pre = torch.empty((rows, spec.so), dtype=torch.float32, device=dev)
     w = _dense_weights(spec, w)
     pack = _pack(spec, w)
     ws = _weights_struct(spec, w, pack)
@@ -903,8 +918,10 @@ def gcp2_backward_data(spec: Gcp2Spec, rows: int, s_src, v_src, frames, w, pack,
                            tb_out=tb_out)
         if res is not None:
             return res
-    if tb_out or any(isinstance(t_, TileBlocked) for t_ in (s_pre, d_s_out, *s_src)):
+    if tb_out or any(isinstance(t_, TileBlocked) for t_ in (d_s_out, *s_src)):
         raise _lib.GcpnetHipError("tile-blocked tensors reached a block the workgroup backward kernel refuses")
+    if isinstance(s_pre, TileBlocked):  # (a single block whose forward ran in the workgroup kernel and whose backward cannot: rows again)
+        s_pre = s_pre.to_rows()
     d_s_in = torch.empty((rows, si), **f32)
     d_v_in = torch.empty((rows, vi, 3), **f32) if vi > 0 else None
     scr, t = _alloc_bwd_scratch(spec, rows, need_w, s_pre.device)
@@ -966,14 +983,14 @@ def _wg_backward(spec: Gcp2Spec, rows: int, s_in, v_in, frames, w, s_pre, gate, 
     # the blocks, ds_pre for the weight-gradient GEMM -- nothing else reads them)
     tb = int(isinstance(s_pre, TileBlocked)) | (int(isinstance(d_s_out, TileBlocked)) << 1) | (int(tb_out) << 2)
     fused = bool(plan.fused)
-    if tb and fused:  # (the fused form reads s_in and keeps ds_pre on chip: row-major tensors only)
+    if (tb & ~3 or isinstance(s_in, TileBlocked)) and fused:  # (the fused form reads s_in as rows; its ds_pre output stays row-major)
         return None
     d_s_in = TileBlocked(rows, si, s_pre.device) if tb_out else torch.empty((rows, si), **f32)
     d_v_in = torch.empty((rows, vi, 3), **f32)
     a.d_s_in, a.d_v_in = _p(d_s_in), _p(d_v_in)
     t = {}
     if (not fused and need_w) or spec.add_plans:
-        if tb and not spec.add_plans and so % 32 == 0:
+        if tb and not fused and not spec.add_plans and so % 32 == 0:
             t["ds_pre"] = TileBlocked(rows, so, s_pre.device)
             tb |= 8
         else:
@@ -1853,7 +1870,9 @@ class _Gcp2Projected(torch.autograd.Function):
             ctx.weights = w
             ctx.use_cells = _note_uses(w)
             ctx.n_w2 = [t is not None for t in w2]
-            ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre, gate, *wvs, *vts, *vadds)
+            ctx.s_pre_tb = isinstance(s_pre, TileBlocked)
+            ctx.save_for_backward(*s_src, *v_src, *[t for t in w2 if t is not None], pack, s_pre.data if ctx.s_pre_tb else s_pre, gate,
+                                  *wvs, *vts, *vadds)
         if spec.vo:
             return s_out, v_out
         return s_out
@@ -1871,6 +1890,8 @@ class _Gcp2Projected(torch.autograd.Function):
             pos += 1 if present else 0
         w2 = tuple(w2)
         pack, s_pre, gate = saved[pos:pos + 3]
+        if getattr(ctx, "s_pre_tb", False):
+            s_pre = TileBlocked(rows, spec.so, s_pre.device, owner=s_pre, offset=0, n=s_pre.numel())
         pos += 3
         wvs = saved[pos:pos + len(vg)]; pos += len(vg)
         vts = saved[pos:pos + len(vg)]; pos += len(vg)

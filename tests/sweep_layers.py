@@ -70,8 +70,8 @@ for case in range(n_cases):
 
         def _spy(spec, *a, **kw):
             r = _orig_launch(spec, *a, **kw)
-            if r[4] is not None:
-                hip_pre.append((r[0], spec.so, r[4]))
+            if r[4] is not None:  # (a tile-blocked s_pre is read back as rows)
+                hip_pre.append((r[0], spec.so, r[4].to_rows() if isinstance(r[4], _ops.TileBlocked) else r[4]))
             return r
         _ops._gcp2_forward_launch = _spy
     ei_d, fr_d, x_d = ei.cuda(), fr.cuda(), x.cuda()

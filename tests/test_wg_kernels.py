@@ -283,6 +283,8 @@ def test_block_backward_with_tile_blocked_tensors_matches_row_major(G):
     fr, ds, dv = torch.randn(rows, 3, 3, generator=g).cuda(), torch.randn(rows, s, generator=g).cuda(), torch.randn(rows, v, 3, generator=g).cuda()
     out_s, _ = ops.gcp2(spec, [x], [vv], fr, w)
     pack, s_pre, gate = out_s.grad_fn.saved_tensors[-3:]
+    assert out_s.grad_fn.s_pre_tb  # (the single block's own s_pre is saved tile-blocked: rows for the reference launch)
+    s_pre = ops.TileBlocked(rows, s, s_pre.device, owner=s_pre, offset=0, n=s_pre.numel()).to_rows()
     with torch.no_grad():
         a_s, a_v, a_t = ops.gcp2_backward_data(spec, rows, [x.detach()], [vv], fr, w, pack, s_pre, gate, ds, dv, need_w=True)
         tbs = [ops.TileBlocked.from_rows(t) for t in (x.detach(), s_pre, ds)]

@@ -27,6 +27,8 @@ w = tuple(None if t is None else t.detach() for t in block._weights())
 out_s, out_v = ops.gcp2(spec, [s], [v], fr, w)
 saved = out_s.grad_fn.saved_tensors
 pack, s_pre, gate = saved[-3], saved[-2], saved[-1]
+if getattr(out_s.grad_fn, "s_pre_tb", False):  # (a single block through the workgroup kernels saves s_pre tile-blocked)
+    s_pre = ops.TileBlocked(E, S, s_pre.device, owner=s_pre, offset=0, n=s_pre.numel()).to_rows()
 ntiles = (E + 31) // 32
 buf = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
 
