@@ -588,6 +588,14 @@ def _gated(spec: Gcp2Spec) -> bool:
 class _WgPackUser:
     __slots__ = ("cache", "dims", "gated", "segs", "w_scalar", "w_gate", "__weakref__")
 
+    # The handle lives in a module's pack cache, i.e. inside the module: copy.deepcopy(model) / torch.save(model) walk over it.  A copy
+    # of the module starts without one (its first _pack_wg makes its own); weak references are neither copyable nor picklable.
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
 
 _WG_PACK_USERS = weakref.WeakSet()
 BATCH_WG_PACKS = os.environ.get("GCPNET_BATCH_WG_PACKS", "1") != "0"

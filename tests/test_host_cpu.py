@@ -228,3 +228,21 @@ def test_compat_aliases_resolve_reference_dotted_names():
         "assert ScalarVector is gcpnet_amd.ScalarVector and localize is gcpnet_amd.localize; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_pack_cache_handles_survive_deepcopy_and_pickle():
+    """The batched-pack handle (ops._WgPackUser) sits in a module's pack cache and holds weak references: a deep copy or a pickle of the
+    module must not trip over it -- the copy starts without a handle."""
+    import copy
+    import pickle
+
+    from gcpnet_amd import ops
+
+    u = ops._WgPackUser()
+    cache = {"wg_user": u, "wg_key": (0, None)}
+    u.cache = cache
+    u.w_scalar, u.w_gate = None, None
+    c2 = copy.deepcopy(cache)
+    assert c2["wg_user"] is None and c2["wg_key"] == (0, None)
+    c3 = pickle.loads(pickle.dumps({"wg_user": u, "wg_key": (0, None)}))
+    assert c3["wg_user"] is None

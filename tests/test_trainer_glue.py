@@ -315,3 +315,36 @@ def test_forward_without_backward_frees_saved_activations(G):
     gc.collect()
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() <= base + (1 << 20), (torch.cuda.memory_allocated() - base)
+
+
+def test_deepcopy_of_a_model_after_a_step_runs_and_agrees(G):
+    """copy.deepcopy(model) after the pack caches have been filled (EMA / SWA copies, checkpointing the whole module): the copy carries
+    no stale packed image and no handle of the original (ops._WgPackUser), and its step gives the same loss and gradients."""
+    import copy
+
+    from gcpnet_amd.synthetic import model_batch
+
+    torch.manual_seed(6)
+    batch, model_cfg, _, _ = model_batch("c1", seed=7)
+    model = G.GCPNetNMS(model_cfg=model_cfg, module_cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg()).cuda().eval()
+    dev = {k: v.cuda() for k, v in batch.items()}
+
+    def run(m):
+        for p in m.parameters():
+            p.grad = None
+        loss, _, _ = m.step(G.Batch(**dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+    l0, g0 = run(model)
+    twin = copy.deepcopy(model)
+    with torch.no_grad():  # (move the original's weights on: the twin must not see the original's images or weights)
+        for p in model.parameters():
+            p.mul_(1.5)
+    l1, g1 = run(twin)
+    assert torch.equal(l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    l2, _ = run(model)
+    assert not torch.equal(l2, l0)
