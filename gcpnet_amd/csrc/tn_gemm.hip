@@ -16,6 +16,7 @@
 // Per-split partial sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
 #include <mutex>
 #include <cstdlib>
+#include <cstdio>
 
 #include "common.h"
 #include "gcp_bf16x3.h"
@@ -890,6 +891,262 @@ __global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
     TN_T_STORE(part, wave, lane);
 }
 
+// ---- pipelined form (round 5): rows HBM -> registers -> ONE split per operand element -> planes in LDS -> products ---------------
+// What bounds a weight-gradient GEMM is its operand stream, not the matrix pipe: an output block of 128 x 160 needs 213 bf16 FLOP
+// per operand byte with all six products of the three-term form, i.e. 11.7 TB/s at the bf16 peak -- twice what HBM delivers; a
+// 256 x 288 block is balanced.  So the kernel to build keeps the operand rows streaming and hides everything else under them.
+// The forms above do neither: every wave re-splits every B fragment it reads (8.8 VALU instructions per MFMA: the products phase
+// runs at 2.4 x its MFMA time) and every chunk is waited for with vmcnt(0) one chunk after it was requested.  Here
+//   * a thread requests one FRAGMENT-LANE per pass -- eight rows of one column, the k-octet a lane of v_mfma_f32_32x32x16_bf16
+//     holds -- straight into registers, two chunks ahead of its use; hipcc counts these waits itself, exactly, because no load
+//     sits behind a branch (tp_load) -- there is no staging buffer, no DMA and no hand-counted vmcnt;
+//   * the lane is split into its three bf16 terms ONCE per workgroup and stored as three 16-byte entries of operand-ordered
+//     planes (double buffered), which every wave reads with ds_read_b128: one barrier per 16-row chunk;
+//   * a wave owns MT m-tiles x the n-tiles of its group and walks them UT at a time, the next B fragments requested from LDS
+//     before the products of the current ones: >= 2 independent accumulators per product round, no dependent MFMA chain;
+//   * passes (split + request) and product groups alternate inside a chunk, so that the matrix pipe is fed while the vector
+//     ALU splits.
+// Two instantiations: 4 waves x (1 x 5) tiles = 128 x 160, 54 KB of LDS, two workgroups per CU; and 4 waves x (2 x 9) tiles =
+// 256 x 288 with one wave per SIMD (~400 registers), 102 KB: the (256,32) message GCPs' 256 x 277 gradients read every operand
+// row ONCE.  Row gathers and activations on load stay with the kernels above (stream_ok).
+constexpr int TS_RK = 16;
+
+struct TpLane {
+    const float* base;  // column of this lane in row 0 of its segment (tile-blocked: its piece + element); a valid address for every kind
+    int ld;             // floats per row; tile-blocked: padded width
+    int kind;           // 0 = data, 1 = the ones column, 2 = padding; | 4 = tile-blocked segment
+};
+
+__device__ __forceinline__ TpLane tp_lane(const gcp_operand_t& op, int c) {  // c: column of the operand ([segments | ones | padding])
+    TpLane L;
+    L.base = op.ptr[0]; L.ld = 0; L.kind = 2;
+    int cbase = 0;
+    for (int sg = 0; sg < op.n; ++sg) {
+        if (c >= cbase && c < cbase + op.dim[sg]) {
+            const int k = c - cbase;
+            L.base = op.ptr[sg] + (op.tb[sg] ? tb_col_offset(k & ~3) + (k & 3) : k);
+            L.ld = op.tb[sg] ? gcp_round_up(op.dim[sg], 32) : op.ld[sg];
+            L.kind = op.tb[sg] ? 4 : 0;
+        }
+        cbase += op.dim[sg];
+    }
+    if (op.ones && c == cbase) L.kind = 1;
+    return L;
+}
+__device__ __forceinline__ int64_t tp_row_offset(const TpLane& L, int64_t r) { return (L.kind & 4) ? tb_row_offset(r, L.ld) : r * L.ld; }
+
+template <int NW, int MT, int NT, int UT>
+struct TpCfg {
+    static constexpr int NTH = 64 * NW, AT = MT * NW, BM = 32 * AT, BN = 32 * NT;
+    static constexpr int PLANES = (AT + NT) * 3 * 256;  // floats per buffer: [fragment][term][64 lanes][4 dwords]
+    static constexpr int LDS_FLOATS = 2 * PLANES;
+    static constexpr int APASS = MT, BPASS = (NT + NW - 1) / NW, NPASS = APASS + BPASS;  // fragment-lanes per thread and chunk
+    static constexpr int NG = (NT + UT - 1) / UT;                                          // product groups per chunk
+};
+
+template <int NW, int MT, int NT, int UT>
+__global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
+    using C = TpCfg<NW, MT, NT, UT>;
+    constexpr int AT = C::AT, BM = C::BM, BN = C::BN, NPASS = C::NPASS, APASS = C::APASS, NG = C::NG;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    int pi = 0;
+    while (pi + 1 < a.n && (int)blockIdx.x >= a.block_start[pi + 1]) ++pi;
+    const gcp_tn_problem_t& P = a.p[pi];
+    const int M = a.M[pi], N = a.N[pi];
+    int b = blockIdx.x - a.block_start[pi];
+    const int split = b % P.splits; b /= P.splits;
+    const int nbi = b % a.nb[pi], mbi = b / a.nb[pi];
+    const int m0 = mbi * BM, n0 = nbi * BN;
+    const int mtiles = gcp_cdiv(min(BM, M - m0), 32), ntiles = gcp_cdiv(min(BN, N - n0), 32);
+    // rows: the FULL 16-row chunks dealt round-robin to the splits (the workgroups of a launch read one contiguous window of the
+    // operands); the ragged last chunk, if any, goes to one split after its loop.  splits is even (gcpnet_tn_splits), so a split's
+    // chunks keep their position inside the 32-row tiles of a tile-blocked segment and every lane advances by a constant.
+    const int full_chunks = P.rows / TS_RK;
+    const int nchunks = full_chunks > split ? gcp_cdiv(full_chunks - split, P.splits) : 0;
+    const bool ragged = (P.rows % TS_RK) != 0 && (full_chunks % P.splits) == split;
+    // tiles of this wave: m-groups of MT tiles, mt_c waves along m, G groups along n (n-tiles g, g + G, ...)
+    const int mgroups = gcp_cdiv(mtiles, MT);
+    const int mt_c = mgroups > NW / 2 ? NW : (mgroups > NW / 4 ? NW / 2 : 1);
+    const int G = NW / mt_c, mg = wave % mt_c, g = wave / mt_c;
+    const int my_n = __builtin_amdgcn_readfirstlane((mg < mgroups && g < ntiles) ? (ntiles - g + G - 1) / G : 0);
+    gcp_u32x4* const planes = reinterpret_cast<gcp_u32x4*>(lds);
+    constexpr int PL4 = C::PLANES / 4;  // 16-byte entries per buffer
+
+    // this thread's fragment-lanes: passes 0 .. MT - 1 = A tiles wave + NW j, the others B tiles wave + NW j (an absent tile re-reads
+    // a valid one and is dropped)
+    bool on[NPASS];
+    int frag[NPASS];
+    TpLane L[NPASS];
+    const float* ptr[NPASS];  // rows of the chunk the next request of the pass goes to
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const bool isA = ps < APASS;
+        const int t = wave + NW * (isA ? ps : ps - APASS);
+        on[ps] = t < (isA ? mtiles : ntiles);
+        frag[ps] = isA ? t : AT + t;
+        L[ps] = isA ? tp_lane(P.a, m0 + 32 * min(t, mtiles - 1) + col) : tp_lane(P.b, n0 + 32 * min(t, ntiles - 1) + col);
+        ptr[ps] = L[ps].base + tp_row_offset(L[ps], (int64_t)min(split, max(full_chunks - 1, 0)) * TS_RK + 8 * hi);
+    }
+    float x[NPASS][8];
+    int issued = 0;  // chunks requested so far (all passes of a chunk advance together; the pointer stops at the split's last chunk)
+    auto load_pass = [&](int ps) {
+        const int step = (L[ps].kind & 4) ? 4 : L[ps].ld;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[ps][q] = ptr[ps][q * step];
+    };
+    auto advance = [&]() {  // after the last pass of a chunk's requests
+        ++issued;
+        if (issued < nchunks) {  // (wave-uniform; pointer arithmetic only)
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) ptr[ps] += (int64_t)(P.splits * TS_RK) * L[ps].ld;  // (tile-blocked: splits / 2 tiles of 32 ld floats)
+        }
+    };
+    auto split_pass = [&](int ps, int buf, int nvalid) {  // nvalid: valid rows of this lane's eight (8 inside the loop)
+        if (!on[ps]) return;  // (wave-uniform)
+        const int kind = L[ps].kind & 3;
+        if (__builtin_amdgcn_ballot_w64(kind != 0)) {  // (wave-uniform) a tile with the ones column or padding in it
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[ps][q] = kind == 0 ? x[ps][q] : (kind == 1 ? 1.f : 0.f);
+        }
+        if (nvalid < 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[ps][q] = q < nvalid ? x[ps][q] : 0.f;
+        }
+        gcp_u32x4 th, tm, tl3;
+        gcp_bf16x3_split8(x[ps], th, tm, tl3);
+        gcp_u32x4* dst = planes + buf * PL4 + (frag[ps] * 3) * 64 + lane;
+        dst[0] = th; dst[64] = tm; dst[128] = tl3;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // the six kept products, small terms first
+    auto read_b = [&](const gcp_u32x4* pl, int i0, gcp_u32x4 (&bt)[UT][3]) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const gcp_u32x4* pb = pl + ((AT + min(g + G * min(i0 + u, NT - 1), ntiles - 1)) * 3) * 64 + lane;
+            bt[u][0] = pb[0]; bt[u][1] = pb[64]; bt[u][2] = pb[128];
+        }
+    };
+    auto read_a = [&](const gcp_u32x4* pl, gcp_u32x4 (&a3)[MT][3]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const gcp_u32x4* pa = pl + (min(mg * MT + m, mtiles - 1) * 3) * 64 + lane;
+            a3[m][0] = pa[0]; a3[m][1] = pa[64]; a3[m][2] = pa[128];
+        }
+    };
+    auto mul_group = [&](int k, const gcp_u32x4 (&a3)[MT][3], const gcp_u32x4 (&bt)[UT][3]) {
+        if (k * UT < my_n) {  // (wave-uniform)
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int u = 0; u < UT; ++u)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        if (k * UT + u < NT) acc[m][k * UT + u] = gcp_mfma_bf16(a3[m][TA[p]], bt[u][TB[p]], acc[m][k * UT + u]);  // (tiles past my_n: computed on a valid fragment, never stored)
+        }
+    };
+
+    // prologue: chunk 0 requested, split into planes[0]; chunk 1 requested
+    if (nchunks > 0) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) load_pass(ps);
+        advance();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            split_pass(ps, 0, 8);
+            load_pass(ps);
+        }
+        advance();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TN_T_DECL;
+    for (int c = 0; c < nchunks; ++c) {
+        const gcp_u32x4* pl = planes + (c & 1) * PL4;
+        gcp_u32x4 a3[MT][3], bt[2][UT][3];
+        read_a(pl, a3);
+        read_b(pl, 0, bt[0]);
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            // passes whose turn it is: pass ps runs ahead of product group (ps NG) / NPASS
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                if ((ps * NG) / NPASS == k) {
+                    TN_T_MARK(3);
+                    if (c + 1 < nchunks) split_pass(ps, (c + 1) & 1, 8);
+                    TN_T_MARK(0);
+                    load_pass(ps);  // chunk c + 2 (unconditional -- past the end: the split's last chunk once more, dropped)
+                    if (ps == NPASS - 1) advance();
+                    TN_T_MARK(1);
+                }
+            }
+            constexpr bool DBUF = NT * MT <= 5;  // two sets of B fragments only where the registers are there (the wide form holds 144 accumulators)
+            if (DBUF) {
+                if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[(k + 1) & 1]);
+                mul_group(k, a3, bt[k & 1]);
+            } else {
+                mul_group(k, a3, bt[0]);
+                if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[0]);  // (behind the group's last MFMA issue; the SIMD's other wave covers the LDS latency)
+            }
+        }
+        TN_T_MARK(3);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes[(c + 1) & 1] complete; everyone is done with planes[c & 1]
+        TN_T_MARK(2);
+    }
+    if (ragged) {  // (workgroup-uniform) the operand's last, partial chunk: requested row by row with the row index clamped, not pipelined
+        const int r0 = full_chunks * TS_RK + 8 * hi, r_last = P.rows - 1;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[ps][q] = L[ps].base[tp_row_offset(L[ps], min(r0 + q, r_last))];
+            split_pass(ps, 0, P.rows - r0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        gcp_u32x4 a3[MT][3], bt[UT][3];
+        read_a(planes, a3);
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            read_b(planes, k * UT, bt);
+            mul_group(k, a3, bt);
+        }
+    }
+    float* part = P.partial + (int64_t)split * M * N;
+    if (my_n > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (mg * MT + m < mtiles) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (i < my_n) {
+                        const int n = n0 + 32 * (g + G * i) + col;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int mm = m0 + 32 * (mg * MT + m) + gcp_crow(r, hi);
+                            if (mm < M && n < N) part[(int64_t)mm * N + n] = acc[m][i][r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    TN_T_STORE(part, wave, lane);
+}
+
+inline bool stream_ok(const gcp_operand_t& o) {
+    if (o.act) return false;
+    for (int k = 0; k < o.n; ++k)
+        if (o.idx[k]) return false;
+    return true;
+}
+
 inline bool big_ok(const gcp_operand_t& o) {
     if (o.act) return false;
     for (int k = 0; k < o.n; ++k)
@@ -973,7 +1230,8 @@ inline bool dma_ok(const gcp_operand_t& o) {
 
 extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
     (void)M; (void)N;
-    return rows <= 0 ? 1 : gcp_cdiv(rows, tn_rows_per_split_host(rows));
+    // (even: a split's 16-row chunks then keep their position inside the 32-row tiles of a tile-blocked operand, tn_pipe_kernel)
+    return rows <= 0 ? 2 : gcp_round_up(gcp_cdiv(rows, tn_rows_per_split_host(rows)), 2);
 }
 
 extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream) {
@@ -1016,6 +1274,75 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     }
     a.block_start[n_problems] = blocks;
     hipStream_t st = (hipStream_t)stream;
+    static const bool trace_env = getenv("GCPNET_TN_TRACE") != nullptr;  // (one line per problem on stderr: what a step asks of this call)
+    if (trace_env)
+        for (int i = 0; i < n_problems; ++i) {
+            const gcp_tn_problem_t& P = problems[i];
+            bool gather = !(stream_ok(P.a) && stream_ok(P.b));
+            fprintf(stderr, "tn_gemm[%d/%d] rows %d M %d N %d splits %d act %d/%d ones %d/%d gather %d dma %d tb %d%d%d%d|%d%d%d%d\n", i, n_problems, P.rows, a.M[i], a.N[i],
+                    P.splits, P.a.act, P.b.act, P.a.ones, P.b.ones, (int)gather, (int)(dma_ok(P.a) && dma_ok(P.b)), P.a.tb[0], P.a.tb[1], P.a.tb[2], P.a.tb[3],
+                    P.b.tb[0], P.b.tb[1], P.b.tb[2], P.b.tb[3]);
+        }
+    const TnArgs all = a;  // (the reduction at the end runs over every problem, whichever kernel produced its partial sums)
+    const int n_all = n_problems, max_mn_all = max_mn;
+    // the pipelined kernels take every problem without a row gather / activation on load whose columns they can address
+    // (GCPNET_TN_PIPE=0: the earlier kernels, for A/B runs)
+    static const bool pipe_env = !(getenv("GCPNET_TN_PIPE") && getenv("GCPNET_TN_PIPE")[0] == '0');
+    const bool x3_ = getenv("GCPNET_TN_FP32") == nullptr;
+    if (pipe_env && x3_) {
+        using Narrow = TpCfg<4, 1, 5, 2>;
+        using Wide = TpCfg<8, 1, 9, 1>;
+        TnArgs narrow, wide, rest;
+        narrow.n = wide.n = rest.n = 0;
+        narrow.cyclic = wide.cyclic = 1; rest.cyclic = a.cyclic;
+        narrow.debug = wide.debug = rest.debug = a.debug;
+        int nblocks = 0, wblocks = 0, rblocks_ = 0, rest_mn = 0;
+        bool rest_dma = true;
+        for (int i = 0; i < n_problems; ++i) {
+            const gcp_tn_problem_t& P = problems[i];
+            const bool ok = P.rows > 0 && (P.splits & 1) == 0 && stream_ok(P.a) && stream_ok(P.b);
+            const bool is_wide = ok && a.M[i] > Narrow::BM;  // (M <= 128 with a wide N: column blocks of the narrow kernel, the thin A re-read)
+            TnArgs& d = !ok ? rest : (is_wide ? wide : narrow);
+            const int k = d.n++;
+            d.p[k] = a.p[i]; d.M[k] = a.M[i]; d.N[k] = a.N[i];
+            if (!ok) {
+                d.mb[k] = a.mb[i]; d.nb[k] = a.nb[i];
+                d.block_start[k] = rblocks_; rblocks_ += a.mb[i] * a.nb[i] * P.splits;
+                rest_mn = max(rest_mn, a.M[i] * a.N[i]);
+                rest_dma = rest_dma && dma_ok(P.a) && dma_ok(P.b) && P.rows > 0;
+            } else if (is_wide) {
+                d.mb[k] = gcp_cdiv(a.M[i], Wide::BM); d.nb[k] = gcp_cdiv(a.N[i], Wide::BN);
+                d.block_start[k] = wblocks; wblocks += d.mb[k] * d.nb[k] * P.splits;
+            } else {
+                d.mb[k] = 1; d.nb[k] = gcp_cdiv(a.N[i], Narrow::BN);
+                d.block_start[k] = nblocks; nblocks += d.nb[k] * P.splits;
+            }
+        }
+        narrow.block_start[narrow.n] = nblocks; wide.block_start[wide.n] = wblocks; rest.block_start[rest.n] = rblocks_;
+        constexpr size_t n_lds = (size_t)Narrow::LDS_FLOATS * sizeof(float), w_lds = (size_t)Wide::LDS_FLOATS * sizeof(float);
+        static bool tp_configured = false;
+        if (!tp_configured) {
+            hipError_t err = hipFuncSetAttribute((const void*)tn_pipe_kernel<4, 1, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_lds);
+            if (err == hipSuccess)
+                err = hipFuncSetAttribute((const void*)tn_pipe_kernel<8, 1, 9, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_lds);
+            if (err != hipSuccess) return (int)err;
+            tp_configured = true;
+        }
+        if (wide.n) {
+            hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1>), dim3(wblocks), dim3(512), w_lds, st, wide);
+            GCP_HIP_CHECK_LAUNCH();
+        }
+        if (narrow.n) {
+            hipLaunchKernelGGL((tn_pipe_kernel<4, 1, 5, 2>), dim3(nblocks), dim3(256), n_lds, st, narrow);
+            GCP_HIP_CHECK_LAUNCH();
+        }
+        if (rest.n == 0) {
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(min(1024, gcp_cdiv(max_mn_all, 64)), n_all), dim3(256), 0, st, all);
+            GCP_HIP_CHECK_LAUNCH();
+            return 0;
+        }
+        a = rest; blocks = rblocks_; max_mn = rest_mn; n_problems = rest.n; dma = rest_dma;
+    }
     // problems whose output needs more than one 128 x 160 block (and fits 256 x 320) go through the big-block kernel, one
     // workgroup per split; the others keep the launch below
     // (the big-block kernel is opt-in since the bf16 form: alone it is the faster one on 256 x 284 outputs, 0.98 against 1.2 ms, but
@@ -1056,7 +1383,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
             GCP_HIP_CHECK_LAUNCH();
             hipLaunchKernelGGL(tn_reduce_kernel, dim3(min(1024, gcp_cdiv(big_mn, 64)), big.n), dim3(256), 0, st, big);
             GCP_HIP_CHECK_LAUNCH();
-            if (rest.n == 0) return 0;
+            if (rest.n == 0 && n_all == big.n) return 0;
             a = rest;
             blocks = rblocks_;
             max_mn = rest_mn;
@@ -1119,8 +1446,9 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         hipLaunchKernelGGL(tn_gemm_kernel, dim3(blocks), dim3(256), 0, st, a);
     }
     GCP_HIP_CHECK_LAUNCH();
-    const int rblocks = min(1024, gcp_cdiv(max_mn, 64));
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(rblocks, n_problems), dim3(256), 0, st, a);
+    (void)max_mn; (void)n_problems;
+    const int rblocks = min(1024, gcp_cdiv(max_mn_all, 64));
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(rblocks, n_all), dim3(256), 0, st, all);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }
