@@ -17,6 +17,7 @@
 #include <mutex>
 #include <cstdlib>
 #include <cstdio>
+#include <type_traits>
 
 #include "common.h"
 #include "gcp_bf16x3.h"
@@ -69,6 +70,8 @@ struct TnArgs {
     int block_start[GCP_TN_MAX_PROBLEMS + 1];
     int debug;   // measurement knob GCPNET_TN_DEBUG: bit 0 = no products, bit 1 = no DMA after the first chunk (results are then wrong)
     int cyclic;  // 32-row chunks dealt round-robin to the splits (chunk c of split s = chunk s + c * splits of the operand)
+    unsigned long long* stamps;  // profiling hook (gcpnet_debug_set_phase_timing): per workgroup of the pipelined kernels start / end time, HW_ID, XCC_ID
+    long long stamp_cap;
 };
 
 __host__ __device__ inline int operand_width(const gcp_operand_t& o) {
@@ -968,11 +971,17 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
     const bool ragged = (P.rows % TS_RK) != 0 && (full_chunks % P.splits) == split;
     // tiles of this wave: m-groups of MT tiles, mt_c waves along m, G groups along n (n-tiles g, g + G, ...)
     const int mgroups = gcp_cdiv(mtiles, MT);
-    const int mt_c = mgroups > NW / 2 ? NW : (mgroups > NW / 4 ? NW / 2 : 1);
+    const int mt_c = mgroups > 4 ? 8 : (mgroups > 2 ? 4 : (mgroups > 1 ? 2 : 1));  // smallest power of two >= mgroups (<= NW)
     const int G = NW / mt_c, mg = wave % mt_c, g = wave / mt_c;
     const int my_n = __builtin_amdgcn_readfirstlane((mg < mgroups && g < ntiles) ? (ntiles - g + G - 1) / G : 0);
     gcp_u32x4* const planes = reinterpret_cast<gcp_u32x4*>(lds);
     constexpr int PL4 = C::PLANES / 4;  // 16-byte entries per buffer
+    if (a.stamps && tid == 0 && (long long)blockIdx.x < a.stamp_cap) {
+        unsigned long long* sp = a.stamps + (long long)blockIdx.x * GCP_MAX_STAMPS;
+        sp[0] = __builtin_amdgcn_s_memtime();
+        sp[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+        sp[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
 
     // this thread's fragment-lanes: passes 0 .. MT - 1 = A tiles wave + NW j, the others B tiles wave + NW j (an absent tile re-reads
     // a valid one and is dropped)
@@ -1069,38 +1078,46 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TN_T_DECL;
-    for (int c = 0; c < nchunks; ++c) {
-        const gcp_u32x4* pl = planes + (c & 1) * PL4;
-        gcp_u32x4 a3[MT][3], bt[2][UT][3];
-        read_a(pl, a3);
-        read_b(pl, 0, bt[0]);
+    // SH: the passes of the second half of an eight-wave workgroup run SH product groups later than those of the first half, so
+    // that of the two waves of a SIMD one splits while the other multiplies (they meet at the same barrier per chunk)
+    auto main_loop = [&](auto shift_c) {
+        constexpr int SH = decltype(shift_c)::value;
+        for (int c = 0; c < nchunks; ++c) {
+            const gcp_u32x4* pl = planes + (c & 1) * PL4;
+            gcp_u32x4 a3[MT][3], bt[2][UT][3];
+            read_a(pl, a3);
+            read_b(pl, 0, bt[0]);
 #pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            // passes whose turn it is: pass ps runs ahead of product group (ps NG) / NPASS
+            for (int k = 0; k < NG; ++k) {
 #pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                if ((ps * NG) / NPASS == k) {
-                    TN_T_MARK(3);
-                    if (c + 1 < nchunks) split_pass(ps, (c + 1) & 1, 8);
-                    TN_T_MARK(0);
-                    load_pass(ps);  // chunk c + 2 (unconditional -- past the end: the split's last chunk once more, dropped)
-                    if (ps == NPASS - 1) advance();
-                    TN_T_MARK(1);
+                for (int ps = 0; ps < NPASS; ++ps) {  // passes whose turn it is: pass ps runs ahead of product group (ps NG) / NPASS + SH
+                    if ((ps * NG) / NPASS + SH == k) {
+                        TN_T_MARK(3);
+                        if (c + 1 < nchunks) split_pass(ps, (c + 1) & 1, 8);
+                        TN_T_MARK(0);
+                        load_pass(ps);  // chunk c + 2 (unconditional -- past the end: the split's last chunk once more, dropped)
+                        if (ps == NPASS - 1) advance();
+                        TN_T_MARK(1);
+                    }
+                }
+                constexpr bool DBUF = NT * MT <= 5;  // two sets of B fragments only where the registers are there (the wide form holds 144 accumulators)
+                if (DBUF) {
+                    if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[(k + 1) & 1]);
+                    mul_group(k, a3, bt[k & 1]);
+                } else {
+                    mul_group(k, a3, bt[0]);
+                    if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[0]);  // (behind the group's last MFMA issue; the SIMD's other wave covers the LDS latency)
                 }
             }
-            constexpr bool DBUF = NT * MT <= 5;  // two sets of B fragments only where the registers are there (the wide form holds 144 accumulators)
-            if (DBUF) {
-                if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[(k + 1) & 1]);
-                mul_group(k, a3, bt[k & 1]);
-            } else {
-                mul_group(k, a3, bt[0]);
-                if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[0]);  // (behind the group's last MFMA issue; the SIMD's other wave covers the LDS latency)
-            }
+            TN_T_MARK(3);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes[(c + 1) & 1] complete; everyone is done with planes[c & 1]
+            TN_T_MARK(2);
         }
-        TN_T_MARK(3);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes[(c + 1) & 1] complete; everyone is done with planes[c & 1]
-        TN_T_MARK(2);
-    }
+    };
+    // (measured: the staggered instantiation needs 27 more registers than the 256 of two waves per SIMD -- spills inside the loop; off)
+    constexpr int STAGGER = 0;
+    if (STAGGER > 0 && wave >= NW / 2) main_loop(std::integral_constant<int, STAGGER>{});
+    else main_loop(std::integral_constant<int, 0>{});
     if (ragged) {  // (workgroup-uniform) the operand's last, partial chunk: requested row by row with the row index clamped, not pipelined
         const int r0 = full_chunks * TS_RK + 8 * hi, r_last = P.rows - 1;
 #pragma unroll
@@ -1138,6 +1155,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
         }
     }
     TN_T_STORE(part, wave, lane);
+    if (a.stamps && tid == 0 && (long long)blockIdx.x < a.stamp_cap) a.stamps[(long long)blockIdx.x * GCP_MAX_STAMPS + 1] = __builtin_amdgcn_s_memtime();
 }
 
 inline bool stream_ok(const gcp_operand_t& o) {
@@ -1228,6 +1246,14 @@ inline bool dma_ok(const gcp_operand_t& o) {
 
 }  // namespace
 
+// resident workgroups per CU of the two pipelined kernels as the runtime sees them (tools/tn_occupancy.py; not part of the ABI header)
+extern "C" int gcpnet_debug_tn_occupancy(int wide) {
+    int n = -1;
+    const hipError_t err = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tn_pipe_kernel<8, 1, 9, 1>, 512, TpCfg<8, 1, 9, 1>::LDS_FLOATS * sizeof(float))
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tn_pipe_kernel<4, 1, 5, 2>, 256, TpCfg<4, 1, 5, 2>::LDS_FLOATS * sizeof(float));
+    return err == hipSuccess ? n : -(int)err;
+}
+
 extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
     (void)M; (void)N;
     // (even: a split's 16-row chunks then keep their position inside the 32-row tiles of a tile-blocked operand, tn_pipe_kernel)
@@ -1239,6 +1265,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     TnArgs a;
     a.n = n_problems;
     a.debug = 0;
+    a.stamps = g_gcp_phase_buf; a.stamp_cap = g_gcp_phase_cap;
 #ifdef GCP_DEBUG_KNOBS
     // Measurement knobs that CHANGE RESULTS exist only in a -DGCP_DEBUG_KNOBS build (never shipped; gcpnet_debug_knobs_compiled()
     // reports it and bench.py refuses such a library).  GCPNET_DEBUG_SKIP_TN: no launch, the gradients stay unwritten ("what would
@@ -1296,6 +1323,8 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         narrow.n = wide.n = rest.n = 0;
         narrow.cyclic = wide.cyclic = 1; rest.cyclic = a.cyclic;
         narrow.debug = wide.debug = rest.debug = a.debug;
+        narrow.stamps = wide.stamps = rest.stamps = a.stamps;
+        narrow.stamp_cap = wide.stamp_cap = rest.stamp_cap = a.stamp_cap;
         int nblocks = 0, wblocks = 0, rblocks_ = 0, rest_mn = 0;
         bool rest_dma = true;
         for (int i = 0; i < n_problems; ++i) {

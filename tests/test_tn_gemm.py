@@ -19,6 +19,11 @@ pytestmark = pytest.mark.gpu
     (3000, 96, 100),      # three m-tiles (the fourth wave idles), last n-tile four columns wide
     (2000, 128, 16),      # one n-tile
     (2000, 160, 128),     # M over one block: two blocks along m in the 128 x 160 kernel when the big-block kernel is off
+    (97, 300, 53),        # second m-block of the 256 x 288 kernel with two m-tiles; six full 16-row chunks + a one-row chunk; N not a multiple of 4
+    (1500, 320, 100),     # m-blocks of eight and two m-tiles
+    (15, 64, 40),         # fewer rows than one chunk
+    (3001, 132, 600),     # M one column over a block (wide kernel, second block one m-tile), three column blocks
+    (2048, 32, 257),      # the gate problem of the (256,32) blocks: narrow kernel, two column blocks
 ])
 @pytest.mark.parametrize("form", ["default", "planes", "planes_off", "big_block", "eight_waves", "fp32", "blocked_rows"])
 def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
