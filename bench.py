@@ -619,8 +619,9 @@ def main():
                     dist.destroy_process_group()
             except Exception:  # noqa: BLE001
                 pass
-            world_job, world = world, 1  # this process now behaves like a single-GPU run; rank 0 scales its own rate
-            args.shard = "batch"
+            if args.shard == "graph":  # a one-graph run cannot degrade to replicas: that would be a different measurement
+                raise SystemExit(f"[bench rank {rank}] --shard graph needs the collective layer and it is unusable: {exc}")
+            world_job, world = world, 1  # this process now behaves like a single-GPU run and REPORTS itself as one (n_gpus = 1)
         else:
             world_job = world
     else:
@@ -653,16 +654,18 @@ def main():
                           "warmup": args.warmup, "config": args.config}))
     elif rank == 0:
         value = wl["total_edges"] * wl["n_layers"] * args.steps / elapsed
-        if rccl_info["fallback"]:  # (replicas: every rank runs this same step on its own GPU; no barrier was possible)
-            value *= world_job
         out = {
-            "metric": "processed edges/sec (GCP fwd+bwd)", "value": value, "unit": "edges/s", "n_gpus": world_job,
+            # (process group unusable: the ranks ran unsynchronised replicas -- the line is this rank's own single-GPU measurement;
+            # what N such replicas would add up to is an extrapolation and lives in rccl.unsynchronised_replica_extrapolation)
+            "metric": "processed edges/sec (GCP fwd+bwd)", "value": value, "unit": "edges/s",
+            "n_gpus": 1 if rccl_info["fallback"] else world_job,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_median": median_ms,
             "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # every switch of this package that the environment sets (the shipped library honours none that changes results)
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("GCPNET_", "BENCH_"))},
-            "rccl": rccl_info,
+            "rccl": dict(rccl_info, **({"requested_gpus": world_job, "unsynchronised_replica_extrapolation": value * world_job}
+                                       if rccl_info["fallback"] else {})),
             "config": {
                 "workload": f"{args.config}: {wl['label']}", "n_edges": wl["n_edges"], "layers": wl["n_layers"],
                 "launch": "hipGraph replay of the captured step" if args.hip_graph else "eager launches",

@@ -123,7 +123,14 @@ __global__ __launch_bounds__(128) void radius_graph_kernel(int N, const float* _
                     if (!FIRST && q == p) continue;
                     const double ex = xs[3 * q] - px, ey = xs[3 * q + 1] - py, ez = xs[3 * q + 2] - pz;
                     double d2 = ex * ex + ey * ey + ez * ez;
-                    if (FIRST ? !(d2 < r2) : d2 > r2) continue;
+                    if (FIRST) {
+                        // torch_cluster 1.6.0's radius kernel decides in the coordinates' own precision: dist accumulated over x, y, z
+                        // in float (`dist += d * d`, contracted to fused multiply-adds by its compiler) and compared with (float)(r * r)
+                        // -- a pair within a float rounding error of the cutoff must fall on the same side here
+                        const float fx = xs[3 * q] - xs[3 * p], fy = xs[3 * q + 1] - xs[3 * p + 1], fz = xs[3 * q + 2] - xs[3 * p + 2];
+                        const float dist = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
+                        if (!(dist < (float)r2)) continue;
+                    } else if (d2 > r2) continue;
                     const int id = order[q];
                     if (FIRST) d2 = (double)id;  // the sort key of this mode
                     // insertion into the ascending list (ties: lower node id first), keeping at most K

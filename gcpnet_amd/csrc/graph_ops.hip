@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int rows, int sdim, 
 }
 
 #define LN_MAX_PER_LANE 16  // sdim <= 1024
-static inline int ln_bwd_blocks(int rows) { return min(gcp_cdiv(rows, 8), 512); }
+// (a wave walks its rows one after the other, each a chain of dependent round trips -- statistics, row, wave sums, store: with 512
+// blocks the 10 000 node rows of configs[1] were five such chains per wave, 51 us for 7 MB; one or two rows per wave up to 4096 blocks)
+static inline int ln_bwd_blocks(int rows) { return min(gcp_cdiv(rows, 4), 4096); }
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, int vdim,
                                                             const float* __restrict__ s_sum,
                                                             const float* __restrict__ v_sum,

@@ -23,6 +23,21 @@ class FusedAdam(torch.optim.Optimizer):
         into a hipGraph (gcpnet_amd.graphs.GraphedStep(step_fn, optimizer=...)).  lr / betas / eps / weight_decay are frozen into
         a capture; every parameter of a group must take part from the first step on."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable))
+        # capturable groups: the device step counter and the parameters that take part, by group index.  NOT in param_groups:
+        # torch serialises every key of a group, and a counter that came back from torch.load(map_location="cpu") would hand a
+        # host pointer to the kernel (ADVICE round 4); load_state_dict drops them and the next step rebuilds them from state["step"]
+        self._step_dev = {}
+        self._members = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_dev, self._members = {}, {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._step_dev, self._members = {}, {}
+        for g in self.param_groups:
+            g.pop("_step_dev", None)  # (pickles of the earlier layout)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -32,9 +47,9 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         lib = _lib.load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             if group.get("capturable"):
-                self._step_capturable(lib, group)
+                self._step_capturable(lib, group, gi)
                 continue
             if capturing:
                 # the step count and the bias corrections derived from it are host values passed as kernel arguments: a captured
@@ -64,18 +79,24 @@ class FusedAdam(torch.optim.Optimizer):
         ops.invalidate_packs()  # (p.data was written through a raw pointer: the packed-weight caches must not outlive it)
         return loss
 
-    def _step_capturable(self, lib, group):
+    def _step_capturable(self, lib, group, gi):
         """One update of a capturable group: the step count is read and advanced on the device."""
         ps = [p for p in group["params"] if p.grad is not None]
         if not ps:
             return
-        dev_step = group.get("_step_dev")
-        if dev_step is None:
+        # one counter per group: a parameter that skipped a step would get the bias corrections of the wrong step count
+        # (torch.optim.Adam counts per parameter), so the set that takes part is fixed by the first step
+        members = tuple(id(p) for p in ps)
+        if self._members.setdefault(gi, members) != members:
+            raise RuntimeError("FusedAdam(capturable=True): the parameters with a gradient changed between two steps of a group "
+                               "(one device step counter per group: every parameter must take part in every step)")
+        dev_step = self._step_dev.get(gi)
+        if dev_step is None or dev_step.device != ps[0].device:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("FusedAdam(capturable=True): run at least one eager step before capturing (state is created there)")
-            known = [self.state[p]["step"] for p in group["params"] if self.state.get(p)]  # (a loaded state_dict: per-parameter tensors)
-            start = int(known[0].item() if torch.is_tensor(known[0]) else known[0]) if known else 0
-            dev_step = group["_step_dev"] = torch.full((1,), start, dtype=torch.int64, device=ps[0].device)
+            known = [self.state[p]["step"] for p in ps if self.state.get(p) and "step" in self.state[p]]  # (a loaded state_dict: per-parameter values)
+            start = int(round(float(known[0].item() if torch.is_tensor(known[0]) else known[0]))) if known else 0
+            dev_step = self._step_dev[gi] = torch.full((1,), start, dtype=torch.int64, device=ps[0].device)
         items = []
         for p in ps:
             if not p.is_cuda or p.dtype != torch.float32:

@@ -858,8 +858,15 @@ def radius_graph(x: Tensor, batch: Tensor, radius: float = 4.5, max_neighbors: i
     candidates, the self loop removed afterwards."""
     xd = x.double()
     if select == "first":
-        d2 = ((xd.unsqueeze(1) - xd.unsqueeze(0)) ** 2).sum(-1)
-        ok = (batch.unsqueeze(1) == batch.unsqueeze(0)) & (d2 < radius * radius)
+        # that kernel decides in the coordinates' own precision: float differences, `dist += d * d` over x, y, z contracted to fused
+        # multiply-adds (one rounding per step: the exact product + the running sum, rounded to float -- restated through float64,
+        # which holds a float product exactly), compared with float(r * r)
+        xf = x.float()
+        df = (xf.unsqueeze(0) - xf.unsqueeze(1)).double()  # df[target, candidate] = x[candidate] - x[target], a float each
+        dist = (df[..., 0] * df[..., 0]).float().double()
+        dist = (df[..., 1] * df[..., 1] + dist).float().double()
+        dist = (df[..., 2] * df[..., 2] + dist).float()
+        ok = (batch.unsqueeze(1) == batch.unsqueeze(0)) & (dist < torch.tensor(radius * radius, dtype=torch.float64).float())
         rank = torch.cumsum(ok.long(), dim=1)  # position of every in-range node in the target's index-order walk (1-based)
         keep = ok & (rank <= max_neighbors + 1)
         keep.fill_diagonal_(False)

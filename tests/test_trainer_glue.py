@@ -348,3 +348,44 @@ def test_deepcopy_of_a_model_after_a_step_runs_and_agrees(G):
         assert torch.equal(a, b)
     l2, _ = run(model)
     assert not torch.equal(l2, l0)
+
+
+def test_capturable_adam_state_dict_round_trip_through_the_cpu(G, tmp_path):
+    """FusedAdam(capturable=True): save -> torch.load(map_location="cpu") -> load_state_dict -> step continues the run (the device step
+    counter is rebuilt on the parameter device, never read through a host pointer), and matches torch.optim.Adam doing the same."""
+    torch.manual_seed(0)
+    w0 = [torch.randn(37, 5), torch.randn(11)]
+    grads = [[torch.randn_like(w) for w in w0] for _ in range(5)]
+
+    def run(make_opt, resume):
+        ps = [torch.nn.Parameter(w.clone().cuda()) for w in w0]
+        opt = make_opt(ps)
+        for k, gs in enumerate(grads):
+            if resume and k == 3:
+                f = tmp_path / "opt.pt"
+                torch.save(opt.state_dict(), f)
+                opt = make_opt(ps)
+                opt.load_state_dict(torch.load(f, map_location="cpu"))
+            for p, g in zip(ps, gs):
+                p.grad = g.cuda()
+            opt.step()
+        torch.cuda.synchronize()
+        return [p.detach().cpu() for p in ps]
+
+    want = run(lambda ps: torch.optim.Adam(ps, lr=1e-2), False)
+    for resume in (False, True):
+        got = run(lambda ps: G.FusedAdam(ps, lr=1e-2, capturable=True), resume)
+        for a, b in zip(got, want):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert "_step_dev" not in G.FusedAdam([torch.nn.Parameter(torch.zeros(1).cuda())], capturable=True).state_dict()["param_groups"][0]
+
+
+def test_capturable_adam_refuses_a_changing_parameter_set(G):
+    ps = [torch.nn.Parameter(torch.randn(4).cuda()) for _ in range(2)]
+    opt = G.FusedAdam(ps, capturable=True)
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    ps[1].grad = None
+    with pytest.raises(RuntimeError, match="every parameter must take part"):
+        opt.step()
