@@ -47,7 +47,6 @@ constexpr int TN_BM = 128, TN_BN = 160, TN_RK = GCP_TN_RK;
 // 212.9 ms, c4 under hipGraph replay 4.37 -> 4.30 ms, configs[3] equal (64 and 96 splits: no further gain;
 // profiles/r03_tn_bf16x3.txt).
 constexpr int TN_TARGET_SPLITS = 128, TN_MIN_ROWS_PER_SPLIT = 64;
-constexpr bool TN_PLANES_DEFAULT = false;  // (tn_gemm_planes_kernel: measured before it becomes the default)
 // host side: rows per split for the target split count (GCPNET_TN_SPLITS overrides the 128: a tuning knob)
 inline int tn_rows_per_split_host(int rows) {
     static const int target = getenv("GCPNET_TN_SPLITS") && atoi(getenv("GCPNET_TN_SPLITS")) > 0 ? atoi(getenv("GCPNET_TN_SPLITS")) : TN_TARGET_SPLITS;
@@ -59,7 +58,6 @@ __host__ __device__ inline int tn_rows_per_split(int rows, int splits) {
     return gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, splits > 0 ? splits : 1), TN_RK);
 }
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
-constexpr int TN_A_SLOTS = TN_RK * TN_BM / 4 / 256, TN_B_SLOTS = TN_RK * TN_BN / 4 / 256;  // 16-byte DMA pieces per thread (4 waves)
 constexpr int TN_DMA_LDS_FLOATS = 2 * TN_RK * (TN_BM + TN_BN);
 
 struct TnArgs {
@@ -378,17 +376,17 @@ __device__ __forceinline__ void store_partial_x3(const gcp_tn_problem_t& P, cons
 }
 
 // MODE 0: fp32 MFMA, tiles dealt round-robin, four waves.  MODE 1: three-term bf16, one m-tile per wave (X3Tiles), four waves.
-// MODE 2: as 1 with EIGHT waves on the same staging buffers -- waves 0-3 take rows 0-15 of every chunk, waves 4-7 rows 16-31, and
-// the two halves are added through LDS at the end -- so that every SIMD holds two waves that cover each other's stalls (DMA issue,
-// LDS latency, barrier skew) without a second set of staging buffers and without more partial sums.
+// (Since round 5 this kernel serves the operands the pipelined form does not take -- row gathers, activations on load -- and, as
+// MODE 0, the tests that hold the bf16 forms against plain fp32 MFMA arithmetic.  The eight-wave, "planes" and big-block variants
+// of rounds 3 - 4 are gone: each was faster alone and slower inside the step; profiles/r03_tn_bf16x3.txt, r04_tn_planes_experiment.txt.)
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 512 : 256) void tn_gemm_dma_kernel(TnArgs a) {
+__global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
     constexpr bool X3 = MODE >= 1;
     constexpr int MT = 1;
-    constexpr int NTH = MODE == 2 ? 512 : 256;
+    constexpr int NTH = 256;
     constexpr int A_SLOTS = (TN_RK * TN_BM / 4 + NTH - 1) / NTH, B_SLOTS = (TN_RK * TN_BN / 4 + NTH - 1) / NTH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;  // (wave: position in the tile layout)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 31, hi = lane >> 5;
     const BlockWork w = locate(a);
     const gcp_tn_problem_t& P = a.p[w.pi];
@@ -489,12 +487,8 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : 256) void tn_gemm_dma_kernel(TnAr
         if (X3 && wave_active && !(a.debug & 1)) {
             const float* As = Abuf(cur) + col + 8 * hi * TN_BM + aoff[0];
             const float* Bs = Bbuf(cur) + col + 8 * hi * TN_BN;
-            if (MODE == 2) {
-                x3_step<MT, TN_BM, TN_BN>(As + 16 * kh * TN_BM, Bs + 16 * kh * TN_BN, boff, my_tiles, acc);
-            } else {
 #pragma unroll 1
-                for (int ks = 0; ks < TN_RK / 16; ++ks) x3_step<MT, TN_BM, TN_BN>(As + 16 * ks * TN_BM, Bs + 16 * ks * TN_BN, boff, my_tiles, acc);
-            }
+            for (int ks = 0; ks < TN_RK / 16; ++ks) x3_step<MT, TN_BM, TN_BN>(As + 16 * ks * TN_BM, Bs + 16 * ks * TN_BN, boff, my_tiles, acc);
         }
         if (!X3 && wave_active) {
             // fragments of step ss + 1 are read (unconditionally: the offsets are clamped to valid tiles) before the MFMAs of
@@ -529,369 +523,13 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : 256) void tn_gemm_dma_kernel(TnAr
             fetch_finish<B_SLOTS>(sb, vb, rb, rn, r_last, gb);
         }
     }
-    if (MODE == 2) {
-        // rows 16 .. 31 of every chunk (waves 4-7) onto rows 0 .. 15 (waves 0-3) through the staging buffers, free now: n-tiles 0-2,
-        // then 3-4 (five tiles of four waves would not fit)
-#pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            const int i0 = round ? 3 : 0, i1 = round ? 5 : 3;
-            __syncthreads();
-            if (kh == 1) {
-#pragma unroll
-                for (int i = i0; i < i1; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane] = acc[0][i][r];
-            }
-            __syncthreads();
-            if (kh == 0) {
-#pragma unroll
-                for (int i = i0; i < i1; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][i][r] += lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane];
-            }
-        }
-    }
     if (X3) {
-        if (wave_active && kh == 0) store_partial_x3(P, w, a.M[w.pi], a.N[w.pi], acc[0], xt, col, hi);
+        if (wave_active) store_partial_x3(P, w, a.M[w.pi], a.N[w.pi], acc[0], xt, col, hi);
         TN_T_MARK(3);
-        TN_T_STORE(P.partial + (int64_t)w.split * a.M[w.pi] * a.N[w.pi], wave + 4 * kh, lane);
+        TN_T_STORE(P.partial + (int64_t)w.split * a.M[w.pi] * a.N[w.pi], wave, lane);
     } else if (wave_active) {
         store_partial(P, w, a.M[w.pi], a.N[w.pi], acc[0], wave, col, hi);
     }
-}
-
-// ---- "planes" form: every operand element is split into its three bf16 terms ONCE per chunk -----------------------------------------
-// In the form above each wave splits its own fragments where it reads them: the five B fragments of a 16-row step are split by all
-// four waves of a workgroup (they share the n-tiles), 12 splits = 528 VALU instructions and 96 ds_read_b32 per wave and chunk for 60
-// MFMAs -- the products phase ran at 2.4 x its MFMA time and the pipe was 20 % busy (profiles/r03_g_pmc_summary.txt).  Here the
-// landed fp32 chunk (32 rows x [128 | 160] columns) is converted by ALL threads, one fragment-lane (eight rows of one column) per
-// thread and pass, into operand-ordered bf16 planes in LDS -- [16-row step][tile][term][64 lanes][16 bytes] -- and the products read
-// whole fragments with three ds_read_b128 each: 1152 splits per chunk instead of 3 072, no redundant LDS reads.  Eight waves: waves
-// 0-3 take rows 0-15 of every chunk, waves 4-7 rows 16-31 (one 16-row step each: 30 MFMAs), the halves are added through LDS at the
-// end.  LDS: two fp32 staging buffers (the next chunk's DMA flies under the split pass and the products) + 54 KB of planes = 126 KB,
-// one workgroup per CU.
-constexpr int TP_NTH = 512;
-constexpr int TP_F32 = TN_RK * (TN_BM + TN_BN);
-constexpr int TP_STEPS = TN_RK / 16;
-constexpr int TP_APL = TP_STEPS * (TN_BM / 32) * 3 * 256, TP_BPL = TP_STEPS * (TN_BN / 32) * 3 * 256;  // floats
-constexpr int TP_LDS_FLOATS = 2 * TP_F32 + TP_APL + TP_BPL;
-
-__global__ __launch_bounds__(TP_NTH) void tn_gemm_planes_kernel(TnArgs a) {
-    constexpr int NTH = TP_NTH;
-    constexpr int A_SLOTS = (TN_RK * TN_BM / 4 + NTH - 1) / NTH, B_SLOTS = (TN_RK * TN_BN / 4 + NTH - 1) / NTH;
-    constexpr int MTA = TN_BM / 32, NTB = TN_BN / 32;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;
-    const int col = lane & 31, hi = lane >> 5;
-    const BlockWork w = locate(a);
-    const gcp_tn_problem_t& P = a.p[w.pi];
-    X3Tiles xt = x3_tiles(w, wave);
-    xt.my_n = __builtin_amdgcn_readfirstlane(xt.my_n);
-    const bool wave_active = xt.my_n > 0;
-    auto Abuf = [&](int b) { return lds + b * TP_F32; };
-    auto Bbuf = [&](int b) { return lds + b * TP_F32 + TN_RK * TN_BM; };
-    gcp_u32x4* const Apl = reinterpret_cast<gcp_u32x4*>(lds + 2 * TP_F32);
-    gcp_u32x4* const Bpl = reinterpret_cast<gcp_u32x4*>(lds + 2 * TP_F32 + TP_APL);
-    const int mtiles = gcp_cdiv(w.mw, 32);
-
-    Slot sa[A_SLOTS], sb[B_SLOTS];
-    make_slots<A_SLOTS, TN_BM, NTH>(P.a, w.m0, sa, tid);
-    make_slots<B_SLOTS, TN_BN, NTH>(P.b, w.n0, sb, tid);
-    const int32_t* ga = any_gather(P.a);
-    const int32_t* gb = any_gather(P.b);
-    const int a_data = operand_width(P.a) - (P.a.ones ? 1 : 0), b_data = operand_width(P.b) - (P.b.ones ? 1 : 0);
-    const int a_ones = P.a.ones ? (a_data - w.m0) : -1, b_ones = P.b.ones ? (b_data - w.n0) : -1;
-    const bool a_has_ones = a_ones >= 0 && a_ones < TN_BM, b_has_ones = b_ones >= 0 && b_ones < TN_BN;
-    const int a_cols = max(0, min(TN_BM, a_data - w.m0)), b_cols = max(0, min(TN_BN, b_data - w.n0));
-
-    for (int i = tid; i < 2 * TP_F32; i += NTH) lds[i] = 0.f;  // columns no DMA piece covers stay zero
-    __syncthreads();
-
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const int r_last = w.r_end - 1;
-    const int nchunks = w.nchunks;
-    auto row0 = [&](int chunk) { return w.r_first + chunk * w.r_step; };
-    int64_t ra[A_SLOTS], rb[B_SLOTS];
-    auto stage = [&](int chunk, int b) {  // rows of `chunk` are in ra / rb
-        const int r0 = row0(chunk);
-        issue_dma<A_SLOTS, NTH>(sa, ra, Abuf(b), tid);
-        issue_dma<B_SLOTS, NTH>(sb, rb, Bbuf(b), tid);
-        if (tid < TN_RK) {
-            const float one = (r0 + tid <= r_last) ? 1.f : 0.f;
-            if (a_has_ones) Abuf(b)[tid * TN_BM + a_ones] = one;
-            if (b_has_ones) Bbuf(b)[tid * TN_BN + b_ones] = one;
-        }
-    };
-    int va[A_SLOTS], vb[B_SLOTS];
-    fetch_issue<A_SLOTS>(sa, va, row0(0), r_last, ga);
-    fetch_issue<B_SLOTS>(sb, vb, row0(0), r_last, gb);
-    fetch_finish<A_SLOTS>(sa, va, ra, row0(0), r_last, ga);
-    fetch_finish<B_SLOTS>(sb, vb, rb, row0(0), r_last, gb);
-#pragma unroll
-    for (int k = 0; k < A_SLOTS; ++k) asm volatile("" : "+v"(ra[k]));
-#pragma unroll
-    for (int k = 0; k < B_SLOTS; ++k) asm volatile("" : "+v"(rb[k]));
-    stage(0, 0);
-    fetch_issue<A_SLOTS>(sa, va, row0(1), r_last, ga);
-    fetch_issue<B_SLOTS>(sb, vb, row0(1), r_last, gb);
-    fetch_finish<A_SLOTS>(sa, va, ra, row0(1), r_last, ga);
-    fetch_finish<B_SLOTS>(sb, vb, rb, row0(1), r_last, gb);
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        __syncthreads();  // vmcnt(0) + barrier: this chunk has landed; every wave is done with the planes and with the other buffer
-        const int nvalid = min(TN_RK, w.r_end - row0(c));
-        if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
-            for (int i = tid; i < (TN_RK - nvalid) * TN_BM; i += NTH) Abuf(cur)[nvalid * TN_BM + i] = 0.f;
-            for (int i = tid; i < (TN_RK - nvalid) * TN_BN; i += NTH) Bbuf(cur)[nvalid * TN_BN + i] = 0.f;
-            __syncthreads();
-        }
-        if (P.a.act || P.b.act) {
-            if (P.a.act) act_in_lds(Abuf(cur), TN_BM, a_cols, nvalid, P.a.act, P.a.slope, tid, NTH);
-            if (P.b.act) act_in_lds(Bbuf(cur), TN_BN, b_cols, nvalid, P.b.act, P.b.slope, tid, NTH);
-            __syncthreads();
-        }
-        const int rn = row0(c + 2);
-        if (c + 1 < nchunks) {  // the next chunk's DMA: in flight under the split pass and the products (the barrier between them is
-            stage(c + 1, cur ^ 1);  // a raw s_barrier: it does not drain vmcnt)
-            fetch_issue<A_SLOTS>(sa, va, rn, r_last, ga);
-            fetch_issue<B_SLOTS>(sb, vb, rn, r_last, gb);
-        }
-        // ---- split pass: one fragment-lane per thread and pass: eight rows of one column -> three 16-byte plane entries ------------
-#pragma unroll
-        for (int k = 0; k < (TP_STEPS * (MTA + NTB) * 64 + NTH - 1) / NTH; ++k) {
-            const int u = tid + NTH * k, t = u >> 6;  // (t: wave-uniform)
-            if (t < TP_STEPS * (MTA + NTB)) {
-                const int ks = t / (MTA + NTB), tile = t - ks * (MTA + NTB);
-                const bool isA = tile < MTA;
-                const int tl = isA ? tile : tile - MTA;
-                if (isA ? tl < mtiles : tl < w.ntiles) {
-                    const float* src = (isA ? Abuf(cur) + 32 * tl : Bbuf(cur) + 32 * tl) + col + (16 * ks + 8 * hi) * (isA ? TN_BM : TN_BN);
-                    const int LD = isA ? TN_BM : TN_BN;
-                    float x[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = src[q * LD];
-                    gcp_u32x4 th, tm, tl3;
-                    gcp_bf16x3_split8(x, th, tm, tl3);
-                    gcp_u32x4* dst = (isA ? Apl + (ks * MTA + tl) * 192 : Bpl + (ks * NTB + tl) * 192) + lane;
-                    dst[0] = th; dst[64] = tm; dst[128] = tl3;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes complete (LDS only: the DMA stays in flight)
-        // ---- products: this wave's m-tile x its n-tiles, rows 16 kh .. 16 kh + 15 of the chunk ------------------------------------
-        if (wave_active && !(a.debug & 1)) {
-            const gcp_u32x4* pa = Apl + (kh * MTA + xt.mi) * 192 + lane;
-            const gcp_u32x4 a3[3] = {pa[0], pa[64], pa[128]};
-            const gcp_u32x4* pb0 = Bpl + kh * NTB * 192 + lane;
-            gcp_u32x4 b0[3], b1[3];
-            auto ldb = [&](gcp_u32x4(&b)[3], int i) {
-                const gcp_u32x4* q = pb0 + min(xt.g + xt.G * i, w.ntiles - 1) * 192;
-                b[0] = q[0]; b[1] = q[64]; b[2] = q[128];
-            };
-            ldb(b0, 0);
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                gcp_u32x4(&bc)[3] = (i & 1) ? b1 : b0;
-                gcp_u32x4(&bn)[3] = (i & 1) ? b0 : b1;
-                if (i + 1 < 5) ldb(bn, i + 1);
-                if (i < xt.my_n) acc[i] = gcp_mfma_bf16x6(a3, bc[0], bc[1], bc[2], acc[i]);
-            }
-        }
-        if (c + 1 < nchunks) {
-            fetch_finish<A_SLOTS>(sa, va, ra, rn, r_last, ga);
-            fetch_finish<B_SLOTS>(sb, vb, rb, rn, r_last, gb);
-        }
-    }
-    // rows 16 .. 31 of every chunk (waves 4-7) onto rows 0 .. 15 (waves 0-3) through the staging buffers, free now
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        const int i0 = round ? 3 : 0, i1 = round ? 5 : 3;
-        __syncthreads();
-        if (kh == 1) {
-#pragma unroll
-            for (int i = i0; i < i1; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane] = acc[i][r];
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int i = i0; i < i1; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] += lds[((wave * 3 + (i - i0)) * 16 + r) * 64 + lane];
-        }
-    }
-    if (wave_active && kh == 0) store_partial_x3(P, w, a.M[w.pi], a.N[w.pi], acc, xt, col, hi);
-}
-
-// ---- big-block path: ONE workgroup owns the whole output of a problem with 128 < M <= 256 or 160 < N <= 320 -------------------
-// The weight gradients of the (256,32) message GCPs of BASELINE configs[4] are 256 x 285 products: cut into 128 x 160 blocks every
-// operand row is fetched by two workgroups (4.3 KB per row for 2.2 KB of operands), and the kernel is bound by its DMA pipeline.
-// Here a workgroup of 8 waves stages 32 rows of BOTH complete operands (73.7 KB per chunk, double buffered: one workgroup per CU) and
-// wave w accumulates the 2 x 5 output tiles (m-tiles 2 (w & 3) .., n-tiles 5 (w >> 2) ..): 160 accumulator registers, seven LDS
-// fragment reads per ten MFMAs instead of ten per five.  Operands: plain segments (no row gather, no activation), DMA-able
-// (widths / strides multiples of four floats); everything else keeps the 128 x 160 kernel.
-constexpr int TB_BM = 256, TB_BN = 320, TB_NW = 8, TB_NTH = 64 * TB_NW;
-constexpr int TB_A_SLOTS = (TN_RK * TB_BM / 4 + TB_NTH - 1) / TB_NTH, TB_B_SLOTS = (TN_RK * TB_BN / 4 + TB_NTH - 1) / TB_NTH;  // 4 and 5 pieces per thread
-constexpr int TB_LDS_FLOATS = 2 * TN_RK * (TB_BM + TB_BN);
-
-struct BigSlot {
-    const float* base;  // segment pointer + column offset of the 16-byte piece; nullptr: no column of the operand there
-    int ld, row;  // (ld < 0: a tile-blocked segment of padded width -ld)
-};
-
-template <int NSLOT, int LD>
-__device__ __forceinline__ void big_slots(const gcp_operand_t& op, BigSlot* s, int tid) {
-#pragma unroll
-    for (int k = 0; k < NSLOT; ++k) {
-        const int f = tid + TB_NTH * k;
-        const bool piece = f < TN_RK * LD / 4;
-        const int row = piece ? f / (LD / 4) : 0, c = 4 * (f % (LD / 4));
-        s[k].row = row; s[k].base = nullptr; s[k].ld = 0;
-        int cbase = 0;
-        for (int sg = 0; sg < op.n; ++sg) {
-            if (piece && c >= cbase && c < cbase + op.dim[sg]) {
-                s[k].base = op.ptr[sg] + (op.tb[sg] ? tb_col_offset(c - cbase) : (c - cbase));
-                s[k].ld = op.tb[sg] ? -gcp_round_up(op.dim[sg], 32) : op.ld[sg];
-            }
-            cbase += op.dim[sg];
-        }
-    }
-}
-
-template <int NSLOT>
-__device__ __forceinline__ void big_issue(const BigSlot* s, float* buf, int r0, int r_last, int tid) {
-#pragma unroll
-    for (int k = 0; k < NSLOT; ++k) {
-        float* dst = buf + (TB_NTH * k + (tid & ~63)) * 4;  // wave-uniform LDS base; the hardware adds lane * 16 bytes
-        if (s[k].base)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(s[k].base + (s[k].ld < 0 ? tb_row_offset(min(r0 + s[k].row, r_last), -s[k].ld)
-                                                                                         : (int64_t)min(r0 + s[k].row, r_last) * s[k].ld)),
-                (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-}
-
-template <bool X3>
-__global__ __launch_bounds__(TB_NTH, 1) void tn_gemm_big_kernel(TnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int col = lane & 31, hi = lane >> 5;
-    int pi = 0;
-    while (pi + 1 < a.n && (int)blockIdx.x >= a.block_start[pi + 1]) ++pi;
-    const gcp_tn_problem_t& P = a.p[pi];
-    const int M = a.M[pi], N = a.N[pi];
-    const int split = blockIdx.x - a.block_start[pi];
-    int r_first, r_step, r_end, nchunks;
-    split_rows(P.rows, P.splits, split, a.cyclic != 0, r_first, r_step, r_end, nchunks);
-    const int r_last = r_end - 1;
-    const int mtiles = gcp_cdiv(M, 32), ntiles = gcp_cdiv(N, 32);
-    const int mt0 = 2 * (wave & 3), nt0 = 5 * (wave >> 2);
-    auto Abuf = [&](int b) { return lds + b * (TN_RK * (TB_BM + TB_BN)); };
-    auto Bbuf = [&](int b) { return lds + b * (TN_RK * (TB_BM + TB_BN)) + TN_RK * TB_BM; };
-
-    BigSlot sa[TB_A_SLOTS], sb[TB_B_SLOTS];
-    big_slots<TB_A_SLOTS, TB_BM>(P.a, sa, tid);
-    big_slots<TB_B_SLOTS, TB_BN>(P.b, sb, tid);
-    const int a_ones = P.a.ones ? M - 1 : -1, b_ones = P.b.ones ? N - 1 : -1;  // the ones column (bias gradients) is written by hand
-
-    for (int i = tid; i < TB_LDS_FLOATS; i += TB_NTH) lds[i] = 0.f;  // columns no piece covers stay zero
-    __syncthreads();
-
-    f32x16 acc[2][5];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-    auto stage = [&](int chunk, int b) {
-        const int r0 = r_first + chunk * r_step;
-        big_issue<TB_A_SLOTS>(sa, Abuf(b), r0, r_last, tid);
-        big_issue<TB_B_SLOTS>(sb, Bbuf(b), r0, r_last, tid);
-        if (tid < TN_RK) {
-            const float one = (r0 + tid <= r_last) ? 1.f : 0.f;
-            if (a_ones >= 0) Abuf(b)[tid * TB_BM + a_ones] = one;
-            if (b_ones >= 0) Bbuf(b)[tid * TB_BN + b_ones] = one;
-        }
-    };
-    if (nchunks > 0) stage(0, 0);
-    const bool m_on[2] = {mt0 < mtiles, mt0 + 1 < mtiles};
-    TN_T_DECL;
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        TN_T_MARK(3);
-        __syncthreads();  // vmcnt(0) + barrier: this chunk has landed, and every wave is done with the other buffer
-        TN_T_MARK(0);
-        const int nvalid = min(TN_RK, r_end - (r_first + c * r_step));
-        if (nvalid < TN_RK) {  // last chunk of the split: rows past the end were clamped duplicates, zero them
-            for (int i = tid; i < (TN_RK - nvalid) * TB_BM; i += TB_NTH) Abuf(cur)[nvalid * TB_BM + i] = 0.f;
-            for (int i = tid; i < (TN_RK - nvalid) * TB_BN; i += TB_NTH) Bbuf(cur)[nvalid * TB_BN + i] = 0.f;
-            __syncthreads();
-        }
-        if (c + 1 < nchunks && !(a.debug & 2)) stage(c + 1, cur ^ 1);
-        TN_T_MARK(1);
-        if (X3 && m_on[0] && nt0 < ntiles && !(a.debug & 1)) {  // three-term bf16 products (x3_step); an absent second m-tile is computed and dropped
-            const float* As = Abuf(cur) + 8 * hi * TB_BM + 32 * mt0 + col;
-            const float* Bs = Bbuf(cur) + 8 * hi * TB_BN + 32 * nt0 + col;
-            const int boff[5] = {0, 32, 64, 96, 128};
-            const int nt = min(5, ntiles - nt0);
-#pragma unroll 1
-            for (int ks = 0; ks < TN_RK / 16; ++ks) x3_step<2, TB_BM, TB_BN>(As + 16 * ks * TB_BM, Bs + 16 * ks * TB_BN, boff, nt, acc);
-        }
-        TN_T_MARK(2);
-        if (!X3 && m_on[0] && nt0 < ntiles) {  // (wave-uniform: waves whose tiles lie outside a narrower problem only keep the barriers)
-            const float* As = Abuf(cur) + hi * TB_BM + 32 * mt0 + col;
-            const float* Bs = Bbuf(cur) + hi * TB_BN + 32 * nt0 + col;
-            float fa[2], fb[5];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fa[j] = As[32 * j];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) fb[i] = Bs[32 * i];
-#pragma unroll
-            for (int ss = 0; ss < TN_RK / 2; ++ss) {
-                float na[2], nb[5];
-                if (ss + 1 < TN_RK / 2) {  // fragments of the next step before this step's MFMAs
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) na[j] = As[2 * (ss + 1) * TB_BM + 32 * j];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) nb[i] = Bs[2 * (ss + 1) * TB_BN + 32 * i];
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if (m_on[j] && nt0 + i < ntiles) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[i], acc[j][i], 0, 0, 0);
-                if (ss + 1 < TN_RK / 2) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) fa[j] = na[j];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) fb[i] = nb[i];
-                }
-            }
-        }
-    }
-    float* part = P.partial + (int64_t)split * M * N;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            if (!(m_on[j] && nt0 + i < ntiles)) continue;
-            const int n = 32 * (nt0 + i) + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = 32 * (mt0 + j) + gcp_crow(r, hi);
-                if (m < M && n < N) part[(int64_t)m * N + n] = acc[j][i][r];
-            }
-        }
-    TN_T_MARK(3);
-    TN_T_STORE(part, wave, lane);
 }
 
 // ---- pipelined form (round 5): rows HBM -> registers -> ONE split per operand element -> planes in LDS -> products ---------------
@@ -938,18 +576,20 @@ __device__ __forceinline__ TpLane tp_lane(const gcp_operand_t& op, int c) {  // 
 }
 __device__ __forceinline__ int64_t tp_row_offset(const TpLane& L, int64_t r) { return (L.kind & 4) ? tb_row_offset(r, L.ld) : r * L.ld; }
 
-template <int NW, int MT, int NT, int UT>
+// NBUF: plane buffers.  2: passes and product groups of a chunk interleave, one barrier per chunk.  1: products, barrier, passes,
+// barrier -- half the LDS and fewer registers (no second set of B fragments): three workgroups per CU instead of two.
+template <int NW, int MT, int NT, int UT, int NBUF = 2>
 struct TpCfg {
     static constexpr int NTH = 64 * NW, AT = MT * NW, BM = 32 * AT, BN = 32 * NT;
     static constexpr int PLANES = (AT + NT) * 3 * 256;  // floats per buffer: [fragment][term][64 lanes][4 dwords]
-    static constexpr int LDS_FLOATS = 2 * PLANES;
+    static constexpr int LDS_FLOATS = NBUF * PLANES;
     static constexpr int APASS = MT, BPASS = (NT + NW - 1) / NW, NPASS = APASS + BPASS;  // fragment-lanes per thread and chunk
     static constexpr int NG = (NT + UT - 1) / UT;                                          // product groups per chunk
 };
 
-template <int NW, int MT, int NT, int UT>
-__global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
-    using C = TpCfg<NW, MT, NT, UT>;
+template <int NW, int MT, int NT, int UT, int NBUF = 2>
+__global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnArgs a) {
+    using C = TpCfg<NW, MT, NT, UT, NBUF>;
     constexpr int AT = C::AT, BM = C::BM, BN = C::BN, NPASS = C::NPASS, APASS = C::APASS, NG = C::NG;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1025,7 +665,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
         }
         gcp_u32x4 th, tm, tl3;
         gcp_bf16x3_split8(x[ps], th, tm, tl3);
-        gcp_u32x4* dst = planes + buf * PL4 + (frag[ps] * 3) * 64 + lane;
+        gcp_u32x4* dst = planes + (buf & (NBUF - 1)) * PL4 + (frag[ps] * 3) * 64 + lane;
         dst[0] = th; dst[64] = tm; dst[128] = tl3;
     };
 
@@ -1078,20 +718,18 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TN_T_DECL;
-    // SH: the passes of the second half of an eight-wave workgroup run SH product groups later than those of the first half, so
-    // that of the two waves of a SIMD one splits while the other multiplies (they meet at the same barrier per chunk)
-    auto main_loop = [&](auto shift_c) {
-        constexpr int SH = decltype(shift_c)::value;
-        for (int c = 0; c < nchunks; ++c) {
-            const gcp_u32x4* pl = planes + (c & 1) * PL4;
-            gcp_u32x4 a3[MT][3], bt[2][UT][3];
-            read_a(pl, a3);
-            read_b(pl, 0, bt[0]);
+    for (int c = 0; c < nchunks; ++c) {
+        const gcp_u32x4* pl = planes + (c & (NBUF - 1)) * PL4;
+        constexpr bool DBUF = NBUF == 2 && NT * MT <= 5;  // two sets of B fragments only where the registers are there (the wide form holds 144 accumulators)
+        gcp_u32x4 a3[MT][3], bt[DBUF ? 2 : 1][UT][3];
+        read_a(pl, a3);
+        read_b(pl, 0, bt[0]);
 #pragma unroll
-            for (int k = 0; k < NG; ++k) {
+        for (int k = 0; k < NG; ++k) {
+            if (NBUF == 2) {
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {  // passes whose turn it is: pass ps runs ahead of product group (ps NG) / NPASS + SH
-                    if ((ps * NG) / NPASS + SH == k) {
+                for (int ps = 0; ps < NPASS; ++ps) {  // passes whose turn it is: pass ps runs ahead of product group (ps NG) / NPASS
+                    if ((ps * NG) / NPASS == k) {
                         TN_T_MARK(3);
                         if (c + 1 < nchunks) split_pass(ps, (c + 1) & 1, 8);
                         TN_T_MARK(0);
@@ -1100,24 +738,29 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
                         TN_T_MARK(1);
                     }
                 }
-                constexpr bool DBUF = NT * MT <= 5;  // two sets of B fragments only where the registers are there (the wide form holds 144 accumulators)
-                if (DBUF) {
-                    if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[(k + 1) & 1]);
-                    mul_group(k, a3, bt[k & 1]);
-                } else {
-                    mul_group(k, a3, bt[0]);
-                    if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[0]);  // (behind the group's last MFMA issue; the SIMD's other wave covers the LDS latency)
-                }
             }
-            TN_T_MARK(3);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes[(c + 1) & 1] complete; everyone is done with planes[c & 1]
-            TN_T_MARK(2);
+            if (DBUF) {
+                if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[(k + 1) & 1]);
+                mul_group(k, a3, bt[DBUF ? (k & 1) : 0]);
+            } else {
+                mul_group(k, a3, bt[0]);
+                if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[0]);  // (behind the group's last MFMA issue; the SIMD's other waves cover the LDS latency)
+            }
         }
-    };
-    // (measured: the staggered instantiation needs 27 more registers than the 256 of two waves per SIMD -- spills inside the loop; off)
-    constexpr int STAGGER = 0;
-    if (STAGGER > 0 && wave >= NW / 2) main_loop(std::integral_constant<int, STAGGER>{});
-    else main_loop(std::integral_constant<int, 0>{});
+        TN_T_MARK(3);
+        if (NBUF == 1) {  // everyone is done with the planes: the next chunk goes into them
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                if (c + 1 < nchunks) split_pass(ps, 0, 8);
+                load_pass(ps);
+            }
+            advance();
+            TN_T_MARK(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // planes of chunk c + 1 complete (NBUF = 2: and everyone is done with those of chunk c)
+        TN_T_MARK(2);
+    }
     if (ragged) {  // (workgroup-uniform) the operand's last, partial chunk: requested row by row with the row index clamped, not pipelined
         const int r0 = full_chunks * TS_RK + 8 * hi, r_last = P.rows - 1;
 #pragma unroll
@@ -1159,13 +802,6 @@ __global__ __launch_bounds__(64 * NW, 2) void tn_pipe_kernel(TnArgs a) {
 }
 
 inline bool stream_ok(const gcp_operand_t& o) {
-    if (o.act) return false;
-    for (int k = 0; k < o.n; ++k)
-        if (o.idx[k]) return false;
-    return true;
-}
-
-inline bool big_ok(const gcp_operand_t& o) {
     if (o.act) return false;
     for (int k = 0; k < o.n; ++k)
         if (o.idx[k]) return false;
@@ -1250,7 +886,7 @@ inline bool dma_ok(const gcp_operand_t& o) {
 extern "C" int gcpnet_debug_tn_occupancy(int wide) {
     int n = -1;
     const hipError_t err = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tn_pipe_kernel<8, 1, 9, 1>, 512, TpCfg<8, 1, 9, 1>::LDS_FLOATS * sizeof(float))
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tn_pipe_kernel<4, 1, 5, 2>, 256, TpCfg<4, 1, 5, 2>::LDS_FLOATS * sizeof(float));
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tn_pipe_kernel<4, 1, 5, 1, 1>, 256, TpCfg<4, 1, 5, 1, 1>::LDS_FLOATS * sizeof(float));
     return err == hipSuccess ? n : -(int)err;
 }
 
@@ -1274,7 +910,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     if (skip_env) return 0;
     a.debug = getenv("GCPNET_TN_DEBUG") ? atoi(getenv("GCPNET_TN_DEBUG")) : 0;
 #endif
-    a.cyclic = getenv("GCPNET_TN_BLOCKED") == nullptr;  // (GCPNET_TN_BLOCKED: contiguous row range per split, the earlier form, for A/B runs)
+    a.cyclic = 1;
     int blocks = 0, max_mn = 0;
     bool dma = true;
     for (int i = 0; i < n_problems; ++i) {
@@ -1314,10 +950,14 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     const int n_all = n_problems, max_mn_all = max_mn;
     // the pipelined kernels take every problem without a row gather / activation on load whose columns they can address
     // (GCPNET_TN_PIPE=0: the earlier kernels, for A/B runs)
-    static const bool pipe_env = !(getenv("GCPNET_TN_PIPE") && getenv("GCPNET_TN_PIPE")[0] == '0');
+    const bool pipe_env = !(getenv("GCPNET_TN_PIPE") && getenv("GCPNET_TN_PIPE")[0] == '0');
     const bool x3_ = getenv("GCPNET_TN_FP32") == nullptr;
     if (pipe_env && x3_) {
-        using Narrow = TpCfg<4, 1, 5, 2>;
+        // narrow: ONE plane buffer, three workgroups per CU (measured against two buffers / two workgroups: eight-problem launches of
+        // the configs[1] / configs[2] shapes 0.405 -> 0.345 ms, 0.332 -> 0.292 ms; the thin gate problems gain most, 0.220 -> 0.173 ms)
+        using Narrow = TpCfg<4, 1, 5, 1, 1>;
+        // (measured and dropped: the wide form as two independent four-wave workgroups per CU, 128 x 288 each -- 256 registers with
+        // spills, 7.36 against 6.75 ms on eight 256 x 276 problems of 10^6 rows, configs[4] step 196.9 against 190.3 ms)
         using Wide = TpCfg<8, 1, 9, 1>;
         TnArgs narrow, wide, rest;
         narrow.n = wide.n = rest.n = 0;
@@ -1351,18 +991,18 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         constexpr size_t n_lds = (size_t)Narrow::LDS_FLOATS * sizeof(float), w_lds = (size_t)Wide::LDS_FLOATS * sizeof(float);
         static bool tp_configured = false;
         if (!tp_configured) {
-            hipError_t err = hipFuncSetAttribute((const void*)tn_pipe_kernel<4, 1, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_lds);
+            hipError_t err = hipFuncSetAttribute((const void*)tn_pipe_kernel<4, 1, 5, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_lds);
             if (err == hipSuccess)
                 err = hipFuncSetAttribute((const void*)tn_pipe_kernel<8, 1, 9, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_lds);
             if (err != hipSuccess) return (int)err;
             tp_configured = true;
         }
         if (wide.n) {
-            hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1>), dim3(wblocks), dim3(512), w_lds, st, wide);
+            hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1>), dim3(wblocks), dim3(Wide::NTH), w_lds, st, wide);
             GCP_HIP_CHECK_LAUNCH();
         }
         if (narrow.n) {
-            hipLaunchKernelGGL((tn_pipe_kernel<4, 1, 5, 2>), dim3(nblocks), dim3(256), n_lds, st, narrow);
+            hipLaunchKernelGGL((tn_pipe_kernel<4, 1, 5, 1, 1>), dim3(nblocks), dim3(256), n_lds, st, narrow);
             GCP_HIP_CHECK_LAUNCH();
         }
         if (rest.n == 0) {
@@ -1372,104 +1012,21 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         }
         a = rest; blocks = rblocks_; max_mn = rest_mn; n_problems = rest.n; dma = rest_dma;
     }
-    // problems whose output needs more than one 128 x 160 block (and fits 256 x 320) go through the big-block kernel, one
-    // workgroup per split; the others keep the launch below
-    // (the big-block kernel is opt-in since the bf16 form: alone it is the faster one on 256 x 284 outputs, 0.98 against 1.2 ms, but
-    // in the configs[4] step the four-wave 128 x 160 kernel wins, 211 against 216 ms -- one 8-wave workgroup with 147 KB of LDS per CU
-    // leaves no room for the caller's stream.  Read per call: the tests switch it.)
-    const bool big_env = getenv("GCPNET_TN_BIG") != nullptr;
-    // (GCPNET_TN_FP32: the fp32-MFMA form of both DMA kernels, kept for A/B measurements and the tests that hold the two against each other)
+    // what is left (row gathers, activations on load, odd split counts, GCPNET_TN_FP32 / GCPNET_TN_PIPE=0): the four-wave DMA kernel
+    // where the operands can be DMA'd (widths / strides multiples of four floats, 16-byte aligned), the register-staged one otherwise
+    // (GCPNET_TN_FP32: plain fp32 MFMA arithmetic, for the tests that hold the bf16 forms against it)
     const bool x3 = getenv("GCPNET_TN_FP32") == nullptr;
-    if (dma && big_env) {
-        TnArgs big, rest;
-        big.n = rest.n = 0;
-        big.cyclic = rest.cyclic = a.cyclic;
-        big.debug = rest.debug = a.debug;
-        int bblocks = 0, rblocks_ = 0, big_mn = 0, rest_mn = 0;
-        for (int i = 0; i < n_problems; ++i) {
-            const gcp_tn_problem_t& P = problems[i];
-            const bool is_big = (a.M[i] > TN_BM || a.N[i] > TN_BN) && a.M[i] <= TB_BM && a.N[i] <= TB_BN && big_ok(P.a) && big_ok(P.b);
-            TnArgs& d = is_big ? big : rest;
-            const int k = d.n++;
-            d.p[k] = a.p[i]; d.M[k] = a.M[i]; d.N[k] = a.N[i]; d.mb[k] = a.mb[i]; d.nb[k] = a.nb[i];
-            if (is_big) { d.block_start[k] = bblocks; bblocks += P.splits; big_mn = max(big_mn, a.M[i] * a.N[i]); }
-            else { d.block_start[k] = rblocks_; rblocks_ += a.mb[i] * a.nb[i] * P.splits; rest_mn = max(rest_mn, a.M[i] * a.N[i]); }
-        }
-        big.block_start[big.n] = bblocks;
-        rest.block_start[rest.n] = rblocks_;
-        if (big.n > 0) {
-            static bool big_configured = false;
-            const size_t big_lds = (size_t)TB_LDS_FLOATS * sizeof(float);
-            if (!big_configured) {
-                hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
-                if (err == hipSuccess)
-                    err = hipFuncSetAttribute((const void*)tn_gemm_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
-                if (err != hipSuccess) return (int)err;
-                big_configured = true;
-            }
-            if (x3) hipLaunchKernelGGL(tn_gemm_big_kernel<true>, dim3(bblocks), dim3(TB_NTH), big_lds, st, big);
-            else hipLaunchKernelGGL(tn_gemm_big_kernel<false>, dim3(bblocks), dim3(TB_NTH), big_lds, st, big);
-            GCP_HIP_CHECK_LAUNCH();
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3(min(1024, gcp_cdiv(big_mn, 64)), big.n), dim3(256), 0, st, big);
-            GCP_HIP_CHECK_LAUNCH();
-            if (rest.n == 0 && n_all == big.n) return 0;
-            a = rest;
-            blocks = rblocks_;
-            max_mn = rest_mn;
-            n_problems = rest.n;
-        }
-    }
     if (dma) {
         static bool configured = false;
-        // (GCPNET_TN_LDS_PAD: tuning knob -- extra bytes of dynamic LDS per workgroup; >= 13 KB leaves ONE workgroup per CU, so that
-        // kernels of the caller's stream can share a CU with the weight-gradient GEMMs of the side stream)
-        static const size_t pad = getenv("GCPNET_TN_LDS_PAD") ? (size_t)atoi(getenv("GCPNET_TN_LDS_PAD")) : 0;
-        const size_t lds_bytes = (size_t)TN_DMA_LDS_FLOATS * sizeof(float) + pad;
+        const size_t lds_bytes = (size_t)TN_DMA_LDS_FLOATS * sizeof(float);
         if (!configured) {
             hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (err == hipSuccess)
                 err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (err == hipSuccess)
-                err = hipFuncSetAttribute((const void*)tn_gemm_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (err != hipSuccess) return (int)err;
             configured = true;
         }
-        // (GCPNET_TN_EIGHT_WAVES: the eight-wave form.  Alone it is the faster kernel -- 69 vs 86 us on the (128,16) weight gradient of
-        // 160 k rows --, inside the training step, where these launches share the chip with the caller's stream, it is the slower
-        // choice: 12.48 vs 12.01 ms per configs[1] step, profiles/r03_tn_bf16x3.txt.  Read per call: the tests switch it.)
-        const bool eight = getenv("GCPNET_TN_EIGHT_WAVES") != nullptr;
-        // (the planes form, see tn_gemm_planes_kernel; GCPNET_TN_PLANES=0 / 1 switches per call: A/B measurements, tests)
-        static bool planes_configured = false;
-        const char* pl_env = getenv("GCPNET_TN_PLANES");
-        const bool planes = x3 && !eight && (pl_env ? pl_env[0] == '1' : TN_PLANES_DEFAULT);
-        if (planes) {
-            const size_t pl_bytes = (size_t)TP_LDS_FLOATS * sizeof(float);
-            if (!planes_configured) {
-                const hipError_t err = hipFuncSetAttribute((const void*)tn_gemm_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_bytes);
-                if (err != hipSuccess) return (int)err;
-                planes_configured = true;
-            }
-            // problems with more than one m-tile go to the planes kernel; the skinny ones (the gate weight gradient: M = vo <= 32, one
-            // m-tile, bound by their DMA latency) keep the four-wave kernel, two of whose workgroups share a CU
-            TnArgs wide, thin;
-            wide.n = thin.n = 0;
-            wide.cyclic = thin.cyclic = a.cyclic;
-            wide.debug = thin.debug = a.debug;
-            int wblocks = 0, tblocks = 0;
-            for (int i = 0; i < n_problems; ++i) {
-                TnArgs& d = a.M[i] > 32 ? wide : thin;
-                int& nb = a.M[i] > 32 ? wblocks : tblocks;
-                const int k = d.n++;
-                d.p[k] = a.p[i]; d.M[k] = a.M[i]; d.N[k] = a.N[i]; d.mb[k] = a.mb[i]; d.nb[k] = a.nb[i];
-                d.block_start[k] = nb;
-                nb += a.mb[i] * a.nb[i] * a.p[i].splits;
-            }
-            wide.block_start[wide.n] = wblocks;
-            thin.block_start[thin.n] = tblocks;
-            if (wide.n) hipLaunchKernelGGL(tn_gemm_planes_kernel, dim3(wblocks), dim3(TP_NTH), pl_bytes, st, wide);
-            if (thin.n) hipLaunchKernelGGL(tn_gemm_dma_kernel<1>, dim3(tblocks), dim3(256), lds_bytes, st, thin);
-        } else if (x3 && eight) hipLaunchKernelGGL(tn_gemm_dma_kernel<2>, dim3(blocks), dim3(512), lds_bytes, st, a);
-        else if (x3) hipLaunchKernelGGL(tn_gemm_dma_kernel<1>, dim3(blocks), dim3(256), lds_bytes, st, a);
+        if (x3) hipLaunchKernelGGL(tn_gemm_dma_kernel<1>, dim3(blocks), dim3(256), lds_bytes, st, a);
         else hipLaunchKernelGGL(tn_gemm_dma_kernel<0>, dim3(blocks), dim3(256), lds_bytes, st, a);
     } else {
         hipLaunchKernelGGL(tn_gemm_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -1717,7 +1717,7 @@ PROJECT_SMALL_LAUNCHES = False  # measured at 10 000 node rows: no gain (the ext
 
 
 def _tn_weight_grad(a2d: Tensor, b2d: Tensor) -> Tensor:
-    """a2d^T b2d for row-major a2d [rows, M], b2d [rows, N] (M, N multiples of 4, 16-byte aligned) through gcpnet_tn_gemm."""
+    """a2d^T b2d for a2d [rows, M], b2d [rows, N] (unit column stride, any widths / row strides) through gcpnet_tn_gemm."""
     lib = _lib.load()
     rows, M = a2d.shape
     N = b2d.shape[1]
@@ -1738,10 +1738,13 @@ def _tn_weight_grad(a2d: Tensor, b2d: Tensor) -> Tensor:
 
 
 def _rows_matmul_small(x2d: Tensor, w: Tensor) -> Tensor:
-    """x2d [rows, K] @ w [K, J] for a tiny w (gcpnet_rows_matmul_small); a library GEMM when w is not tiny."""
+    """x2d [rows, K] @ w [K, J]: gcpnet_rows_matmul_small for a tiny w, the workgroup kernel's plain-Linear form otherwise."""
     K, J = w.shape
     if K * J > 4096:
-        return torch.matmul(x2d, w)
+        out = wg_linear(x2d.contiguous(), w, J, K, trans=True)
+        if out is None:
+            raise _lib.GcpnetHipError(f"rows x [{K}, {J}] product outside the HIP kernels' shapes (no library fallback)")
+        return out
     lib = _lib.load()
     x2d = _req(x2d, "rows")
     out = torch.empty((x2d.shape[0], J), dtype=torch.float32, device=x2d.device)
@@ -1815,8 +1818,10 @@ class _Gcp2Projected(torch.autograd.Function):
         # no library GEMM); the columns the edge kernel keeps -- [un-gathered sources | norms | frame scalars] -- as a view too
         adds = []
         for k in sg:
-            a = wg_linear(s_src[k], w_scalar, spec.so, dims[k], col0=offs[k]) if USE_WG_KERNELS else None
-            adds.append(a if a is not None else torch.matmul(s_src[k], w_scalar[:, offs[k]:offs[k] + dims[k]].t()))
+            a = wg_linear(s_src[k], w_scalar, spec.so, dims[k], col0=offs[k])  # (whatever USE_WG_KERNELS says: there is no other Linear)
+            if a is None:
+                raise _lib.GcpnetHipError("node-level projection outside the workgroup kernel's shapes (no library fallback)")
+            adds.append(a)
         segs = [(offs[k], dims[k]) for k in rest] + ([(spec.si, spec.K - spec.si)] if spec.K > spec.si else [])
         use_view = USE_WG_KERNELS and len(segs) <= 3 and w_scalar.stride(1) == 1
         w_rest = None if use_view else torch.cat([w_scalar[:, a:a + m] for a, m in segs], dim=1)
@@ -1937,8 +1942,10 @@ class _Gcp2Projected(torch.autograd.Function):
             g = ds_pre if pl is None else _segment_reduce_raw(ds_pre, 0, spec.so, spec.so, pl, False)
             dP.append(g)
             if ctx.needs_input_grad[base + k]:
-                dx = wg_linear(g, w_scalar, dims[k], spec.so, col0=offs[k], trans=True) if USE_WG_KERNELS else None
-                grads_s[k] = dx if dx is not None else torch.matmul(g, w_scalar[:, offs[k]:offs[k] + dims[k]])
+                dx = wg_linear(g, w_scalar, dims[k], spec.so, col0=offs[k], trans=True)
+                if dx is None:
+                    raise _lib.GcpnetHipError("node-level projection adjoint outside the workgroup kernel's shapes (no library fallback)")
+                grads_s[k] = dx
         grads_v: List[Optional[Tensor]] = [None] * n_v
         off2 = 0
         for k in vr:
@@ -2016,7 +2023,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         out = wg_linear(x, weight, weight.shape[0], weight.shape[1], bias=bias)
         if out is None:
-            out = torch.addmm(bias, x, weight.t())
+            raise _lib.GcpnetHipError("Linear outside the workgroup kernel's shapes (no library fallback)")
         ctx.save_for_backward(x, weight)
         return out
 
@@ -2030,7 +2037,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = wg_linear(g, weight, dim, so, trans=True)
             if dx is None:
-                dx = torch.matmul(g, weight)
+                raise _lib.GcpnetHipError("Linear adjoint outside the workgroup kernel's shapes (no library fallback)")
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             n = x.shape[0]
@@ -2269,10 +2276,7 @@ class _ProjectV(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n, _, hfp = dq.shape
             V = vt.shape[2]
-            if hfp % 4 == 0 and V % 4 == 0 and n > 0:
-                dw = _tn_weight_grad(dq.view(3 * n, hfp), vt.view(3 * n, V))
-            else:
-                dw = torch.matmul(dq.reshape(3 * n, hfp).t(), vt.reshape(3 * n, V))
+            dw = _tn_weight_grad(dq.reshape(3 * n, hfp), vt.reshape(3 * n, V)) if n > 0 else torch.zeros((hfp, V), dtype=torch.float32, device=dq.device)
         return dv, dw
 
 
@@ -2303,28 +2307,47 @@ class _SplitCols(torch.autograd.Function):
 
 
 class _Project(torch.autograd.Function):
-    """P = x @ w^T for x [n, dim] (a column slice of a source is fine) and w [so, dim] (a column slice of scalar_out.weight):
-    the forward and the input gradient are plain library GEMMs; the weight gradient dP^T x reduces over the n rows and goes
-    through gcpnet_tn_gemm (row-split, deterministic), which a BLAS call without split-K handles poorly at n ~ 1e4."""
+    """P = x @ w^T for x [n, dim] (contiguous) and w [so, dim] (a column slice of scalar_out.weight is fine): the leading columns
+    of a block input too wide for one workgroup-kernel launch (the (1049 -> 256) feed-forward block of BASELINE configs[4]).
+    Forward and input gradient: the workgroup kernel's plain-Linear form (wg_linear; a library GEMM until round 5); the weight
+    gradient dP^T x reduces over the n rows and goes through gcpnet_tn_gemm (row-split, deterministic)."""
 
     @staticmethod
     def forward(ctx, x, w):
-        w = w.contiguous()  # (a column slice of scalar_out.weight: the BLAS heuristics do badly on its leading dimension)
+        x = x.contiguous()  # (the leading columns of a wider tensor: the workgroup kernel reads rows of exactly `dim` floats)
         ctx.save_for_backward(x, w)
-        return torch.matmul(x, w.t())
+        base, col0 = _Project._stored(w)
+        out = wg_linear(x, base, w.shape[0], w.shape[1], col0=col0)
+        if out is None:
+            raise _lib.GcpnetHipError("projection outside the workgroup kernel's shapes (no library fallback)")
+        return out
+
+    @staticmethod
+    def _stored(w):
+        """(stored matrix, first column) of a column-slice view: wg_linear caches the packed image per stored tensor object."""
+        base = w._base
+        if base is not None and base.dim() == 2 and base.stride(1) == 1 and w.stride() == base.stride():
+            col0 = w.storage_offset() - base.storage_offset()
+            if 0 <= col0 and col0 + w.shape[1] <= base.shape[1] and w.shape[0] == base.shape[0]:
+                return base, col0
+        return w, 0
 
     @staticmethod
     def backward(ctx, dP):
         x, w = ctx.saved_tensors
-        dx = torch.matmul(dP, w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            base, col0 = _Project._stored(w)
+            dx = wg_linear(_req(dP, "grad"), base, w.shape[1], w.shape[0], col0=col0, trans=True)
+            if dx is None:
+                raise _lib.GcpnetHipError("projection adjoint outside the workgroup kernel's shapes (no library fallback)")
         dw = None
         if ctx.needs_input_grad[1]:
             dP = _req(dP, "grad")
             n, so = dP.shape
             dim = x.shape[1]
-            ok = (x.stride(1) == 1 and x.stride(0) % 4 == 0 and dim % 4 == 0 and so % 4 == 0 and x.data_ptr() % 16 == 0 and n > 0)
-            if not ok:
-                dw = torch.matmul(dP.t(), x)
+            if n == 0:
+                dw = torch.zeros((so, dim), dtype=torch.float32, device=dP.device)
             else:
                 lib = _lib.load()
                 a, b = Operand(), Operand()

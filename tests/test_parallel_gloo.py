@@ -196,10 +196,11 @@ def _sharded_job(rank, world, halo=False, skew=False):
 
 
 @pytest.mark.parametrize("halo,world,skew", [(False, 2, False), (True, 2, False), (False, 4, False), (True, 4, False),
-                                             (False, 4, True), (True, 4, True)])
+                                             (False, 4, True), (True, 4, True), (False, 8, True), (True, 8, True)])
 def test_sharded_graph_matches_unsharded(halo, world, skew):
     """halo=False: all-gather of the whole feature table; halo=True: all-to-all of the rows the peers' in-edges reference.  2 and 4
-    ranks; `skew`: hub nodes and nodes without in-edges, so that the equal-edge cut leaves the ranks with very uneven node ranges."""
+    ranks, and 8 (one per GPU of a node: the world size the driver's scaling run uses) on the skewed graph; `skew`: hub nodes and
+    nodes without in-edges, so that the equal-edge cut leaves the ranks with very uneven node ranges."""
     from oracle import gcp_oracle as O
 
     P, ei, x, ins, lw, cfg, lcfg, n = _sharded_case(skew)

@@ -1,6 +1,7 @@
-"""The weight-gradient GEMM out[m, n] = sum_r A[r, m] B[r, n] (gcpnet_tn_gemm) against float64 matmul: the 128 x 160 block kernel,
-the big-block kernel (one workgroup owns an output of up to 256 x 320: the (256,32) message GCPs of BASELINE configs[4]) and the
-register-staged generic kernel, at row counts that end inside a 32-row chunk; the bias column (`ones`) through _Linear's call."""
+"""The weight-gradient GEMM out[m, n] = sum_r A[r, m] B[r, n] (gcpnet_tn_gemm) against float64 matmul: the pipelined kernels
+(128 x 160 and 256 x 288 blocks: the (128,16) and (256,32) message GCPs of BASELINE configs[1] / [4]), the earlier four-wave DMA
+kernel and the register-staged generic kernel behind them, at row counts that end inside a 16-row chunk; the bias column (`ones`)
+through _Linear's call."""
 import pytest
 import torch
 
@@ -25,15 +26,15 @@ pytestmark = pytest.mark.gpu
     (3001, 132, 600),     # M one column over a block (wide kernel, second block one m-tile), three column blocks
     (2048, 32, 257),      # the gate problem of the (256,32) blocks: narrow kernel, two column blocks
 ])
-@pytest.mark.parametrize("form", ["default", "planes", "planes_off", "big_block", "eight_waves", "fp32", "blocked_rows"])
+@pytest.mark.parametrize("form", ["default", "earlier", "fp32"])
 def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
     """`form`: the switches of gcpnet_tn_gemm that select another kernel or row distribution for the same product."""
     from gcpnet_amd import ops
 
-    env = {"big_block": "GCPNET_TN_BIG", "eight_waves": "GCPNET_TN_EIGHT_WAVES", "fp32": "GCPNET_TN_FP32",
-           "blocked_rows": "GCPNET_TN_BLOCKED", "planes": "GCPNET_TN_PLANES", "planes_off": "GCPNET_TN_PLANES"}.get(form)
-    if env:
-        monkeypatch.setenv(env, "0" if form == "planes_off" else "1")
+    if form == "fp32":       # plain fp32 MFMA arithmetic (the four-wave DMA kernel's MODE 0)
+        monkeypatch.setenv("GCPNET_TN_FP32", "1")
+    elif form == "earlier":  # the kernels the pipelined form took over from (they still serve gathered / activated operands)
+        monkeypatch.setenv("GCPNET_TN_PIPE", "0")
 
     g = torch.Generator().manual_seed(rows + M)
     a = torch.randn(rows, M, generator=g)
@@ -65,16 +66,16 @@ def test_linear_weight_and_bias_gradient_wide():
         assert err <= 1e-5 * float(want.abs().max()) + 1e-5, f"{name}: {err:.3e}"
 
 
-@pytest.mark.parametrize("big", [False, True], ids=["128x160", "big-block"])
+@pytest.mark.parametrize("earlier", [False, True], ids=["pipelined", "earlier"])
 @pytest.mark.parametrize("rows,M,N", [(40000, 128, 144), (20000, 256, 284)])
-def test_bf16_three_term_products_are_fp32_accurate(rows, M, N, big, monkeypatch):
+def test_bf16_three_term_products_are_fp32_accurate(rows, M, N, earlier, monkeypatch):
     """The default kernels multiply on the bf16 pipe with three-term operand splits (six MFMAs per product block); the fp32-MFMA
     form of the same kernels stays behind GCPNET_TN_FP32.  Both against float64: the split form must not be less accurate than
     fp32 arithmetic itself (bound: twice the fp32 form's own error + one ulp of the result scale)."""
     from gcpnet_amd import ops
 
-    if big:
-        monkeypatch.setenv("GCPNET_TN_BIG", "1")
+    if earlier:
+        monkeypatch.setenv("GCPNET_TN_PIPE", "0")
     g = torch.Generator().manual_seed(11)
     a = torch.randn(rows, M, generator=g) * torch.logspace(-3, 3, M)[None, :]   # columns of very different magnitude
     b = torch.randn(rows, N, generator=g)

@@ -10,7 +10,7 @@ from gcpnet_amd import ops  # noqa: E402
 
 args = [int(a) for a in sys.argv[1:]]
 shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(159913, 128, 144), (999995, 256, 284), (999995, 128, 144)]
-forms = [("bf16x3", None), ("fp32", "1")]  # (GCPNET_TN_PLANES=0 / 1 in the environment selects the bf16 kernel)
+forms = [("bf16x3", None), ("fp32", "1")]  # (GCPNET_TN_PIPE=0 in the environment: the kernels of rounds 3 - 4)
 for rows, M, N in [(r, m, n) for (r, m, n) in shapes for _ in forms]:
     form = forms[0] if not hasattr(sys, "_tn_i") or sys._tn_i % 2 == 0 else forms[1]
     sys._tn_i = getattr(sys, "_tn_i", 0) + 1
