@@ -148,9 +148,9 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
             def tn():
                 ops.run_weight_grad_jobs([ops._WeightGradJob(specs[k], n_edges, [ins[k][0]], outs[k][2], scrs[k]) for k in range(n)])
 
-            times["tn_gemm_dma_kernel(+reduce)"] = timeit(tn)
-        kbytes.update({"gcp2_chain_bwd_kernel": bytes_bwd, "tn_gemm_dma_kernel(+reduce)": bytes_tn})
-        kflops.update({"gcp2_chain_bwd_kernel": flops, "tn_gemm_dma_kernel(+reduce)": flops})
+            times["tn_pipe_kernel(+reduce)"] = timeit(tn)
+        kbytes.update({"gcp2_chain_bwd_kernel": bytes_bwd, "tn_pipe_kernel(+reduce)": bytes_tn})
+        kflops.update({"gcp2_chain_bwd_kernel": flops, "tn_pipe_kernel(+reduce)": flops})
     else:  # wider chains: block by block through the workgroup backward kernel, weight-gradient GEMMs included (2x the FLOPs)
         del probe
 
@@ -171,7 +171,7 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     return dict(times=times, bytes=kbytes, flops=kflops, n_blocks=n)
 
 
-PMC_FILE = "profiles/r04_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
+PMC_FILE = "profiles/r05_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
 
 
 def _pmc_file():
@@ -270,6 +270,23 @@ def other_configs_block(G, ops, args):
             del graphed
         except Exception as exc:  # (a capture failure must not cost the run its headline line)
             rec["hipgraph_error"] = f"{type(exc).__name__}: {exc}"[:300]
+        if cfg == "c3":  # the LBA step's dominant kernels: the (100,16) residual message chain of one layer on the batch's edge rows
+            try:
+                layer = wl["model"].interaction_layers[0]
+                n_e = wl["n_edges"]
+                fr = torch.randn(n_e, 3, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+                kr = kernel_roofline(G, ops, layer, fr, n_e, 100, 16, iters=10)
+                dom = min(kr["times"], key=lambda k_: kr["flops"][k_] / kr["times"][k_])
+                ach = kr["flops"][dom] / kr["times"][dom] / 1e12
+                rec["roofline"] = {"kernel": f"{dom} on the {kr['n_blocks']}-block residual message chain (100,16)->(100,16) of one layer, {n_e} rows",
+                                   "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                                   "median_launch_ms": kr["times"][dom] * 1e3, "flop_per_launch": kr["flops"][dom],
+                                   "note": "FLOPs of the unpadded (100,16) block (SURVEY.md 8d gcp()); the kernels run the width padded to 128",
+                                   "all_kernels_ms": {k_: v_ * 1e3 for k_, v_ in kr["times"].items()},
+                                   "all_kernels_tflops": {k_: kr["flops"][k_] / v_ / 1e12 for k_, v_ in kr["times"].items()},
+                                   "traffic": None}
+            except Exception as exc:  # noqa: BLE001 -- must not cost the run its headline line
+                rec["roofline_error"] = f"{type(exc).__name__}: {exc}"[:300]
         out[cfg] = rec
         del wl
         torch.cuda.synchronize()
@@ -731,6 +748,8 @@ def main():
                     out["other_configs"] = other_configs_block(G, ops, args)
                 if not args.no_c5_block:
                     out["c5_single_gpu"] = c5_block(G, ops, args)
+                    # the configuration north_star's target sentence is written on, at the top level of the line as well
+                    out["roofline_c5"] = out["c5_single_gpu"].get("roofline")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

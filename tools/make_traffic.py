@@ -59,7 +59,7 @@ res = {"source": f"{root}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFM
        "correction": "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes), WRITE_SIZE as reported; KB x 1024",
        "mfma_busy_frac": {"note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}}
 targets = [("gcp2_chain_bwd_kernel", "", "gcp2_chain_bwd_kernel", None), ("gcp2_chain_fwd_kernel", "", "gcp2_chain_fwd_kernel<4, true, false, false", None),
-           ("tn_gemm_dma_kernel(+reduce)", "", "tn_gemm_dma_kernel", 2), ("gcp_wg_bwd_kernel (256,32)", "_c5", "gcp_wg_bwd_kernel<8, 1, 0, true, 2", None)]
+           ("tn_pipe_kernel(+reduce)", "", "tn_pipe_kernel<4", 2), ("gcp_wg_bwd_kernel (256,32)", "_c5", "gcp_wg_bwd_kernel<8, 1, 0, true, 2", None)]
 for key, suffix, prefix, rank in targets:
     f = pick(load("pmc_FETCH_SIZE" + suffix), prefix, rank).get("FETCH_SIZE")
     w = pick(load("pmc_WRITE_SIZE" + suffix), prefix, rank).get("WRITE_SIZE")
