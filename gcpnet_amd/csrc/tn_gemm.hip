@@ -641,6 +641,10 @@ __global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnA
     float x[NPASS][8];
     int issued = 0;  // chunks requested so far (all passes of a chunk advance together; the pointer stops at the split's last chunk)
     auto load_pass = [&](int ps) {
+        // (the LAST pass is real for one wave only when the B tiles do not divide by the waves -- the ninth / fifth tile: the others
+        // skip its requests.  A branch around loads makes hipcc's later counted waits assume the path without them; behind the last
+        // pass that only lets the one wave with the extra requests wait a little too long)
+        if (ps == NPASS - 1 && NPASS > 2 && !on[ps]) return;
         const int step = (L[ps].kind & 4) ? 4 : L[ps].ld;
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[ps][q] = ptr[ps][q * step];
@@ -704,6 +708,30 @@ __global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnA
         }
     };
 
+    // One tile with ONE set of B fragment registers: the products are ordered so that a term's registers retire early (bl after the
+    // first product, bm after the third) and take the next tile's term at once -- the LDS latency of the next tile's fragments is
+    // spent under this tile's remaining MFMAs without a second register set (UT == 1; the sums still run small terms first)
+    auto mul_rot = [&](int k, const gcp_u32x4 (&a3)[MT][3], gcp_u32x4 (&bt)[3], const gcp_u32x4* pl, bool more) {
+        if (k < my_n) {  // (wave-uniform)
+            const gcp_u32x4* pn = pl + ((AT + min(g + G * min(k + 1, NT - 1), ntiles - 1)) * 3) * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][0], bt[2], acc[m][k]);
+            if (more) { bt[2] = pn[128]; __builtin_amdgcn_sched_barrier(0); }  // (pinned: hipcc otherwise sinks the request behind the tile's last product)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][1], bt[1], acc[m][k]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][0], bt[1], acc[m][k]);
+            if (more) { bt[1] = pn[64]; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][2], bt[0], acc[m][k]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][1], bt[0], acc[m][k]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][0], bt[0], acc[m][k]);
+            if (more) bt[0] = pn[0];
+        }
+    };
+
     // prologue: chunk 0 requested, split into planes[0]; chunk 1 requested
     if (nchunks > 0) {
 #pragma unroll
@@ -742,6 +770,8 @@ __global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnA
             if (DBUF) {
                 if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[(k + 1) & 1]);
                 mul_group(k, a3, bt[DBUF ? (k & 1) : 0]);
+            } else if (UT == 1) {
+                mul_rot(k, a3, bt[0][0], pl, k + 1 < NG);
             } else {
                 mul_group(k, a3, bt[0]);
                 if (k + 1 < NG) read_b(pl, (k + 1) * UT, bt[0]);  // (behind the group's last MFMA issue; the SIMD's other waves cover the LDS latency)
