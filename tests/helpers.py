@@ -27,6 +27,12 @@ def close(a, b, atol=1e-6, rtol=1e-5):
     err = (a.double() - b.double()).abs()
     tol = atol + rtol * b.double().abs()
     worst = (err - tol).max().item() if err.numel() else -1.0
+    rep = os.environ.get("GCPNET_PARITY_REPORT")  # (tools/parity_table.py: what every comparison of a run actually achieved)
+    if rep and err.numel():
+        unit = (err / (1e-5 + 1e-5 * b.double().abs())).max().item()  # in units of the north_star tolerance (1e-5 abs + 1e-5 rel)
+        with open(rep, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{tuple(a.shape)}\t{err.max().item():.3e}\t"
+                    f"{b.abs().max().item():.3e}\t{atol:g}\t{rtol:g}\t{unit:.3f}\n")
     assert worst <= 0, f"max abs err {err.max().item():.3e} (scale {b.abs().max().item():.3e})"
 
 

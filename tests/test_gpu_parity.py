@@ -223,8 +223,8 @@ def test_gcp2_ragged_vs_oracle(G, rows, dims_in, dims_out, bott):
     ws, wv = O.gcp2(P, "", s, v, ei, fr, nonlinearities=("silu", None))
     sg, vg = s.detach().cuda().requires_grad_(), v.detach().cuda().requires_grad_()
     gs, gv = mod((sg, vg), ei.cuda(), fr.cuda())
-    close(gs.detach().cpu(), ws.detach(), atol=2e-5, rtol=2e-5)
-    close(gv.detach().cpu(), wv.detach(), atol=2e-5, rtol=2e-5)
+    close(gs.detach().cpu(), ws.detach(), atol=1e-5, rtol=1e-5)
+    close(gv.detach().cpu(), wv.detach(), atol=1e-5, rtol=1e-5)
     sq_loss(ws, wv).backward()
     sq_loss(gs, gv).backward()
     close(sg.grad.cpu(), s.grad, **GRAD)
@@ -263,10 +263,10 @@ def test_message_passing_golden(G):
     ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
     ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
     msg = mp.message((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
-    close(msg.detach().cpu(), f.o["messages"], atol=2e-5, rtol=2e-5)
+    close(msg.detach().cpu(), f.o["messages"], atol=1e-5, rtol=1e-5)
     s, v = mp((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
-    close(s.detach().cpu(), f.o["s"], atol=2e-5, rtol=2e-5)
-    close(v.detach().cpu(), f.o["v"], atol=2e-5, rtol=2e-5)
+    close(s.detach().cpu(), f.o["s"], atol=1e-5, rtol=1e-5)
+    close(v.detach().cpu(), f.o["v"], atol=1e-5, rtol=1e-5)
     sq_loss(s, v).backward()
     for k, t in ins.items():
         close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=5e-4)
@@ -285,10 +285,10 @@ def test_message_passing_ablations_golden(G, flag):
     ins = {k: f.i[k].cuda().requires_grad_() for k in ("h", "chi", "e", "xi")}
     ei, fr = f.i["edge_index"].cuda(), f.i["frames"].cuda()
     msg = mp.message((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
-    close(msg.detach().cpu(), f.o["messages"], atol=2e-5, rtol=2e-5)
+    close(msg.detach().cpu(), f.o["messages"], atol=1e-5, rtol=1e-5)
     s, v = mp((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
-    close(s.detach().cpu(), f.o["s"], atol=2e-5, rtol=2e-5)
-    close(v.detach().cpu(), f.o["v"], atol=2e-5, rtol=2e-5)
+    close(s.detach().cpu(), f.o["s"], atol=1e-5, rtol=1e-5)
+    close(v.detach().cpu(), f.o["v"], atol=1e-5, rtol=1e-5)
     if flag == "ablate_scalars":
         assert float(s.detach().abs().max()) == 0.0
     else:
@@ -316,7 +316,7 @@ def test_interactions_golden(G, name):
         h, chi = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
         outs = dict(h=h, chi=chi)
     for k, t in outs.items():
-        close(t.detach().cpu(), f.o[k], atol=2e-5, rtol=2e-5)
+        close(t.detach().cpu(), f.o[k], atol=1e-5, rtol=1e-5)
     sq_loss(*outs.values()).backward()
     for k, t in ins.items():
         close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=1e-3)
@@ -396,7 +396,7 @@ def test_interactions_masked_and_autoregressive_golden(G, name):
         t = t.detach().cpu()
         fin = torch.isfinite(f.o[k])
         assert torch.equal(torch.isfinite(t), fin), k
-        close(t[fin], f.o[k][fin], atol=2e-5, rtol=2e-5)
+        close(t[fin], f.o[k][fin], atol=1e-5, rtol=1e-5)
     if upd:
         fin = torch.isfinite(outs["x"]).all(dim=1)
         loss = sq_loss(outs["h"], outs["chi"], outs["x"][fin])
@@ -477,7 +477,7 @@ def test_interactions2_golden(G, name):
         h, chi = layer((ins["h"], ins["chi"]), (ins["e"], ins["xi"]), ei, fr)
         outs = dict(h=h, chi=chi)
     for k, t in outs.items():
-        close(t.detach().cpu(), f.o[k], atol=2e-5, rtol=2e-5)
+        close(t.detach().cpu(), f.o[k], atol=1e-5, rtol=1e-5)
     sq_loss(*outs.values()).backward()
     for k, t in ins.items():
         close(t.grad.cpu(), f.g[k], atol=1e-5, rtol=1e-3)
@@ -512,7 +512,7 @@ def test_interactions2_large_vs_oracle(G, upd):
     wl = [want[0][0], want[0][1], want[1]] if upd else list(want)
     gl = [got[0][0], got[0][1], got[1]] if upd else list(got)
     for a, b in zip(gl, wl):
-        close(a.detach().cpu(), b.detach(), atol=2e-5 * max(1.0, float(b.detach().abs().max())), rtol=2e-5)
+        close(a.detach().cpu(), b.detach(), atol=1e-5 * max(1.0, float(b.detach().abs().max())), rtol=1e-5)
     lw = [torch.randn(t.shape, generator=g) for t in wl]
     sum((t * w).sum() for t, w in zip(wl, lw)).backward()
     sum((t * w.cuda()).sum() for t, w in zip(gl, lw)).backward()
@@ -533,8 +533,8 @@ def test_interactions_prenorm_silu_golden(G):
     layer.load_state_dict(f.p)
     i = {k: v.cuda() for k, v in f.i.items()}
     h, chi = layer((i["h"], i["chi"]), (i["e"], i["xi"]), i["edge_index"], i["frames"])
-    close(h.cpu(), f.o["h"], atol=2e-5, rtol=2e-5)
-    close(chi.cpu(), f.o["chi"], atol=2e-5, rtol=2e-5)
+    close(h.cpu(), f.o["h"], atol=1e-5, rtol=1e-5)
+    close(chi.cpu(), f.o["chi"], atol=1e-5, rtol=1e-5)
 
 
 def _check_step_grads(f, model, leaves):
@@ -610,8 +610,8 @@ def test_interactions_large_vs_oracle(G, n, e, dims, act):
                                 O.default_module_cfg(scalar_nonlinearity=act, nonlinearities=(act, None)), O.default_layer_cfg())
     gi = {k: t.cuda().requires_grad_() for k, t in ins.items()}
     gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
-    close(gh.detach().cpu(), wh.detach(), atol=2e-5, rtol=2e-5)
-    close(gc.detach().cpu(), wc.detach(), atol=2e-5, rtol=2e-5)
+    close(gh.detach().cpu(), wh.detach(), atol=1e-5, rtol=1e-5)
+    close(gc.detach().cpu(), wc.detach(), atol=1e-5, rtol=1e-5)
     # a random linear functional of the outputs: |LayerNorm(x)|^2 is constant for gamma = 1, beta = 0, so a squared loss on
     # this post-norm layer would have (analytically) zero gradient through the scalar path and only compare round-off
     lh, lc = torch.randn(wh.shape, generator=g), torch.randn(wc.shape, generator=g)
