@@ -999,7 +999,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         bool rest_dma = true;
         for (int i = 0; i < n_problems; ++i) {
             const gcp_tn_problem_t& P = problems[i];
-            const bool ok = P.rows > 0 && (P.splits & 1) == 0 && stream_ok(P.a) && stream_ok(P.b);
+            const bool ok = P.rows > 0 && (P.splits & 1) == 0 && P.a.n > 0 && P.b.n > 0 && stream_ok(P.a) && stream_ok(P.b);  // (n > 0: a lane without a column of its own reads segment 0)
             const bool is_wide = ok && a.M[i] > Narrow::BM;  // (M <= 128 with a wide N: column blocks of the narrow kernel, the thin A re-read)
             TnArgs& d = !ok ? rest : (is_wide ? wide : narrow);
             const int k = d.n++;

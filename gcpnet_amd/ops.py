@@ -1672,11 +1672,10 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
         rows = spec.s_plans[0].rows if spec.s_plans[0] is not None else s_sources[0].shape[0]
         wide = _too_wide(spec, s_sources, rows)
         if wide is not None:
-            # scalar_out is linear, so leading columns of the widest source can go through a plain library GEMM and enter as
-            # an addend; the kernel reduces over the remaining columns.  Done (a) when the 32 x (si + H + 9) merged tile of a
-            # wave does not fit in LDS (the second feed-forward GCP at (256,32): 1024 scalar inputs) and (b) for launches of
-            # few rows (node rows: 313 wave-tiles for 1024 SIMDs), where the wave-per-tile kernel is latency-bound on its
-            # serial k loop while the library GEMM spreads the same FLOPs over the whole chip.
+            # scalar_out is linear, so leading columns of the widest source can go through the workgroup kernel's plain-Linear form
+            # and enter as an addend; the block kernel reduces over the remaining columns.  Done when the 32 x (si + H + 9) merged
+            # tile of a wave does not fit in LDS (the second feed-forward GCP at (256,32): 1024 scalar inputs).  (The same split for
+            # launches of few rows -- measured at 10 000 node rows in round 3: no gain -- is gone.)
             k, cut = wide
             w_scalar = weights[0]
             dims = [t.shape[1] for t in s_sources]
@@ -1688,21 +1687,7 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
             s_sources = list(s_sources[:k]) + [right] + list(s_sources[k + 1:])
             spec = replace(spec, si=spec.si - cut, pack_cache=None, add_plans=[spec.s_plans[k]])
             weights = (w_rest,) + tuple(weights[1:])
-            vadds = []
-            if _head_shaped_after_split(spec, s_sources, v_sources, rows):
-                # few rows and a block that then fits the register-resident head kernel (so <= 128): project all but four
-                # vector channels as well ([n, 3, V] x [V, H + 3] at the rows themselves, added un-gathered)
-                v = v_sources[0]
-                vc = v.shape[1] - 4
-                w_down, w_frames = weights[2], weights[3]
-                H = spec.hidden
-                hfp = (H + 3 + 3) // 4 * 4
-                wseg = torch.nn.functional.pad(torch.cat([w_down[:, :vc], w_frames[:, :vc]], dim=0), (0, 0, 0, hfp - (H + 3)))
-                vadds = [_ProjectV.apply(v[:, :vc], wseg)]
-                weights = (weights[0], weights[1], w_down[:, vc:].contiguous(), w_frames[:, vc:].contiguous()) + tuple(weights[4:])
-                v_sources = [v[:, vc:].contiguous()]
-                spec = replace(spec, vi=4, vadd_plans=[None])
-            return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, add, *vadds)
+            return _Gcp2.apply(spec, frames, *s_sources, *v_sources, res_s, res_v, *weights, add)
     if proj is not None:
         # "Project, then gather" (see _Gcp2Projected): the shares of GATHERED sources (h[row], h[col] / chi[row], chi[col] in a
         # message GCP, reference gcpnet.py:907-917) in scalar_out / vector_down(.frames) are computed once per source row.
@@ -1713,7 +1698,6 @@ def gcp2(spec: Gcp2Spec, s_sources: Sequence[Tensor], v_sources: Sequence[Tensor
 
 
 PROJECT_GATHERED_SCALARS = True  # module switches (tests compare both paths)
-PROJECT_SMALL_LAUNCHES = False  # measured at 10 000 node rows: no gain (the extra small launches cost what the shorter k loop saves)
 
 
 def _tn_weight_grad(a2d: Tensor, b2d: Tensor) -> Tensor:
@@ -2254,32 +2238,6 @@ def row_gate(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
     return _RowGate.apply(_req(x, "x"), _req(w, "w"), _req(b, "b"))
 
 
-class _ProjectV(torch.autograd.Function):
-    """Q[n, d, x] = sum_c W[x, c] v[n, c, d] for v [n, V, 3], W [HF', V]: [vector_down ; vector_down_frames] applied at the
-    source rows.  Forward and input gradient are plain library GEMMs on the xyz-major copy of v; the weight gradient reduces
-    over the 3 n rows and goes through gcpnet_tn_gemm (a BLAS call without split-K takes ~110 us for it at n = 1e4)."""
-
-    @staticmethod
-    def forward(ctx, v, w):
-        vt = v.transpose(1, 2).contiguous()  # [n, 3, V]
-        ctx.save_for_backward(vt, w)
-        return _rows_matmul_small(vt.view(-1, vt.shape[2]), w.t().contiguous()).view(vt.shape[0], 3, w.shape[0])
-
-    @staticmethod
-    def backward(ctx, dq):
-        vt, w = ctx.saved_tensors
-        dq = _req(dq, "grad")
-        dv = None
-        if ctx.needs_input_grad[0]:  # [n, V, 3] as a strided view of the xyz-major product
-            dv = _rows_matmul_small(dq.view(-1, dq.shape[2]), w.contiguous()).view(dq.shape[0], 3, w.shape[1]).transpose(1, 2)
-        dw = None
-        if ctx.needs_input_grad[1]:
-            n, _, hfp = dq.shape
-            V = vt.shape[2]
-            dw = _tn_weight_grad(dq.reshape(3 * n, hfp), vt.reshape(3 * n, V)) if n > 0 else torch.zeros((hfp, V), dtype=torch.float32, device=dq.device)
-        return dv, dw
-
-
 class _SplitCols(torch.autograd.Function):
     """x [n, w] -> (x[:, :cut] as a view, x[:, cut:] as a contiguous copy).  The backward writes the two gradient pieces into ONE
     fresh [n, w] tensor.  Plain slicing leaves this to autograd, which builds a zero-filled [n, w] tensor per slice and adds them:
@@ -2369,8 +2327,6 @@ class _Project(torch.autograd.Function):
 LDS_LIMIT = 160 * 1024
 
 
-SMALL_LAUNCH_ROWS = 32768  # below this a launch has fewer wave-tiles (rows / 32) than the chip has SIMDs
-SPLIT_KEEP_COLUMNS = 32
 
 
 def _too_wide(spec: Gcp2Spec, s_sources, rows: int):
@@ -2382,22 +2338,11 @@ def _too_wide(spec: Gcp2Spec, s_sources, rows: int):
     dims = [t.shape[1] for t in s_sources]
     k = max(range(len(dims)), key=lambda i: dims[i])
     if need(spec.si) <= LDS_LIMIT:
-        # (only where the remainder then runs in the register-resident head kernel: so <= 128; measured: no gain otherwise)
-        if (PROJECT_SMALL_LAUNCHES and rows <= SMALL_LAUNCH_ROWS and dims[k] >= 3 * SPLIT_KEEP_COLUMNS and dims[k] % 4 == 0
-                and spec.so in (64, 128) and len(s_sources) == 1 and spec.s_plans[0] is None):
-            return k, (dims[k] - SPLIT_KEEP_COLUMNS) // 32 * 32
         return None
     cut = 0
     while cut + 32 < dims[k] and need(spec.si - cut) > LDS_LIMIT // 2:  # leave room for two waves per CU
         cut += 32
     return (k, cut) if cut > 0 and need(spec.si - cut) <= LDS_LIMIT else None
-
-
-def _head_shaped_after_split(spec: Gcp2Spec, s_sources, v_sources, rows: int) -> bool:
-    return (PROJECT_SMALL_LAUNCHES and rows <= SMALL_LAUNCH_ROWS and len(s_sources) == 1 and len(v_sources) == 1
-            and spec.s_plans[0] is None and spec.v_plans[0] is None and spec.so in (64, 128) and spec.si <= 64
-            and spec.vi > 4 and 0 < spec.vo <= 32 and spec.vo % 4 == 0 and spec.use_frames and spec.hidden + 3 <= 32
-            and not spec.vector_residual)
 
 
 PROJECT_GATHERED_VECTORS = True
