@@ -150,6 +150,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// PL: scalar columns per lane (compile-time trip count, see layernorm_bwd_kernel): the row stays in registers between the three
+// passes (sum, variance, output) instead of being re-read from the s_sum it has just been stored to, and every request of the row
+// is in flight before the first wave sum.
+template <int PL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int rows, int sdim, int vdim, const float* __restrict__ s_a,
                                                             const float* __restrict__ s_b,
                                                             const float* __restrict__ v_a,
@@ -162,31 +166,40 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int rows, int sdim, 
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
     const int64_t so = (int64_t)r * sdim;
+    float x[PL];
     float acc = 0.f;
-    for (int j = lane; j < sdim; j += 64) {
-        float x = s_a[so + j];
-        if (s_b) x += s_b[so + j];
-        s_sum[so + j] = x;
-        acc += x;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+        const int j = min(lane + 64 * i, sdim - 1);
+        x[i] = s_a[so + j];
+        if (s_b) x[i] += s_b[so + j];  // (wave-uniform)
     }
-    const float mean = wave_sum(acc) / (float)sdim;
-    float var = 0.f;
-    for (int j = lane; j < sdim; j += 64) {
-        const float d = s_sum[so + j] - mean;
-        var += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)sdim + 1e-5f);
-    for (int j = lane; j < sdim; j += 64) s_out[so + j] = (s_sum[so + j] - mean) * rstd * gamma[j] + beta[j];
-    float vn = 1.f;
-    if (vdim > 0) {
-        const int64_t vo = (int64_t)r * vdim * 3;
-        float q = 0.f;
+    const int64_t vo = (int64_t)r * vdim * 3;
+    float q = 0.f;
+    if (vdim > 0) {  // the vector part's requests before the scalar part's wave sums
         for (int c = lane; c < vdim; c += 64) {
             float x0 = v_a[vo + 3 * c], x1 = v_a[vo + 3 * c + 1], x2 = v_a[vo + 3 * c + 2];
             if (v_b) { x0 += v_b[vo + 3 * c]; x1 += v_b[vo + 3 * c + 1]; x2 += v_b[vo + 3 * c + 2]; }
             v_sum[vo + 3 * c] = x0; v_sum[vo + 3 * c + 1] = x1; v_sum[vo + 3 * c + 2] = x2;
             q += fmaxf(x0 * x0 + x1 * x1 + x2 * x2, 1e-8f);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < PL; ++i)
+        if (lane + 64 * i < sdim) { s_sum[so + lane + 64 * i] = x[i]; acc += x[i]; }
+    const float mean = wave_sum(acc) / (float)sdim;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+        const float d = x[i] - mean;
+        var += lane + 64 * i < sdim ? d * d : 0.f;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)sdim + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < PL; ++i)
+        if (lane + 64 * i < sdim) s_out[so + lane + 64 * i] = (x[i] - mean) * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
+    float vn = 1.f;
+    if (vdim > 0) {
         vn = sqrtf(wave_sum(q) / (float)vdim);
         const float inv = 1.0f / vn;
         for (int i = lane; i < 3 * vdim; i += 64) v_out[vo + i] = v_sum[vo + i] * inv;
@@ -198,6 +211,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int rows, int sdim, 
 // (a wave walks its rows one after the other, each a chain of dependent round trips -- statistics, row, wave sums, store: with 512
 // blocks the 10 000 node rows of configs[1] were five such chains per wave, 51 us for 7 MB; one or two rows per wave up to 4096 blocks)
 static inline int ln_bwd_blocks(int rows) { return min(gcp_cdiv(rows, 4), 4096); }
+// PL: scalar columns per lane, ceil(sdim / 64) rounded up to 1, 2, 4, 8 or 16 -- a compile-time trip count, and NO branch around a
+// load: every request of a row (and the next row's statistics) is in flight before the first wave sum (with a run-time trip count
+// and `if (j < sdim)` around each column hipcc waited for every column on the spot: 341 us for the 100 000 x (256,32) node rows of
+// configs[4], ~0.5 GB of traffic).  Columns past sdim read column sdim - 1 and are masked.
+template <int PL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, int vdim,
                                                             const float* __restrict__ s_sum,
                                                             const float* __restrict__ v_sum,
@@ -209,45 +227,77 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, 
     __shared__ float red[4][2 * 64 * LN_MAX_PER_LANE / 4];  // per-wave column sums, sdim <= 256 per pass
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    float dg[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE];
+    float dg[PL], db[PL], gm[PL];
+    int jc[PL];
+    bool on[PL];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < PL; ++i) {
+        dg[i] = 0.f; db[i] = 0.f;
+        const int j = lane + 64 * i;
+        on[i] = j < sdim; jc[i] = on[i] ? j : sdim - 1;
+        gm[i] = gamma[jc[i]];
+    }
     for (int r = wave; r < rows; r += nwaves) {
         const int64_t so = (int64_t)r * sdim;
         const float mean = stats[(int64_t)r * 3], rstd = stats[(int64_t)r * 3 + 1], vn = stats[(int64_t)r * 3 + 2];
-        float s1 = 0.f, s2 = 0.f;
+        float dy[PL], xs[PL];
 #pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-            const int j = lane + 64 * i;
-            if (j < sdim) {
-                const float dy = d_s_out[so + j], xh = (s_sum[so + j] - mean) * rstd, g = dy * gamma[j];
-                s1 += g; s2 += g * xh;
-                dg[i] += dy * xh; db[i] += dy;
-            }
+        for (int i = 0; i < PL; ++i) { dy[i] = d_s_out[so + jc[i]]; xs[i] = s_sum[so + jc[i]]; }
+        // the vector part's requests too, before anything is waited for (vdim <= 64: at most three pieces of 64 floats per lane)
+        const int64_t vo = (int64_t)r * vdim * 3;
+        float dvv[3], vsv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = min(lane + 64 * i, max(3 * vdim - 1, 0));
+            dvv[i] = vdim > 0 ? d_v_out[vo + idx] : 0.f;
+            vsv[i] = vdim > 0 ? v_sum[vo + idx] : 0.f;
+        }
+        float s1 = 0.f, s2 = 0.f, xh[PL];
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            xh[i] = (xs[i] - mean) * rstd;
+            const float g = on[i] ? dy[i] * gm[i] : 0.f;
+            s1 += g; s2 += g * xh[i];
+            dg[i] += on[i] ? dy[i] * xh[i] : 0.f; db[i] += on[i] ? dy[i] : 0.f;
         }
         s1 = wave_sum(s1) / (float)sdim;
         s2 = wave_sum(s2) / (float)sdim;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-            const int j = lane + 64 * i;
-            if (j < sdim) {
-                const float xh = (s_sum[so + j] - mean) * rstd;
-                d_s[so + j] = rstd * (d_s_out[so + j] * gamma[j] - s1 - xh * s2);
-            }
-        }
+        for (int i = 0; i < PL; ++i)
+            if (on[i]) d_s[so + lane + 64 * i] = rstd * (dy[i] * gm[i] - s1 - xh[i] * s2);
         if (vdim > 0) {
-            const int64_t vo = (int64_t)r * vdim * 3;
-            float dot = 0.f;
-            for (int i = lane; i < 3 * vdim; i += 64) dot += d_v_out[vo + i] * v_sum[vo + i];
-            dot = wave_sum(dot);
-            const float inv = 1.0f / vn;
-            const float coef = dot * inv * inv * inv / (float)vdim;
-            for (int c = lane; c < vdim; c += 64) {
-                const float x0 = v_sum[vo + 3 * c], x1 = v_sum[vo + 3 * c + 1], x2 = v_sum[vo + 3 * c + 2];
-                const float m = (x0 * x0 + x1 * x1 + x2 * x2) > 1e-8f ? coef : 0.f;  // clamp(min=eps) passes no gradient below eps
-                d_v[vo + 3 * c] = d_v_out[vo + 3 * c] * inv - m * x0;
-                d_v[vo + 3 * c + 1] = d_v_out[vo + 3 * c + 1] * inv - m * x1;
-                d_v[vo + 3 * c + 2] = d_v_out[vo + 3 * c + 2] * inv - m * x2;
+            if (vdim <= 64) {
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dot += lane + 64 * i < 3 * vdim ? dvv[i] * vsv[i] : 0.f;
+                dot = wave_sum(dot);
+                const float inv = 1.0f / vn;
+                const float coef = dot * inv * inv * inv / (float)vdim;
+                // per channel: |v|^2 of the channel this element belongs to (its two neighbours sit in the lanes next door or in
+                // the next piece: read back from memory, L1-resident)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int idx = lane + 64 * i;
+                    if (idx < 3 * vdim) {
+                        const int c = idx / 3;
+                        const float x0 = v_sum[vo + 3 * c], x1 = v_sum[vo + 3 * c + 1], x2 = v_sum[vo + 3 * c + 2];
+                        const float m = (x0 * x0 + x1 * x1 + x2 * x2) > 1e-8f ? coef : 0.f;  // clamp(min=eps) passes no gradient below eps
+                        d_v[vo + idx] = dvv[i] * inv - m * vsv[i];
+                    }
+                }
+            } else {
+                float dot = 0.f;
+                for (int i = lane; i < 3 * vdim; i += 64) dot += d_v_out[vo + i] * v_sum[vo + i];
+                dot = wave_sum(dot);
+                const float inv = 1.0f / vn;
+                const float coef = dot * inv * inv * inv / (float)vdim;
+                for (int c = lane; c < vdim; c += 64) {
+                    const float x0 = v_sum[vo + 3 * c], x1 = v_sum[vo + 3 * c + 1], x2 = v_sum[vo + 3 * c + 2];
+                    const float m = (x0 * x0 + x1 * x1 + x2 * x2) > 1e-8f ? coef : 0.f;
+                    d_v[vo + 3 * c] = d_v_out[vo + 3 * c] * inv - m * x0;
+                    d_v[vo + 3 * c + 1] = d_v_out[vo + 3 * c + 1] * inv - m * x1;
+                    d_v[vo + 3 * c + 2] = d_v_out[vo + 3 * c + 2] * inv - m * x2;
+                }
             }
         }
     }
@@ -256,12 +306,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int rows, int sdim, 
     const int w = threadIdx.x >> 6;
     float* mine = part + (int64_t)blockIdx.x * 2 * sdim;
 #pragma unroll
-    for (int i0 = 0; i0 < LN_MAX_PER_LANE; i0 += 4) {
+    for (int i0 = 0; i0 < PL; i0 += 4) {
         if (64 * i0 >= sdim) break;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            red[w][64 * i + lane] = dg[i0 + i];
-            red[w][256 + 64 * i + lane] = db[i0 + i];
+            red[w][64 * i + lane] = i0 + i < PL ? dg[i0 + i < PL ? i0 + i : 0] : 0.f;
+            red[w][256 + 64 * i + lane] = i0 + i < PL ? db[i0 + i < PL ? i0 + i : 0] : 0.f;
         }
         __syncthreads();
         for (int c = threadIdx.x; c < 512; c += 256) {
@@ -402,8 +452,16 @@ extern "C" int gcpnet_layernorm_forward(int rows, int sdim, int vdim, const floa
     if (rows < 0 || sdim <= 0 || vdim < 0 || !s_a || !gamma || !beta || !s_out || !stats || !s_sum) return GCPNET_E_BADARG;
     if (vdim > 0 && (!v_a || !v_out || !v_sum)) return GCPNET_E_BADARG;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)gcp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows,
-                       sdim, vdim, s_a, s_b, v_a, v_b, gamma, beta, s_out, v_out, stats, s_sum, v_sum);
+    if (sdim > 64 * LN_MAX_PER_LANE) return GCPNET_E_UNSUPPORTED;
+    const int pl = gcp_cdiv(sdim, 64);
+#define LN_LAUNCH(PL) hipLaunchKernelGGL(layernorm_fwd_kernel<PL>, dim3((unsigned)gcp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, \
+                                         sdim, vdim, s_a, s_b, v_a, v_b, gamma, beta, s_out, v_out, stats, s_sum, v_sum)
+    if (pl <= 1) LN_LAUNCH(1);
+    else if (pl <= 2) LN_LAUNCH(2);
+    else if (pl <= 4) LN_LAUNCH(4);
+    else if (pl <= 8) LN_LAUNCH(8);
+    else LN_LAUNCH(16);
+#undef LN_LAUNCH
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -427,8 +485,15 @@ extern "C" int gcpnet_layernorm_backward(int rows, int sdim, int vdim, const flo
         return err == hipSuccess ? 0 : (int)err;
     }
     const int blocks = ln_bwd_blocks(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, sdim, vdim, s_sum,
-                       v_sum, stats, gamma, d_s_out, d_v_out, d_s, d_v, scratch);
+    const int pl = gcp_cdiv(sdim, 64);
+#define LN_LAUNCH(PL) hipLaunchKernelGGL(layernorm_bwd_kernel<PL>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, sdim, vdim, s_sum, \
+                                         v_sum, stats, gamma, d_s_out, d_v_out, d_s, d_v, scratch)
+    if (pl <= 1) LN_LAUNCH(1);
+    else if (pl <= 2) LN_LAUNCH(2);
+    else if (pl <= 4) LN_LAUNCH(4);
+    else if (pl <= 8) LN_LAUNCH(8);
+    else LN_LAUNCH(16);
+#undef LN_LAUNCH
     GCP_HIP_CHECK_LAUNCH();
     gcp_reduce_job_t job;
     job.parts = scratch; job.n_parts = blocks; job.width = 2 * sdim;
@@ -446,12 +511,21 @@ __global__ __launch_bounds__(256) void rows_matmul_small_kernel(int64_t rows, in
     for (int i = threadIdx.x; i < K * J; i += 256) w[i] = W[i];
     __syncthreads();
     const int64_t total = rows * J;
+    const bool small = total < (1ll << 31);  // (a 64-bit division per output element costs more than the K multiply-adds it serves)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / J;
+        const int64_t r = small ? (int64_t)((unsigned)i / (unsigned)J) : i / J;
         const int j = (int)(i - r * J);
         const float* x = in + r * ld_in;
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[k * J + j], acc);
+        int k = 0;
+        for (; k + 7 < K; k += 8) {  // eight inputs requested before the first is used (same order of the multiply-adds)
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(xv[u], w[(k + u) * J + j], acc);
+        }
+        for (; k < K; ++k) acc = fmaf(x[k], w[k * J + j], acc);
         out[r * ld_out + j] = acc;
     }
 }

@@ -893,6 +893,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
     for (int c = threadIdx.x; c < width; c += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int q = p0;
+        // sixteen rows in flight (the additions keep the order of the four-row loop below: bit-identical sums) -- with four, a group
+        // of 64 parts was sixteen dependent round trips per column: 162 us per launch for the 31 250 per-tile partials of a
+        // (256,32) block on 10^6 rows
+        for (; q + 15 < p1; q += 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = in[(int64_t)(q + u) * width + c];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
+        }
         for (; q + 3 < p1; q += 4) {
             a0 += in[(int64_t)q * width + c];
             a1 += in[(int64_t)(q + 1) * width + c];

@@ -586,7 +586,7 @@ def _gated(spec: Gcp2Spec) -> bool:
 # NMS model step otherwise).  An image built ahead of its use is keyed on the weights' (address, version) like any other: a weight
 # changed again before the block runs, or a block that asks with another column view, just misses again.
 class _WgPackUser:
-    __slots__ = ("cache", "dims", "gated", "segs", "w_scalar", "w_gate", "__weakref__")
+    __slots__ = ("cache", "dims", "gated", "segs", "w_scalar", "w_gate", "epoch", "__weakref__")
 
     # The handle lives in a module's pack cache, i.e. inside the module: copy.deepcopy(model) / torch.save(model) walk over it.  A copy
     # of the module starts without one (its first _pack_wg makes its own); weak references are neither copyable nor picklable.
@@ -625,8 +625,12 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
             _WG_PACK_USERS.add(me)
         me.dims, me.gated, me.segs = dims, todo[0][2], segs
         me.w_scalar, me.w_gate = weakref.ref(w_scalar), (None if w_gate is None else weakref.ref(w_gate))
+        me.epoch = _PACK_EPOCH
+        # others ride along only if they took part in the step before this one: a frozen teacher, a second model or a block that is
+        # no longer called would otherwise be re-packed at every optimizer step -- and, inside a GraphedStep capture, have their
+        # images allocated in the graph's private pool and the extra work baked into every replay
         for u in list(_WG_PACK_USERS):
-            if u is me or "wg_key" not in u.cache:
+            if u is me or "wg_key" not in u.cache or getattr(u, "epoch", -1) < _PACK_EPOCH - 1:
                 continue
             ws2, wg2 = u.w_scalar(), (None if u.w_gate is None else u.w_gate())
             if ws2 is None or (u.w_gate is not None and wg2 is None) or ws2.device != w_scalar.device:
