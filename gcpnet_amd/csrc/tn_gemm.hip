@@ -1,19 +1,19 @@
 // Weight-gradient GEMMs on gfx950: out[m, n] = sum_r A[r, m] * B[r, n], a "TN" GEMM whose reduction axis (rows =
 // edges or nodes, 1e4..1e6) is huge and whose output (a weight matrix, <= 1024 x 1100) is small.
 //
-// The reference gets these from autograd through nn.Linear (src/models/components/gcpnet.py:303-324); here they
-// are explicit.  Decomposition: the row axis is split across workgroups (512 rows each); a workgroup of 4 waves
-// owns a 128 x 160 block of the output, wave w holding m-tile w and up to five 32x32 fp32 accumulators
-// (v_mfma_f32_32x32x2_f32, reduction over row pairs).  Both operands are staged through LDS 32 rows at a time in
-// dense row-major order, which is bank-conflict free for both fragment reads (a fragment reads 32 consecutive
-// floats of one row per lane half).  Fast path: the rows go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round
-// trip), double buffered, one barrier per 32-row chunk, next chunk in flight under the current chunk's MFMAs; each
-// lane's source address is computed per lane, so operands that are concatenations of GATHERED sources
-// ([h_row | e | h_col | norms | frame scalars]) cost nothing extra and are never materialised.  A generic register-
-// staged kernel covers operands the DMA cannot (widths or strides that are not multiples of 4 floats).  Operands can
-// be passed through an activation (applied at fragment read) and carry a column of ones (bias gradients).
-// the row axis is split across workgroups (see tn_rows_per_split).
-// Per-split partial sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).
+// The reference gets these from autograd through nn.Linear (src/models/components/gcpnet.py:303-324); here they are explicit.
+// The row axis is split across workgroups (an even number of splits, 16- or 32-row chunks dealt round-robin); per-split partial
+// sums go to scratch and a second kernel reduces them in a fixed order (deterministic; no atomics).  Products run on the bf16
+// matrix pipe as three-term splits with six products kept (gcp_bf16x3.h: fp32 round-off).  Three kernels, in the order the host
+// function tries them:
+//   * tn_pipe_kernel (round 5; the long comment in front of it): rows HBM -> registers -> ONE split per operand element -> planes
+//     in LDS -> products; 128 x 160 (three workgroups per CU) and 256 x 288 (every operand row read once) instantiations.  Takes
+//     every problem whose operands are plain or tile-blocked segments (+ a column of ones for the bias gradient);
+//   * tn_gemm_dma_kernel (rounds 2 - 4): four waves, 128 x 160 block, rows DMA'd into LDS 32 at a time (global_load_lds_dwordx4,
+//     double buffered), every wave splits what it reads.  Serves operands with ROW GATHERS ([h_row | e | h_col | ...] is never
+//     materialised: each 16-byte piece's source address is computed per lane) or an ACTIVATION on load, and, as MODE 0, plain
+//     fp32-MFMA arithmetic for the tests (GCPNET_TN_FP32);
+//   * tn_gemm_kernel: register-staged, any widths / strides / alignments (what the DMA cannot address).
 #include <mutex>
 #include <cstdlib>
 #include <cstdio>
@@ -53,10 +53,6 @@ inline int tn_rows_per_split_host(int rows) {
     const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, target), TN_RK);
     return r < TN_MIN_ROWS_PER_SPLIT ? TN_MIN_ROWS_PER_SPLIT : r;
 }
-// device side: derived from the problem's split count (whatever the host chose): whole chunks, every row covered
-__host__ __device__ inline int tn_rows_per_split(int rows, int splits) {
-    return gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, splits > 0 ? splits : 1), TN_RK);
-}
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
 constexpr int TN_DMA_LDS_FLOATS = 2 * TN_RK * (TN_BM + TN_BN);
 
@@ -67,7 +63,6 @@ struct TnArgs {
     int mb[GCP_TN_MAX_PROBLEMS], nb[GCP_TN_MAX_PROBLEMS];
     int block_start[GCP_TN_MAX_PROBLEMS + 1];
     int debug;   // measurement knob GCPNET_TN_DEBUG: bit 0 = no products, bit 1 = no DMA after the first chunk (results are then wrong)
-    int cyclic;  // 32-row chunks dealt round-robin to the splits (chunk c of split s = chunk s + c * splits of the operand)
     unsigned long long* stamps;  // profiling hook (gcpnet_debug_set_phase_timing): per workgroup of the pipelined kernels start / end time, HW_ID, XCC_ID
     long long stamp_cap;
 };
@@ -88,19 +83,13 @@ struct BlockWork {
     int r_first, r_step, r_end, nchunks;  // chunk c covers rows r_first + c * r_step .. + 31, cut at r_end
 };
 
-// Rows of a split.  Blocked: one contiguous range per split.  Cyclic (the default): 32-row chunks dealt round-robin, so that the
-// workgroups of a launch, which advance in lockstep, read ONE contiguous window of the operands at any time (splits x 32 rows:
-// every HBM channel busy) instead of `splits` windows a fixed stride apart (which camp on a few channels).
-__device__ __forceinline__ void split_rows(int rows, int splits, int split, bool cyclic, int& r_first, int& r_step, int& r_end, int& nchunks) {
-    if (cyclic) {
-        const int total = gcp_cdiv(rows, TN_RK);
-        r_first = split * TN_RK; r_step = splits * TN_RK; r_end = rows;
-        nchunks = total > split ? gcp_cdiv(total - split, splits) : 0;
-    } else {
-        const int rps = tn_rows_per_split(rows, splits);
-        r_first = split * rps; r_step = TN_RK; r_end = min(rows, r_first + rps);
-        nchunks = r_end > r_first ? gcp_cdiv(r_end - r_first, TN_RK) : 0;
-    }
+// Rows of a split: 32-row chunks dealt round-robin, so that the workgroups of a launch, which advance in lockstep, read ONE contiguous
+// window of the operands at any time (splits x 32 rows: every HBM channel busy) instead of `splits` windows a fixed stride apart
+// (which camp on a few channels; the contiguous-range form of round 3 is gone).
+__device__ __forceinline__ void split_rows(int rows, int splits, int split, int& r_first, int& r_step, int& r_end, int& nchunks) {
+    const int total = gcp_cdiv(rows, TN_RK);
+    r_first = split * TN_RK; r_step = splits * TN_RK; r_end = rows;
+    nchunks = total > split ? gcp_cdiv(total - split, splits) : 0;
 }
 
 __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
@@ -116,7 +105,7 @@ __device__ __forceinline__ BlockWork locate(const TnArgs& a) {
     w.mw = min(TN_BM, a.M[pi] - w.m0);
     w.nw = min(TN_BN, a.N[pi] - w.n0);
     w.ntiles = gcp_cdiv(w.nw, 32);
-    split_rows(P.rows, P.splits, w.split, a.cyclic != 0, w.r_first, w.r_step, w.r_end, w.nchunks);
+    split_rows(P.rows, P.splits, w.split, w.r_first, w.r_step, w.r_end, w.nchunks);
     return w;
 }
 
@@ -950,7 +939,6 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
     if (skip_env) return 0;
     a.debug = getenv("GCPNET_TN_DEBUG") ? atoi(getenv("GCPNET_TN_DEBUG")) : 0;
 #endif
-    a.cyclic = 1;
     int blocks = 0, max_mn = 0;
     bool dma = true;
     for (int i = 0; i < n_problems; ++i) {
@@ -1001,7 +989,6 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         using Wide = TpCfg<8, 1, 9, 1>;
         TnArgs narrow, wide, rest;
         narrow.n = wide.n = rest.n = 0;
-        narrow.cyclic = wide.cyclic = 1; rest.cyclic = a.cyclic;
         narrow.debug = wide.debug = rest.debug = a.debug;
         narrow.stamps = wide.stamps = rest.stamps = a.stamps;
         narrow.stamp_cap = wide.stamp_cap = rest.stamp_cap = a.stamp_cap;

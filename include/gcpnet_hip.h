@@ -344,7 +344,8 @@ typedef struct {
 
 #define GCP_TN_MAX_PROBLEMS 8
 int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream);
-/* scratch floats a problem of this shape needs (splits * M * N) and the split count the library will use */
+/* the split count the library will use for `rows` (always even, >= 2; `splits` of a problem must equal it): a problem needs
+ * splits * M * N floats of scratch in `partial` */
 int gcpnet_tn_splits(int rows, int M, int N);
 
 /* Column sums out[width] = sum_p parts[p, width] in a fixed order (deterministic); tmp holds
