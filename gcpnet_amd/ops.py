@@ -671,7 +671,7 @@ def wg_linear(x: Tensor, W: Tensor, out_dim: int, in_dim: int, col0: int = 0, tr
               bias: Optional[Tensor] = None) -> Optional[Tensor]:
     """x [n, in_dim] @ W'^T -> [n, out_dim] through the workgroup forward kernel (a block without vectors is a plain Linear), with
     W' a view of the stored matrix W [*, ld]: W'[r, c] = W[r, col0 + c], or with `trans` W'[r, c] = W[c, col0 + r] (the input
-    gradient of the former).  Returns None for shapes outside the kernel (the caller then uses a library GEMM)."""
+    gradient of the former).  Returns None for shapes outside the kernel (the callers raise: there is no library GEMM on this path)."""
     lib = _lib.load()
     n = x.shape[0]
     if out_dim % 4 or out_dim < 4 or n == 0 or not x.is_contiguous() or x.shape[1] != in_dim:
