@@ -22,7 +22,7 @@ EXPORTS = [
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
-    "gcpnet_debug_set_phase_timing", "gcpnet_debug_set_fp32_mfma",
+    "gcpnet_debug_set_phase_timing", "gcpnet_debug_set_fp32_mfma", "gcpnet_debug_tn_occupancy",
     "gcpnet_wg_pack_floats", "gcpnet_wg_pack", "gcpnet_wg_pack_view", "gcpnet_wg_forward", "gcpnet_wg_backward_plan", "gcpnet_wg_backward",
     "gcpnet_wg_reduce", "gcpnet_wg_reduce_multi", "gcpnet_dropout", "gcpnet_adam_step", "gcpnet_adam_step_dev", "gcpnet_copy2d_multi", "gcpnet_axpy_clamp_backward", "gcpnet_nms_edge_features", "gcpnet_nms_node_features", "gcpnet_radius_graph", "gcpnet_radius_graph_first", "gcpnet_activation", "gcpnet_frame_gate_forward", "gcpnet_frame_gate_backward",
     "gcpnet_frame_gate_bwd_parts", "gcpnet_node_scalarize", "gcpnet_orientations",
@@ -193,6 +193,7 @@ def load():
     lib.gcpnet_row_gate_bwd_blocks.argtypes = [i64]
     lib.gcpnet_debug_set_phase_timing.argtypes = [vp, i64]
     lib.gcpnet_debug_set_fp32_mfma.argtypes = [i32]
+    lib.gcpnet_debug_tn_occupancy.argtypes = [i32]
     lib.gcpnet_gcp2_chain_forward_registers_ok.argtypes = [i32] * 6
     lib.gcpnet_gcp2_chain_backward_ok.argtypes = [i32] * 6
     lib.gcpnet_tb_floats.argtypes = [i32, i32]

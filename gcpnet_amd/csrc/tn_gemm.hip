@@ -911,7 +911,7 @@ inline bool dma_ok(const gcp_operand_t& o) {
 
 }  // namespace
 
-// resident workgroups per CU of the two pipelined kernels as the runtime sees them (tools/tn_occupancy.py; not part of the ABI header)
+// resident workgroups per CU of the two pipelined kernels as the runtime sees them (include/gcpnet_hip.h; tools/tn_occupancy.py)
 extern "C" int gcpnet_debug_tn_occupancy(int wide) {
     int n = -1;
     const hipError_t err = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tn_pipe_kernel<8, 1, 9, 1>, 512, TpCfg<8, 1, 9, 1>::LDS_FLOATS * sizeof(float))

@@ -571,6 +571,10 @@ int gcpnet_debug_set_fp32_mfma(int on);
  * (GCPNET_DEBUG_SKIP_TN, GCPNET_TN_DEBUG).  The shipped build returns 0; bench.py refuses to produce a line with a 1. */
 int gcpnet_debug_knobs_compiled(void);
 
+/* Resident workgroups per CU of the pipelined weight-gradient GEMM kernels (0: the 128 x 160 form, 1: the 256 x 288 form) as
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor reports them; negative: a HIP error code (tools/tn_occupancy.py). */
+int gcpnet_debug_tn_occupancy(int wide);
+
 int gcpnet_abi_version(void);
 
 #ifdef __cplusplus

@@ -9,5 +9,5 @@ import torch  # noqa: E402,F401
 from gcpnet_amd import _lib  # noqa: E402
 
 torch.zeros(1, device="cuda")
-lib = ctypes.CDLL(_lib.LIB_PATH)
+lib = _lib.load()
 print("narrow (4 waves, 54 KB):", lib.gcpnet_debug_tn_occupancy(0), " wide (8 waves, 102 KB):", lib.gcpnet_debug_tn_occupancy(1))
