@@ -10,4 +10,4 @@ from gcpnet_amd import _lib  # noqa: E402
 
 torch.zeros(1, device="cuda")
 lib = _lib.load()
-print("narrow (4 waves, 54 KB):", lib.gcpnet_debug_tn_occupancy(0), " wide (8 waves, 102 KB):", lib.gcpnet_debug_tn_occupancy(1))
+print("narrow (4 waves, 27 KB):", lib.gcpnet_debug_tn_occupancy(0), " wide (8 waves, 102 KB):", lib.gcpnet_debug_tn_occupancy(1))
