@@ -344,8 +344,9 @@ typedef struct {
 
 #define GCP_TN_MAX_PROBLEMS 8
 int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream);
-/* the split count the library will use for `rows` (always even, >= 2; `splits` of a problem must equal it): a problem needs
- * splits * M * N floats of scratch in `partial` */
+/* the row-split count to give a [rows, M]^T [rows, N] problem (always even, >= 2; fewer for a problem of several output blocks;
+ * M = N = 0: the count for one block).  `splits` of a problem is the caller's to choose (1 .. 4096; an odd count is served by the
+ * earlier kernels): a problem needs splits * M * N floats of scratch in `partial` */
 int gcpnet_tn_splits(int rows, int M, int N);
 
 /* Column sums out[width] = sum_p parts[p, width] in a fixed order (deterministic); tmp holds

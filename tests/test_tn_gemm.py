@@ -89,3 +89,50 @@ def test_bf16_three_term_products_are_fp32_accurate(rows, M, N, earlier, monkeyp
     e_f32 = ((f32 - want).abs() / scale).max().item()
     assert not torch.equal(x3, f32), "the switch must select a different kernel"
     assert e_x3 <= 2 * e_f32 + 2 ** -22, f"three-term {e_x3:.3e} vs fp32 {e_f32:.3e} (of sum |a b|)"
+
+
+@pytest.mark.parametrize("splits", [None, 2, 10, 7, 200])
+@pytest.mark.parametrize("rows", [5007, 64, 33])
+def test_tn_segments_tile_blocked_ones_and_callers_split_count(rows, splits):
+    """One gcpnet_tn_gemm problem through the C ABI with everything the chain's weight gradients use at once: a tile-blocked A
+    operand, a B operand of three segments (tile-blocked | row-major with a row stride | the ones column -> the bias gradient in
+    `out2`), an output narrower than the product (`out_n`), and a split count of the caller's choice (gcpnet_tn_splits only
+    recommends; an odd count is served by the earlier kernels).  Against float64."""
+    import ctypes as C
+
+    from gcpnet_amd import _lib, ops
+    from gcpnet_amd._lib import Operand, TnProblem, check
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows)
+    M, N1, N2, ld2 = 128, 96, 12, 20
+    a = torch.randn(rows, M, generator=g).cuda()
+    b1 = torch.randn(rows, N1, generator=g).cuda()
+    b2w = torch.randn(rows, ld2, generator=g).cuda()           # the segment is its first N2 columns
+    a_tb, b1_tb = ops.TileBlocked.from_rows(a), ops.TileBlocked.from_rows(b1)
+    N = N1 + N2 + 1
+    pr = TnProblem()
+    pr.rows = rows
+    pr.a.n = 1
+    pr.a.ptr[0], pr.a.dim[0], pr.a.ld[0], pr.a.tb[0] = a_tb.data_ptr(), M, M, 1
+    pr.b.n, pr.b.ones = 2, 1
+    pr.b.ptr[0], pr.b.dim[0], pr.b.ld[0], pr.b.tb[0] = b1_tb.data_ptr(), N1, N1, 1
+    pr.b.ptr[1], pr.b.dim[1], pr.b.ld[1], pr.b.tb[1] = b2w.data_ptr(), N2, ld2, 0
+    out = torch.full((M, N - 1), float("nan"), device="cuda")
+    bias = torch.full((M,), float("nan"), device="cuda")
+    pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = out.data_ptr(), N - 1, 1, M, N - 1
+    pr.out2, pr.out2_n = bias.data_ptr(), N - 1
+    pr.splits = splits if splits is not None else lib.gcpnet_tn_splits(rows, M, N)
+    part = torch.empty((pr.splits, M, N), device="cuda")
+    pr.partial = part.data_ptr()
+    check(lib.gcpnet_tn_gemm(1, C.byref(pr), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tn_gemm")
+    torch.cuda.synchronize()
+    bfull = torch.cat([b1, b2w[:, :N2]], dim=1).cpu().double()
+    want = a.cpu().double().t() @ bfull
+    want_bias = a.cpu().double().sum(0)
+    tol = 2e-6 * float(want.abs().max()) + 1e-5 * rows ** 0.5
+    assert (out.cpu().double() - want).abs().max().item() <= tol
+    assert (bias.cpu().double() - want_bias).abs().max().item() <= tol
+    bad = TnProblem.from_buffer_copy(pr)
+    bad.splits = 0
+    assert lib.gcpnet_tn_gemm(1, C.byref(bad), None) != 0, "a split count below 1 is refused"

@@ -11,7 +11,9 @@ from gcpnet_amd import ops  # noqa: E402
 
 MIX = {"c2": (159913, [(128, 144), (16, 128)]), "c5": (999995, [(256, 276), (32, 256)]), "c3": (199746, [(100, 128), (16, 100)]),
        "c2n": (10000, [(512, 144), (128, 532)]), "c5n": (100000, [(1024, 276), (256, 896)]),
-       "c2s": (159913, [(128, 144)]), "c2g": (159913, [(16, 128)]), "c5s": (999995, [(256, 276)]), "c5g": (999995, [(32, 256)])}
+       "c2s": (159913, [(128, 144)]), "c2g": (159913, [(16, 128)]), "c5s": (999995, [(256, 276)]), "c5g": (999995, [(32, 256)]),
+       "c1": (2000, [(128, 144), (16, 128)]), "c1n": (500, [(512, 144), (128, 532)]),
+       "c4": (38000, [(128, 144), (16, 128)]), "c4n": (2000, [(512, 144), (128, 532)])}
 for name in (sys.argv[1:] or ["c2", "c5"]):
     rows, shapes = MIX[name]
     items = []
