@@ -48,9 +48,9 @@ constexpr int TN_BM = 128, TN_BN = 160, TN_RK = GCP_TN_RK;
 // profiles/r03_tn_bf16x3.txt).
 constexpr int TN_TARGET_SPLITS = 128, TN_MIN_ROWS_PER_SPLIT = 64;
 // host side: rows per split for the target split count (GCPNET_TN_SPLITS overrides the 128: a tuning knob)
-inline int tn_rows_per_split_host(int rows, int divide = 1) {
+inline int tn_rows_per_split_host(int rows) {
     static const int target = getenv("GCPNET_TN_SPLITS") && atoi(getenv("GCPNET_TN_SPLITS")) > 0 ? atoi(getenv("GCPNET_TN_SPLITS")) : TN_TARGET_SPLITS;
-    const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, target / divide > 0 ? target / divide : 1), TN_RK);
+    const int r = gcp_round_up(gcp_cdiv(rows > 0 ? rows : 1, target), TN_RK);
     return r < TN_MIN_ROWS_PER_SPLIT ? TN_MIN_ROWS_PER_SPLIT : r;
 }
 constexpr int TN_LDA = TN_BM + 1, TN_LDB = TN_BN + 1;  // generic path: padded strides
@@ -922,16 +922,12 @@ extern "C" int gcpnet_debug_tn_occupancy(int wide) {
 extern "C" int gcpnet_tn_splits(int rows, int M, int N) {
     // The row-split count to launch a [rows, M]^T [rows, N] problem with (the caller sizes `partial` by it; gcpnet_tn_gemm takes any
     // count).  Even: a split's 16-row chunks then keep their position inside the 32-row tiles of a tile-blocked operand
-    // (tn_pipe_kernel).  A problem of several output blocks fills the CUs with fewer splits per block, and every split costs an
-    // M x N partial written and read again: 128 splits for one block, 64 for two, 32 from four on (the feed-forward GCPs' weight
-    // gradients, 10^4 rows of (512,144) / (128,532): 0.188 -> 0.126 ms per eight problems, profiles/r05_tn_splits_sweep.txt; M = N = 0: one block)
-    if (rows <= 0) return 2;
-    int rps = tn_rows_per_split_host(rows);
-    if (M > 0 && N > 0) {
-        const int blocks = M > TN_BM ? gcp_cdiv(M, 256) * gcp_cdiv(N, 288) : gcp_cdiv(N, TN_BN);
-        if (blocks > 1) rps = max(rps, tn_rows_per_split_host(rows, blocks >= 4 ? 4 : 2));
-    }
-    return gcp_round_up(gcp_cdiv(rows, rps), 2);
+    // (tn_pipe_kernel).  By rows only: fewer splits for a problem of several output blocks (fewer M x N partials to write and sum)
+    // win when eight such problems share a launch (10^4 rows of (512,144) / (128,532): 0.188 -> 0.126 ms,
+    // profiles/r05_tn_splits_sweep.txt) and lose in the step, where the feed-forward GCPs' launches carry one or two problems and
+    // 32 splits x 4 blocks leave half the CUs without a workgroup (configs[4] 191.6 -> 192.7 ms, same box)
+    (void)M; (void)N;
+    return rows <= 0 ? 2 : gcp_round_up(gcp_cdiv(rows, tn_rows_per_split_host(rows)), 2);
 }
 
 extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream) {
@@ -1137,8 +1133,9 @@ extern "C" int64_t gcpnet_gcp2_weight_grads_workspace(int n, const gcp2_wgrad_jo
     for (int i = 0; i < n; ++i) {
         const gcp2_wgrad_job_t& J = jobs[i];
         const WgradDims d = wgrad_dims(J);
-        fl += (int64_t)gcpnet_tn_splits(J.rows, J.so, d.n1) * J.so * d.n1;
-        if (d.gated) fl += (int64_t)gcpnet_tn_splits(J.rows, d.VOP, J.so + 1) * d.VOP * (J.so + 1);
+        const int64_t splits = gcpnet_tn_splits(J.rows, 0, 0);
+        fl += splits * J.so * d.n1;
+        if (d.gated) fl += splits * d.VOP * (J.so + 1);
         if (d.has_vec && J.w_part) fl += (int64_t)gcpnet_reduce_partials_groups(J.n_parts) * J.w_width;
     }
     return fl;
@@ -1171,8 +1168,8 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
     for (int i = 0; i < n; ++i) {
         const gcp2_wgrad_job_t& J = jobs[i];
         const WgradDims d = wgrad_dims(J);
+        const int splits = gcpnet_tn_splits(J.rows, 0, 0);
         {   // d scalar_out.weight | bias: ds_pre^T [s segments | ext | 1]
-            const int splits = gcpnet_tn_splits(J.rows, J.so, d.n1);
             gcp_tn_problem_t& P = probs[np++];
             P = gcp_tn_problem_t{};
             P.rows = J.rows;
@@ -1201,7 +1198,6 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
             P.b.act = J.act_v; P.b.ones = 1;
             P.out = J.d_w_gate; P.out_sm = J.so; P.out_sn = 1; P.out_m = J.vo; P.out_n = J.so;
             P.out2 = J.d_b_gate; P.out2_n = J.so;
-            const int splits = gcpnet_tn_splits(J.rows, d.VOP, J.so + 1);
             P.splits = splits;
             P.partial = ws;
             ws += (int64_t)splits * d.VOP * (J.so + 1);

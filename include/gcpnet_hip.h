@@ -344,9 +344,9 @@ typedef struct {
 
 #define GCP_TN_MAX_PROBLEMS 8
 int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, void* stream);
-/* the row-split count to give a [rows, M]^T [rows, N] problem (always even, >= 2; fewer for a problem of several output blocks;
- * M = N = 0: the count for one block).  `splits` of a problem is the caller's to choose (1 .. 4096; an odd count is served by the
- * earlier kernels): a problem needs splits * M * N floats of scratch in `partial` */
+/* the row-split count the library recommends for a [rows, M]^T [rows, N] problem (always even, >= 2; by `rows` only at present).
+ * `splits` of a problem is the caller's to choose (1 .. 4096; an odd count is served by the earlier kernels): a problem needs
+ * splits * M * N floats of scratch in `partial` */
 int gcpnet_tn_splits(int rows, int M, int N);
 
 /* Column sums out[width] = sum_p parts[p, width] in a fixed order (deterministic); tmp holds

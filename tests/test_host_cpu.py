@@ -38,10 +38,7 @@ def test_host_only_entry_points():
     assert lib.gcpnet_tn_splits(160000, 128, 142) == 126
     assert lib.gcpnet_debug_knobs_compiled() == 0  # the shipped build carries no result-changing measurement knob
     assert lib.gcpnet_tn_splits(0, 1, 1) == 2
-    # a problem of several output blocks takes fewer splits per block: two blocks (M = 512: two 256-row blocks) ~64, four or more ~32
-    assert lib.gcpnet_tn_splits(160000, 0, 0) == 126
-    assert lib.gcpnet_tn_splits(10000, 512, 145) == 64 and lib.gcpnet_tn_splits(10000, 128, 533) == 32
-    assert lib.gcpnet_tn_splits(100000, 1024, 277) == 32 and lib.gcpnet_tn_splits(100000, 256, 897) == 32
+    assert lib.gcpnet_tn_splits(160000, 0, 0) == 126 and lib.gcpnet_tn_splits(10000, 512, 145) == 106  # (by rows only: 96 rows per split)
     # packed image of a chainable block: the fp32 sections + the three-term bf16 sections B6 / F6 / C6 (csrc/gcp_bf16x3.h):
     # (128,16,H=4): NTG = 4, NKT = 5 -> 2*4*5*768 + 2*4*4*768 + 2*4*768 floats on top
     base = lambda si, vi, so, vo, H: lib.gcpnet_gcp2_pack_floats(si, vi, so, vo, H, 1)
