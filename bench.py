@@ -602,7 +602,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL, the contract's command)
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching under torch.distributed.run\n")
+        os.execv(sys.executable, cmd)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"bench.py --gpus {args.gpus} ...` (or run `python bench.py --gpus {args.gpus}` without WORLD_SIZE set: it re-launches itself)")
     # test hooks (a 1-GPU box can rehearse the N > 1 code path): BENCH_SHARE_GPU=1 puts every rank on cuda:0,
     # BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
     if os.environ.get("BENCH_SHARE_GPU") == "1":

@@ -1021,7 +1021,13 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         }
         narrow.block_start[narrow.n] = nblocks; wide.block_start[wide.n] = wblocks; rest.block_start[rest.n] = rblocks_;
         constexpr size_t n_lds = (size_t)Narrow::LDS_FLOATS * sizeof(float), w_lds = (size_t)Wide::LDS_FLOATS * sizeof(float);
-        static bool tp_configured = false;
+        // (the attribute is per device: one flag per device ordinal, written once under a mutex)
+        static std::mutex tp_mu;
+        static bool tp_configured_dev[64] = {};
+        int tp_dev = 0;
+        if (hipGetDevice(&tp_dev) != hipSuccess || tp_dev < 0 || tp_dev >= 64) tp_dev = 0;
+        std::lock_guard<std::mutex> tp_lock(tp_mu);
+        bool& tp_configured = tp_configured_dev[tp_dev];
         if (!tp_configured) {
             hipError_t err = hipFuncSetAttribute((const void*)tn_pipe_kernel<4, 1, 5, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_lds);
             if (err == hipSuccess)

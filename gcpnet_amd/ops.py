@@ -406,6 +406,17 @@ def _opts_struct(spec: Gcp2Spec, fused_residual: bool = False) -> Gcp2Opts:
 
 
 _PACK_EPOCH = 0
+# Which epoch the uses of the step before the current one fell into (the batched re-pack of _pack_wg lets only blocks that were
+# used then ride along).  An epoch may advance more than once per optimizer step (FusedAdam plus an EMA swap): the first use after
+# any number of invalidations closes the previous "use epoch".
+_LAST_USE_EPOCH = 0
+_PREV_USE_EPOCH = 0
+
+
+def _note_pack_use() -> None:
+    global _LAST_USE_EPOCH, _PREV_USE_EPOCH
+    if _LAST_USE_EPOCH != _PACK_EPOCH:
+        _PREV_USE_EPOCH, _LAST_USE_EPOCH = _LAST_USE_EPOCH, _PACK_EPOCH
 
 
 def _dense_weights(spec: Gcp2Spec, w):
@@ -612,7 +623,11 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
     segs = None if view is None else tuple(view[1])
     key = _wg_pack_key(segs, w_scalar, w_gate)
     cache = spec.pack_cache
+    _note_pack_use()
     if cache is not None and cache.get("wg_key") == key:
+        me = cache.get("wg_user")
+        if me is not None:
+            me.epoch = _PACK_EPOCH  # "asked for in this epoch" -- also when the image was built ahead by another block's miss
         return cache["wg_pack"]
     dims = (spec.si, spec.vi, spec.so, spec.vo, spec.hidden, int(spec.use_frames))
     # (cache, dims, gated, column view, scalar weight matrix, gate weight, key) of every image this launch builds; the asked one first
@@ -630,7 +645,7 @@ def _pack_wg(spec: Gcp2Spec, w) -> Tensor:
         # no longer called would otherwise be re-packed at every optimizer step -- and, inside a GraphedStep capture, have their
         # images allocated in the graph's private pool and the extra work baked into every replay
         for u in list(_WG_PACK_USERS):
-            if u is me or "wg_key" not in u.cache or getattr(u, "epoch", -1) < _PACK_EPOCH - 1:
+            if u is me or "wg_key" not in u.cache or getattr(u, "epoch", -1) < _PREV_USE_EPOCH:
                 continue
             ws2, wg2 = u.w_scalar(), (None if u.w_gate is None else u.w_gate())
             if ws2 is None or (u.w_gate is not None and wg2 is None) or ws2.device != w_scalar.device:
@@ -674,8 +689,10 @@ def wg_linear(x: Tensor, W: Tensor, out_dim: int, in_dim: int, col0: int = 0, tr
     gradient of the former).  Returns None for shapes outside the kernel (the callers raise: there is no library GEMM on this path)."""
     lib = _lib.load()
     n = x.shape[0]
-    if out_dim % 4 or out_dim < 4 or n == 0 or not x.is_contiguous() or x.shape[1] != in_dim:
+    if out_dim % 4 or out_dim < 4 or not x.is_contiguous() or x.shape[1] != in_dim:
         return None
+    if n == 0:  # (a rank of the one-graph sharding without local rows: nothing to launch)
+        return x.new_empty((0, out_dim))
     spec = Gcp2Spec(si=in_dim, vi=0, so=out_dim, vo=0, hidden=0, use_frames=False, act_s=None, act_v=None, slope=0.0,
                     vmode=VMODE_NONE, vector_residual=False, e3=False, s_plans=[None], v_plans=[])
     dev = x.device
@@ -1729,10 +1746,12 @@ def _rows_matmul_small(x2d: Tensor, w: Tensor) -> Tensor:
     """x2d [rows, K] @ w [K, J]: gcpnet_rows_matmul_small for a tiny w, the workgroup kernel's plain-Linear form otherwise."""
     K, J = w.shape
     if K * J > 4096:
-        out = wg_linear(x2d.contiguous(), w, J, K, trans=True)
+        pad = (-J) % 4  # (the workgroup kernel's output width is a multiple of 4: zero columns for the launch, sliced back)
+        wp = w if not pad else torch.nn.functional.pad(w, (0, pad))
+        out = wg_linear(x2d.contiguous(), wp, J + pad, K, trans=True)
         if out is None:
             raise _lib.GcpnetHipError(f"rows x [{K}, {J}] product outside the HIP kernels' shapes (no library fallback)")
-        return out
+        return out if not pad else out[:, :J]
     lib = _lib.load()
     x2d = _req(x2d, "rows")
     out = torch.empty((x2d.shape[0], J), dtype=torch.float32, device=x2d.device)
@@ -2027,7 +2046,10 @@ class _Linear(torch.autograd.Function):
             if dx is None:
                 raise _lib.GcpnetHipError("Linear adjoint outside the workgroup kernel's shapes (no library fallback)")
         dw = db = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and x.shape[0] == 0:
+            dw = torch.zeros((so, dim), dtype=torch.float32, device=g.device)
+            db = torch.zeros((so,), dtype=torch.float32, device=g.device)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             n = x.shape[0]
             a, b = Operand(), Operand()
             a.n, b.n = 1, 1

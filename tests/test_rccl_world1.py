@@ -101,3 +101,70 @@ def test_rccl_branches_with_one_rank():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", JOB], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+DDP_JOB = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["GCP_REPO"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import gcpnet_amd as G
+from gcpnet_amd import ops
+from tests.helpers import rand_graph
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+class Stack(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(G.GCPInteractions((64, 16), (32, 4), cfg=G.default_module_cfg(scalar_nonlinearity="silu"),
+                                                            layer_cfg=G.default_layer_cfg(), dropout=0.0) for _ in range(2))
+    def forward(self, h, chi, e, xi, ei, fr):
+        for l in self.layers:
+            h, chi = l((h, chi), (e, xi), ei, fr)
+        return h, chi
+
+torch.manual_seed(0)
+n, e = 200, 2400
+model = Stack().cuda().train()
+ei, x = rand_graph(n, e, 3, sort_by_col=True)
+g = torch.Generator().manual_seed(1)
+ins = [torch.randn(n, 64, generator=g).cuda(), torch.randn(n, 16, 3, generator=g).cuda(), torch.randn(e, 32, generator=g).cuda(),
+       torch.randn(e, 4, 3, generator=g).cuda()]
+lw = [torch.randn(n, 64, generator=g).cuda(), torch.randn(n, 16, 3, generator=g).cuda()]
+fr = G.localize(x.cuda(), ei.cuda())
+def run(m):
+    for p in model.parameters():
+        p.grad = None
+    h, chi = m(*ins, ei.cuda(), fr)
+    ((h * lw[0]).sum() + (chi * lw[1]).sum()).backward()
+    torch.cuda.synchronize()
+    return [p.grad.clone() for p in model.parameters()]
+want = run(model)  # unwrapped (no process-group consumer of the gradients: the weight-gradient stream may be used)
+ddp = DDP(model, device_ids=[0])  # what the reference's trainer does (configs/trainer/default.yaml:8, ddp.yaml)
+for side in (True, False):
+    ops.WEIGHT_GRADS_ON_SIDE_STREAM = side
+    got = run(ddp)
+    for (name, _), a, b in zip(model.named_parameters(), got, want):
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= 1e-6 * max(scale, 1.0), f"side stream {side}: {name}: {err:.3e} (scale {scale:.3e})"
+dist.barrier()
+dist.destroy_process_group()
+print("DDP_WORLD1_OK")
+"""
+
+
+def test_distributed_data_parallel_wrapper_gets_the_unwrapped_gradients():
+    """INTEGRATION.md says the mirror works under torch's DistributedDataParallel, which is what the reference's trainer uses
+    (configs/trainer/default.yaml:8): DDP's bucket hooks read every weight gradient INSIDE the backward pass, so the weight-gradient
+    stream must stand down by itself (ops._side_stream_ok).  One rank over RCCL; gradients must equal the unwrapped model's with the
+    side-stream switch on and off."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GCP_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", DDP_JOB], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

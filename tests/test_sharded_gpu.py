@@ -199,3 +199,21 @@ def test_bench_two_ranks_on_one_gpu_prints_its_line(extra):
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["scaling"] == ("strong" if extra else "weak")
     assert line["rccl"]["world"] == 2 and line["rccl"]["fallback"] is None
+
+
+def test_bench_gpus_2_without_a_launcher_relaunches_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's 1-GPU command with another N) must not
+    die on an assertion: it re-executes itself under torch.distributed.run.  Rehearsed on one GPU over gloo."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", BENCH_WATCHDOG_S="150")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "2000",
+           "--no-cpu-baseline", "--no-c5-block", "--no-other-configs"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["world"] == 2 and line["rccl"]["fallback"] is None

@@ -332,3 +332,77 @@ def test_stale_workgroup_images_are_rebuilt_together_and_equal_single_packs(G):
     with torch.no_grad():
         mods[1].scalar_out.weight.mul_(2.0)
     assert ops._pack_wg(specs[1], mods[1]._weights()) is not single[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("invalidations", [1, 2], ids=["one-invalidation-per-step", "two-per-step"])
+def test_batched_repack_is_one_launch_in_every_consecutive_round(G, invalidations, monkeypatch):
+    """the ride-along filter of ops._pack_wg must hold over CONSECUTIVE optimizer steps (a block whose image was
+    built ahead by another block's miss still counts as "used in that step"), and when the epoch advances more than once per step
+    (FusedAdam plus an EMA swap).  Four rounds of update -> invalidate -> use all blocks: one gcpnet_wg_pack_multi launch per round."""
+    from gcpnet_amd import _lib, ops
+
+    torch.manual_seed(10)
+    mods = [G.GCP2((64, 16), (64, 16), nonlinearities=("silu", "silu"), bottleneck=4).cuda() for _ in range(4)]
+    specs = [m.make_spec([None], [None]) for m in mods]
+    lib = _lib.load()
+    real = lib.gcpnet_wg_pack_multi
+    calls = []
+
+    def counted(n, jobs, stream):
+        calls.append(int(n))
+        return real(n, jobs, stream)
+
+    monkeypatch.setattr(lib, "gcpnet_wg_pack_multi", counted)
+    for sp, m in zip(specs, mods):  # round 0: every block packs on its own first use
+        ops._pack_wg(sp, m._weights())
+    for rnd in range(4):
+        with torch.no_grad():
+            for m in mods:
+                m.scalar_out.weight.add_(0.125)
+        for _ in range(invalidations):
+            ops.invalidate_packs()
+        calls.clear()
+        packs = [ops._pack_wg(sp, m._weights()) for sp, m in zip(specs, mods)]
+        assert calls == [len(mods)], f"round {rnd}: launches {calls}"
+        assert all(ops._pack_wg(sp, m._weights()) is p for sp, m, p in zip(specs, mods, packs))
+    # a block that is no longer called (a frozen teacher) stops riding along after one step
+    for rnd in range(2):
+        with torch.no_grad():
+            for m in mods:
+                m.scalar_out.weight.add_(0.125)
+        ops.invalidate_packs()
+        calls.clear()
+        for sp, m in zip(specs[:3], mods[:3]):
+            ops._pack_wg(sp, m._weights())
+        assert calls == ([4] if rnd == 0 else [3]), f"teacher round {rnd}: {calls}"
+
+
+@pytest.mark.gpu
+def test_zero_row_linears_and_unaligned_rows_matmul(G):
+    """with the library-GEMM fallbacks gone, the legal zero-row case (a ShardedGraph rank without local nodes) must
+    still return empty outputs and zero weight gradients, and _rows_matmul_small must take a channel count that is not a multiple
+    of 4 through the workgroup kernel (padded for the launch)."""
+    from gcpnet_amd import ops
+
+    torch.manual_seed(11)
+    w = torch.randn(24, 40, device="cuda", requires_grad=True)
+    b = torch.randn(24, device="cuda", requires_grad=True)
+    x = torch.zeros(0, 40, device="cuda", requires_grad=True)
+    y = ops.linear(x, w, b)
+    assert y.shape == (0, 24)
+    y.sum().backward()
+    assert x.grad.shape == (0, 40) and torch.count_nonzero(w.grad) == 0 and torch.count_nonzero(b.grad) == 0
+    w2 = torch.randn(24, 40, device="cuda", requires_grad=True)
+    x2 = torch.zeros(0, 40, device="cuda", requires_grad=True)
+    p = ops._Project.apply(x2, w2)
+    assert p.shape == (0, 24)
+    p.sum().backward()
+    assert torch.count_nonzero(w2.grad) == 0
+    # K * J > 4096 with J % 4 != 0
+    xs = torch.randn(70, 96, device="cuda")
+    ws = torch.randn(96, 50, device="cuda")
+    got = ops._rows_matmul_small(xs, ws)
+    want = (xs.double() @ ws.double()).float()
+    assert got.shape == (70, 50)
+    assert torch.allclose(got, want, atol=1e-4, rtol=1e-5)
