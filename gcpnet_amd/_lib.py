@@ -18,7 +18,7 @@ EXPORTS = [
     "gcpnet_abi_version", "gcpnet_debug_knobs_compiled", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_pack_gcp2_weights_multi", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
     "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_chain_forward_registers_ok", "gcpnet_gcp2_headchain_forward",
-    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_chain_backward_ok", "gcpnet_tb_floats", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
+    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_chain_backward_ok", "gcpnet_gcp2_chain_backward_flags", "gcpnet_debug_force_chain_split", "gcpnet_gcp2_chain_backward_split", "gcpnet_tb_floats", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
@@ -167,6 +167,10 @@ def load():
                                          vp, vp, vp, P(BwdScratch), vp]
     lib.gcpnet_gcp2_chain_backward.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp]
     lib.gcpnet_gcp2_chain_backward_gathered.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp, vp, vp]
+    lib.gcpnet_gcp2_chain_backward_split.argtypes = [i32, vp, i32, P(ChainBwdItem), vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.gcpnet_gcp2_chain_backward_flags.argtypes = [i32] * 8
+    lib.gcpnet_debug_force_chain_split.argtypes = [i32, i32, i32]
+    lib.gcpnet_debug_force_chain_split.restype = None
     lib.gcpnet_tn_gemm.argtypes = [i32, P(TnProblem), vp]
     lib.gcpnet_tn_splits.argtypes = [i32, i32, i32]
     lib.gcpnet_gcp2_bwd_tiles.argtypes = [i32]
@@ -228,7 +232,7 @@ def load():
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",
                         "gcpnet_wg_pack_floats", "gcpnet_tb_floats", "gcpnet_gcp2_weight_grads_workspace"):
             fn.restype = i32
-    if lib.gcpnet_abi_version() != 3:
+    if lib.gcpnet_abi_version() != 4:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -20,8 +20,15 @@
 #include "vec_mfma.h"
 #include "gcp_bf16x3.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 #ifndef GCP_CB_TNC
 #define GCP_CB_TNC 3  // independent accumulator chains of a pass (1..3)
@@ -32,7 +39,7 @@
 
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
                              const float* d_v_out, const int32_t* out_idx, const float* out_scale, float* d_s_in, float* d_v_in,
-                             hipStream_t st);
+                             unsigned* flags, int n_flags, hipStream_t st);
 
 namespace {
 
@@ -67,6 +74,13 @@ struct ChainBwdParams {
     unsigned long long* stamps;
     long long stamp_cap;
     GcpShape sh;
+    // Tail split (cb_plan_split below): workgroups [0, n_split) run only the blocks n - 1 .. k_split of the tiles [0, n_split) and
+    // hand their state over through d_s_in / d_v_in; workgroups [tiles, tiles + n_split) finish those tiles (blocks k_split - 1 .. 0).
+    // flags[tile]: 0 = untouched, 1 = first half claimed, 2 = first half done, 3 = the second-half workgroup took the whole tile
+    // over (it found the flag at 0: no dispatch order is assumed, only used).  n_split == 0: every workgroup runs a whole tile.
+    int tiles, n_split, k_split;
+    int rev;  // test hook: workgroup indices reversed (second halves dispatched FIRST: they take tiles over or wait for a running first half)
+    unsigned* flags;
 };
 
 struct CbLds {
@@ -192,7 +206,44 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #define p (*(const ChainBwdParams*)kp)
     int lane = threadIdx.x;
     int e = lane & 31, hi = lane >> 5;
-    const int r0 = blockIdx.x * GCP_TILE_ROWS;
+    // which tile and which blocks of it (tail split, see ChainBwdParams): wave-uniform, decided before anything is loaded
+    const int wg = p.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    int tile = wg, k_hi = p.n - 1, k_lo = 0;
+    bool handed = false;   // the incoming gradient is the state another workgroup left in d_s_in / d_v_in
+    // (k_lo > 0: this workgroup leaves such a state behind)
+    if (p.n_split > 0) {
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        if (wg < p.n_split) {
+            gu32* fl = (gu32*)(p.flags + tile);
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_compare_exchange_strong(fl, &old, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : old;
+            if (__builtin_amdgcn_readfirstlane(old) != 0) return;  // taken over by the workgroup of the second half
+            k_lo = p.k_split;
+        } else if (wg >= p.tiles) {
+            tile = wg - p.tiles;
+            gu32* fl = (gu32*)(p.flags + tile);
+            unsigned f = 0;
+            if (lane == 0) {
+                for (;;) {
+                    f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (f == 0) {  // nobody has started this tile: run all of it here
+                        unsigned exp0 = 0;
+                        if (__hip_atomic_compare_exchange_strong(fl, &exp0, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { f = 3; break; }
+                        continue;
+                    }
+                    if (f == 2) break;
+                    __builtin_amdgcn_s_sleep(32);  // (f == 1: the first half is running on some CU and will finish)
+                }
+            }
+            f = __builtin_amdgcn_readfirstlane(f);
+            if (f == 2) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one buffer_inv sc1 after the match, then plain loads
+                k_hi = p.k_split - 1;
+                handed = true;
+            }
+        }
+    }
+    const int r0 = tile * GCP_TILE_ROWS;
     int row = r0 + e;
     GcpShape S;
     CbLds L;
@@ -233,7 +284,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         row = r0 + e;                                                                                                     \
         CB_RELOAD();                                                                                                      \
     } while (0)
-    kcur = p.n - 1;
+    kcur = k_hi;
     CB_RELOAD();
 
     gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
@@ -247,16 +298,17 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         gcp_load_gate<VQ>(scalar_gate ? it.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
         int64_t orow0 = row;
         float osc0 = 1.f;
-        if (p.out_idx) {  // (wave-uniform) gathered incoming gradient: source row and weight of this lane's row
+        if (p.out_idx && !handed) {  // (wave-uniform) gathered incoming gradient: source row and weight of this lane's row
             orow0 = p.out_idx[row_ok ? row : rows - 1];
             if (p.out_scale) osc0 = p.out_scale[orow0];
         }
+        const float* ds_src = handed ? p.d_s_in : p.d_s_out;
 #pragma unroll
         for (int t = 0; t < NTG; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j0 = 32 * t + 8 * q + 4 * hi;
-                const float4 b = gcp_load4(p.d_s_out, orow0, so, j0, row_ok, true);
+                const float4 b = gcp_load4(ds_src, orow0, so, j0, row_ok, true);
                 dyr[t][4 * q] = osc0 * b.x; dyr[t][4 * q + 1] = osc0 * b.y; dyr[t][4 * q + 2] = osc0 * b.z; dyr[t][4 * q + 3] = osc0 * b.w;
             }
         cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
@@ -290,12 +342,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         }
     };
     float dvs[3][NV];  // d(V) state entering the current block: channel crow(r, hi) of row e.  Loaded here for the last block;
-    load_state(p.d_v_out, dvs, p.out_idx != nullptr);  // afterwards carried over in registers from the end of the block before, where it is computed
+    load_state(handed ? p.d_v_in : p.d_v_out, dvs, p.out_idx != nullptr && !handed);  // afterwards carried over in registers from the end of the block before, where it is computed
     // sums of the second partial-sum pass of the block before and where they go: they leave with the NEXT block's small stores (end
     // of its step C), so that the coming block's requests do not queue behind them
     f32x4 tn2 = f32x4{0.f, 0.f, 0.f, 0.f};
     float* tn2_part = nullptr;
-    for (int k = p.n - 1; k >= 0; --k) {
+    for (int k = k_hi; k >= k_lo; --k) {
         kcur = k;
         CB_LAUNDER();
         const bool stamp_here = k == 0;
@@ -474,7 +526,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                             make_float4(dgr[4 * q], dgr[4 * q + 1], dgr[4 * q + 2], dgr[4 * q + 3]);
             }
         }
-        float* part = it.w_part ? it.w_part + (int64_t)blockIdx.x * (vi * H + vi * HF) : nullptr;
+        float* part = it.w_part ? it.w_part + (int64_t)(r0 >> 5) * (vi * H + vi * HF) : nullptr;  // (GCP_TILE_ROWS == 32)
 #ifdef GCP_CB_FINE2
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 #endif
@@ -618,7 +670,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         CB_LAUNDER();
 
-        if (k == 0) gcp_store_acc_rows_half_dense<NTG, PAD>(p.d_s_in, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip
+        if (k == k_lo) gcp_store_acc_rows_half_dense<NTG, PAD>(p.d_s_in, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip (or waits for the second half)
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
 
         // ---- F. adjoint of the vector prologue: d[vh | vf] = Wu^T dvu + (norm and frame-scalar terms), d(V) += Wdf^T d[vh | vf] ---
@@ -668,7 +720,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_xyz_zero(dv);
             gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
             float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
-            load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st, k == p.n - 1 && p.out_idx != nullptr);
+            load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st, k == p.n - 1 && p.out_idx != nullptr);  // (a handed-over tile starts below n - 1)
 #pragma unroll
             for (int q = 0; q < VQ; ++q) {
                 const int o0 = 8 * q + 4 * hi;
@@ -702,7 +754,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (part) { tn2 = small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF); small_tn_store(tn2, vi, HF, part + vi * H, true); }
         gcp_wave_lds_sync();
         CB_LAUNDER();
-        if (k > 0) {
+        if (k > k_lo) {
             CbVin vb;
             cb_vin_issue(vb, p.it[k - 1].v_in, vi, r0, rows, lane);
             gcp_load_gate<VQ>(scalar_gate ? p.it[k - 1].gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
@@ -719,6 +771,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         }
     }
     gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
+    if (k_lo > 0) {
+        // the state this workgroup leaves in d_s_in / d_v_in for the workgroup of the second half (cdna_hip_programming.md, Guideline
+        // 16): every store of the wave retired, one agent-scope release, the flag from one lane
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store((gu32*)(p.flags + (r0 >> 5)), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 #undef p
@@ -732,7 +793,7 @@ int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
     static const bool b6_env = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
     const bool pad = p.sh.so != 32 * NTG;  // (padded widths: bf16 form only)
     const bool b6 = pad || (g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0);
-    const dim3 grid((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS));
+    const dim3 grid((unsigned)(p.tiles + p.n_split));
     if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4): hidden channel count known at compile time
         if (pad) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
         else if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
@@ -755,6 +816,76 @@ int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, hipStream_t 
 
 }  // namespace
 
+// ---- tail split -------------------------------------------------------------------------------------------------------------
+// A tile's chain is one wave's serial job of n blocks, two waves per SIMD: `slots` tiles run at a time.  tiles = F slots + R leaves a
+// last round of R < slots waves whose CUs are half empty while it lasts a whole chain (measured, tools/chain_rows_sweep.py: 4 998
+// tiles on 2 048 slots take the time of 3 rounds, not 2.44).  The launch therefore cuts x tiles in two -- blocks n - 1 .. a first,
+// dispatched ahead of everything, the rest of those tiles last -- so that the pieces fill the slots the last round would leave idle.
+// (x, a) by simulating the in-order dispatch (workgroup costs in block units + a fixed cost per workgroup); the order is only what
+// makes it fast: the hand-over protocol (ChainBwdParams::flags) is correct under any dispatch order.
+static double cb_simulate(int tiles, int n, int slots, int x, int a) {
+    const double c0 = 0.4;  // prologue / epilogue of a workgroup, in block units
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int i = 0; i < slots; ++i) free_at.push(0.0);
+    std::vector<double> first_done((size_t)x);
+    double end = 0.0;
+    auto run = [&](double len, double not_before) {
+        double t = free_at.top();
+        free_at.pop();
+        if (t < not_before) t = not_before;
+        t += len;
+        free_at.push(t);
+        if (t > end) end = t;
+        return t;
+    };
+    for (int i = 0; i < x; ++i) first_done[(size_t)i] = run(c0 + (n - a), 0.0);
+    for (int i = x; i < tiles; ++i) run(c0 + n, 0.0);
+    for (int i = 0; i < x; ++i) run(c0 + a, first_done[(size_t)i]);
+    return end;
+}
+
+// (n_split, k_split) for a launch; n_split == 0: no split
+static void cb_plan_split(int tiles, int n, int slots, int* n_split, int* k_split) {
+    *n_split = 0; *k_split = 0;
+    if (n < 2 || tiles <= slots || slots <= 0) return;
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, std::pair<int, int>> memo;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(tiles, n, slots);
+    auto hit = memo.find(key);
+    if (hit == memo.end()) {
+        const int R = tiles % slots;
+        double best = cb_simulate(tiles, n, slots, 0, 0) * 0.97;  // a split must buy at least 3 %
+        std::pair<int, int> pick(0, 0);
+        if (R > 0)
+            for (int x : {R, R / 2, std::min(tiles, R + slots / 2)})
+                for (int a = 1; a < n && x > 0; ++a) {  // a = blocks left for the second half (k_split)
+                    const double t = cb_simulate(tiles, n, slots, x, a);
+                    if (t < best) { best = t; pick = std::make_pair(x, a); }
+                }
+        hit = memo.emplace(key, pick).first;
+    }
+    *n_split = hit->second.first; *k_split = hit->second.second;
+}
+
+// test hook (gcpnet_debug_force_chain_split): n_split < 0 = plan as above; otherwise the first min(n_split, tiles) tiles are cut at
+// k_split whatever the size, `rev` != 0 reverses the workgroup order
+static int g_cb_force[3] = {-1, 0, 0};
+extern "C" void gcpnet_debug_force_chain_split(int n_split, int k_split, int rev) {
+    g_cb_force[0] = n_split; g_cb_force[1] = k_split; g_cb_force[2] = rev;
+}
+
+static int cb_slots(size_t lds_bytes) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, c = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus = c;
+    }
+    const int by_lds = lds_bytes ? (int)((size_t)160 * 1024 / lds_bytes) : 8;
+    return cus * std::min(8, std::max(1, by_lds));  // two waves per SIMD (__launch_bounds__), LDS permitting
+}
+
 static bool chain_bwd_shape_ok(const gcp2_weights_t& w0, const GcpShape& S) {
     if (S.NG != 1 || w0.si != w0.so || w0.vi != w0.vo || w0.vi <= 0 || (w0.si & 3) || S.NTG < 2 || S.NTS != S.NTG) return false;
     // register budget of the kernel: vi == vo <= 16 (two register quads per xyz component), H + 3 <= 16, H + 9 <= 32
@@ -767,7 +898,7 @@ static bool chain_bwd_shape_ok(const gcp2_weights_t& w0, const GcpShape& S) {
 // (gcpnet_gcp2_backward), passing the state through HBM.
 int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
                              const float* d_v_out, const int32_t* out_idx, const float* out_scale, float* d_s_in, float* d_v_in,
-                             hipStream_t st) {
+                             unsigned* flags, int n_flags, hipStream_t st) {
     const gcp2_weights_t& w0 = items[0].w;
     const GcpShape S = gcp_shape(w0.si, w0.vi, w0.so, w0.vo, w0.hidden, w0.use_frames);
     if (!chain_bwd_shape_ok(w0, S)) return GCPNET_E_UNSUPPORTED;
@@ -795,8 +926,45 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
     p.sh = S;
     const size_t lds_bytes = (size_t)cb_lds(S).total * sizeof(float);
     if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
+    p.tiles = gcp_cdiv(rows, GCP_TILE_ROWS);
+    p.n_split = 0; p.k_split = 0; p.flags = nullptr; p.rev = 0;
+    if (flags && n_flags > 0) {
+        if (g_cb_force[0] >= 0) {
+            p.n_split = n >= 2 ? std::min(g_cb_force[0], p.tiles) : 0;
+            p.k_split = std::min(std::max(g_cb_force[1], 1), n - 1);
+            p.rev = g_cb_force[2];
+        } else {
+            cb_plan_split(p.tiles, n, cb_slots(lds_bytes), &p.n_split, &p.k_split);
+        }
+        if (p.n_split > n_flags) p.n_split = 0;
+        if (p.n_split > 0) {
+            p.flags = flags;
+            hipError_t err = hipMemsetAsync(flags, 0, (size_t)p.n_split * sizeof(unsigned), st);  // (a memset node under capture: zero at every replay)
+            if (err != hipSuccess) return (int)err;
+        }
+    }
+#ifdef GCP_CB_ONLY_SHIPPED  // (development builds: only the instantiation configs[1] runs -- tools/kres.py / the ISA tools in seconds)
+    hipLaunchKernelGGL((gcp2_chain_bwd_kernel<4, 2, true, 4, true>), dim3((unsigned)(p.tiles + p.n_split)), dim3(GCP_WAVE), lds_bytes, st, p);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+#else
     if (S.NTG == 2) return launch_cb2<2>(p, lds_bytes, pwl, st);
     return launch_cb2<4>(p, lds_bytes, pwl, st);
+#endif
+}
+
+// How many flag words a launch of this chain on `rows` rows would use for its tail split (0: it would not split): the caller passes
+// a buffer of at least that many to gcpnet_gcp2_chain_backward_split.
+extern "C" int gcpnet_gcp2_chain_backward_flags(int rows, int n, int si, int vi, int so, int vo, int hidden, int use_frames) {
+    if (rows <= 0 || n < 2) return 0;
+    gcp2_weights_t w0{};
+    w0.si = si; w0.vi = vi; w0.so = so; w0.vo = vo; w0.hidden = hidden; w0.use_frames = use_frames;
+    const GcpShape S = gcp_shape(si, vi, so, vo, hidden, use_frames);
+    if (!chain_bwd_shape_ok(w0, S)) return 0;
+    int x = 0, a = 0;
+    if (g_cb_force[0] >= 0) return std::min(g_cb_force[0], gcp_cdiv(rows, GCP_TILE_ROWS));
+    cb_plan_split(gcp_cdiv(rows, GCP_TILE_ROWS), n, cb_slots((size_t)cb_lds(S).total * sizeof(float)), &x, &a);
+    return x;
 }
 
 extern "C" int gcpnet_gcp2_chain_backward_ok(int si, int vi, int so, int vo, int hidden, int use_frames) {
@@ -807,7 +975,7 @@ extern "C" int gcpnet_gcp2_chain_backward_ok(int si, int vi, int so, int vo, int
 
 static int chain_backward_checked(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items, const float* d_s_out,
                                   const float* d_v_out, const int32_t* out_idx, const float* out_scale, float* d_s_in, float* d_v_in,
-                                  void* stream) {
+                                  void* stream, unsigned* flags = nullptr, int n_flags = 0) {
     if (rows < 0 || n < 1 || n > GCP_MAX_CHAIN || !items || !d_s_out || !d_v_out || !d_s_in || !d_v_in) return GCPNET_E_BADARG;
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_bwd_item_t& c = items[k];
@@ -822,7 +990,9 @@ static int chain_backward_checked(int rows, const float* frames, int n, const gc
             misaligned(items[k].sc.dgate) || misaligned(items[k].sc.ext))
             return GCPNET_E_UNSUPPORTED;
     if (misaligned(d_s_out) || misaligned(d_v_out) || misaligned(d_s_in) || misaligned(d_v_in)) return GCPNET_E_UNSUPPORTED;
-    return gcp2_chain_bwd_registers(rows, frames, n, items, d_s_out, d_v_out, out_idx, out_scale, d_s_in, d_v_in, (hipStream_t)stream);
+    if (flags && (reinterpret_cast<uintptr_t>(flags) & 3)) return GCPNET_E_BADARG;
+    return gcp2_chain_bwd_registers(rows, frames, n, items, d_s_out, d_v_out, out_idx, out_scale, d_s_in, d_v_in, flags, n_flags,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
@@ -836,4 +1006,13 @@ extern "C" int gcpnet_gcp2_chain_backward_gathered(int rows, const float* frames
                                                    const float* out_scale, float* d_s_in, float* d_v_in, void* stream) {
     if (!out_idx) return GCPNET_E_BADARG;
     return chain_backward_checked(rows, frames, n, items, d_s_tab, d_v_tab, out_idx, out_scale, d_s_in, d_v_in, stream);
+}
+
+// Both forms above with the tail split (see cb_plan_split): `flags` = n_flags >= gcpnet_gcp2_chain_backward_flags(...) words of device
+// memory that only this launch touches while it runs (zeroed here, on the stream); out_idx NULL = the plain form.  Same results.
+extern "C" int gcpnet_gcp2_chain_backward_split(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
+                                                const float* d_s_out, const float* d_v_out, const int32_t* out_idx,
+                                                const float* out_scale, float* d_s_in, float* d_v_in, uint32_t* flags, int n_flags,
+                                                void* stream) {
+    return chain_backward_checked(rows, frames, n, items, d_s_out, d_v_out, out_idx, out_scale, d_s_in, d_v_in, stream, flags, n_flags);
 }

@@ -501,6 +501,12 @@ FORCE_WG_CHAIN_BACKWARD = False  # tests: the workgroup backward also for chains
 CHAIN_TILE_BLOCKED = os.environ.get("GCPNET_CHAIN_TB", "1") != "0"
 # (the same for the s_pre of a SINGLE block that runs in the workgroup kernels both ways: first message GCP, feed-forward GCPs)
 BLOCK_TILE_BLOCKED = os.environ.get("GCPNET_BLOCK_TB", "1") != "0"
+# Tail split of the wave-per-tile chain backward (include/gcpnet_hip.h, gcpnet_gcp2_chain_backward_split): the chains of some tiles
+# run as two workgroups so that a partly filled last round of waves does not cost a whole one.  Bit-identical results
+# (tests/test_chain_split.py), but OFF by default: measured (round 6, tools/chain_rows_sweep.py) the partial round of 902 tiles of
+# configs[1] costs 0.15 - 0.17 ms against 0.125 ms for the same tiles at the full-round rate -- lone waves run 1.4 x faster than
+# paired ones -- and the second workgroups' prologues eat what is left: 0.750 ms split against 0.744 ms.  GCPNET_CHAIN_SPLIT=1: on.
+CHAIN_TAIL_SPLIT = os.environ.get("GCPNET_CHAIN_SPLIT", "0") == "1"
 
 
 def copy2d_multi(jobs) -> None:
@@ -1617,7 +1623,10 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
     o_dg = o_ext + (r64(rows * EP) if has_vec else 0)
     o_wp = o_dg + (r64(rows * VOP) if gated else 0)
     per = o_wp + (r64(tiles * w_width) if has_vec else 0)
-    flat = torch.empty((per * n,), dtype=torch.float32, device=d_s.device)
+    # flag words of the launch's tail split (gcpnet_gcp2_chain_backward_split), behind the blocks' regions of the same allocation
+    n_flags = (int(lib.gcpnet_gcp2_chain_backward_flags(rows, n, sp0.si, vi, so, vo, H, int(sp0.use_frames)))
+               if CHAIN_TAIL_SPLIT and has_vec else 0)
+    flat = torch.empty((per * n + r64(n_flags),), dtype=torch.float32, device=d_s.device)
     for k in range(n):
         assert isinstance(outs[k][2], TileBlocked) == tb_all
         base = per * k
@@ -1648,8 +1657,12 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
         items[k].sc = scr
     d_s_in = torch.empty((rows, specs[0].si), dtype=torch.float32, device=d_s.device)
     d_v_in = torch.empty((rows, specs[0].vi, 3), dtype=torch.float32, device=d_s.device)
-    if out_agg is not None:
-        plan, mean = out_agg
+    plan, mean = out_agg if out_agg is not None else (None, False)
+    if n_flags > 0:
+        rc = lib.gcpnet_gcp2_chain_backward_split(rows, _p(frames), n, items, _p(d_s), _p(d_v), None if plan is None else _p(plan.idx),
+                                                  _p(plan.inv_count) if mean else None, _p(d_s_in), _p(d_v_in),
+                                                  C.c_void_p(flat.data_ptr() + 4 * per * n), n_flags, _stream())
+    elif plan is not None:
         rc = lib.gcpnet_gcp2_chain_backward_gathered(rows, _p(frames), n, items, _p(d_s), _p(d_v), _p(plan.idx),
                                                      _p(plan.inv_count) if mean else None, _p(d_s_in), _p(d_v_in), _stream())
     else:

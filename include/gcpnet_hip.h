@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GCPNET_ABI_VERSION 3
+#define GCPNET_ABI_VERSION 4
 
 #define GCPNET_E_BADARG (-1)
 #define GCPNET_E_UNSUPPORTED (-2)
@@ -310,6 +310,21 @@ int gcpnet_gcp2_chain_backward(int rows, const float* frames, int n, const gcp2_
 int gcpnet_gcp2_chain_backward_gathered(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
                                         const float* d_s_tab, const float* d_v_tab, const int32_t* out_idx, const float* out_scale,
                                         float* d_s_in, float* d_v_in, void* stream);
+/* Both forms with the TAIL SPLIT (ABI 4).  A tile's chain (the loop of components/gcpnet.py:921-924, walked backwards) is one wave's
+ * serial job and a CU holds eight of them: when the tile count leaves a last, partly filled round of waves, the launch cuts some
+ * tiles' chains in two -- the first halves are dispatched ahead of everything, the second halves last -- so that the pieces fill
+ * the idle slots (same arithmetic, same results; the hand-over of d(s), d(V) between the two workgroups of a tile goes through
+ * d_s_in / d_v_in and one flag word per tile, agent-scope release / acquire, correct under any dispatch order).
+ * gcpnet_gcp2_chain_backward_flags: how many flag words a launch of this shape would use (0: it would not split).
+ * `flags`: n_flags >= that many uint32 of device memory no other launch touches meanwhile (zeroed by the call, on the stream);
+ * out_idx NULL = the plain form (d_s_out / d_v_out per-row tensors). */
+int gcpnet_gcp2_chain_backward_flags(int rows, int n, int si, int vi, int so, int vo, int hidden, int use_frames);
+/* test hook: n_split >= 0 cuts the first min(n_split, tiles) tiles at block k_split whatever the size (rev != 0: reversed workgroup
+ * order, so that second halves run first and take tiles over); n_split < 0 = back to the planned split */
+void gcpnet_debug_force_chain_split(int n_split, int k_split, int rev);
+int gcpnet_gcp2_chain_backward_split(int rows, const float* frames, int n, const gcp2_chain_bwd_item_t* items,
+                                     const float* d_s_out, const float* d_v_out, const int32_t* out_idx, const float* out_scale,
+                                     float* d_s_in, float* d_v_in, uint32_t* flags, int n_flags, void* stream);
 
 /* ---- weight-gradient GEMM: out[m, n] (+)= sum_r A[r, m] * B[r, n] -------------------------------------------
  * A and B are row-wise concatenations (gcp_concat_t with per-segment leading dimension), optionally passed

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gcpnet_abi_version() == 3
+    assert lib.gcpnet_abi_version() == 4
 
 
 def test_host_only_entry_points():
