@@ -30,6 +30,12 @@
 #include <type_traits>
 #include <vector>
 
+// GCP_CB_X: measurement builds whose RESULTS ARE WRONG (tools/cb_variants.sh): bits remove one cost each so that its share of the
+// launch time can be read under real contention.  1: step E's fragments loaded once; 2: no partial-sum passes; 4: no steps A - C;
+// 8: no step F; 16: no gate MFMAs in D; 32: no ds_pre store; 64: no s_pre load; 128: no step E
+#ifndef GCP_CB_X
+#define GCP_CB_X 0
+#endif
 #ifndef GCP_CB_TNC
 #define GCP_CB_TNC 3  // independent accumulator chains of a pass (1..3)
 #endif
@@ -362,7 +368,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         //         (element-wise) go to the weight-gradient GEMM's operand `ext` -- through the LDS tile `dext` (free until the end of
         //         step E), from which they leave as full rows behind the s_pre requests at the end of step C: no store in step A -----
         float dgr[NV];
-        {
+        if constexpr (GCP_CB_X & 4) {
+#pragma unroll
+            for (int r = 0; r < NV; ++r) dgr[r] = sg[r] + dvs[0][r];
+        } else {
             gcp_xyz_acc u;
             gcp_vmm_down<10>(it.pack + S.offVA + lane, S.SVA, vi, vt + e * L.VS, hi, u);
             float f[9];
@@ -478,7 +487,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         };
         // s_pre of this block: requested here, where few registers are live, and in flight under the first partial-sum pass
         f32x16 spr[NTG];
-        {
+        if constexpr (GCP_CB_X & 64) {
+#pragma unroll
+            for (int t = 0; t < NTG; ++t) spr[t] = dyr[t];
+        } else {
             // (one address select per request instead of two code paths: a wave-uniform branch around loads makes hipcc wait for
             // them where the sides merge.  Tile-blocked: piece (t, q) of this lane, 1 KB per instruction; rows of [rows, so] otherwise)
             const int64_t off_rm = (int64_t)(row_ok ? row : 0) * so, off_tb = (int64_t)r0 * (32 * NTG) + 4 * lane;
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 #endif
         f32x4 tn1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (part) { tn1 = small_tn(xt, L.VS, 3, 1, vi, vht, L.HS, 3, 1, H); small_tn_store(tn1, vi, H, part, false); }  // d vector_up[o, h] = sum dvu[row, o, d] vh[row, h, d]
+        if ((GCP_CB_X & 2) == 0 && part) { tn1 = small_tn(xt, L.VS, 3, 1, vi, vht, L.HS, 3, 1, H); small_tn_store(tn1, vi, H, part, false); }  // d vector_up[o, h] = sum dvu[row, o, d] vh[row, h, d]
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
         CB_LAUNDER();
 
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 f32x16 gacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
-                if (scalar_gate) {
+                if (scalar_gate && !(GCP_CB_X & 16)) {
                     if (t + 1 < NTG) {
 #pragma unroll
                         for (int r = 0; r < NV; ++r) ga[(t + 1) & 1][r] = wg[(int64_t)r * 64 * NTG + t + 1];
@@ -572,7 +584,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #ifdef GCP_CB_FINE3  // (measurement build: stamps 0 / 1 of block 0 = end of step D / end of the ds_pre store)
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
 #endif
-        if (it.tb) {  // tile-blocked: sixteen 1 KB pieces straight from the registers (rows past the end are zeros, the buffer holds whole tiles)
+        if constexpr (GCP_CB_X & 32) {
+        } else if (it.tb) {  // tile-blocked: sixteen 1 KB pieces straight from the registers (rows past the end are zeros, the buffer holds whole tiles)
             float4* bp = reinterpret_cast<float4*>(it.ds_pre + (int64_t)r0 * (32 * NTG)) + lane;
 #pragma unroll
             for (int t = 0; t < NTG; ++t)
@@ -613,7 +626,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if constexpr (B6) {
+        if constexpr (GCP_CB_X & 128) {
+#pragma unroll
+            for (int t = 0; t < NTG; ++t) dyr[t] += spr[t];
+        } else if constexpr (B6) {
             // 2 NTG slabs of K = 16 (eight ds_pre registers each, split into three bf16 terms on the fly) x (NTG + 1) output tiles
             // of the merged axis; one stage = (slab, tile) = three 16-byte weight fragments per lane and six MFMAs, fragments
             // requested three stages ahead
@@ -645,7 +661,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 gcp_u32x4(&a)[3] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
                 if (uu < NTG) dyr[uu < NTG ? uu : 0] = gcp_mfma_bf16x6(a, bh, bm, bl, dyr[uu < NTG ? uu : 0]);
                 else accx = gcp_mfma_bf16x6(a, bh, bm, bl, accx);
-                if (sg + 3 < NST) ld(a, sg + 3);
+                if ((GCP_CB_X & 1) == 0 && sg + 3 < NST) ld(a, sg + 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -674,7 +690,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
 
         // ---- F. adjoint of the vector prologue: d[vh | vf] = Wu^T dvu + (norm and frame-scalar terms), d(V) += Wdf^T d[vh | vf] ---
-        {
+        if constexpr (GCP_CB_X & 8) {
+        } else {
             float dvu[3][NV];  // d(vector_up output), back from its row-major copy
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
@@ -751,7 +768,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
 #endif
         // d [vector_down ; vector_down_frames][x, c] = sum v[row, c, d] [dvh | dvf][row, d, x], stored as [H + 3, vi]
-        if (part) { tn2 = small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF); small_tn_store(tn2, vi, HF, part + vi * H, true); }
+        if ((GCP_CB_X & 2) == 0 && part) { tn2 = small_tn(vt, L.VS, 3, 1, vi, xt, L.FS, 1, HF, HF); small_tn_store(tn2, vi, HF, part + vi * H, true); }
         gcp_wave_lds_sync();
         CB_LAUNDER();
         if (k > k_lo) {
