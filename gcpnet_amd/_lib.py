@@ -18,7 +18,7 @@ EXPORTS = [
     "gcpnet_abi_version", "gcpnet_debug_knobs_compiled", "gcpnet_gcp2_pack_floats", "gcpnet_pack_gcp2_weights", "gcpnet_pack_gcp2_weights_multi", "gcpnet_gcp2_forward",
     "gcpnet_gcp2_forward_lds_bytes",
     "gcpnet_gcp2_chain_forward", "gcpnet_gcp2_chain_forward_registers_ok", "gcpnet_gcp2_headchain_forward",
-    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_chain_backward_ok", "gcpnet_gcp2_chain_backward_flags", "gcpnet_debug_force_chain_split", "gcpnet_gcp2_chain_backward_split", "gcpnet_tb_floats", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
+    "gcpnet_gcp2_backward", "gcpnet_gcp2_chain_backward", "gcpnet_gcp2_chain_backward_gathered", "gcpnet_gcp2_chain_backward_ok", "gcpnet_gcp2_chain_backward_flags", "gcpnet_debug_force_chain_split", "gcpnet_gcp2_chain_backward_split", "gcpnet_tb_floats", "gcpnet_tb_sign_words", "gcpnet_gcp2_bwd_tiles", "gcpnet_tn_gemm", "gcpnet_tn_splits", "gcpnet_reduce_partials",
     "gcpnet_reduce_partials_groups", "gcpnet_segment_reduce", "gcpnet_gather_rows",
     "gcpnet_localize", "gcpnet_layernorm_forward", "gcpnet_layernorm_backward", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_axpy_clamp", "gcpnet_rows_matmul_small", "gcpnet_edge_force_forward", "gcpnet_edge_force_backward",
     "gcpnet_edge_force_bwd_blocks", "gcpnet_row_gate_forward", "gcpnet_row_gate_backward", "gcpnet_row_gate_bwd_blocks",
@@ -54,7 +54,7 @@ class Gcp2Opts(C.Structure):
 
 class ChainItem(C.Structure):
     _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("s_out", C.c_void_p), ("v_out", C.c_void_p), ("s_pre", C.c_void_p),
-                ("gate", C.c_void_p), ("s_out_tb", C.c_int), ("s_pre_tb", C.c_int)]
+                ("gate", C.c_void_p), ("s_out_tb", C.c_int), ("s_pre_tb", C.c_int), ("s_sign", C.c_void_p)]
 
 
 class Head(C.Structure):
@@ -98,7 +98,7 @@ class BwdScratch(C.Structure):
 
 class ChainBwdItem(C.Structure):
     _fields_ = [("w", Gcp2Weights), ("o", Gcp2Opts), ("v_in", C.c_void_p), ("s_pre", C.c_void_p), ("gate", C.c_void_p),
-                ("sc", BwdScratch), ("tb", C.c_int)]
+                ("sc", BwdScratch), ("tb", C.c_int), ("s_sign", C.c_void_p)]
 
 
 class Operand(C.Structure):
@@ -202,6 +202,8 @@ def load():
     lib.gcpnet_gcp2_chain_backward_ok.argtypes = [i32] * 6
     lib.gcpnet_tb_floats.argtypes = [i32, i32]
     lib.gcpnet_tb_floats.restype = i64
+    lib.gcpnet_tb_sign_words.argtypes = [i32, i32]
+    lib.gcpnet_tb_sign_words.restype = i64
     lib.gcpnet_wg_pack_floats.restype = i64
     lib.gcpnet_wg_pack_floats.argtypes = [i32] * 7
     lib.gcpnet_wg_pack.argtypes = [P(Gcp2Weights), i32, vp, vp]
@@ -230,7 +232,7 @@ def load():
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",
-                        "gcpnet_wg_pack_floats", "gcpnet_tb_floats", "gcpnet_gcp2_weight_grads_workspace"):
+                        "gcpnet_wg_pack_floats", "gcpnet_tb_floats", "gcpnet_tb_sign_words", "gcpnet_gcp2_weight_grads_workspace"):
             fn.restype = i32
     if lib.gcpnet_abi_version() != 4:
         raise GcpnetHipError("libgcpnet_hip.so ABI version mismatch")

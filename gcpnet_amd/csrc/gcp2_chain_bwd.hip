@@ -60,6 +60,7 @@ struct ChainItemB {
     float* w_part;
     int act_s, act_v;
     int tb;  // s_pre / ds_pre in the tile-blocked layout (include/gcpnet_hip.h, gcp2_chain_item_t)
+    const unsigned* sign;  // sign mask of s_pre (SGN instantiations: read instead of s_pre)
 };
 
 struct ChainBwdParams {
@@ -198,8 +199,13 @@ __device__ __forceinline__ void cb_vin_commit(const CbVin& b, float* vt, int VS,
 // B6: W^T ds_pre on the bf16 matrix pipe, both operands as three bf16 terms, six products (gcp_bf16x3.h: exact to fp32 round-off)
 // PAD: si == so is a multiple of 4 below 32 NTG (LBA: 100): the tile loads already return zeros past column so, the weight images
 // are zero-padded, so the padding columns of d(s) stay zero through the chain; only the two full-line stores need the column test.
-template <int NTG, int VQ, bool PWL, int HC, bool B6, bool PAD = false>
+// SGN: act'(s_pre) from the forward's sign mask (one bit per element, gcp2_chain_item_t.s_sign) instead of s_pre itself: piecewise-
+// linear activations only.  Two words per lane and block instead of sixteen 16-byte pieces -- 16 KB less HBM traffic per tile and
+// block, and no 64-register request in flight between steps C and D (measured with GCP_CB_X & 64: the s_pre request costs 8.6 % of
+// the launch where it is, and cannot move earlier: its 64 destination registers do not fit beside steps A - C).
+template <int NTG, int VQ, bool PWL, int HC, bool B6, bool PAD = false, bool SGN = false>
 __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdParams p_kernarg) {
+    static_assert(!SGN || (PWL && NTG % 2 == 0), "sign masks: piecewise-linear activations, whole words");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = 4 * VQ;  // registers per xyz component of a vector-channel quantity
     constexpr int NX = HC ? 4 * ((HC + 3 + 7) / 8) : 8;  // registers per xyz component of a [vh | vf] quantity (H + 3 <= 16)
@@ -296,12 +302,17 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
     gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
     f32x16 dyr[NTG];
     float sg[NV];  // sigmoid(gate) of the current block: channel crow(r, hi) of row e
+    unsigned sm[NTG / 2 > 0 ? NTG / 2 : 1];  // SGN: sign words of the current block's s_pre (bit 16 t + r = register r of tile t)
     // ---- prologue: everything the LAST block needs, plus the incoming gradients, in one memory round trip ----------
     {
         CbVin vb;
         cb_vin_issue(vb, it.v_in, vi, r0, rows, lane);
         if (S.nf) gcp_load_frames(p.frames, r0, rows, fr, lane);
         gcp_load_gate<VQ>(scalar_gate ? it.gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
+        if constexpr (SGN) {
+#pragma unroll
+            for (int w = 0; w < NTG / 2; ++w) sm[w] = it.sign[((int64_t)(r0 >> 5) * (NTG / 2) + w) * 64 + lane];
+        }
         int64_t orow0 = row;
         float osc0 = 1.f;
         if (p.out_idx && !handed) {  // (wave-uniform) gathered incoming gradient: source row and weight of this lane's row
@@ -487,7 +498,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         };
         // s_pre of this block: requested here, where few registers are live, and in flight under the first partial-sum pass
         f32x16 spr[NTG];
-        if constexpr (GCP_CB_X & 64) {
+        if constexpr (SGN) {
+        } else if constexpr (GCP_CB_X & 64) {
 #pragma unroll
             for (int t = 0; t < NTG; ++t) spr[t] = dyr[t];
         } else {
@@ -574,9 +586,16 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float sp = spr[t][r];
-                    float d = dyr[t][r] * gcp_dactf<PWL>(it.act_s, ns_s, slope, sp);
-                    if (scalar_gate) d += gcp_dactf<PWL>(it.act_v, ns_v, slope, sp) * gacc[r];
+                    float d;
+                    if constexpr (SGN) {
+                        const bool pos = ((sm[(16 * t + r) >> 5] >> ((16 * t + r) & 31)) & 1u) != 0;
+                        d = dyr[t][r] * (pos ? 1.f : ns_s);
+                        if (scalar_gate) d += (pos ? 1.f : ns_v) * gacc[r];
+                    } else {
+                        const float sp = spr[t][r];
+                        d = dyr[t][r] * gcp_dactf<PWL>(it.act_s, ns_s, slope, sp);
+                        if (scalar_gate) d += gcp_dactf<PWL>(it.act_v, ns_v, slope, sp) * gacc[r];
+                    }
                     spr[t][r] = row_ok ? d : 0.f;
                 }
             }
@@ -775,6 +794,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             CbVin vb;
             cb_vin_issue(vb, p.it[k - 1].v_in, vi, r0, rows, lane);
             gcp_load_gate<VQ>(scalar_gate ? p.it[k - 1].gate : nullptr, row, vi, hi, row_ok, vec_vo, sg);
+            if constexpr (SGN) {
+#pragma unroll
+                for (int w = 0; w < NTG / 2; ++w) sm[w] = p.it[k - 1].sign[((int64_t)(r0 >> 5) * (NTG / 2) + w) * 64 + lane];
+            }
             cb_vin_commit(vb, vt, L.VS, vi, r0, rows, lane);
         }
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 6, lane);
@@ -804,13 +827,26 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #undef CB_LAUNDER
 
 template <int NTG, int VQ, bool PWL>
-int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
+int launch_cb(const ChainBwdParams& p, size_t lds_bytes, bool sgn, hipStream_t st) {
     // W^T ds_pre on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_BWD_FP32_MFMA / gcpnet_debug_set_fp32_mfma select the
     // fp32 MFMA form of the same product (A/B switch)
     static const bool b6_env = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
     const bool pad = p.sh.so != 32 * NTG;  // (padded widths: bf16 form only)
     const bool b6 = pad || (g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0);
     const dim3 grid((unsigned)(p.tiles + p.n_split));
+    if constexpr (PWL) {
+        if (sgn && b6) {  // sign masks instead of s_pre (the forward wrote them for every block)
+            if (p.sh.H == 4 && p.sh.nf) {
+                if (pad) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, true, 4, true, true, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+                else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, true, 4, true, false, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+            } else {
+                if (pad) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, true, 0, true, true, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+                else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, true, 0, true, false, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
+            }
+            GCP_HIP_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (p.sh.H == 4 && p.sh.nf) {  // the shipped shape (V = 16, bottleneck 4): hidden channel count known at compile time
         if (pad) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
         else if (b6) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<NTG, VQ, PWL, 4, true>), grid, dim3(GCP_WAVE), lds_bytes, st, p);
@@ -826,9 +862,9 @@ int launch_cb(const ChainBwdParams& p, size_t lds_bytes, hipStream_t st) {
 }
 
 template <int NTG>
-int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, hipStream_t st) {
-    if (p.sh.vi <= 8) return pwl ? launch_cb<NTG, 1, true>(p, lds_bytes, st) : launch_cb<NTG, 1, false>(p, lds_bytes, st);
-    return pwl ? launch_cb<NTG, 2, true>(p, lds_bytes, st) : launch_cb<NTG, 2, false>(p, lds_bytes, st);
+int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, bool sgn, hipStream_t st) {
+    if (p.sh.vi <= 8) return pwl ? launch_cb<NTG, 1, true>(p, lds_bytes, sgn, st) : launch_cb<NTG, 1, false>(p, lds_bytes, false, st);
+    return pwl ? launch_cb<NTG, 2, true>(p, lds_bytes, sgn, st) : launch_cb<NTG, 2, false>(p, lds_bytes, false, st);
 }
 
 }  // namespace
@@ -923,7 +959,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
     p.rows = rows; p.frames = frames; p.o = items[0].o; p.n = n;
     p.d_s_out = d_s_out; p.d_v_out = d_v_out; p.d_s_in = d_s_in; p.d_v_in = d_v_in;
     p.out_idx = out_idx; p.out_scale = out_idx ? out_scale : nullptr;
-    bool pwl = true;
+    bool pwl = true, sgn = true;
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_bwd_item_t& c = items[k];
         const gcp2_opts_t& o = c.o;
@@ -937,8 +973,11 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
         it.ds_pre = c.sc.ds_pre; it.dgate = c.sc.dgate; it.ext = c.sc.ext; it.w_part = c.sc.w_part;
         it.act_s = o.act_s; it.act_v = o.act_v;
         it.tb = c.tb;
+        it.sign = c.s_sign;
+        sgn = sgn && c.s_sign != nullptr && (reinterpret_cast<uintptr_t>(c.s_sign) & 3) == 0;
         pwl = pwl && gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
     }
+    sgn = sgn && pwl;
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     p.sh = S;
     const size_t lds_bytes = (size_t)cb_lds(S).total * sizeof(float);
@@ -960,13 +999,14 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
             if (err != hipSuccess) return (int)err;
         }
     }
-#ifdef GCP_CB_ONLY_SHIPPED  // (development builds: only the instantiation configs[1] runs -- tools/kres.py / the ISA tools in seconds)
-    hipLaunchKernelGGL((gcp2_chain_bwd_kernel<4, 2, true, 4, true>), dim3((unsigned)(p.tiles + p.n_split)), dim3(GCP_WAVE), lds_bytes, st, p);
+#ifdef GCP_CB_ONLY_SHIPPED  // (development builds: only the instantiations configs[1] runs -- tools/kres.py / the ISA tools in seconds)
+    if (sgn) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<4, 2, true, 4, true, false, true>), dim3((unsigned)(p.tiles + p.n_split)), dim3(GCP_WAVE), lds_bytes, st, p);
+    else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<4, 2, true, 4, true>), dim3((unsigned)(p.tiles + p.n_split)), dim3(GCP_WAVE), lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 #else
-    if (S.NTG == 2) return launch_cb2<2>(p, lds_bytes, pwl, st);
-    return launch_cb2<4>(p, lds_bytes, pwl, st);
+    if (S.NTG == 2) return launch_cb2<2>(p, lds_bytes, pwl, sgn, st);
+    return launch_cb2<4>(p, lds_bytes, pwl, sgn, st);
 #endif
 }
 

@@ -31,6 +31,7 @@ struct ChainItemF {
     float* gate;
     int act_s, act_v;
     int s_out_tb, s_pre_tb;  // tile-blocked outputs (include/gcpnet_hip.h, gcp2_chain_item_t)
+    unsigned* s_sign;        // optional sign mask of s_pre (include/gcpnet_hip.h)
 };
 
 // Optional head block in front of the chain: the first message GCP after project-then-gather, (se, vi0) -> (s, V) with the
@@ -518,6 +519,18 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             if (it.s_pre_tb) gcp_store_acc_tb<NT>(it.s_pre, r0, acc, lane);
             else gcp_store_acc_rows_any<NT>(it.s_pre, so, r0, rows, acc, stage, lane);
         }
+        if constexpr ((NT % 2) == 0) {
+            if (it.s_sign) {  // (wave-uniform) where s_pre is positive, one bit per register element: all the backward needs of it
+                unsigned* sp = it.s_sign + ((int64_t)blockIdx.x * (NT / 2)) * 64 + lane;
+#pragma unroll
+                for (int w = 0; w < NT / 2; ++w) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int b = 0; b < 32; ++b) m |= acc[2 * w + b / 16][b % 16] > 0.f ? (1u << b) : 0u;
+                    sp[w * 64] = m;
+                }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -622,6 +635,7 @@ static int fill_chain(ChainParams& p, const GcpShape& S, int n, const gcp2_chain
         it.b_gate = c.w.b_gate; it.s_out = c.s_out; it.v_out = c.v_out; it.s_pre = c.s_pre;
         it.gate = c.gate; it.act_s = c.o.act_s; it.act_v = c.o.act_v;
         it.s_out_tb = c.s_out_tb; it.s_pre_tb = c.s_pre_tb;
+        it.s_sign = c.s_sign;
         pwl = pwl && gcp_is_pwl(c.o.act_s) && gcp_is_pwl(c.o.act_v);
     }
     (void)S;
@@ -722,6 +736,7 @@ extern "C" int gcpnet_gcp2_headchain_forward(int rows, const gcp2_head_t* head, 
     it.s_out = head->s_out; it.v_out = head->v_out; it.s_pre = head->s_pre; it.gate = head->gate;
     it.act_s = head->o.act_s; it.act_v = head->o.act_v;
     it.s_out_tb = it.s_pre_tb = 0;
+    it.s_sign = nullptr;
     const size_t lds_bytes = (size_t)chain_lds(S, &S0).total * sizeof(float);
     if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

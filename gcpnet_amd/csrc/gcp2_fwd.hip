@@ -746,6 +746,11 @@ extern "C" int gcpnet_abi_version(void) { return GCPNET_ABI_VERSION; }
 extern "C" int64_t gcpnet_tb_floats(int rows, int width) {
     return (int64_t)gcp_cdiv(rows > 0 ? rows : 0, GCP_TILE_ROWS) * GCP_TILE_ROWS * gcp_round_up(width > 0 ? width : 0, 32);
 }
+extern "C" int64_t gcpnet_tb_sign_words(int rows, int width) {
+    const int nt = gcp_cdiv(width > 0 ? width : 0, 32);
+    if (nt & 1) return 0;  // (two 32-wide tiles = 32 register elements per lane = one word)
+    return (int64_t)gcp_cdiv(rows > 0 ? rows : 0, GCP_TILE_ROWS) * (nt / 2) * 64;
+}
 extern "C" int gcpnet_debug_knobs_compiled(void) {
 #ifdef GCP_DEBUG_KNOBS
     return 1;
@@ -861,7 +866,7 @@ extern "C" int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float*
         if (rc != GCPNET_E_UNSUPPORTED) return rc;
     }
     for (int k = 0; k < n; ++k)  // (the tile-blocked outputs exist in the register-resident kernel only)
-        if (items[k].s_out_tb || items[k].s_pre_tb) return GCPNET_E_UNSUPPORTED;
+        if (items[k].s_out_tb || items[k].s_pre_tb || items[k].s_sign) return GCPNET_E_UNSUPPORTED;
     FwdParams p;
     p.rows = rows;
     p.s_in.n = 1; p.s_in.ptr[0] = s0; p.s_in.idx[0] = nullptr; p.s_in.dim[0] = w0.si;

@@ -507,6 +507,11 @@ BLOCK_TILE_BLOCKED = os.environ.get("GCPNET_BLOCK_TB", "1") != "0"
 # configs[1] costs 0.15 - 0.17 ms against 0.125 ms for the same tiles at the full-round rate -- lone waves run 1.4 x faster than
 # paired ones -- and the second workgroups' prologues eat what is left: 0.750 ms split against 0.744 ms.  GCPNET_CHAIN_SPLIT=1: on.
 CHAIN_TAIL_SPLIT = os.environ.get("GCPNET_CHAIN_SPLIT", "0") == "1"
+# Sign masks of s_pre (include/gcpnet_hip.h, gcp2_chain_item_t.s_sign): the register-resident chain forward writes, beside s_pre, one
+# bit per element -- where it is positive -- and the chain backward kernel reads that instead of s_pre when every activation of the
+# chain is piecewise linear (all its derivative depends on).  GCPNET_CHAIN_SIGN=0: s_pre itself as before (A/B; bit-identical results).
+CHAIN_SIGN_MASKS = os.environ.get("GCPNET_CHAIN_SIGN", "1") != "0"
+_PWL_ACTS = (None, "relu", "leakyrelu")
 
 
 def copy2d_multi(jobs) -> None:
@@ -532,10 +537,11 @@ def copy2d_multi(jobs) -> None:
 class TileBlocked:
     """A [rows, width] fp32 matrix in the tile-blocked layout: gcpnet_tb_floats(rows, width) floats, its own allocation or (`owner`,
     `offset` in floats) a region of a flat one."""
-    __slots__ = ("rows", "width", "ptr", "_n", "_data", "_owner", "_off")
+    __slots__ = ("rows", "width", "ptr", "_n", "_data", "_owner", "_off", "sign")
 
     def __init__(self, rows: int, width: int, device, owner: Optional[Tensor] = None, offset: int = 0, n: Optional[int] = None):
         self.rows, self.width = rows, width
+        self.sign = None  # address of the sign mask written beside an s_pre (include/gcpnet_hip.h, gcp2_chain_item_t.s_sign)
         self._n = int(n) if n is not None else int(_lib.load().gcpnet_tb_floats(rows, width))
         if owner is None:
             self._data = torch.empty((self._n,), dtype=torch.float32, device=device)
@@ -1442,7 +1448,11 @@ class _Gcp2Chain(torch.autograd.Function):
             o_gate = r64(n_tb)
             o_sout = o_gate + (r64(rows * vo) if gated0 else 0)
             o_vout = o_sout + r64(n_tb)
-            per = o_vout + r64(rows * 3 * vo)
+            o_sign = o_vout + r64(rows * 3 * vo)
+            # sign masks of s_pre: all the chain backward kernel needs of it when the activations are piecewise linear
+            n_sign = (int(lib.gcpnet_tb_sign_words(rows, so))
+                      if CHAIN_SIGN_MASKS and all(sp.act_s in _PWL_ACTS and sp.act_v in _PWL_ACTS for sp in specs) else 0)
+            per = o_sign + r64(n_sign)
             flat = torch.empty((per * n,), **f32)
         for k, spec in enumerate(specs):
             w = all_w[k]
@@ -1453,6 +1463,8 @@ class _Gcp2Chain(torch.autograd.Function):
                 assert (spec.so, spec.vo, gated) == (so, vo, gated0)
                 base = per * k
                 s_pre = TileBlocked(rows, so, dev, owner=flat, offset=base, n=n_tb)
+                if n_sign:
+                    s_pre.sign = flat.data_ptr() + 4 * (base + o_sign)
                 gate = _Region(flat, base + o_gate, rows, vo) if gated else None
                 if last:
                     s_out, v_out = torch.empty((rows, so), **f32), torch.empty((rows, vo, 3), **f32)
@@ -1477,6 +1489,7 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
             items[k].gate = gate.data_ptr() if gate is not None else None
             items[k].s_out_tb, items[k].s_pre_tb = int(isinstance(s_out, TileBlocked)), int(isinstance(s_pre, TileBlocked))
+            items[k].s_sign = getattr(s_pre, "sign", None)
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         if rows == 0:  # (an empty edge set: nothing to launch)
             if need_grad:
@@ -1653,6 +1666,7 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
         items[k].v_in = ins[k][1].data_ptr()
         items[k].tb = int(tb_all)
         items[k].s_pre = outs[k][2].data_ptr()
+        items[k].s_sign = getattr(outs[k][2], "sign", None) if CHAIN_SIGN_MASKS else None
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
         items[k].sc = scr
     d_s_in = torch.empty((rows, specs[0].si), dtype=torch.float32, device=d_s.device)

@@ -116,6 +116,16 @@ int gcpnet_gcp2_forward(int rows, const gcp_concat_t* s_in, const gcp_concat_t* 
  * touching 32 rows (row-major, each lane pair owns 32 bytes of a row), and needs no LDS transposition.  A tb buffer holds
  * gcpnet_tb_floats(rows, W) floats (whole tiles); rows past the end hold unspecified finite values. */
 int64_t gcpnet_tb_floats(int rows, int width);
+/* Sign mask of s_pre (ABI 4).  The backward of a block with piecewise-linear activations (None / relu / leakyrelu: every shipped
+ * configuration) needs of s_pre only WHERE it is positive -- act'(s_pre) of components/gcpnet.py:441,465 and of the gate's input,
+ * :345-347 -- i.e. one bit per element instead of four bytes.  s_sign [ceil(rows / 32)][Wp / 64][64 lanes] uint32, Wp = 32 ceil(W / 32)
+ * (even number of 32-wide tiles): bit (16 t + r) % 32 of word (16 t + r) / 32 of lane (r_ % 32, half) of a tile is s_pre > 0 for
+ * register r of accumulator tile t of that lane (the element the tile-blocked layout above puts at piece (t, r / 4), float r % 4).
+ * The register-resident chain forward writes it when s_sign != NULL (beside s_pre, which the weight-gradient GEMM still reads);
+ * gcpnet_gcp2_chain_backward reads it INSTEAD of s_pre when every item carries one: 16 KB less HBM traffic per 32-row tile and
+ * block at width 128, and no 64-register request in flight through the block's vector stage.
+ * gcpnet_tb_sign_words(rows, width): uint32 words of such a buffer (0 when the width has an odd number of tiles). */
+int64_t gcpnet_tb_sign_words(int rows, int width);
 typedef struct {
     gcp2_weights_t w;
     gcp2_opts_t o;
@@ -125,6 +135,7 @@ typedef struct {
     float* gate;
     int s_out_tb;  /* s_out is written tile-blocked (register-resident kernel only: E_UNSUPPORTED elsewhere) */
     int s_pre_tb;  /* s_pre is written tile-blocked */
+    uint32_t* s_sign;  /* optional sign mask of s_pre (see above; register-resident kernel, piecewise-linear activations only) */
 } gcp2_chain_item_t;
 #define GCP_MAX_CHAIN 8
 int gcpnet_gcp2_chain_forward(int rows, const float* s0, const float* v0, const float* frames, int n,
@@ -297,6 +308,7 @@ typedef struct {
     const float* gate;
     gcp2_bwd_scratch_t sc;
     int tb;  /* s_pre is read and sc.ds_pre written in the tile-blocked layout (see gcp2_chain_item_t) */
+    const uint32_t* s_sign;  /* optional sign mask of s_pre (gcp2_chain_item_t.s_sign): read instead of s_pre when EVERY item has one */
 } gcp2_chain_bwd_item_t;
 /* 1 if gcpnet_gcp2_chain_backward takes a chain of residual blocks of this shape (callers that save tile-blocked tensors in the
  * forward ask first: there is no other consumer of that layout) */
