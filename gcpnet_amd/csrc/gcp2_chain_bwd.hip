@@ -378,6 +378,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         // ---- A. recompute [vh | vf] = [vector_down ; vector_down_frames] v on the matrix cores; norms and frame scalars
         //         (element-wise) go to the weight-gradient GEMM's operand `ext` -- through the LDS tile `dext` (free until the end of
         //         step E), from which they leave as full rows behind the s_pre requests at the end of step C: no store in step A -----
+        // GATE_PRE (sign-mask instantiations at width 128): the gate adjoint's weight fragments -- the four output tiles of a step are
+        // 16 contiguous bytes per lane -- requested in front of step C as eight 16-byte loads; step D then starts without a memory
+        // round trip (its 32 4-byte requests, issued tile by tile inside step D, cost 8.5 % of the launch with their MFMAs, GCP_CB_X & 16)
+#ifdef GCP_CB_NO_GATE_PRE
+        constexpr bool GATE_PRE = false;
+#else
+        constexpr bool GATE_PRE = SGN && NTG == 4;
+#endif
+        float4 gq[GATE_PRE ? NV : 1];
         float dgr[NV];
         if constexpr (GCP_CB_X & 4) {
 #pragma unroll
@@ -413,6 +422,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_xyz_acc vu;
             gcp_xyz_zero(vu);
             gcp_vmm_regs<NX>(it.pack + S.offVB + lane, SVB, u, vu);
+            if constexpr (GATE_PRE) {
+                const float* wg = it.pack + S.offD + (int64_t)lane * NTG;
+#pragma unroll
+                for (int r = 0; r < NV; ++r) gq[r] = *reinterpret_cast<const float4*>(wg + (int64_t)r * 64 * NTG);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- C. adjoint of the vector epilogue (gcpnet.py:364-391), element-wise: d(vector_up output), d(gate) ------
             const bool vres = p.o.vector_residual != 0;
 #pragma unroll
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             // fragments requested before this tile's MFMAs
             const float* wg = it.pack + S.offD + (int64_t)lane * NTG;
             float ga[2][NV];
-            if (scalar_gate) {
+            if (scalar_gate && !GATE_PRE) {
 #pragma unroll
                 for (int r = 0; r < NV; ++r) ga[0][r] = wg[(int64_t)r * 64 * NTG];
             }
@@ -575,7 +590,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 f32x16 gacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
-                if (scalar_gate && !(GCP_CB_X & 16)) {
+                if constexpr (GATE_PRE) {
+                    if (scalar_gate && !(GCP_CB_X & 16)) {
+#pragma unroll
+                        for (int r = 0; r < NV; ++r) {
+                            const float a = t == 0 ? gq[r].x : (t == 1 ? gq[r].y : (t == 2 ? gq[r].z : gq[r].w));
+                            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dgr[r], gacc, 0, 0, 0);
+                        }
+                    }
+                } else if (scalar_gate && !(GCP_CB_X & 16)) {
                     if (t + 1 < NTG) {
 #pragma unroll
                         for (int r = 0; r < NV; ++r) ga[(t + 1) & 1][r] = wg[(int64_t)r * 64 * NTG + t + 1];
@@ -603,21 +626,39 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #ifdef GCP_CB_FINE3  // (measurement build: stamps 0 / 1 of block 0 = end of step D / end of the ds_pre store)
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
 #endif
-        if constexpr (GCP_CB_X & 32) {
-        } else if (it.tb) {  // tile-blocked: sixteen 1 KB pieces straight from the registers (rows past the end are zeros, the buffer holds whole tiles)
-            float4* bp = reinterpret_cast<float4*>(it.ds_pre + (int64_t)r0 * (32 * NTG)) + lane;
+        // ds_pre leaves for the weight-gradient GEMM.  STORE_LATE (the sign-mask instantiations): behind step E -- the registers are step
+        // E's B operands until then anyway -- and behind the requests of step F, so that no load of the block queues behind these sixteen
+        // stores (vmcnt retires loads and stores in issue order; in front of step E they cost 12 % of the launch, GCP_CB_X & 32)
+#ifdef GCP_CB_STORE_EARLY
+        constexpr bool STORE_LATE = false;
+#else
+        constexpr bool STORE_LATE = SGN && B6;
+#endif
+        auto store_ds_pre = [&]() {
+            if constexpr (GCP_CB_X & 32) {
+            } else if (it.tb) {  // tile-blocked: sixteen 1 KB pieces straight from the registers (rows past the end are zeros, the buffer holds whole tiles)
+                float4* bp = reinterpret_cast<float4*>(it.ds_pre + (int64_t)r0 * (32 * NTG)) + lane;
 #pragma unroll
-            for (int t = 0; t < NTG; ++t)
+                for (int t = 0; t < NTG; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bp[(t * 4 + q) * 64] = make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]);
-        } else {
-            gcp_store_acc_rows_half_dense<NTG, PAD>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG or PAD; 16-byte aligned: host checks)
-        }
+                    for (int q = 0; q < 4; ++q) bp[(t * 4 + q) * 64] = make_float4(spr[t][4 * q], spr[t][4 * q + 1], spr[t][4 * q + 2], spr[t][4 * q + 3]);
+            } else {
+                gcp_store_acc_rows_half_dense<NTG, PAD>(it.ds_pre, so, r0, rows, spr, stage, lane);  // (so == 32 NTG or PAD; 16-byte aligned: host checks)
+            }
+        };
+        if constexpr (!STORE_LATE) store_ds_pre();
 #ifdef GCP_CB_FINE3
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 1, lane);
 #endif
         CB_LAUNDER();
 
+        // STORE_LATE: what step F requests from memory -- the two small products' weight fragments and the block's incoming d(V) state --
+        // is requested inside step E's last stages, ahead of the ds_pre stores
+        float vc_f[NV], vd_f[NX];
+        auto request_f = [&]() {
+            gcp_vmm_frags<NV>(it.pack + S.offVC + lane, S.SVC, vc_f);
+            gcp_vmm_frags<NX>(it.pack + S.offVD + lane, SVD, vd_f);
+        };
         // ---- E. d(s) += W^T ds_pre: 16 * NTG k-pair steps whose B operands are the ds_pre registers; the weight
         //         fragments rotate through three batches of 4 steps, requested two batches ahead and pinned there ------
         auto data_gemm = [&](auto nu_tag, const float* wq, f32x16* acc) {
@@ -681,8 +722,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 if (uu < NTG) dyr[uu < NTG ? uu : 0] = gcp_mfma_bf16x6(a, bh, bm, bl, dyr[uu < NTG ? uu : 0]);
                 else accx = gcp_mfma_bf16x6(a, bh, bm, bl, accx);
                 if ((GCP_CB_X & 1) == 0 && sg + 3 < NST) ld(a, sg + 3);
+                if constexpr (STORE_LATE) {
+                    if (sg == NST - 3) request_f();  // (the first fragment buffer has retired)
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (STORE_LATE) store_ds_pre();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int x = gcp_crow(r, hi);
@@ -724,7 +769,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             gcp_wave_lds_sync();  // ... before xt is overwritten below
             gcp_xyz_acc dacc;
             gcp_xyz_zero(dacc);
-            gcp_vmm_arr<NV>(it.pack + S.offVC + lane, S.SVC, dvu, dacc);
+            if constexpr (STORE_LATE) gcp_vmm_arr_pre<NV>(vc_f, S.SVC, dvu, dacc);
+            else gcp_vmm_arr<NV>(it.pack + S.offVC + lane, S.SVC, dvu, dacc);
             float f[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) f[i] = fr[e * 9 + i];  // (unconditional: only the channels [H, HF) use them, and they exist only with frames)
@@ -754,7 +800,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             }
             gcp_xyz_acc dv;
             gcp_xyz_zero(dv);
-            gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
+            if constexpr (STORE_LATE) gcp_vmm_regs_pre<NX>(vd_f, SVD, dacc, dv);
+            else gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
             float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
             load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st, k == p.n - 1 && p.out_idx != nullptr);  // (a handed-over tile starts below n - 1)
 #pragma unroll

@@ -1,13 +1,15 @@
 #!/bin/bash
-# Builds measurement variants of the chain backward kernel (GCP_CB_X bits, results WRONG -- only the clock is read) into
-# tools/variants/libgcpnet_hip_cbx<bits>.so (git-ignored; they travel to the GPU box).  usage: tools/cb_variants.sh 0 1 2 4 ...
+# Builds variants of the chain backward kernel into tools/variants/libgcpnet_hip_cb_<tag>.so (git-ignored; they travel to the GPU box).
+# Every argument is tag=flags, e.g.  tools/cb_variants.sh base= x1=-DGCP_CB_X=1 early=-DGCP_CB_STORE_EARLY
+# (GCP_CB_X bits: measurement builds whose results are WRONG -- only the clock is read; see gcp2_chain_bwd.hip.)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/gcpnet_amd/csrc; V=$R/tools/variants; mkdir -p $V
 OBJS=$(ls $C/*.o | grep -v gcp2_chain_bwd.o)
-for X in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DGCP_CB_ONLY_SHIPPED -DGCP_CB_X=$X ${CB_EXTRA} \
-      -c $C/gcp2_chain_bwd.hip -o $V/cbx$X.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libgcpnet_hip_cbx$X.so $OBJS $V/cbx$X.o
-  rm -f $V/cbx$X.o
-  echo built cbx$X
+for A in "$@"; do
+  TAG=${A%%=*}; FL=${A#*=}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DGCP_CB_ONLY_SHIPPED $FL \
+      -c $C/gcp2_chain_bwd.hip -o $V/cb_$TAG.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libgcpnet_hip_cb_$TAG.so $OBJS $V/cb_$TAG.o
+  rm -f $V/cb_$TAG.o
+  echo built cb_$TAG "($FL)"
 done
