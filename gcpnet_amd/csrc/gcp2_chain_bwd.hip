@@ -532,6 +532,23 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                     spr[t][4 * q] = in ? a.x : 0.f; spr[t][4 * q + 1] = in ? a.y : 0.f; spr[t][4 * q + 2] = in ? a.z : 0.f; spr[t][4 * q + 3] = in ? a.w : 0.f;
                 }
         }
+        // E_PRE (sign-mask instantiations): step E's first three stages of weight fragments are requested HERE, in front of the block's small
+        // stores (requested at the top of step E they queue behind those stores)
+#ifdef GCP_CB_NO_E_PRE
+        constexpr bool E_PRE = false;
+#else
+        constexpr bool E_PRE = SGN && B6;
+#endif
+        gcp_u32x4 EA0[3], EA1[3], EA2[3];
+        if constexpr (E_PRE) {
+            const float* wq0 = it.pack + S.offB6 + (int64_t)lane * 4;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                EA0[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + tm * 256);
+                EA1[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + 768 + tm * 256);
+                EA2[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + 2 * 768 + tm * 256);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ... and BEHIND the requests the block's small stores.  (vmcnt retires loads and stores in issue order, and a store is only
         // retired once L2 has acknowledged it: a load requested behind a batch of stores cannot be used before all of them are
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 
         // STORE_LATE: what step F requests from memory -- the two small products' weight fragments and the block's incoming d(V) state --
         // is requested inside step E's last stages, ahead of the ds_pre stores
-        float vc_f[NV], vd_f[NX];
+        float vc_f[NV], vd_f[NX], stf[3][NV];
         auto request_f = [&]() {
             gcp_vmm_frags<NV>(it.pack + S.offVC + lane, S.SVC, vc_f);
             gcp_vmm_frags<NX>(it.pack + S.offVD + lane, SVD, vd_f);
@@ -704,9 +721,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #pragma unroll
                 for (int tm = 0; tm < 3; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
             };
-            ld(A0, 0);
-            ld(A1, 1);
-            ld(A2, 2);
+            if constexpr (E_PRE) {
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) { A0[tm] = EA0[tm]; A1[tm] = EA1[tm]; A2[tm] = EA2[tm]; }
+            } else {
+                ld(A0, 0);
+                ld(A1, 1);
+                ld(A2, 2);
+            }
             __builtin_amdgcn_sched_barrier(0);
             gcp_u32x4 bh, bm, bl;
 #pragma unroll
@@ -727,7 +749,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (STORE_LATE) store_ds_pre();
+            if constexpr (STORE_LATE) {
+                // (the state too -- into the registers the fragment buffers have just left -- so that step F reads nothing behind the stores)
+                load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, stf, k == p.n - 1 && p.out_idx != nullptr);  // (a handed-over tile starts below n - 1)
+                __builtin_amdgcn_sched_barrier(0);
+                store_ds_pre();
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int x = gcp_crow(r, hi);
@@ -803,7 +830,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             if constexpr (STORE_LATE) gcp_vmm_regs_pre<NX>(vd_f, SVD, dacc, dv);
             else gcp_vmm_regs<NX>(it.pack + S.offVD + lane, SVD, dacc, dv);
             float st[3][NV];  // ResGCP pass-through + this block's contribution -> the new state
-            load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st, k == p.n - 1 && p.out_idx != nullptr);  // (a handed-over tile starts below n - 1)
+            if constexpr (STORE_LATE) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int r = 0; r < NV; ++r) st[d][r] = stf[d][r];
+            } else {
+                load_state(k == p.n - 1 ? p.d_v_out : p.d_v_in, st, k == p.n - 1 && p.out_idx != nullptr);  // (a handed-over tile starts below n - 1)
+            }
 #pragma unroll
             for (int q = 0; q < VQ; ++q) {
                 const int o0 = 8 * q + 4 * hi;
