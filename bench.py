@@ -127,8 +127,13 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     row_s, row_v = 4 * sdim, 12 * vdim
     ext, gate = 4 * ((H + 9 + 3) // 4 * 4), 4 * vdim
     # algorithmic HBM bytes per launch (every tensor a kernel must read or write once, per edge row)
-    bytes_fwd = n_edges * ((row_s + row_v + 36) + n * (row_s + row_v + row_s + gate))
-    bytes_bwd = n_edges * (2 * (row_s + row_v) + 36 + n * ((row_s + row_v + gate) + (row_s + gate + ext)))
+    # (sign masks, round 6: the forward writes one bit per s_pre element beside s_pre, the backward reads those bits INSTEAD of s_pre
+    # when the chain's activations are piecewise linear)
+    signed = bool(ops.CHAIN_SIGN_MASKS and all(sp.act_s in ops._PWL_ACTS and sp.act_v in ops._PWL_ACTS for sp in specs)
+                  and sdim % 64 == 0 and sdim <= 128)
+    bits = row_s // 32 if signed else 0
+    bytes_fwd = n_edges * ((row_s + row_v + 36) + n * (row_s + row_v + row_s + gate + bits))
+    bytes_bwd = n_edges * (2 * (row_s + row_v) + 36 + n * (((bits if signed else row_s) + row_v + gate) + (row_s + gate + ext)))
     bytes_tn = n_edges * n * ((row_s + row_s + ext) + (gate + row_s))
     fwd_name = "gcp_wg_fwd_kernel" if ops.WG_STATS["fwd_chain"] > 0 else "gcp2_chain_fwd_kernel"
     times, kbytes, kflops = {fwd_name: t_fwd}, {fwd_name: bytes_fwd}, {fwd_name: flops}

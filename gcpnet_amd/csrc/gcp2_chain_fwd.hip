@@ -19,6 +19,13 @@
 #include "vec_mfma.h"
 #include "gcp_bf16x3.h"
 
+// GCP_CF_X: measurement builds whose RESULTS ARE WRONG (tools/cf_variants.sh): bits remove one cost each so that its share of the
+// launch time can be read under real contention.  1: scalar_out's fragments loaded once; 2: no s_pre store; 4: no s_out store;
+// 8: no gate GEMM; 16: no vector prologue MFMAs; 32: no vector epilogue; 64: no v_out store; 128: no scalar_out MFMAs; 256: no sign words
+#ifndef GCP_CF_X
+#define GCP_CF_X 0
+#endif
+
 namespace {
 
 struct ChainItemF {
@@ -278,7 +285,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         //      in registers) the norms of vh and the projections of vf onto the row's frame -> the 32 x XS extras tile ------
         {
             gcp_xyz_acc u;
-            if constexpr (PRE) gcp_vmm_down_pre<NVA>(va_pre, B.SVA, vib, vt + e * L.VS, hi, u);
+            if constexpr (GCP_CF_X & 16) gcp_xyz_zero(u);
+            else if constexpr (PRE) gcp_vmm_down_pre<NVA>(va_pre, B.SVA, vib, vt + e * L.VS, hi, u);
             else gcp_vmm_down<16>(it.pack + B.offVA + lane, B.SVA, vib, vt + e * L.VS, hi, u);
             if (head) {
 #pragma unroll
@@ -382,8 +390,8 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                         gcp_bf16x3_split8(x, bh, bm, bl);
                     }
                     gcp_u32x4(&a)[3] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
-                    acc[t] = gcp_mfma_bf16x6(a, bh, bm, bl, acc[t]);
-                    if (sg + 3 < NSTG) ld6(a, sg + 3);
+                    if constexpr ((GCP_CF_X & 128) == 0) acc[t] = gcp_mfma_bf16x6(a, bh, bm, bl, acc[t]);
+                    if ((GCP_CF_X & 1) == 0 && sg + 3 < NSTG) ld6(a, sg + 3);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if (!head) {
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
 #endif
         // ---- vector gate Linear, B fragments = the accumulator registers ---------------------------------------------------
-        if (F6 && scalar_gate) {
+        if (F6 && scalar_gate && !(GCP_CF_X & 8)) {
             const float* q6 = it.pack + S.offC6 + (int64_t)lane * 4;
 #pragma unroll
             for (int j2 = 0; j2 < 2 * NT; ++j2) {
@@ -515,12 +523,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- s_pre (saved for the backward) and the new state x += act(s_pre), both straight from / in registers ----------
-        if (it.s_pre) {
+        if ((GCP_CF_X & 2) == 0 && it.s_pre) {
             if (it.s_pre_tb) gcp_store_acc_tb<NT>(it.s_pre, r0, acc, lane);
             else gcp_store_acc_rows_any<NT>(it.s_pre, so, r0, rows, acc, stage, lane);
         }
         if constexpr ((NT % 2) == 0) {
-            if (it.s_sign) {  // (wave-uniform) where s_pre is positive, one bit per register element: all the backward needs of it
+            if ((GCP_CF_X & 256) == 0 && it.s_sign) {  // (wave-uniform) where s_pre is positive, one bit per register element: all the backward needs of it
                 unsigned* sp = it.s_sign + ((int64_t)blockIdx.x * (NT / 2)) * 64 + lane;
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) {
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 const float y = gcp_actf<PWL>(it.act_s, ns_s, slope, acc[t][r]);
                 xs[t][r] = head ? y : xs[t][r] + y;
             }
-        if (it.s_out) {
+        if ((GCP_CF_X & 4) == 0 && it.s_out) {
             if (it.s_out_tb) gcp_store_acc_tb<NT>(it.s_out, r0, xs, lane);
             else gcp_store_acc_rows_any<NT>(it.s_out, so, r0, rows, xs, stage, lane);
         }
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
 #endif
         // ---- vector epilogue: vector_up on the matrix cores (B fragments = the parked vector_down outputs), then sigmoid
         //      gate, gating and residual element-wise in registers; the vector tile is updated in place ------------------
-        {
+        if constexpr ((GCP_CF_X & 32) == 0) {
             gcp_xyz_acc uin, vu;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         if (head)  // back to the chain blocks' extras layout: their k padding must read as zero
             for (int i = H + S.nf + hi; i < 2 * NX; i += 2) ext[e * L.XS + i] = 0.f;
         gcp_wave_lds_sync();
-        if (it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
+        if ((GCP_CF_X & 64) == 0 && it.v_out) gcp_store_tile(it.v_out, 3 * vo, 0, 3 * vo, r0, rows, vt, L.VS, lane);
 #ifndef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 7, lane);
 #endif
@@ -665,8 +673,14 @@ int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const f
     p.sh = S;
     const size_t lds_bytes = (size_t)chain_lds(S).total * sizeof(float);
     if (lds_bytes > 64 * 1024) return GCPNET_E_UNSUPPORTED;
+#ifdef GCP_CF_ONLY_SHIPPED  // (development builds: only the instantiation configs[1] runs)
+    hipLaunchKernelGGL((gcp2_chain_fwd_kernel<4, true, false, false, 4, true>), dim3((unsigned)gcp_cdiv(p.rows, GCP_TILE_ROWS)), dim3(GCP_WAVE), lds_bytes, st, p);
+    GCP_HIP_CHECK_LAUNCH();
+    return 0;
+#else
     if (S.NTG == 2) return pwl ? launch_chain<2, true>(p, lds_bytes, st) : launch_chain<2, false>(p, lds_bytes, st);
     return pwl ? launch_chain<4, true>(p, lds_bytes, st) : launch_chain<4, false>(p, lds_bytes, st);
+#endif
 }
 
 // 1 if a chain of residual blocks of this shape runs in the register-resident kernel above (callers that have another fast

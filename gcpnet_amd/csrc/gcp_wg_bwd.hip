@@ -19,6 +19,17 @@
 
 #include "gcp_wg.h"
 
+// GCP_WG_X: measurement builds whose RESULTS ARE WRONG (tools/wg_variants.sh): bits remove one cost each so that its share of the
+// launch time can be read under real contention.  1: P4's fragments from 6 KB (= GCP_WG_EXP1); 2: no P7; 4: no P8; 8: no P9;
+// 16: no P1; 32: no P2; 64: no gate MFMAs in P3; 128: no ds_pre store; 256: no P4 MFMAs; 512: no s_pre / d(s_out) requests of the later
+// output tiles in P3
+#ifndef GCP_WG_X
+#define GCP_WG_X 0
+#endif
+#if (GCP_WG_X & 1) && !defined(GCP_WG_EXP1)
+#define GCP_WG_EXP1
+#endif
+
 namespace {
 
 // Everything about a block's shape that the kernel needs as integers: dimensions, tile counts, LDS strides and offsets.  One
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         {
             const float* vrow = V + prow * VS;
             const int grow = min(r0 + prow, rows - 1);
-            for (int x = psub; x < HF; x += TPR) {
+            for (int x = psub; x < ((GCP_WG_X & 16) ? 0 : HF); x += TPR) {
                 float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                 for (int k = 0; k < p.v_add.n; ++k) {  // shares of the pre-projected (gathered) vector sources
                     const int32_t* ix = p.v_add.idx[k];
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         stamp(2);
         WG_LAUNDER();
         // ---- P2: adjoint of the vector epilogue (gcpnet.py:364-391) --------------------------------------------------------
-        if (vo > 0) {
+        if (vo > 0 && !(GCP_WG_X & 32)) {
             for (int o = psub; o < vo; o += TPR) {
                 const float* wu = WU + o * WSU;
                 const float* vh = VH + prow * HS;
@@ -505,9 +516,29 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         const int gb = 4 * ot_base, ge = MP ? min(SG, gb + 4 * NW * tpp) : SG;  // ... = these groups of eight columns of so
         // ---- P3: ds_pre = d(s_out) act_s'(s_pre) + act_v'(s_pre) (Wg^T dgate), this wave's tiles of so -> DS ---------------
         f32x16 spa;  // act_v(s_pre) of the wave's tile (fused: B operand of the gate weight gradient)
+        // B6: the first four slabs of P4's weight fragments are requested HERE, in front of P3's ds_pre stores (requested at the top of
+        // P4 they queue behind those stores: vmcnt retires loads and stores in issue order)
+#ifndef GCP_WG_P4_PRE  // (measured, round 6: 2.349 against 2.376 ms per (256,32) launch, inside the box's noise; a build option)
+        constexpr bool P4_PRE = false;
+#else
+        constexpr bool P4_PRE = B6;
+#endif
+        gcp_u32x4 pre0[3], pre1[3], pre2[3], pre3[3];
+        if constexpr (P4_PRE) {
+            const int NFT0 = split ? NKT - 1 : NKT, NSL0 = 2 * NT;
+            const gcp_u32x4* q0 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)min(w, NFT0 - 1) * NSL0 * 192 + lane;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                pre0[tm] = q0[tm * 64];
+                pre1[tm] = q0[(int64_t)min(1, NSL0 - 1) * 192 + tm * 64];
+                pre2[tm] = q0[(int64_t)min(2, NSL0 - 1) * 192 + tm * 64];
+                pre3[tm] = q0[(int64_t)min(3, NSL0 - 1) * 192 + tm * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         for (int t = t_lo; t < t_lo + tpp && w + NW * t < NT; ++t) {
             const int ot = w + NW * t;
-            if (t > 0) {
+            if (t > 0 && !(GCP_WG_X & 512)) {
                 const int64_t tbo = (int64_t)tile * 32 * so + (int64_t)ot * 1024 + lane * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -519,7 +550,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
             f32x16 gacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
-            if (gated) {
+            if (gated && !(GCP_WG_X & 64)) {
                 const float* pg = p.pk + p.offG2 + ((int64_t)ot * VG * 64 + lane) * 4;
                 for (int g = 0; g < VG; ++g) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(pg + (int64_t)g * 256);
@@ -557,7 +588,8 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     pl[jh * 192] = th; pl[jh * 192 + 64] = tm; pl[jh * 192 + 128] = tl;
                 }
             }
-            if (p.ds_pre && (p.tb & 8)) {  // tile-blocked operand of gcpnet_tn_gemm: straight from the registers (zeros in the rows past the end)
+            if (GCP_WG_X & 128) {
+            } else if (p.ds_pre && (p.tb & 8)) {  // tile-blocked operand of gcpnet_tn_gemm: straight from the registers (zeros in the rows past the end)
                 float* dst = p.ds_pre + (int64_t)tile * 32 * so + (int64_t)ot * 1024 + lane * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -662,14 +694,19 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                         a[0] = q[0]; a[1] = q[64]; a[2] = q[128];
                     };
                     gcp_u32x4 a0[3], a1[3], a2[3], a3[3];
-                    lda(a0, 0); lda(a1, 1); lda(a2, 2); lda(a3, 3);
+                    if constexpr (P4_PRE) {
+#pragma unroll
+                        for (int tm = 0; tm < 3; ++tm) { a0[tm] = pre0[tm]; a1[tm] = pre1[tm]; a2[tm] = pre2[tm]; a3[tm] = pre3[tm]; }
+                    } else {
+                        lda(a0, 0); lda(a1, 1); lda(a2, 2); lda(a3, 3);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     for (int sj = 0; sj < NSL; sj += 4) {  // (NSL = 2 NT; a trailing pair is guarded)
 #define WG_B6_STEP(A, S)                                                                                       \
     if ((S) < NSL) {                                                                                           \
         const gcp_u32x4* qb = pb6 + (int64_t)(S) * 192;                                                        \
         const gcp_u32x4 bh = qb[0], bm = qb[64], bl = qb[128];                                                 \
-        acc2[0] = gcp_mfma_bf16x6(A, bh, bm, bl, acc2[0]);                                                     \
+        if constexpr ((GCP_WG_X & 256) == 0) acc2[0] = gcp_mfma_bf16x6(A, bh, bm, bl, acc2[0]);                \
         lda(A, (S) + 4);                                                                                       \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
@@ -852,7 +889,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 #if defined(GCP_WG_STAMP_TAIL) && GCP_WG_STAMP_TAIL == 3  // (variant 3: P7 without its arithmetic -- what the phase costs empty; results wrong)
             for (int x = psub; x < 0; x += TPR) {
 #else
-            for (int x = psub; x < HF; x += TPR) {
+            for (int x = psub; x < ((GCP_WG_X & 2) ? 0 : HF); x += TPR) {
 #endif
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                 // d(extras) of this thread's entry (one column for a hidden channel, three for a frame row), REQUESTED here -- all
@@ -936,6 +973,15 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 
         WG_LAUNDER();
         // ---- P8: d(v_in) = [vector_down ; vector_down_frames]^T d[vh | vf] (+ pass-through terms) ----------------------------
+        // d(v_in) leaves through an LDS tile (the split-K partial slots, free since the barrier behind P7) as whole 16-byte pieces of
+        // its rows at the end of the tile: written from here as three 4-byte stores per (row, channel) with a 12-byte lane stride,
+        // P8 cost 9 % of the (256,32) launch (GCP_WG_X & 4) -- most of it those stores
+#ifndef GCP_WG_STAGE_DVIN  // (measured, round 6: 2.349 against 2.355 ms per (256,32) launch -- not the stores; left as a build option)
+        const bool stage_dv = false;
+#else
+        const bool stage_dv = ((3 * vi) & 3) == 0 && wg_aligned16(p.d_v_in) && NW * EPS >= 3 * vi + 4;
+#endif
+        const int DVS = 4 * ((3 * vi) / 4 | 1);  // row stride of the staged tile (an odd number of 16-byte pieces)
         auto p8 = [&](int c, bool pre, float h0, float h1, float h2) {
             const float* wt = WDT + c * WTV;
             const float* dq = DVHF + prow * FS;
@@ -962,13 +1008,20 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                         a0 += g[0]; a1 += g[1]; a2 += g[2];
                     }
                 }
-                float* dp = p.d_v_in + ((int64_t)(r0 + prow) * vi + c) * 3;
-                dp[0] = a0; dp[1] = a1; dp[2] = a2;
+                if (stage_dv) {
+                    float* dp = EPART + prow * DVS + 3 * c;
+                    dp[0] = a0; dp[1] = a1; dp[2] = a2;
+                } else {
+                    float* dp = p.d_v_in + ((int64_t)(r0 + prow) * vi + c) * 3;
+                    dp[0] = a0; dp[1] = a1; dp[2] = a2;
+                }
             }
         };
+        if constexpr ((GCP_WG_X & 4) == 0) {
         if (psub < vi) p8(psub, true, gpre[0][0], gpre[0][1], gpre[0][2]);
         if (psub + TPR < vi) p8(psub + TPR, true, gpre[1][0], gpre[1][1], gpre[1][2]);
         for (int c = psub + 2 * TPR; c < vi; c += TPR) p8(c, false, 0.f, 0.f, 0.f);
+        }
         if (p.dvhf) {  // d[vh | vf] per row, [3, HF'] xyz-major: the gradient of the pre-projected vector tables' gathered rows
             const int wdt = 3 * HFP;
             for (int i = tid; i < nvalid * wdt; i += NTH) {
@@ -989,7 +1042,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
         {
             const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-            for (int sl = 0; sl < NSW; ++sl) {
+            for (int sl = 0; sl < ((GCP_WG_X & 8) ? 0 : NSW); ++sl) {
                 const int t = w + NW * sl;
                 if (t < sm_tiles) {
                     const bool up = t < sm_up_tiles;
@@ -1020,6 +1073,8 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
             }
         }
         wg_barrier();  // the tiles are free for the next iteration's loads
+        if (stage_dv)  // (the staged d(v_in) rows; the slots are next written in P3 / P4 of the following tile, two barriers from here)
+            wg_tile_store<NTH>(p.d_v_in + (int64_t)r0 * 3 * vi, EPART, DVS, 3 * vi, nvalid, tid, true, DM(mg_v));
         stamp(7);
     }
 
@@ -1305,6 +1360,11 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     p.stamps = g_gcp_phase_buf; p.stamp_cap = g_gcp_phase_cap;
     hipStream_t st = (hipStream_t)stream;
     const int grid = pl.grid;
+#ifdef GCP_WG_ONLY_SHIPPED  // (development builds: only the instantiation of the configs[4] chain)
+    if (pwl && !pl.fused && NW == 8 && pl.kt == 1 && b6 && wg_bwd_is_shape<2, 8, 0, true>(p, w, gated))
+        return launch_bwd<8, 1, 0, 2, true>(p, pwl, grid, lds_bytes, st);
+    return GCPNET_E_UNSUPPORTED;
+#else
     // compile-time shapes: the residual message GCPs of BASELINE configs[1] (fused, 4 waves) and configs[4] (8 waves)
     if (pwl && !getenv("GCPNET_WG_BWD_NOSHAPE")) {
         if (pl.fused && NW == 4 && wg_bwd_is_shape<1, 4, 5>(p, w, gated)) return launch_bwd<4, 1, 5, 1>(p, pwl, grid, lds_bytes, st);
@@ -1322,4 +1382,5 @@ extern "C" int gcpnet_wg_backward(int rows, const gcp_wg_bwd_args_t* a, void* st
     if (pl.fused) return NW == 4 ? launch_bwd<4, 1, 5>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 1, 5>(p, pwl, grid, lds_bytes, st);
     if (NW == 4) return pl.kt == 1 ? launch_bwd<4, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<4, 4, 0>(p, pwl, grid, lds_bytes, st);
     return pl.kt == 1 ? launch_bwd<8, 1, 0>(p, pwl, grid, lds_bytes, st) : launch_bwd<8, 4, 0>(p, pwl, grid, lds_bytes, st);
+#endif
 }

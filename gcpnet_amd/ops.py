@@ -1489,7 +1489,7 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
             items[k].gate = gate.data_ptr() if gate is not None else None
             items[k].s_out_tb, items[k].s_pre_tb = int(isinstance(s_out, TileBlocked)), int(isinstance(s_pre, TileBlocked))
-            items[k].s_sign = getattr(s_pre, "sign", None)
+            items[k].s_sign = s_pre.sign if isinstance(s_pre, TileBlocked) else None
             ws.append(w); packs.append(pack); outs.append((s_out, v_out, s_pre, gate))
         if rows == 0:  # (an empty edge set: nothing to launch)
             if need_grad:
@@ -1666,7 +1666,7 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
         items[k].v_in = ins[k][1].data_ptr()
         items[k].tb = int(tb_all)
         items[k].s_pre = outs[k][2].data_ptr()
-        items[k].s_sign = getattr(outs[k][2], "sign", None) if CHAIN_SIGN_MASKS else None
+        items[k].s_sign = outs[k][2].sign if (CHAIN_SIGN_MASKS and isinstance(outs[k][2], TileBlocked)) else None
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
         items[k].sc = scr
     d_s_in = torch.empty((rows, specs[0].si), dtype=torch.float32, device=d_s.device)

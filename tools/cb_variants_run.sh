@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: times the chain backward of every tools/variants/libgcpnet_hip_cb_*.so at the given tile counts (chain_rows_sweep.py)
+# GPU box: times the chain backward of every tools/variants/libgcpnet_hip_c[bf]_*.so at the given tile counts (chain_rows_sweep.py)
 R=$PWD; OUT=$R/gpurun_out/${1:-cbx}.txt; shift; T=${1:-4998,2048}
 : > $OUT
-for L in $(ls $R/tools/variants/libgcpnet_hip_cb_*.so | sort -V); do
+for L in $(ls $R/tools/variants/libgcpnet_hip_c[bf]_*.so | sort -V); do
   echo "== $(basename $L)" >> $OUT
   GCPNET_HIP_LIB=$L python $R/tools/chain_rows_sweep.py --tiles $T --iters 11 2>&1 | grep tiles | python -c "
 import sys, json
