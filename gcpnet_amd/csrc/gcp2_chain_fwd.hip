@@ -532,9 +532,14 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 unsigned* sp = it.s_sign + ((int64_t)blockIdx.x * (NT / 2)) * 64 + lane;
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) {
+                    // (x > 0 for a finite x  <=>  its bit pattern, read as a signed integer, is > 0: one v_med3_i32 to 0 / 1 and one
+                    // v_lshl_or_b32 per element instead of compare + select + or; +0.0 and every negative value give 0, as x > 0 does)
                     unsigned m = 0;
 #pragma unroll
-                    for (int b = 0; b < 32; ++b) m |= acc[2 * w + b / 16][b % 16] > 0.f ? (1u << b) : 0u;
+                    for (int b = 0; b < 32; ++b) {
+                        const int bits = __float_as_int(acc[2 * w + b / 16][b % 16]);
+                        m |= (unsigned)min(max(bits, 0), 1) << b;
+                    }
                     sp[w * 64] = m;
                 }
             }

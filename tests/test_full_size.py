@@ -46,8 +46,10 @@ def _layer_case(G, n_nodes, k, dims, act, seed):
     P, ci, wh, wc = oracle(torch.float32)
     gi = {k_: t.cuda().requires_grad_() for k_, t in ins.items()}
     gh, gc = layer((gi["h"], gi["chi"]), (gi["e"], gi["xi"]), ei.cuda(), fr.cuda())
-    close(gh.detach().cpu(), wh.detach(), atol=1e-5 * max(1.0, float(wh.detach().abs().max())), rtol=1e-5)
-    close(gc.detach().cpu(), wc.detach(), atol=1e-5 * max(1.0, float(wc.detach().abs().max())), rtol=1e-5)
+    # north_star's bar as it is written: outputs within 1e-5 (absolute) of the reference's fp32 path (+ 1e-5 relative for the few
+    # elements above 1); achieved: 1.4e-6 on the full configs[1] graph (profiles/r05_parity_table.txt)
+    close(gh.detach().cpu(), wh.detach(), atol=1e-5, rtol=1e-5)
+    close(gc.detach().cpu(), wc.detach(), atol=1e-5, rtol=1e-5)
     # a random linear functional of the outputs (a squared loss behind a LayerNorm has no gradient through the scalar path)
     lh, lc = torch.randn(wh.shape, generator=g), torch.randn(wc.shape, generator=g)
     ((wh * lh).sum() + (wc * lc).sum()).backward()
@@ -291,8 +293,8 @@ def test_layer_full_c5_graph_on_a_subproblem(G):
         P64, c64, _, _ = oracle(torch.float64)
     finally:
         trace, O.TRACE_PRE = O.TRACE_PRE, None
-    close(gh.detach()[tg].cpu(), wh, atol=1e-5 * max(1.0, float(wh.abs().max())), rtol=1e-5)
-    close(gc.detach()[tg].cpu(), wc, atol=1e-5 * max(1.0, float(wc.abs().max())), rtol=1e-5)
+    close(gh.detach()[tg].cpu(), wh, atol=1e-5, rtol=1e-5)  # (1e-5 absolute, as north_star states it; achieved 1.6e-6)
+    close(gc.detach()[tg].cpu(), wc, atol=1e-5, rtol=1e-5)
     rows = dict(h=nodes, chi=nodes, e=keep_e, xi=keep_e)
     for k_ in ins:
         got = gi[k_].grad.cpu()
