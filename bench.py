@@ -610,6 +610,20 @@ def c5_block(G, ops, args):
            "algorithmic_tflops_per_s": fl * k / elapsed / 1e12,
            "frac_of_fp32_mfma_peak": fl * k / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            "frac_of_fp32_mfma_peak_median_step": fl / (med * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    # the memory route (ops.CHAIN_RECOMPUTE: the message chain recomputed in the backward, SURVEY.md 8d's byte model): what it holds
+    # and what it costs, same graph, same weights
+    try:
+        prev = ops.CHAIN_RECOMPUTE
+        ops.CHAIN_RECOMPUTE = True
+        torch.cuda.empty_cache()
+        el_r, med_r = timed_steps(wl["step"], 5, 2, 1, None)
+        out["recompute_route"] = {"switch": "GCPNET_CHAIN_RECOMPUTE=1 / ops.CHAIN_RECOMPUTE", "saved_activation_bytes_per_layer": saved_activation_bytes(wl),
+                                  "ms_per_step": el_r / 5 * 1e3, "ms_per_step_median": med_r, "steps": 5, "warmup": 2}
+    except Exception as exc:  # noqa: BLE001 -- must not cost the run its headline line
+        out["recompute_route_error"] = f"{type(exc).__name__}: {exc}"[:300]
+    finally:
+        ops.CHAIN_RECOMPUTE = prev
+        torch.cuda.empty_cache()
     if not args.no_cpu_baseline:
         try:  # ONE layer on a 1/10-size graph of the same recipe, labelled as such; with its own parity check
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(wl, a)

@@ -511,6 +511,11 @@ CHAIN_TAIL_SPLIT = os.environ.get("GCPNET_CHAIN_SPLIT", "0") == "1"
 # bit per element -- where it is positive -- and the chain backward kernel reads that instead of s_pre when every activation of the
 # chain is piecewise linear (all its derivative depends on).  GCPNET_CHAIN_SIGN=0: s_pre itself as before (A/B; bit-identical results).
 CHAIN_SIGN_MASKS = os.environ.get("GCPNET_CHAIN_SIGN", "1") != "0"
+# The memory route (SURVEY.md section 7 step 6 / section 8d's byte model: "message chain recomputed in backward, no saved per-edge
+# activations"): a ResGCP chain keeps only its inputs for the backward, which runs the chain's forward again to get s_pre / gates /
+# the intermediate states back -- 1.4 GB instead of 20.8 GB per layer at configs[4] size for one more chain forward per layer and step.
+# Same launches on the same inputs: gradients equal the plain route's bit for bit.  GCPNET_CHAIN_RECOMPUTE=1 or ops.CHAIN_RECOMPUTE.
+CHAIN_RECOMPUTE = os.environ.get("GCPNET_CHAIN_RECOMPUTE", "0") == "1"
 _PWL_ACTS = (None, "relu", "leakyrelu")
 
 
@@ -1414,7 +1419,11 @@ class _Gcp2Chain(torch.autograd.Function):
         lib = _lib.load()
         n = len(specs)
         rows, dev = s0.shape[0], s0.device
-        need_grad = any(ctx.needs_input_grad)
+        want_grad = any(ctx.needs_input_grad)
+        # CHAIN_RECOMPUTE (the memory route): the forward keeps NOTHING per block -- no s_pre, gates, intermediate states -- only the
+        # chain's inputs; the backward first runs this forward again, in saving mode (`_recompute_pass`), and then proceeds as usual
+        light = CHAIN_RECOMPUTE and want_grad and rows > 0 and not getattr(ctx, "_recompute_pass", False)
+        need_grad = want_grad and not light
         f32 = dict(dtype=torch.float32, device=dev)
         items = (ChainItem * n)()
         ws, packs, outs = [], [], []
@@ -1509,6 +1518,14 @@ class _Gcp2Chain(torch.autograd.Function):
                 raise _lib.GcpnetHipError("gcpnet_wg_forward refused a chain whose backward plan it accepted (tile-blocked activations)")
         if rc == _lib.E_UNSUPPORTED:
             check(lib.gcpnet_gcp2_chain_forward(rows, _p(s0), _p(v0), _p(frames), n, items, _stream()), "gcp2_chain_forward")
+        if light:
+            ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
+            ctx.state = (s0, v0, None, None, None)
+            ctx.in_versions = (s0._version, v0._version)
+            ctx.w_leaf = not any(sp.shared_weights for sp in specs)
+            ctx.weights = weights
+            ctx.use_cells = _note_uses(weights)
+            ctx.agg, ctx.tb, ctx.wtb, ctx.fwd_items, ctx.recompute = agg, False, False, None, True
         if need_grad:
             ctx.specs, ctx.frames, ctx.rows = specs, frames, rows
             # (the chain's own outputs must not hang off ctx: output -> grad_fn -> ctx -> output is a cycle through C++ that the
@@ -1518,11 +1535,12 @@ class _Gcp2Chain(torch.autograd.Function):
             ctx.in_versions = (s0._version, v0._version)  # (plain attributes bypass autograd's saved-tensor check: do it by hand)
             ctx.w_leaf = not any(sp.shared_weights for sp in specs)
             ctx.weights = weights
-            ctx.use_cells = _note_uses(weights)
+            ctx.use_cells = None if getattr(ctx, "_recompute_pass", False) else _note_uses(weights)
             ctx.agg = agg
             ctx.tb = tb
             ctx.wtb = wtb
             ctx.fwd_items = items  # (the backward's records start from these: same weights, packs, options)
+            ctx.recompute = False
         if agg is not None:
             plan, mean = agg
             m_s, m_v = outs[-1][0], outs[-1][1]
@@ -1542,9 +1560,18 @@ class _Gcp2Chain(torch.autograd.Function):
             return (None, None, None, d_s, d_v, *wz)
         specs, frames, rows = ctx.specs, ctx.frames, ctx.rows
         s0, v0, ws, packs, outs = ctx.state
+        ctx_tb, ctx_wtb, ctx_items = ctx.tb, getattr(ctx, "wtb", False), getattr(ctx, "fwd_items", None)
         if (s0._version, v0._version) != ctx.in_versions:  # (e.g. a masked layer's in-place row update, gcpnet.py:1248-1251, on a tensor
             raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation "  # this
                                "(the input state of a ResGCP chain)")                                                             # chain read)
+        if getattr(ctx, "recompute", False):  # the memory route: the saving forward runs now (same launches, same bits as the plain route)
+            import types
+
+            again = types.SimpleNamespace(needs_input_grad=(False, False, False, True, True) + (True,) * len(ctx.weights), _recompute_pass=True)
+            with torch.no_grad():
+                _Gcp2Chain.forward(again, specs, None, frames, s0, v0, *ctx.weights)
+            _, _, ws, packs, outs = again.state
+            ctx_tb, ctx_wtb, ctx_items = again.tb, again.wtb, again.fwd_items
         n = len(specs)
         f32 = dict(dtype=torch.float32, device=s0.device)
         out_rows = agg[0].n_src if agg is not None else rows
@@ -1561,11 +1588,15 @@ class _Gcp2Chain(torch.autograd.Function):
         # (256,32) -- go block by block through the workgroup kernel; shapes outside both through the generic kernel.
         res = None
         side_ok = ctx.w_leaf and _side_stream_ok(ctx.weights, _take_use_cells(ctx))  # (asked once: the cells are released by the question)
-        wave_chain = ctx.tb or (not getattr(ctx, "wtb", False) and _wave_chain_backward(specs[0]))
+        if getattr(ctx, "recompute", False):
+            # (the weight-gradient stream keeps its operands -- here the recomputed s_pre / states, 20 GB per layer at configs[4] size --
+            # alive until the end-of-backward join: on the memory route the GEMMs run on the caller's stream and the buffers go back
+            # to the allocator as soon as this Function returns)
+            side_ok = False
+        wave_chain = ctx_tb or (not ctx_wtb and _wave_chain_backward(specs[0]))
         if wave_chain:  # (with `agg` the kernel reads the segment-level tables itself)
-            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg,
-                                           fwd_items=getattr(ctx, "fwd_items", None))
-            assert res is not None or not ctx.tb, "tile-blocked activations were saved for a chain the backward kernel refuses"
+            res = gcp2_chain_backward_data(specs, rows, ins, outs, frames, ws, packs, d_s, d_v, nws, out_agg=agg, fwd_items=ctx_items)
+            assert res is not None or not ctx_tb, "tile-blocked activations were saved for a chain the backward kernel refuses"
         if res is None and agg is not None:
             # block-by-block routes take per-row gradients: the adjoint of the aggregation as its own launches
             plan, mean = agg
@@ -1583,7 +1614,7 @@ class _Gcp2Chain(torch.autograd.Function):
                 s_in, v_in = ins[k]
                 _, _, s_pre, gate = outs[k]
                 d_s, d_v, scr = gcp2_backward_data(specs[k], rows, [s_in], [v_in], frames, ws[k], packs[k], s_pre, gate, d_s,
-                                                   d_v, need_w=nws[k], side_reduce=side, tb_out=bool(getattr(ctx, "wtb", False)) and k > 0)
+                                                   d_v, need_w=nws[k], side_reduce=side, tb_out=bool(ctx_wtb) and k > 0)
                 if nws[k]:
                     jobs[k] = _WeightGradJob(specs[k], rows, [s_in], s_pre, scr)
         live = [j for j in jobs if j is not None]

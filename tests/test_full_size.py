@@ -369,3 +369,38 @@ def test_eight_layer_stack_at_c5_size_fits_one_gpu(G):
     assert peak < 280 * 2**30
     assert bool(torch.isfinite(h).all()) and all(bool(torch.isfinite(t.grad).all()) for t in gi.values())
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in layers.parameters())
+
+
+def test_sixteen_layer_stack_at_c5_size_runs_on_the_memory_route(G):
+    """Twice the depth of the test above does NOT fit on the plain route (16 x 20.8 GB of chain activations alone): with
+    ops.CHAIN_RECOMPUTE the chains keep only their inputs and the backward runs each chain's forward again (SURVEY.md section 7 step 6,
+    the loop of components/gcpnet.py:921-924).  Forward + backward of a 16-layer (256,32) stack on the 10^6-edge graph on ONE GPU."""
+    from gcpnet_amd import ops
+    from gcpnet_amd.synthetic import make_inputs
+
+    dims, n_nodes = (256, 32), 100000
+    ins = make_inputs(n_nodes, 10, node_dims=dims, seed=0)
+    ei, x = ins.pop("edge_index").cuda(), ins.pop("x").cuda()
+    torch.manual_seed(13)
+    layers = torch.nn.ModuleList(G.GCPInteractions(dims, (32, 4), cfg=G.default_module_cfg(), layer_cfg=G.default_layer_cfg(), dropout=0.0)
+                                 for _ in range(16)).cuda().train()
+    gi = {k_: t.cuda().requires_grad_() for k_, t in ins.items()}
+    fr = G.localize(x, ei)
+    saved = ops.CHAIN_RECOMPUTE
+    try:
+        ops.CHAIN_RECOMPUTE = True
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        h, chi = gi["h"], gi["chi"]
+        for layer in layers:
+            h, chi = layer((h, chi), (gi["e"], gi["xi"]), ei, fr)
+        held = torch.cuda.memory_allocated()
+        (h.sum() + chi.sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.CHAIN_RECOMPUTE = saved
+    peak = torch.cuda.max_memory_allocated()
+    print(f"16 layers at configs[4] size, memory route: {held / 2**30:.1f} GiB held after the forward, peak {peak / 2**30:.1f} GiB")
+    assert held < 120 * 2**30 and peak < 200 * 2**30
+    assert bool(torch.isfinite(h).all()) and all(bool(torch.isfinite(t.grad).all()) for t in gi.values())
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in layers.parameters())
