@@ -598,6 +598,42 @@ __global__ __launch_bounds__(256) void rows_matmul_small_row_kernel(int64_t rows
     }
 }
 
+// Wide outputs (J a multiple of 4, 16-byte aligned output rows): a thread computes FOUR consecutive outputs of a row -- a quarter of
+// the input requests per output, W as 16-byte LDS reads, one 16-byte store (the order of the multiply-adds of each output unchanged).
+__global__ __launch_bounds__(256) void rows_matmul_small_j4_kernel(int64_t rows, int K, int J, const float* __restrict__ in,
+                                                                   int64_t ld_in, const float* __restrict__ W,
+                                                                   float* __restrict__ out, int64_t ld_out) {
+    __shared__ __attribute__((aligned(16))) float w[4096];
+    for (int i = threadIdx.x; i < K * J; i += 256) w[i] = W[i];
+    __syncthreads();
+    const int J4 = J >> 2;
+    const int64_t total = rows * J4;
+    const bool small = total < (1ll << 31);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = small ? (int64_t)((unsigned)i / (unsigned)J4) : i / J4;
+        const int j = 4 * (int)(i - r * J4);
+        const float* x = in + r * ld_in;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 7 < K; k += 8) {
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + (k + u) * J + j);
+                acc.x = fmaf(xv[u], wv.x, acc.x); acc.y = fmaf(xv[u], wv.y, acc.y); acc.z = fmaf(xv[u], wv.z, acc.z); acc.w = fmaf(xv[u], wv.w, acc.w);
+            }
+        }
+        for (; k < K; ++k) {
+            const float xk = x[k];
+            const float4 wv = *reinterpret_cast<const float4*>(w + k * J + j);
+            acc.x = fmaf(xk, wv.x, acc.x); acc.y = fmaf(xk, wv.y, acc.y); acc.z = fmaf(xk, wv.z, acc.z); acc.w = fmaf(xk, wv.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(out + r * ld_out + j) = acc;
+    }
+}
+
 extern "C" int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float* in, int64_t ld_in, const float* W, float* out,
                                         int64_t ld_out, void* stream) {
     if (rows < 0 || K <= 0 || J <= 0 || K * J > 4096 || !in || !W || !out) return GCPNET_E_BADARG;
@@ -611,6 +647,13 @@ extern "C" int gcpnet_rows_matmul_small(int64_t rows, int K, int J, const float*
         if (J <= 4) hipLaunchKernelGGL(rows_matmul_small_row_kernel<4>, grid, block, 0, st, rows, K, J, in, ld_in, W, out, ld_out);
         else if (J <= 8) hipLaunchKernelGGL(rows_matmul_small_row_kernel<8>, grid, block, 0, st, rows, K, J, in, ld_in, W, out, ld_out);
         else hipLaunchKernelGGL(rows_matmul_small_row_kernel<16>, grid, block, 0, st, rows, K, J, in, ld_in, W, out, ld_out);
+        GCP_HIP_CHECK_LAUNCH();
+        return 0;
+    }
+    if ((J & 3) == 0 && (ld_out & 3) == 0 && aligned16(out) && rows >= 4096) {
+        const int64_t nb4 = (rows * (J >> 2) + 255) / 256;
+        hipLaunchKernelGGL(rows_matmul_small_j4_kernel, dim3((unsigned)(nb4 < 8192 ? nb4 : 8192)), dim3(256), 0, (hipStream_t)stream, rows,
+                           K, J, in, ld_in, W, out, ld_out);
         GCP_HIP_CHECK_LAUNCH();
         return 0;
     }
