@@ -870,7 +870,8 @@ def main():
                                              "peak": ag["peak"], "unit": "GB/s", "bytes": ag["bytes_per_launch"], "avg_launch_ms": ag["avg_launch_ms"]}
             out["roofline"]["hbm_kernel_gather"] = {"kernel": ga["kernel"], "workload": ga["workload"], "frac": ga["frac"], "achieved": ga["achieved"],
                                                     "peak": ga["peak"], "unit": "GB/s", "bytes": ga["bytes_per_launch"], "avg_launch_ms": ga["avg_launch_ms"]}
-            out["kernels_per_step"] = count_device_kernels(step_fn)
+            if world == 1:  # (a step of a multi-rank job holds a collective: rank 0 alone must not run one)
+                out["kernels_per_step"] = count_device_kernels(step_fn)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], out["parity_check"] = cpu_baseline(wl, args)
             if world == 1 and args.config == "c2" and not (args.no_c5_block and args.no_other_configs):
