@@ -132,9 +132,12 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     signed = bool(ops.CHAIN_SIGN_MASKS and all(sp.act_s in ops._PWL_ACTS and sp.act_v in ops._PWL_ACTS for sp in specs)
                   and sdim % 64 == 0 and sdim <= 128)
     bits = row_s // 32 if signed else 0
-    bytes_fwd = n_edges * ((row_s + row_v + 36) + n * (row_s + row_v + row_s + gate + bits))
+    # (round 6: with the sign masks and an identity gate activation nothing reads s_pre any more: the forward does not store it and the
+    # gate weight gradients come from dgate^T [s | ext], the scalar_out gradient's own second operand -- ops.CHAIN_SKIP_S_PRE)
+    no_pre = bool(signed and ops.CHAIN_SKIP_S_PRE and ops.GATE_GRADS_FROM_INPUTS and all(sp.act_v is None for sp in specs))
+    bytes_fwd = n_edges * ((row_s + row_v + 36) + n * (row_s + row_v + (0 if no_pre else row_s) + gate + bits))
     bytes_bwd = n_edges * (2 * (row_s + row_v) + 36 + n * (((bits if signed else row_s) + row_v + gate) + (row_s + gate + ext)))
-    bytes_tn = n_edges * n * ((row_s + row_s + ext) + (gate + row_s))
+    bytes_tn = n_edges * n * ((row_s + row_s + ext) + (gate + (row_s + ext if no_pre else row_s)))
     fwd_name = "gcp_wg_fwd_kernel" if ops.WG_STATS["fwd_chain"] > 0 else "gcp2_chain_fwd_kernel"
     times, kbytes, kflops = {fwd_name: t_fwd}, {fwd_name: bytes_fwd}, {fwd_name: flops}
     s0, v0, ws_, packs, outs = keep["out"][0].grad_fn.state
@@ -151,7 +154,7 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
             scrs = keep["bwd"][2]
 
             def tn():
-                ops.run_weight_grad_jobs([ops._WeightGradJob(specs[k], n_edges, [ins[k][0]], outs[k][2], scrs[k]) for k in range(n)])
+                ops.run_weight_grad_jobs([ops._WeightGradJob(specs[k], n_edges, [ins[k][0]], outs[k][2], scrs[k], w=ws_[k]) for k in range(n)])
 
             times["tn_pipe_kernel(+reduce)"] = timeit(tn)
         kbytes.update({"gcp2_chain_bwd_kernel": bytes_bwd, "tn_pipe_kernel(+reduce)": bytes_tn})

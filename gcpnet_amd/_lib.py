@@ -125,7 +125,8 @@ class WgradJob(C.Structure):
                 ("gated", C.c_int), ("act_v", C.c_int), ("slope", C.c_float), ("s_in", Operand), ("ds_pre", C.c_void_p),
                 ("ds_pre_tb", C.c_int), ("s_pre", C.c_void_p), ("s_pre_tb", C.c_int), ("ext", C.c_void_p), ("dgate", C.c_void_p),
                 ("w_part", C.c_void_p), ("n_parts", C.c_int), ("w_width", C.c_int), ("d_w_scalar", C.c_void_p),
-                ("d_b_scalar", C.c_void_p), ("d_w_small", C.c_void_p), ("d_w_gate", C.c_void_p), ("d_b_gate", C.c_void_p)]
+                ("d_b_scalar", C.c_void_p), ("d_w_small", C.c_void_p), ("d_w_gate", C.c_void_p), ("d_b_gate", C.c_void_p),
+                ("gate_lin", C.c_int), ("w_scalar", C.c_void_p), ("b_scalar", C.c_void_p)]
 
 
 class WgReduceJob(C.Structure):

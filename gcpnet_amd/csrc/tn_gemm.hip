@@ -1127,8 +1127,31 @@ inline WgradDims wgrad_dims(const gcp2_wgrad_job_t& J) {
 inline bool wgrad_job_ok(const gcp2_wgrad_job_t& J) {
     if (J.rows <= 0 || J.so <= 0 || J.s_in.n < 0 || J.s_in.n + (J.vi > 0 ? 1 : 0) > GCP_TN_MAX_SEG || !J.ds_pre || !J.d_w_scalar || !J.d_b_scalar) return false;
     if (J.vi > 0 && (!J.ext || (J.w_part && (J.n_parts <= 0 || J.w_width <= 0 || !J.d_w_small)))) return false;
-    if (J.gated && J.vi > 0 && J.vo > 0 && (!J.dgate || !J.s_pre || !J.d_w_gate || !J.d_b_gate)) return false;
+    if (J.gated && J.vi > 0 && J.vo > 0 && (!J.dgate || !J.d_w_gate || !J.d_b_gate)) return false;
+    if (J.gated && J.vi > 0 && J.vo > 0 && (J.gate_lin ? (J.act_v != GCP_ACT_NONE || !J.w_scalar || !J.b_scalar) : !J.s_pre)) return false;
     return true;
+}
+
+// gate_lin: d vector_out_scale.weight[o, j] = sum_k G[o, k] W[j, k] + db[o] b[j] for the jobs of a call (G = dgate^T [s | ext] from the
+// GEMM, db = its ones column): vo * so outputs of K multiply-adds per job -- one launch for all of them
+struct GateFinishArgs {
+    const float* G[GCP_TN_MAX_PROBLEMS * 2];
+    const float* W[GCP_TN_MAX_PROBLEMS * 2];
+    const float* b[GCP_TN_MAX_PROBLEMS * 2];
+    const float* db[GCP_TN_MAX_PROBLEMS * 2];
+    float* out[GCP_TN_MAX_PROBLEMS * 2];
+    int vo[GCP_TN_MAX_PROBLEMS * 2], so[GCP_TN_MAX_PROBLEMS * 2], K[GCP_TN_MAX_PROBLEMS * 2];
+};
+__global__ __launch_bounds__(256) void gate_finish_kernel(GateFinishArgs a) {
+    const int q = blockIdx.y, vo = a.vo[q], so = a.so[q], K = a.K[q];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= vo * so) return;
+    const int o = i / so, j = i - o * so;
+    const float* g = a.G[q] + (int64_t)o * K;
+    const float* w = a.W[q] + (int64_t)j * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(g[k], w[k], acc);
+    a.out[q][i] = fmaf(a.db[q][o], a.b[q][j], acc);
 }
 
 }  // namespace
@@ -1141,7 +1164,7 @@ extern "C" int64_t gcpnet_gcp2_weight_grads_workspace(int n, const gcp2_wgrad_jo
         const WgradDims d = wgrad_dims(J);
         const int64_t splits = gcpnet_tn_splits(J.rows, 0, 0);
         fl += splits * J.so * d.n1;
-        if (d.gated) fl += splits * d.VOP * (J.so + 1);
+        if (d.gated) fl += J.gate_lin ? splits * d.VOP * d.n1 + (int64_t)J.vo * d.n1 : splits * d.VOP * (J.so + 1);
         if (d.has_vec && J.w_part) fl += (int64_t)gcpnet_reduce_partials_groups(J.n_parts) * J.w_width;
     }
     return fl;
@@ -1153,8 +1176,17 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
         if (!wgrad_job_ok(jobs[i])) return GCPNET_E_BADARG;
     gcp_tn_problem_t probs[GCP_TN_MAX_PROBLEMS];
     gcp_reduce_job_t reds[GCP_REDUCE_MAX_JOBS];
-    int np = 0, nr = 0;
+    GateFinishArgs fin;
+    int np = 0, nr = 0, nfin = 0, fin_blocks = 1;
     float* ws = workspace;
+    auto flush_f = [&]() -> int {
+        if (nfin) {
+            hipLaunchKernelGGL(gate_finish_kernel, dim3((unsigned)fin_blocks, (unsigned)nfin), dim3(256), 0, (hipStream_t)stream, fin);
+            GCP_HIP_CHECK_LAUNCH();
+        }
+        nfin = 0; fin_blocks = 1;
+        return 0;
+    };
     auto flush_p = [&]() -> int {
         const int rc = np ? gcpnet_tn_gemm(np, probs, stream) : 0;
         np = 0;
@@ -1194,7 +1226,36 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
             ws += (int64_t)splits * J.so * d.n1;
             if (np == GCP_TN_MAX_PROBLEMS) { const int rc = flush_p(); if (rc) return rc; }
         }
-        if (d.gated) {  // d vector_out_scale.weight | bias: dgate^T [act_v(s_pre) | 1]
+        if (d.gated && J.gate_lin) {  // G | d bias = dgate^T [s segments | ext | 1]: the first product's second operand again, no s_pre
+            gcp_tn_problem_t& P = probs[np++];
+            P = gcp_tn_problem_t{};
+            P.rows = J.rows;
+            plain(P.a, J.dgate, d.VOP, 0);
+            P.b = J.s_in;
+            P.b.act = 0; P.b.slope = J.slope; P.b.ones = 1;
+            P.a.slope = J.slope;
+            if (d.has_vec) {
+                const int k = P.b.n++;
+                P.b.ptr[k] = J.ext; P.b.idx[k] = nullptr; P.b.dim[k] = d.EP; P.b.ld[k] = d.EP; P.b.tb[k] = 0;
+            }
+            const int K = d.si + (d.has_vec ? J.hidden + d.nf : 0);
+            float* G = ws;
+            ws += (int64_t)J.vo * d.n1;
+            P.out = G; P.out_sm = K; P.out_sn = 1; P.out_m = J.vo; P.out_n = K;
+            P.out2 = J.d_b_gate; P.out2_n = d.n1 - 1;
+            P.splits = splits;
+            P.partial = ws;
+            ws += (int64_t)splits * d.VOP * d.n1;
+            fin.G[nfin] = G; fin.W[nfin] = J.w_scalar; fin.b[nfin] = J.b_scalar; fin.db[nfin] = J.d_b_gate; fin.out[nfin] = J.d_w_gate;
+            fin.vo[nfin] = J.vo; fin.so[nfin] = J.so; fin.K[nfin] = K;
+            fin_blocks = max(fin_blocks, gcp_cdiv(J.vo * J.so, 256));
+            ++nfin;
+            // (the finishing launch reads what the GEMM launches of its jobs wrote: flush both together)
+            if (np == GCP_TN_MAX_PROBLEMS || nfin == GCP_TN_MAX_PROBLEMS * 2) {
+                int rc = flush_p(); if (rc) return rc;
+                rc = flush_f(); if (rc) return rc;
+            }
+        } else if (d.gated) {  // d vector_out_scale.weight | bias: dgate^T [act_v(s_pre) | 1]
             gcp_tn_problem_t& P = probs[np++];
             P = gcp_tn_problem_t{};
             P.rows = J.rows;
@@ -1211,6 +1272,7 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
         }
     }
     { const int rc = flush_p(); if (rc) return rc; }
+    { const int rc = flush_f(); if (rc) return rc; }
     for (int i = 0; i < n; ++i) {
         const gcp2_wgrad_job_t& J = jobs[i];
         if (!(J.vi > 0 && J.w_part)) continue;

@@ -516,6 +516,12 @@ CHAIN_SIGN_MASKS = os.environ.get("GCPNET_CHAIN_SIGN", "1") != "0"
 # the intermediate states back -- 1.4 GB instead of 20.8 GB per layer at configs[4] size for one more chain forward per layer and step.
 # Same launches on the same inputs: gradients equal the plain route's bit for bit.  GCPNET_CHAIN_RECOMPUTE=1 or ops.CHAIN_RECOMPUTE.
 CHAIN_RECOMPUTE = os.environ.get("GCPNET_CHAIN_RECOMPUTE", "0") == "1"
+# d vector_out_scale.weight from the block's INPUTS instead of s_pre when the gate's activation is the identity (include/gcpnet_hip.h,
+# gcp2_wgrad_job_t.gate_lin), and -- with the sign masks -- a chain forward that does not store s_pre at all (CHAIN_SKIP_S_PRE): 512 of
+# the 1 280 bytes a block writes per row at width 128.  GCPNET_GATE_FROM_INPUTS=0 / GCPNET_CHAIN_SKIP_S_PRE=0: as before (A/B; the gate
+# weight gradients then differ by fp32 round-off, everything else is bit-identical).
+GATE_GRADS_FROM_INPUTS = os.environ.get("GCPNET_GATE_FROM_INPUTS", "1") != "0"
+CHAIN_SKIP_S_PRE = os.environ.get("GCPNET_CHAIN_SKIP_S_PRE", "1") != "0"
 _PWL_ACTS = (None, "relu", "leakyrelu")
 
 
@@ -542,11 +548,12 @@ def copy2d_multi(jobs) -> None:
 class TileBlocked:
     """A [rows, width] fp32 matrix in the tile-blocked layout: gcpnet_tb_floats(rows, width) floats, its own allocation or (`owner`,
     `offset` in floats) a region of a flat one."""
-    __slots__ = ("rows", "width", "ptr", "_n", "_data", "_owner", "_off", "sign")
+    __slots__ = ("rows", "width", "ptr", "_n", "_data", "_owner", "_off", "sign", "absent")
 
     def __init__(self, rows: int, width: int, device, owner: Optional[Tensor] = None, offset: int = 0, n: Optional[int] = None):
         self.rows, self.width = rows, width
         self.sign = None  # address of the sign mask written beside an s_pre (include/gcpnet_hip.h, gcp2_chain_item_t.s_sign)
+        self.absent = False  # an s_pre the forward did not store (CHAIN_SKIP_S_PRE): only its sign mask exists, `ptr` is a placeholder
         self._n = int(n) if n is not None else int(_lib.load().gcpnet_tb_floats(rows, width))
         if owner is None:
             self._data = torch.empty((self._n,), dtype=torch.float32, device=device)
@@ -1139,7 +1146,7 @@ def _alloc_bwd_scratch(spec: Gcp2Spec, rows: int, need_w: bool, device, tb: bool
 class _WeightGradJob:
     """TN-GEMM problems for the weight gradients of one GCP2 block, fed by the backward kernel's scratch `t`."""
 
-    def __init__(self, spec: Gcp2Spec, rows: int, s_src, s_pre, t):
+    def __init__(self, spec: Gcp2Spec, rows: int, s_src, s_pre, t, w=None):
         lib = _lib.load()
         f32 = dict(dtype=torch.float32, device=s_pre.device)  # (s_pre: a Tensor or a TileBlocked)
         H, vi, vo, so = spec.hidden, spec.vi, spec.vo, spec.so
@@ -1175,6 +1182,15 @@ class _WeightGradJob:
             g[5], g[6] = torch.empty((vo, so), **f32), torch.empty((vo,), **f32)
             j.dgate, j.s_pre, j.s_pre_tb = t["dgate"].data_ptr(), s_pre.data_ptr(), int(isinstance(s_pre, TileBlocked))
             j.d_w_gate, j.d_b_gate = g[5].data_ptr(), g[6].data_ptr()
+            # act_v = identity (every shipped configuration): the gate Linear reads s_pre = [s | norms | frame scalars] W^T + b itself,
+            # so its weight gradient follows from dgate^T [s | ...] -- the operand the scalar_out gradient streams anyway -- and s_pre
+            # is not needed (gcp2_wgrad_job_t.gate_lin); REQUIRED when the forward did not store it (TileBlocked.absent)
+            absent = bool(getattr(s_pre, "absent", False))
+            if GATE_GRADS_FROM_INPUTS and spec.act_v is None and w is not None and w[0] is not None and w[1] is not None and w[0].is_contiguous():
+                j.gate_lin, j.w_scalar, j.b_scalar = 1, w[0].data_ptr(), w[1].data_ptr()
+                self.keep.append((w[0], w[1]))
+            elif absent:
+                raise _lib.GcpnetHipError("s_pre was not stored by the forward and the gate gradients cannot be formed from the block's inputs")
         if has_vec:  # d vector_up / vector_down(.frames): the backward kernel left one partial sum per tile
             j.ext = t["ext"].data_ptr()
             part = t["w_part"]
@@ -1461,6 +1477,11 @@ class _Gcp2Chain(torch.autograd.Function):
             # sign masks of s_pre: all the chain backward kernel needs of it when the activations are piecewise linear
             n_sign = (int(lib.gcpnet_tb_sign_words(rows, so))
                       if CHAIN_SIGN_MASKS and all(sp.act_s in _PWL_ACTS and sp.act_v in _PWL_ACTS for sp in specs) else 0)
+            # ... and then s_pre itself need not be stored when nothing else reads it: the gate gradients come from the block's inputs
+            skip_pre = bool(n_sign and CHAIN_SKIP_S_PRE and GATE_GRADS_FROM_INPUTS and gated0 and not light and
+                            all(sp.act_v is None and w_[0] is not None and w_[1] is not None and w_[0].is_contiguous() for sp, w_ in zip(specs, all_w)))
+            if skip_pre:  # (its region goes: everything behind it moves up)
+                o_gate, o_sout, o_vout, o_sign = (o - r64(n_tb) for o in (o_gate, o_sout, o_vout, o_sign))
             per = o_sign + r64(n_sign)
             flat = torch.empty((per * n,), **f32)
         for k, spec in enumerate(specs):
@@ -1471,7 +1492,8 @@ class _Gcp2Chain(torch.autograd.Function):
             if tb:
                 assert (spec.so, spec.vo, gated) == (so, vo, gated0)
                 base = per * k
-                s_pre = TileBlocked(rows, so, dev, owner=flat, offset=base, n=n_tb)
+                s_pre = TileBlocked(rows, so, dev, owner=flat, offset=base, n=0 if skip_pre else n_tb)
+                s_pre.absent = skip_pre
                 if n_sign:
                     s_pre.sign = flat.data_ptr() + 4 * (base + o_sign)
                 gate = _Region(flat, base + o_gate, rows, vo) if gated else None
@@ -1495,7 +1517,7 @@ class _Gcp2Chain(torch.autograd.Function):
             items[k].o = _opts_struct(spec)
             items[k].s_out = s_out.data_ptr() if s_out is not None else None
             items[k].v_out = v_out.data_ptr() if v_out is not None else None
-            items[k].s_pre = s_pre.data_ptr() if s_pre is not None else None
+            items[k].s_pre = s_pre.data_ptr() if (s_pre is not None and not getattr(s_pre, "absent", False)) else None
             items[k].gate = gate.data_ptr() if gate is not None else None
             items[k].s_out_tb, items[k].s_pre_tb = int(isinstance(s_out, TileBlocked)), int(isinstance(s_pre, TileBlocked))
             items[k].s_sign = s_pre.sign if isinstance(s_pre, TileBlocked) else None
@@ -1607,7 +1629,7 @@ class _Gcp2Chain(torch.autograd.Function):
             d_s, d_v, scrs = res
             for k in range(n):
                 if nws[k]:
-                    jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k])
+                    jobs[k] = _WeightGradJob(specs[k], rows, [ins[k][0]], outs[k][2], scrs[k], w=ws[k])
         else:
             side = side_ok
             for k in range(n - 1, -1, -1):
@@ -1696,6 +1718,8 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
             items[k].o = _opts_struct(specs[k], fused_residual=True)
         items[k].v_in = ins[k][1].data_ptr()
         items[k].tb = int(tb_all)
+        if getattr(outs[k][2], "absent", False) and not (CHAIN_SIGN_MASKS and outs[k][2].sign):
+            raise _lib.GcpnetHipError("this chain's forward stored sign masks instead of s_pre: the backward needs ops.CHAIN_SIGN_MASKS")
         items[k].s_pre = outs[k][2].data_ptr()
         items[k].s_sign = outs[k][2].sign if (CHAIN_SIGN_MASKS and isinstance(outs[k][2], TileBlocked)) else None
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None

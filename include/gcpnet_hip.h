@@ -394,6 +394,10 @@ int gcpnet_reduce_partials_groups(int n_parts);
  * d vector_up and d vector_out_scale.weight / bias.)  For each job the call builds
  *     d scalar_out.weight | bias        = ds_pre^T [scalar input segments | norms, frame scalars (ext) | 1]
  *     d vector_out_scale.weight | bias  = dgate^T [act_v(s_pre) | 1]                                   (gated blocks)
+ *       or, with gate_lin (act_v is the identity, every shipped configuration: the gate Linear reads s_pre itself, gcpnet.py:345-347):
+ *       G = dgate^T [scalar input segments | ext | 1] -- the SAME second operand as the first product -- and then
+ *       d vector_out_scale.weight = G[:, :K] scalar_out.weight^T + G[:, K] (x) scalar_out.bias   (s_pre = [s | ext] W^T + b is linear in
+ *       what the block's input already holds), so that s_pre is never read -- and, with the chain kernels' sign masks, never stored
  *     d [vector_up | vector_down | vector_down_frames] = column sums of the per-tile partial sums w_part
  * as gcp_tn_problem_t / gcp_reduce_job_t records and launches them GCP_TN_MAX_PROBLEMS / GCP_REDUCE_MAX_JOBS at a time -- what the
  * host mirror otherwise assembles block by block in its own language (40 small records and 24 scratch allocations per 7-block chain).
@@ -419,6 +423,9 @@ typedef struct {
     float* d_w_small;     /* [w_width] */
     float* d_w_gate;      /* [vo, so] */
     float* d_b_gate;      /* [vo] */
+    int gate_lin;            /* the gate gradients from the block's inputs (see above); needs act_v == GCP_ACT_NONE and the two weights below */
+    const float* w_scalar;   /* scalar_out.weight [so, si + hidden + 9 use_frames] (gate_lin) */
+    const float* b_scalar;   /* scalar_out.bias [so] (gate_lin) */
 } gcp2_wgrad_job_t;
 int64_t gcpnet_gcp2_weight_grads_workspace(int n, const gcp2_wgrad_job_t* jobs);
 int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, float* workspace, void* stream);

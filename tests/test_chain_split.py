@@ -29,7 +29,12 @@ def _chain(G, dims, rows, act):
     v = torch.randn(rows, dims[1], 3, device="cuda", generator=g).requires_grad_()
     x = torch.randn(rows, 3, 3, device="cuda", generator=g)
     frames = x / x.norm(dim=-1, keepdim=True)
-    out = ops.gcp2_chain(specs, s, v, frames, ws)
+    saved = ops.CHAIN_SKIP_S_PRE
+    try:
+        ops.CHAIN_SKIP_S_PRE = False  # (these tests run the backward with and without the sign masks: s_pre must exist)
+        out = ops.gcp2_chain(specs, s, v, frames, ws)
+    finally:
+        ops.CHAIN_SKIP_S_PRE = saved
     s0, v0, ws_, packs, outs = out[0].grad_fn.state
     n = len(blocks)
     ins = [(s0, v0) if k == 0 else (outs[k - 1][0], outs[k - 1][1]) for k in range(n)]
