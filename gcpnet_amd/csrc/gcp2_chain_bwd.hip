@@ -715,7 +715,12 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             f32x16 accx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accx[r] = 0.f;
-            gcp_u32x4 A0[3], A1[3], A2[3];
+#ifdef GCP_CB_E4  // (experiment: four fragment buffers, requests four stages ahead)
+            constexpr int ENB = 4;
+#else
+            constexpr int ENB = 3;
+#endif
+            gcp_u32x4 A0[3], A1[3], A2[3], A3[3];
             auto ld = [&](gcp_u32x4(&a)[3], int sg) {
                 const float* q = wq + (int64_t)(sg < NST ? sg : NST - 1) * 768;
 #pragma unroll
@@ -729,6 +734,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 ld(A1, 1);
                 ld(A2, 2);
             }
+            if constexpr (ENB == 4) ld(A3, 3);
             __builtin_amdgcn_sched_barrier(0);
             gcp_u32x4 bh, bm, bl;
 #pragma unroll
@@ -740,12 +746,13 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                     for (int i = 0; i < 8; ++i) x[i] = spr[j / 2][8 * (j % 2) + i];
                     gcp_bf16x3_split8(x, bh, bm, bl);
                 }
-                gcp_u32x4(&a)[3] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
+                gcp_u32x4(&a)[3] = ENB == 4 ? ((sg % 4 == 0) ? A0 : ((sg % 4 == 1) ? A1 : ((sg % 4 == 2) ? A2 : A3)))
+                                             : ((sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2));
                 if (uu < NTG) dyr[uu < NTG ? uu : 0] = gcp_mfma_bf16x6(a, bh, bm, bl, dyr[uu < NTG ? uu : 0]);
                 else accx = gcp_mfma_bf16x6(a, bh, bm, bl, accx);
-                if ((GCP_CB_X & 1) == 0 && sg + 3 < NST) ld(a, sg + 3);
+                if ((GCP_CB_X & 1) == 0 && sg + ENB < NST) ld(a, sg + ENB);
                 if constexpr (STORE_LATE) {
-                    if (sg == NST - 3) request_f();  // (the first fragment buffer has retired)
+                    if (sg == NST - ENB) request_f();  // (the first fragment buffer has retired)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -1143,15 +1143,41 @@ struct GateFinishArgs {
     int vo[GCP_TN_MAX_PROBLEMS * 2], so[GCP_TN_MAX_PROBLEMS * 2], K[GCP_TN_MAX_PROBLEMS * 2];
 };
 __global__ __launch_bounds__(256) void gate_finish_kernel(GateFinishArgs a) {
+    // a WAVE per output column j (sixteen columns per workgroup): its lanes read row j of W as one contiguous piece (k = lane, lane + 64,
+    // lane + 128), multiply it with the <= 32 rows of G held in LDS and reduce each product over the wave.  (One thread per output with
+    // W[j, :] read straight from memory -- a 564-byte stride between lanes -- took 54 us per launch: 0.55 ms of a configs[1] step.)
+    __shared__ float Gs[32 * 193];
     const int q = blockIdx.y, vo = a.vo[q], so = a.so[q], K = a.K[q];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= vo * so) return;
-    const int o = i / so, j = i - o * so;
-    const float* g = a.G[q] + (int64_t)o * K;
-    const float* w = a.W[q] + (int64_t)j * K;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(g[k], w[k], acc);
-    a.out[q][i] = fmaf(a.db[q][o], a.b[q][j], acc);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (vo > 32 || K > 192) {  // (outside the tile sizes: the plain form)
+        for (int i = blockIdx.x * 256 + tid; i < vo * so; i += gridDim.x * 256) {
+            const int o = i / so, j = i - o * so;
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) acc = fmaf(a.G[q][(int64_t)o * K + k], a.W[q][(int64_t)j * K + k], acc);
+            a.out[q][i] = fmaf(a.db[q][o], a.b[q][j], acc);
+        }
+        return;
+    }
+    for (int i = tid; i < vo * K; i += 256) Gs[(i / K) * 193 + i % K] = a.G[q][i];
+    __syncthreads();
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = blockIdx.x * 16 + w * 4 + jj;
+        if (j >= so) break;  // (wave-uniform)
+        const float* wr = a.W[q] + (int64_t)j * K;
+        float wv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wv[c] = lane + 64 * c < K ? wr[lane + 64 * c] : 0.f;
+        const float bj = a.b[q][j];
+        for (int o = 0; o < vo; ++o) {
+            const float* g = Gs + o * 193;
+            float p = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p = fmaf(lane + 64 * c < K ? g[lane + 64 * c] : 0.f, wv[c], p);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+            if (lane == 0) a.out[q][(int64_t)o * so + j] = fmaf(a.db[q][o], bj, p);
+        }
+    }
 }
 
 }  // namespace
@@ -1248,10 +1274,12 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
             ws += (int64_t)splits * d.VOP * d.n1;
             fin.G[nfin] = G; fin.W[nfin] = J.w_scalar; fin.b[nfin] = J.b_scalar; fin.db[nfin] = J.d_b_gate; fin.out[nfin] = J.d_w_gate;
             fin.vo[nfin] = J.vo; fin.so[nfin] = J.so; fin.K[nfin] = K;
-            fin_blocks = max(fin_blocks, gcp_cdiv(J.vo * J.so, 256));
+            fin_blocks = max(fin_blocks, gcp_cdiv(J.so, 16));
             ++nfin;
             // (the finishing launch reads what the GEMM launches of its jobs wrote: flush both together)
-            if (np == GCP_TN_MAX_PROBLEMS || nfin == GCP_TN_MAX_PROBLEMS * 2) {
+            // (the finishing launch reads what the GEMM launches wrote: it follows the last of them, or comes when its table is full)
+            if (np == GCP_TN_MAX_PROBLEMS) { const int rc = flush_p(); if (rc) return rc; }
+            if (nfin == GCP_TN_MAX_PROBLEMS * 2) {
                 int rc = flush_p(); if (rc) return rc;
                 rc = flush_f(); if (rc) return rc;
             }
