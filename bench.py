@@ -179,7 +179,7 @@ def kernel_roofline(G, ops, layer, frames, n_edges, sdim, vdim, iters=20):
     return dict(times=times, bytes=kbytes, flops=kflops, n_blocks=n)
 
 
-PMC_FILE = "profiles/r05_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
+PMC_FILE = "profiles/r06_traffic.json"  # HBM bytes / MFMA-busy share per launch from committed rocprofv3 --pmc passes
 
 
 def _pmc_file():
