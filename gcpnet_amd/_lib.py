@@ -228,8 +228,8 @@ def load():
     lib.gcpnet_frame_gate_backward.argtypes = [i64, i32, vp, i32, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp]
     lib.gcpnet_frame_gate_bwd_parts.argtypes = [i64]
     lib.gcpnet_node_scalarize.argtypes = [i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
-    lib.gcpnet_radius_graph.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]
-    lib.gcpnet_radius_graph_first.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]
+    lib.gcpnet_radius_graph.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, C.c_double, i32, vp, vp, vp]
+    lib.gcpnet_radius_graph_first.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, C.c_double, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gcpnet_gcp2_pack_floats", "gcpnet_layernorm_bwd_scratch_floats", "gcpnet_gcp2_forward_lds_bytes",

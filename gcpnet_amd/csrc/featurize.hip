@@ -191,26 +191,26 @@ extern "C" int gcpnet_orientations(int64_t N, const float* x, const int32_t* bat
 }
 
 extern "C" int gcpnet_radius_graph(int N, const float* x_sorted, const int32_t* order, const int32_t* cell_of, const int32_t* cell_start,
-                                   int nx, int ny, int nz, float radius, int max_neighbors, int32_t* nbr, int32_t* count, void* stream) {
-    if (N < 0 || !x_sorted || !order || !cell_of || !cell_start || nx < 1 || ny < 1 || nz < 1 || !(radius > 0.f) || max_neighbors < 1 ||
+                                   int nx, int ny, int nz, double radius, int max_neighbors, int32_t* nbr, int32_t* count, void* stream) {
+    if (N < 0 || !x_sorted || !order || !cell_of || !cell_start || nx < 1 || ny < 1 || nz < 1 || !(radius > 0.0) || max_neighbors < 1 ||
         max_neighbors > RG_MAX_K || !nbr || !count)
         return GCPNET_E_BADARG;
     if (N == 0) return 0;
     hipLaunchKernelGGL(radius_graph_kernel<false>, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, x_sorted, order,
-                       cell_of, cell_start, nx, ny, nz, (double)radius * (double)radius, max_neighbors, nbr, count);
+                       cell_of, cell_start, nx, ny, nz, radius * radius, max_neighbors, nbr, count);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gcpnet_radius_graph_first(int N, const float* x_sorted, const int32_t* order, const int32_t* cell_of,
-                                         const int32_t* cell_start, int nx, int ny, int nz, float radius, int max_neighbors, int32_t* nbr,
+                                         const int32_t* cell_start, int nx, int ny, int nz, double radius, int max_neighbors, int32_t* nbr,
                                          int32_t* count, void* stream) {
-    if (N < 0 || !x_sorted || !order || !cell_of || !cell_start || nx < 1 || ny < 1 || nz < 1 || !(radius > 0.f) || max_neighbors < 1 ||
+    if (N < 0 || !x_sorted || !order || !cell_of || !cell_start || nx < 1 || ny < 1 || nz < 1 || !(radius > 0.0) || max_neighbors < 1 ||
         max_neighbors + 1 > RG_MAX_K || !nbr || !count)
         return GCPNET_E_BADARG;
     if (N == 0) return 0;
     hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, x_sorted, order,
-                       cell_of, cell_start, nx, ny, nz, (double)radius * (double)radius, max_neighbors + 1, nbr, count);
+                       cell_of, cell_start, nx, ny, nz, radius * radius, max_neighbors + 1, nbr, count);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 }

@@ -579,14 +579,14 @@ int gcpnet_orientations(int64_t N, const float* x, const int32_t* batch, float* 
  * >= radius (x_sorted [N,3], order = node id per sorted position, cell_of, cell_start [n_graphs*nx*ny*nz + 1]).  Edge (row =
  * neighbour, col = node) lists built from it are col-sorted by construction. */
 int gcpnet_radius_graph(int N, const float* x_sorted, const int32_t* order, const int32_t* cell_of, const int32_t* cell_start, int nx,
-                        int ny, int nz, float radius, int max_neighbors, int32_t* nbr, int32_t* count, void* stream);
+                        int ny, int nz, double radius /* double: r * r is formed as torch_cluster forms it, (float)(double r * double r) */, int max_neighbors, int32_t* nbr, int32_t* count, void* stream);
 /* The same cell list with torch_cluster 1.6.0's neighbour selection (`radius_graph(x, r, batch, loop=False, max_num_neighbors)`,
  * the call of atom3d_dataset.py:110-112): candidates are met in ascending node id (its CUDA kernel walks a graph's nodes in index
  * order), distance test strict (d^2 < r^2), the walk stops at max_neighbors + 1 hits WITH the node itself among the candidates, the
  * self loop is removed afterwards -- so a node keeps the lowest ids, not the nearest, and up to max_neighbors + 1 of them when its
  * own id is not among the first max_neighbors + 1 in range.  nbr [N, max_neighbors + 1] (-1 padded), ascending by id. */
 int gcpnet_radius_graph_first(int N, const float* x_sorted, const int32_t* order, const int32_t* cell_of, const int32_t* cell_start,
-                              int nx, int ny, int nz, float radius, int max_neighbors, int32_t* nbr, int32_t* count, void* stream);
+                              int nx, int ny, int nz, double radius /* double: r * r is formed as torch_cluster forms it, (float)(double r * double r) */, int max_neighbors, int32_t* nbr, int32_t* count, void* stream);
 
 /* ---- profiling hook: when `buf` (device memory, n_tiles * 8 uint64) is non-NULL, each 32-row wave-tile of the GCP2
  * forward / backward kernels writes s_memtime stamps at its phase boundaries; NULL switches it off. */

@@ -169,6 +169,26 @@ def test_lba_featurize_neighbour_cap_first_found(G):
     assert torch.equal(eb, torch.cat((f.o["edge_index"], f.o["edge_index"] + n), dim=1))
 
 
+@pytest.mark.parametrize("radius", [4.6, 0.3, 7.1])
+def test_radius_graph_first_takes_the_cutoff_as_torch_cluster_forms_it(G, radius):
+    """select="first" compares float d^2 with (float)(double r * double r), as torch_cluster does; the C ABI therefore
+    takes the radius as a double (a float parameter squared in double differs by an ulp for radii that are not representable in
+    float, and pairs at the boundary land on the other side).  Pairs placed EXACTLY at the two candidate thresholds decide."""
+    import numpy as np
+    from oracle import gcp_oracle as O
+
+    thr = np.float32(radius * radius)                       # torch_cluster's threshold
+    alt = np.float32(np.float64(np.float32(radius)) ** 2)   # the threshold a float-typed parameter would give
+    pts = [[0.0, 0.0, 0.0]]
+    for t in {float(thr), float(alt), float(np.nextafter(thr, np.float32(0))), float(np.nextafter(thr, np.float32(np.inf)))}:
+        pts.append([float(np.sqrt(np.float64(t))), 0.0, 0.0])  # (x^2 in float is then within an ulp of t: both sides get covered)
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat((torch.tensor(pts, dtype=torch.float32), torch.rand(300, 3, generator=g) * 2.5 * radius))
+    want = O.radius_graph(x, torch.zeros(x.shape[0], dtype=torch.long), radius, 32, select="first")
+    got = G.radius_graph(x.cuda(), r=radius, max_num_neighbors=32, select="first").cpu()
+    assert torch.equal(got, want)
+
+
 def test_radius_graph_matches_scipy_bit_for_bit(G):
     """GPU cell-list radius graph: the committed scipy fixture (3 graphs: dense, sparse, fewer nodes than K) and a fresh 20 000-node
     cloud against gcpnet_amd.synthetic.radius_graph -- identical edge_index arrays, col-sorted."""
