@@ -110,7 +110,8 @@ class Operand(C.Structure):
 class TnProblem(C.Structure):
     _fields_ = [("rows", C.c_int), ("a", Operand), ("b", Operand), ("out", C.c_void_p), ("out_sm", C.c_int64),
                 ("out_sn", C.c_int64), ("out_m", C.c_int), ("out_n", C.c_int), ("out2", C.c_void_p), ("out2_n", C.c_int),
-                ("partial", C.c_void_p), ("splits", C.c_int)]
+                ("partial", C.c_void_p), ("splits", C.c_int), ("m_split", C.c_int), ("out_b", C.c_void_p), ("out_b_sm", C.c_int64),
+                ("out2_b", C.c_void_p)]
 
 
 class ReduceJob(C.Structure):

@@ -915,13 +915,16 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #undef CB_LAUNDER
 
 template <int NTG, int VQ, bool PWL>
-int launch_cb(const ChainBwdParams& p, size_t lds_bytes, bool sgn, hipStream_t st) {
+int launch_cb(const ChainBwdParams& p, size_t lds_bytes, bool sgn, bool need_sgn, hipStream_t st) {
     // W^T ds_pre on the bf16 pipe (three-term split, six products) unless GCPNET_CHAIN_BWD_FP32_MFMA / gcpnet_debug_set_fp32_mfma select the
     // fp32 MFMA form of the same product (A/B switch)
     static const bool b6_env = getenv("GCPNET_CHAIN_BWD_FP32_MFMA") == nullptr;
     const bool pad = p.sh.so != 32 * NTG;  // (padded widths: bf16 form only)
     const bool b6 = pad || (g_gcp_fp32_mfma < 0 ? b6_env : g_gcp_fp32_mfma == 0);
     const dim3 grid((unsigned)(p.tiles + p.n_split));
+    // need_sgn: a block whose forward stored only the sign mask (s_pre NULL) -- only the sign-mask instantiations (piecewise-linear
+    // activations, bf16 form) can run it; the fp32 A/B switch with such a chain is the caller's error, never a read of a missing s_pre
+    if (need_sgn && !(PWL && sgn && b6)) return GCPNET_E_BADARG;
     if constexpr (PWL) {
         if (sgn && b6) {  // sign masks instead of s_pre (the forward wrote them for every block)
             if (p.sh.H == 4 && p.sh.nf) {
@@ -950,9 +953,9 @@ int launch_cb(const ChainBwdParams& p, size_t lds_bytes, bool sgn, hipStream_t s
 }
 
 template <int NTG>
-int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, bool sgn, hipStream_t st) {
-    if (p.sh.vi <= 8) return pwl ? launch_cb<NTG, 1, true>(p, lds_bytes, sgn, st) : launch_cb<NTG, 1, false>(p, lds_bytes, false, st);
-    return pwl ? launch_cb<NTG, 2, true>(p, lds_bytes, sgn, st) : launch_cb<NTG, 2, false>(p, lds_bytes, false, st);
+int launch_cb2(const ChainBwdParams& p, size_t lds_bytes, bool pwl, bool sgn, bool need_sgn, hipStream_t st) {
+    if (p.sh.vi <= 8) return pwl ? launch_cb<NTG, 1, true>(p, lds_bytes, sgn, need_sgn, st) : launch_cb<NTG, 1, false>(p, lds_bytes, false, need_sgn, st);
+    return pwl ? launch_cb<NTG, 2, true>(p, lds_bytes, sgn, need_sgn, st) : launch_cb<NTG, 2, false>(p, lds_bytes, false, need_sgn, st);
 }
 
 }  // namespace
@@ -1047,7 +1050,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
     p.rows = rows; p.frames = frames; p.o = items[0].o; p.n = n;
     p.d_s_out = d_s_out; p.d_v_out = d_v_out; p.d_s_in = d_s_in; p.d_v_in = d_v_in;
     p.out_idx = out_idx; p.out_scale = out_idx ? out_scale : nullptr;
-    bool pwl = true, sgn = true;
+    bool pwl = true, sgn = true, need_sgn = false;
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_bwd_item_t& c = items[k];
         const gcp2_opts_t& o = c.o;
@@ -1063,6 +1066,7 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
         it.tb = c.tb;
         it.sign = c.s_sign;
         sgn = sgn && c.s_sign != nullptr && (reinterpret_cast<uintptr_t>(c.s_sign) & 3) == 0;
+        need_sgn = need_sgn || c.s_pre == nullptr;
         pwl = pwl && gcp_is_pwl(o.act_s) && gcp_is_pwl(o.act_v);
     }
     sgn = sgn && pwl;
@@ -1088,13 +1092,14 @@ int gcp2_chain_bwd_registers(int rows, const float* frames, int n, const gcp2_ch
         }
     }
 #ifdef GCP_CB_ONLY_SHIPPED  // (development builds: only the instantiations configs[1] runs -- tools/kres.py / the ISA tools in seconds)
+    if (need_sgn && !sgn) return GCPNET_E_BADARG;
     if (sgn) hipLaunchKernelGGL((gcp2_chain_bwd_kernel<4, 2, true, 4, true, false, true>), dim3((unsigned)(p.tiles + p.n_split)), dim3(GCP_WAVE), lds_bytes, st, p);
     else hipLaunchKernelGGL((gcp2_chain_bwd_kernel<4, 2, true, 4, true>), dim3((unsigned)(p.tiles + p.n_split)), dim3(GCP_WAVE), lds_bytes, st, p);
     GCP_HIP_CHECK_LAUNCH();
     return 0;
 #else
-    if (S.NTG == 2) return launch_cb2<2>(p, lds_bytes, pwl, sgn, st);
-    return launch_cb2<4>(p, lds_bytes, pwl, sgn, st);
+    if (S.NTG == 2) return launch_cb2<2>(p, lds_bytes, pwl, sgn, need_sgn, st);
+    return launch_cb2<4>(p, lds_bytes, pwl, sgn, need_sgn, st);
 #endif
 }
 
@@ -1124,7 +1129,7 @@ static int chain_backward_checked(int rows, const float* frames, int n, const gc
     if (rows < 0 || n < 1 || n > GCP_MAX_CHAIN || !items || !d_s_out || !d_v_out || !d_s_in || !d_v_in) return GCPNET_E_BADARG;
     for (int k = 0; k < n; ++k) {
         const gcp2_chain_bwd_item_t& c = items[k];
-        if (!c.w.pack || !c.w.w_down || !c.w.w_up || !c.v_in || !c.s_pre || !c.sc.ds_pre || !c.sc.ext) return GCPNET_E_BADARG;
+        if (!c.w.pack || !c.w.w_down || !c.w.w_up || !c.v_in || (!c.s_pre && !c.s_sign) || !c.sc.ds_pre || !c.sc.ext) return GCPNET_E_BADARG;
         if (c.w.use_frames && (!frames || !c.w.w_frames)) return GCPNET_E_BADARG;
         if (c.o.vmode == GCP_VMODE_SCALAR_GATE && (!c.gate || !c.sc.dgate)) return GCPNET_E_BADARG;
     }

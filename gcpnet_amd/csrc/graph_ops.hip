@@ -921,7 +921,7 @@ extern "C" int gcpnet_axpy_clamp(int64_t n, const float* a, const float* b, floa
 
 extern "C" int gcpnet_debug_set_fp32_mfma(int on) {
     const int prev = g_gcp_fp32_mfma;
-    g_gcp_fp32_mfma = on ? 1 : 0;
+    g_gcp_fp32_mfma = on < 0 ? -1 : (on ? 1 : 0);  // (negative: back to the environment's choice -- what a caller restoring `prev` passes)
     return prev;
 }
 

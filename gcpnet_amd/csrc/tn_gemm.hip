@@ -577,7 +577,7 @@ struct TpCfg {
 };
 
 template <int NW, int MT, int NT, int UT, int NBUF = 2>
-__global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn_pipe_kernel(TnArgs a) {
     using C = TpCfg<NW, MT, NT, UT, NBUF>;
     constexpr int AT = C::AT, BM = C::BM, BN = C::BN, NPASS = C::NPASS, APASS = C::APASS, NG = C::NG;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -600,7 +600,8 @@ __global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnA
     const bool ragged = (P.rows % TS_RK) != 0 && (full_chunks % P.splits) == split;
     // tiles of this wave: m-groups of MT tiles, mt_c waves along m, G groups along n (n-tiles g, g + G, ...)
     const int mgroups = gcp_cdiv(mtiles, MT);
-    const int mt_c = mgroups > 4 ? 8 : (mgroups > 2 ? 4 : (mgroups > 1 ? 2 : 1));  // smallest power of two >= mgroups (<= NW)
+    // smallest power of two >= mgroups (<= NW); the five-wave form (160 x 160 blocks): one tile of M per wave
+    const int mt_c = NW == 5 ? 5 : (mgroups > 4 ? 8 : (mgroups > 2 ? 4 : (mgroups > 1 ? 2 : 1)));
     const int G = NW / mt_c, mg = wave % mt_c, g = wave / mt_c;
     const int my_n = __builtin_amdgcn_readfirstlane((mg < mgroups && g < ntiles) ? (ntiles - g + G - 1) / G : 0);
     gcp_u32x4* const planes = reinterpret_cast<gcp_u32x4*>(lds);
@@ -820,6 +821,11 @@ __global__ __launch_bounds__(64 * NW, NBUF == 1 ? 3 : 2) void tn_pipe_kernel(TnA
     if (a.stamps && tid == 0 && (long long)blockIdx.x < a.stamp_cap) a.stamps[(long long)blockIdx.x * GCP_MAX_STAMPS + 1] = __builtin_amdgcn_s_memtime();
 }
 
+inline bool tn_mid_enabled() {  // GCPNET_TN_MID=0: the five-wave form and the fused gradients that need it off (an A/B knob)
+    static const bool on = !(getenv("GCPNET_TN_MID") && getenv("GCPNET_TN_MID")[0] == '0');
+    return on;
+}
+
 inline bool stream_ok(const gcp_operand_t& o) {
     if (o.act) return false;
     for (int k = 0; k < o.n; ++k)
@@ -856,7 +862,10 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a) {
         __syncthreads();
         if (w == 0 && ok && m < P.out_m) {  // gradients leave in their final layouts: weight block, bias column; padding dropped
             const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            if (n < P.out_n) P.out[m * P.out_sm + n * P.out_sn] = v;
+            if (P.m_split > 0 && m >= P.m_split) {  // (the second gradient of a fused product)
+                if (n < P.out_n) P.out_b[(m - P.m_split) * P.out_b_sm + n * P.out_sn] = v;
+                else if (P.out2_b && n == P.out2_n) P.out2_b[m - P.m_split] = v;
+            } else if (n < P.out_n) P.out[m * P.out_sm + n * P.out_sn] = v;
             else if (P.out2 && n == P.out2_n) P.out2[m] = v;
         }
         __syncthreads();
@@ -961,6 +970,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         if (a.M[i] <= 0 || a.N[i] <= 0) return GCPNET_E_BADARG;
         if (P.out_m < 0 || P.out_m > a.M[i] || P.out_n < 0 || P.out_n > a.N[i] || (P.out2 && (P.out2_n < 0 || P.out2_n >= a.N[i])))
             return GCPNET_E_BADARG;
+        if (P.m_split < 0 || P.m_split > P.out_m || (P.m_split > 0 && !P.out_b) || (P.out2_b && !P.out2)) return GCPNET_E_BADARG;
         dma = dma && dma_ok(P.a) && dma_ok(P.b) && P.rows > 0;
         a.mb[i] = gcp_cdiv(a.M[i], TN_BM);
         a.nb[i] = gcp_cdiv(a.N[i], TN_BN);
@@ -992,18 +1002,23 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         // (measured and dropped: the wide form as two independent four-wave workgroups per CU, 128 x 288 each -- 256 registers with
         // spills, 7.36 against 6.75 ms on eight 256 x 276 problems of 10^6 rows, configs[4] step 196.9 against 190.3 ms)
         using Wide = TpCfg<8, 1, 9, 1>;
-        TnArgs narrow, wide, rest;
-        narrow.n = wide.n = rest.n = 0;
-        narrow.debug = wide.debug = rest.debug = a.debug;
-        narrow.stamps = wide.stamps = rest.stamps = a.stamps;
-        narrow.stamp_cap = wide.stamp_cap = rest.stamp_cap = a.stamp_cap;
-        int nblocks = 0, wblocks = 0, rblocks_ = 0, rest_mn = 0;
+        // mid (round 6): FIVE waves x (1 x 5) tiles = 160 x 160, the narrow form's structure with one more tile of M: a (128,16) block's
+        // [ds_pre | dgate]^T [s | norms | frame scalars | 1] is 144 x 145 -- both weight gradients of the block in ONE pass over its operands
+        using Mid = TpCfg<5, 1, 5, 1, 1>;
+        TnArgs narrow, wide, rest, mid;
+        narrow.n = wide.n = rest.n = mid.n = 0;
+        narrow.debug = wide.debug = rest.debug = mid.debug = a.debug;
+        narrow.stamps = wide.stamps = rest.stamps = mid.stamps = a.stamps;
+        narrow.stamp_cap = wide.stamp_cap = rest.stamp_cap = mid.stamp_cap = a.stamp_cap;
+        int nblocks = 0, wblocks = 0, rblocks_ = 0, rest_mn = 0, mblocks = 0;
+        const bool mid_env = tn_mid_enabled();
         bool rest_dma = true;
         for (int i = 0; i < n_problems; ++i) {
             const gcp_tn_problem_t& P = problems[i];
             const bool ok = P.rows > 0 && (P.splits & 1) == 0 && P.a.n > 0 && P.b.n > 0 && stream_ok(P.a) && stream_ok(P.b);  // (n > 0: a lane without a column of its own reads segment 0)
-            const bool is_wide = ok && a.M[i] > Narrow::BM;  // (M <= 128 with a wide N: column blocks of the narrow kernel, the thin A re-read)
-            TnArgs& d = !ok ? rest : (is_wide ? wide : narrow);
+            const bool is_mid = ok && mid_env && a.M[i] > Narrow::BM && a.M[i] <= Mid::BM && a.N[i] <= Mid::BN;
+            const bool is_wide = ok && !is_mid && a.M[i] > Narrow::BM;  // (M <= 128 with a wide N: column blocks of the narrow kernel, the thin A re-read)
+            TnArgs& d = !ok ? rest : (is_mid ? mid : (is_wide ? wide : narrow));
             const int k = d.n++;
             d.p[k] = a.p[i]; d.M[k] = a.M[i]; d.N[k] = a.N[i];
             if (!ok) {
@@ -1011,6 +1026,9 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
                 d.block_start[k] = rblocks_; rblocks_ += a.mb[i] * a.nb[i] * P.splits;
                 rest_mn = max(rest_mn, a.M[i] * a.N[i]);
                 rest_dma = rest_dma && dma_ok(P.a) && dma_ok(P.b) && P.rows > 0;
+            } else if (is_mid) {
+                d.mb[k] = 1; d.nb[k] = 1;
+                d.block_start[k] = mblocks; mblocks += P.splits;
             } else if (is_wide) {
                 d.mb[k] = gcp_cdiv(a.M[i], Wide::BM); d.nb[k] = gcp_cdiv(a.N[i], Wide::BN);
                 d.block_start[k] = wblocks; wblocks += d.mb[k] * d.nb[k] * P.splits;
@@ -1020,6 +1038,7 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
             }
         }
         narrow.block_start[narrow.n] = nblocks; wide.block_start[wide.n] = wblocks; rest.block_start[rest.n] = rblocks_;
+        mid.block_start[mid.n] = mblocks;
         constexpr size_t n_lds = (size_t)Narrow::LDS_FLOATS * sizeof(float), w_lds = (size_t)Wide::LDS_FLOATS * sizeof(float);
         // (the attribute is per device: one flag per device ordinal, written once under a mutex)
         static std::mutex tp_mu;
@@ -1037,6 +1056,10 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         }
         if (wide.n) {
             hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1>), dim3(wblocks), dim3(Wide::NTH), w_lds, st, wide);
+            GCP_HIP_CHECK_LAUNCH();
+        }
+        if (mid.n) {  // (30 KB of LDS: below the default limit, no attribute)
+            hipLaunchKernelGGL((tn_pipe_kernel<5, 1, 5, 1, 1>), dim3(mblocks), dim3(Mid::NTH), (size_t)Mid::LDS_FLOATS * sizeof(float), st, mid);
             GCP_HIP_CHECK_LAUNCH();
         }
         if (narrow.n) {
@@ -1233,6 +1256,10 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
         const gcp2_wgrad_job_t& J = jobs[i];
         const WgradDims d = wgrad_dims(J);
         const int splits = gcpnet_tn_splits(J.rows, 0, 0);
+        // both gradients of a gated block in ONE product when [ds_pre | dgate] fits a block of rows of the pipelined kernels (128, or 160
+        // with the five-wave form when the second operand fits 160 too): the second operand -- the larger one -- is then read once
+        const int mf = J.so + d.VOP;
+        const bool fuse = d.gated && J.gate_lin && (mf <= 128 || (mf <= 160 && d.n1 <= 160 && tn_mid_enabled()));
         {   // d scalar_out.weight | bias: ds_pre^T [s segments | ext | 1]
             gcp_tn_problem_t& P = probs[np++];
             P = gcp_tn_problem_t{};
@@ -1250,9 +1277,27 @@ extern "C" int gcpnet_gcp2_weight_grads(int n, const gcp2_wgrad_job_t* jobs, flo
             P.splits = splits;
             P.partial = ws;
             ws += (int64_t)splits * J.so * d.n1;
+            if (fuse) {  // rows so .. so + vo - 1 of the product: G | d gate bias
+                const int k = P.a.n++;
+                P.a.ptr[k] = J.dgate; P.a.idx[k] = nullptr; P.a.dim[k] = d.VOP; P.a.ld[k] = d.VOP; P.a.tb[k] = 0;
+                ws += (int64_t)splits * d.VOP * d.n1;  // (the partial sums: so + VOP rows per split)
+                float* G = ws;
+                ws += (int64_t)J.vo * d.n1;
+                P.m_split = J.so; P.out_m = J.so + J.vo;
+                P.out_b = G; P.out_b_sm = K; P.out2_b = J.d_b_gate;
+                fin.G[nfin] = G; fin.W[nfin] = J.w_scalar; fin.b[nfin] = J.b_scalar; fin.db[nfin] = J.d_b_gate; fin.out[nfin] = J.d_w_gate;
+                fin.vo[nfin] = J.vo; fin.so[nfin] = J.so; fin.K[nfin] = K;
+                fin_blocks = max(fin_blocks, gcp_cdiv(J.so, 16));
+                ++nfin;
+            }
             if (np == GCP_TN_MAX_PROBLEMS) { const int rc = flush_p(); if (rc) return rc; }
+            if (nfin == GCP_TN_MAX_PROBLEMS * 2) {
+                int rc = flush_p(); if (rc) return rc;
+                rc = flush_f(); if (rc) return rc;
+            }
         }
-        if (d.gated && J.gate_lin) {  // G | d bias = dgate^T [s segments | ext | 1]: the first product's second operand again, no s_pre
+        if (fuse) {
+        } else if (d.gated && J.gate_lin) {  // G | d bias = dgate^T [s segments | ext | 1]: the first product's second operand again, no s_pre
             gcp_tn_problem_t& P = probs[np++];
             P = gcp_tn_problem_t{};
             P.rows = J.rows;

@@ -1720,7 +1720,7 @@ def gcp2_chain_backward_data(specs, rows: int, ins, outs, frames, ws, packs, d_s
         items[k].tb = int(tb_all)
         if getattr(outs[k][2], "absent", False) and not (CHAIN_SIGN_MASKS and outs[k][2].sign):
             raise _lib.GcpnetHipError("this chain's forward stored sign masks instead of s_pre: the backward needs ops.CHAIN_SIGN_MASKS")
-        items[k].s_pre = outs[k][2].data_ptr()
+        items[k].s_pre = None if getattr(outs[k][2], "absent", False) else outs[k][2].data_ptr()  # (absent: only the sign-mask kernels can run it -- the library refuses any other form)
         items[k].s_sign = outs[k][2].sign if (CHAIN_SIGN_MASKS and isinstance(outs[k][2], TileBlocked)) else None
         items[k].gate = outs[k][3].data_ptr() if outs[k][3] is not None else None
         items[k].sc = scr

@@ -308,7 +308,10 @@ typedef struct {
     const float* gate;
     gcp2_bwd_scratch_t sc;
     int tb;  /* s_pre is read and sc.ds_pre written in the tile-blocked layout (see gcp2_chain_item_t) */
-    const uint32_t* s_sign;  /* optional sign mask of s_pre (gcp2_chain_item_t.s_sign): read instead of s_pre when EVERY item has one */
+    const uint32_t* s_sign;  /* optional sign mask of s_pre (gcp2_chain_item_t.s_sign): read instead of s_pre when EVERY item has one.
+                              * s_pre may then be NULL (a forward that stored only the mask): the call returns GCPNET_E_BADARG, and
+                              * launches nothing, if it cannot run the sign-mask kernel for the chain (an item without a mask, an
+                              * activation that is not piecewise linear, or the fp32-MFMA A/B form forced by gcpnet_debug_set_fp32_mfma) */
 } gcp2_chain_bwd_item_t;
 /* 1 if gcpnet_gcp2_chain_backward takes a chain of residual blocks of this shape (callers that save tile-blocked tensors in the
  * forward ask first: there is no other consumer of that layout) */
@@ -367,6 +370,13 @@ typedef struct {
     int out2_n;
     float* partial;    /* scratch [splits, M, N] */
     int splits;
+    /* optional second destination for the rows m >= m_split of the result (m_split > 0; ABI 4): out_b[(m - m_split) * out_b_sm + n] for
+     * m < out_m, n < out_n and out2_b[m - m_split] for the ones column -- two weight gradients that share their second operand in ONE
+     * product (d scalar_out.weight and, below it, G of gcp2_wgrad_job_t.gate_lin) */
+    int m_split;
+    float* out_b;
+    int64_t out_b_sm;
+    float* out2_b;
 } gcp_tn_problem_t;
 
 #define GCP_TN_MAX_PROBLEMS 8
@@ -599,7 +609,7 @@ int gcpnet_debug_set_phase_timing(void* buf, int64_t n_tiles);
  * csrc/gcp_bf16x3.h).  on != 0 selects the v_mfma_f32_32x32x2_f32 form of the same products instead; the environment
  * variables GCPNET_CHAIN_BWD_FP32_MFMA, GCPNET_CHAIN_FWD_FP32_MFMA, GCPNET_WG_BWD_FP32_MFMA and GCPNET_WG_FWD_B6=0 set the
  * initial state per kernel (GCPNET_WG_FWD_B6=all: the bf16 form for the 4-wave shapes of gcpnet_wg_forward too).  Returns
- * the previous setting (-1: never set). */
+ * the previous setting (-1: never set); on < 0 returns to that state (restoring a saved `previous`). */
 int gcpnet_debug_set_fp32_mfma(int on);
 
 /* 1 when the library was built with -DGCP_DEBUG_KNOBS: only such a build honours the measurement knobs that change RESULTS

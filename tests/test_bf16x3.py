@@ -69,8 +69,10 @@ def test_chain_kernels_bf16_and_fp32_forms_agree(dims, act):
 
     def run(fp32_mfma, wg_forward, dtype=torch.float32):
         prev = lib.gcpnet_debug_set_fp32_mfma(int(fp32_mfma))
-        saved = ops.PREFER_WAVE_CHAIN_FORWARD
+        saved, saved_skip = ops.PREFER_WAVE_CHAIN_FORWARD, ops.CHAIN_SKIP_S_PRE
         ops.PREFER_WAVE_CHAIN_FORWARD = not wg_forward
+        if fp32_mfma:  # (the fp32 form of the chain backward reads s_pre: it has no sign-mask instantiation)
+            ops.CHAIN_SKIP_S_PRE = False
         try:
             s = s0.clone().requires_grad_()
             v = v0.clone().requires_grad_()
@@ -84,9 +86,8 @@ def test_chain_kernels_bf16_and_fp32_forms_agree(dims, act):
             out.update({f"w{k}.{n}": q.grad for k, m in enumerate(mods) for n, q in m.named_parameters()})
             return {k: t.clone() for k, t in out.items()}
         finally:
-            ops.PREFER_WAVE_CHAIN_FORWARD = saved
-            if prev >= 0:
-                lib.gcpnet_debug_set_fp32_mfma(prev)
+            ops.PREFER_WAVE_CHAIN_FORWARD, ops.CHAIN_SKIP_S_PRE = saved, saved_skip
+            lib.gcpnet_debug_set_fp32_mfma(prev)
 
     # so <= 128: wave-per-tile forward + chain backward; wider: workgroup forward + workgroup backward block by block
     fp32 = run(True, wg_forward=False)       # v_mfma_f32_32x32x2_f32 everywhere
@@ -100,3 +101,36 @@ def test_chain_kernels_bf16_and_fp32_forms_agree(dims, act):
         assert err <= tol, f"{k}: bf16 x 6 and fp32 MFMA forms differ by {err:.3e} (scale {scale:.3e})"
         err = float((wg[k] - bf16[k]).abs().max())
         assert err <= tol, f"{k}: workgroup / wave forward routes differ by {err:.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.gpu
+def test_fp32_form_refuses_a_chain_that_kept_only_sign_masks():
+    """A chain forward with piecewise-linear activations keeps sign masks INSTEAD of s_pre (ops.CHAIN_SKIP_S_PRE); only the sign-mask
+    instantiations of the chain backward (bf16 form) can run it.  With the fp32-MFMA A/B form forced the library must refuse the
+    launch -- never read the s_pre that is not there."""
+    import gcpnet_amd as G
+    from gcpnet_amd import _lib, ops
+
+    if not (ops.CHAIN_SKIP_S_PRE and ops.CHAIN_SIGN_MASKS and ops.GATE_GRADS_FROM_INPUTS):
+        pytest.skip("the forward stores s_pre under these switches")
+    lib = _lib.load()
+    torch.manual_seed(0)
+    rows = 500
+    mods = [G.GCP2((128, 16), (128, 16), nonlinearities=("relu", None), bottleneck=4).cuda() for _ in range(3)]
+    specs = [m.make_spec([None], [None], residual=True) for m in mods]
+    s = torch.randn(rows, 128, device="cuda").requires_grad_()
+    v = torch.randn(rows, 16, 3, device="cuda").requires_grad_()
+    fr = torch.randn(rows, 3, 3, device="cuda")
+    saved = ops.PREFER_WAVE_CHAIN_FORWARD
+    ops.PREFER_WAVE_CHAIN_FORWARD = True
+    try:
+        o_s, o_v = ops.gcp2_chain(specs, s, v, fr, [m._weights() for m in mods])
+        prev = lib.gcpnet_debug_set_fp32_mfma(1)
+        try:
+            with pytest.raises(_lib.GcpnetHipError):
+                torch.autograd.backward([o_s, o_v], [torch.ones_like(o_s), torch.ones_like(o_v)])
+        finally:
+            lib.gcpnet_debug_set_fp32_mfma(prev)
+        torch.cuda.synchronize()
+    finally:
+        ops.PREFER_WAVE_CHAIN_FORWARD = saved

@@ -25,6 +25,9 @@ pytestmark = pytest.mark.gpu
     (15, 64, 40),         # fewer rows than one chunk
     (3001, 132, 600),     # M one column over a block (wide kernel, second block one m-tile), three column blocks
     (2048, 32, 257),      # the gate problem of the (256,32) blocks: narrow kernel, two column blocks
+    (50001, 144, 157),    # [ds_pre | dgate]^T [s | norms | frames | 1] of a (128,16) block: the five-wave 160 x 160 kernel, ragged last chunk
+    (37, 160, 160),       # the five-wave kernel's full block, two chunks + a ragged one
+    (900, 132, 36),       # five m-tiles (the last four rows wide), two n-tiles
 ])
 @pytest.mark.parametrize("form", ["default", "earlier", "fp32"])
 def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
@@ -136,3 +139,65 @@ def test_tn_segments_tile_blocked_ones_and_callers_split_count(rows, splits):
     bad = TnProblem.from_buffer_copy(pr)
     bad.splits = 0
     assert lib.gcpnet_tn_gemm(1, C.byref(bad), None) != 0, "a split count below 1 is refused"
+
+
+@pytest.mark.parametrize("mid", ["1", "0"], ids=["five-wave", "wide"])
+@pytest.mark.parametrize("rows,so,vo", [(5007, 128, 16), (6000, 128, 10), (333, 100, 16), (4000, 96, 16)])
+def test_tn_two_gradients_from_one_product(rows, so, vo, mid):
+    """`m_split` (ABI 4): the rows m >= m_split of a product leave into a second matrix / bias vector -- d scalar_out.weight | bias and,
+    below it, G | d gate bias of gcp2_wgrad_job_t.gate_lin with their common second operand read once.  A = [tile-blocked so | row-major
+    vo padded to a multiple of 4], B = [tile-blocked 128 | row-major 28 | ones]; both halves against float64, with the five-wave
+    kernel (M = 144 <= 160) and without it (GCPNET_TN_MID=0 in a fresh process: the 256-row kernel or, for M <= 128, the 128-row one
+    either way)."""
+    import os
+    import subprocess
+    import sys
+
+    if mid == "0" and os.environ.get("GCPNET_TN_MID") != "0":  # (the switch is read once per process)
+        env = dict(os.environ, GCPNET_TN_MID="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", f"{__file__}::test_tn_two_gradients_from_one_product[{rows}-{so}-{vo}-wide]"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    import ctypes as C
+
+    from gcpnet_amd import _lib, ops
+    from gcpnet_amd._lib import TnProblem, check
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows + so)
+    vop, N1, N2 = (vo + 3) // 4 * 4, 128, 28
+    a1 = torch.randn(rows, so, generator=g).cuda()
+    a2 = torch.randn(rows, vop, generator=g).cuda()
+    b1 = torch.randn(rows, N1, generator=g).cuda()
+    b2 = torch.randn(rows, N2, generator=g).cuda()
+    a1_tb, b1_tb = ops.TileBlocked.from_rows(a1), ops.TileBlocked.from_rows(b1)
+    K, N = N1 + N2, N1 + N2 + 1
+    pr = TnProblem()
+    pr.rows = rows
+    pr.a.n = 2
+    pr.a.ptr[0], pr.a.dim[0], pr.a.ld[0], pr.a.tb[0] = a1_tb.data_ptr(), so, so, 1
+    pr.a.ptr[1], pr.a.dim[1], pr.a.ld[1], pr.a.tb[1] = a2.data_ptr(), vop, vop, 0
+    pr.b.n, pr.b.ones = 2, 1
+    pr.b.ptr[0], pr.b.dim[0], pr.b.ld[0], pr.b.tb[0] = b1_tb.data_ptr(), N1, N1, 1
+    pr.b.ptr[1], pr.b.dim[1], pr.b.ld[1], pr.b.tb[1] = b2.data_ptr(), N2, N2, 0
+    nan = float("nan")
+    out, bias = torch.full((so, K), nan, device="cuda"), torch.full((so,), nan, device="cuda")
+    out_b, bias_b = torch.full((vo, K), nan, device="cuda"), torch.full((vo,), nan, device="cuda")
+    pr.out, pr.out_sm, pr.out_sn, pr.out_m, pr.out_n = out.data_ptr(), K, 1, so + vo, K
+    pr.out2, pr.out2_n = bias.data_ptr(), K
+    pr.m_split, pr.out_b, pr.out_b_sm, pr.out2_b = so, out_b.data_ptr(), K, bias_b.data_ptr()
+    M = so + vop
+    pr.splits = lib.gcpnet_tn_splits(rows, M, N)
+    part = torch.empty((pr.splits, M, N), device="cuda")
+    pr.partial = part.data_ptr()
+    check(lib.gcpnet_tn_gemm(1, C.byref(pr), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tn_gemm")
+    torch.cuda.synchronize()
+    bfull = torch.cat([b1, b2], dim=1).cpu().double()
+    tol = 2e-6 * float((a1.cpu().double().t() @ bfull).abs().max()) + 1e-5 * rows ** 0.5
+    for got, want, name in ((out, a1.cpu().double().t() @ bfull, "out"), (bias, a1.cpu().double().sum(0), "out2"),
+                            (out_b, a2[:, :vo].cpu().double().t() @ bfull, "out_b"), (bias_b, a2[:, :vo].cpu().double().sum(0), "out2_b")):
+        assert (got.cpu().double() - want).abs().max().item() <= tol, name
+    bad = TnProblem.from_buffer_copy(pr)
+    bad.out_b = None
+    assert lib.gcpnet_tn_gemm(1, C.byref(bad), None) != 0, "m_split without a second destination is refused"
