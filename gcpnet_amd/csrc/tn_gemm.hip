@@ -821,9 +821,14 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
     if (a.stamps && tid == 0 && (long long)blockIdx.x < a.stamp_cap) a.stamps[(long long)blockIdx.x * GCP_MAX_STAMPS + 1] = __builtin_amdgcn_s_memtime();
 }
 
-inline bool tn_mid_enabled() {  // GCPNET_TN_MID=0: the five-wave form and the fused gradients that need it off (an A/B knob)
-    static const bool on = !(getenv("GCPNET_TN_MID") && getenv("GCPNET_TN_MID")[0] == '0');
-    return on;
+// GCPNET_TN_MID=1: the five-wave 160 x 160 form and, with it, both weight gradients of a gated (128,16) block as ONE product.
+// OFF by default -- measured (same box, profiles/r06_tn_mid_ab.txt): the fused product reads 34 % fewer operand bytes, but the seven-
+// block job list of a configs[1] layer takes 0.58 ms alone against 0.52 ms as two products per block (five waves on four SIMDs: one SIMD
+// carries two waves' 30 MFMAs per chunk; 155 registers = two workgroups per CU), and the step does not move (10.02 - 10.08 ms against
+// 10.03 - 10.04).  The kernel is bound by issue / latency at low occupancy, not by HBM bytes.
+inline bool tn_mid_enabled() {  // (read per call, like GCPNET_TN_PIPE / GCPNET_TN_FP32: tests switch it inside one process)
+    const char* e = getenv("GCPNET_TN_MID");
+    return e && e[0] == '1';
 }
 
 inline bool stream_ok(const gcp_operand_t& o) {

@@ -61,3 +61,23 @@ def test_gate_gradients_from_inputs_and_no_stored_s_pre(dims, n, e):
     assert n_gate == 7
     # 7 blocks x 4 so bytes per edge row less
     assert held_old - held_new >= 0.9 * 7 * e * 4 * ((dims[0] + 31) // 32 * 32), (held_old, held_new)
+
+
+def test_both_weight_gradients_of_a_block_from_one_product(monkeypatch):
+    """GCPNET_TN_MID=1 (opt-in): the job builder of gcpnet_gcp2_weight_grads puts [ds_pre | dgate]^T [s | norms | frame scalars | 1] of a
+    gated (128,16) block into ONE product on the five-wave 160 x 160 kernel (gcp_tn_problem_t.m_split).  Same sums in another kernel:
+    data gradients bit-identical, every weight gradient within fp32 round-off of the two-product route."""
+    import gcpnet_amd as G
+    from gcpnet_amd import ops
+
+    two, _ = _run(G, ops, (128, 16), 700, 9000, skip=True, lin=True)
+    monkeypatch.setenv("GCPNET_TN_MID", "1")
+    one, _ = _run(G, ops, (128, 16), 700, 9000, skip=True, lin=True)
+    assert two.keys() == one.keys()
+    for k in two:
+        if k.startswith("w."):
+            scale = max(float(two[k].abs().max()), 1e-6)
+            err = float((two[k] - one[k]).abs().max())
+            assert err <= 2e-5 * scale, f"{k}: {err:.3e} (scale {scale:.3e})"
+        else:
+            assert torch.equal(two[k], one[k]), f"{k} changed"

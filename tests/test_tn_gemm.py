@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
     (37, 160, 160),       # the five-wave kernel's full block, two chunks + a ragged one
     (900, 132, 36),       # five m-tiles (the last four rows wide), two n-tiles
 ])
-@pytest.mark.parametrize("form", ["default", "earlier", "fp32"])
+@pytest.mark.parametrize("form", ["default", "earlier", "fp32", "five-wave"])
 def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
     """`form`: the switches of gcpnet_tn_gemm that select another kernel or row distribution for the same product."""
     from gcpnet_amd import ops
@@ -38,6 +38,8 @@ def test_tn_weight_grad_vs_float64(rows, M, N, form, monkeypatch):
         monkeypatch.setenv("GCPNET_TN_FP32", "1")
     elif form == "earlier":  # the kernels the pipelined form took over from (they still serve gathered / activated operands)
         monkeypatch.setenv("GCPNET_TN_PIPE", "0")
+    elif form == "five-wave":  # the opt-in 160 x 160 form for 128 < M <= 160, N <= 160 (other shapes: unchanged routing)
+        monkeypatch.setenv("GCPNET_TN_MID", "1")
 
     g = torch.Generator().manual_seed(rows + M)
     a = torch.randn(rows, M, generator=g)
@@ -141,24 +143,14 @@ def test_tn_segments_tile_blocked_ones_and_callers_split_count(rows, splits):
     assert lib.gcpnet_tn_gemm(1, C.byref(bad), None) != 0, "a split count below 1 is refused"
 
 
-@pytest.mark.parametrize("mid", ["1", "0"], ids=["five-wave", "wide"])
+@pytest.mark.parametrize("mid", ["1", "0"], ids=["five-wave", "wide"])  # (GCPNET_TN_MID: the five-wave form is opt-in)
 @pytest.mark.parametrize("rows,so,vo", [(5007, 128, 16), (6000, 128, 10), (333, 100, 16), (4000, 96, 16)])
-def test_tn_two_gradients_from_one_product(rows, so, vo, mid):
+def test_tn_two_gradients_from_one_product(rows, so, vo, mid, monkeypatch):
     """`m_split` (ABI 4): the rows m >= m_split of a product leave into a second matrix / bias vector -- d scalar_out.weight | bias and,
     below it, G | d gate bias of gcp2_wgrad_job_t.gate_lin with their common second operand read once.  A = [tile-blocked so | row-major
     vo padded to a multiple of 4], B = [tile-blocked 128 | row-major 28 | ones]; both halves against float64, with the five-wave
-    kernel (M = 144 <= 160) and without it (GCPNET_TN_MID=0 in a fresh process: the 256-row kernel or, for M <= 128, the 128-row one
-    either way)."""
-    import os
-    import subprocess
-    import sys
-
-    if mid == "0" and os.environ.get("GCPNET_TN_MID") != "0":  # (the switch is read once per process)
-        env = dict(os.environ, GCPNET_TN_MID="0")
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", f"{__file__}::test_tn_two_gradients_from_one_product[{rows}-{so}-{vo}-wide]"],
-                           env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return
+    kernel (GCPNET_TN_MID=1: M = 144 <= 160) and without it (the 256-row kernel or, for M <= 128, the 128-row one either way)."""
+    monkeypatch.setenv("GCPNET_TN_MID", mid)
     import ctypes as C
 
     from gcpnet_amd import _lib, ops
