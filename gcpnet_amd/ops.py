@@ -6,6 +6,7 @@ PyTorch provides device allocations, the current stream and the autograd graph -
 from __future__ import annotations
 
 import os
+import sys
 
 import ctypes as C
 import weakref
@@ -1348,9 +1349,24 @@ def _make_side_stream(dev: int):
     interleaved group through hipExtStreamCreateWithCUMask, so that the TN GEMMs cannot occupy the whole chip while the caller's
     stream runs its small launches; default: an ordinary stream."""
     n = int(os.environ.get("GCPNET_SIDE_CU_MASK", "0") or 0)
-    if n <= 0:
+    prio = os.environ.get("GCPNET_SIDE_PRIORITY", "")
+    if n <= 0 and prio == "":
         return torch.cuda.Stream(device=dev)
     hip = C.CDLL("libamdhip64.so")
+    if n <= 0:  # GCPNET_SIDE_PRIORITY=<p> (tuning knob): a HIP stream priority for the weight-gradient stream (1 = low on this runtime,
+        #          0 = normal, -1 = high; clamped to the device's range), so that the caller's stream's launches get the CUs first
+        lo, hi_ = C.c_int(), C.c_int()
+        raw = C.c_void_p()
+        with torch.cuda.device(dev):
+            if hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi_)) != 0:
+                raise _lib.GcpnetHipError("hipDeviceGetStreamPriorityRange failed")
+            p_ = max(min(int(prio), lo.value), hi_.value)  # (least priority = the larger number)
+            err = hip.hipStreamCreateWithPriority(C.byref(raw), C.c_uint(1), C.c_int(p_))  # (hipStreamNonBlocking)
+        if err != 0:
+            raise _lib.GcpnetHipError(f"hipStreamCreateWithPriority failed: {err}")
+        if os.environ.get("GCPNET_SIDE_PRIORITY_VERBOSE"):
+            sys.stderr.write(f"[gcpnet_amd] weight-gradient stream priority {p_} (device range: least {lo.value}, greatest {hi_.value})\n")
+        return torch.cuda.ExternalStream(raw.value, device=dev)
     total = torch.cuda.get_device_properties(dev).multi_processor_count
     words = (total + 31) // 32
     mask = (C.c_uint32 * words)()
