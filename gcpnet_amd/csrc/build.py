@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gcp2_fwd.hip", "gcp2_chain_fwd.hip", "gcp2_bwd.hip", "gcp2_chain_bwd.hip", "tn_gemm.hip", "graph_ops.hip", "gcp_wg_fwd.hip", "gcp_wg_bwd.hip", "misc_ops.hip", "featurize.hip"]
-HEADERS = ["common.h", "tile_io.h", "vec_mfma.h", "gcp_wg.h", "gcp_bf16x3.h", os.path.join("..", "..", "include", "gcpnet_hip.h")]
+HEADERS = ["common.h", "tile_io.h", "vec_mfma.h", "gcp_wg.h", "gcp_bf16x3.h", "gcp_f16x2.h", os.path.join("..", "..", "include", "gcpnet_hip.h")]
 LIB = os.path.join(HERE, "libgcpnet_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

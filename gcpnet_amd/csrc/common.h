@@ -78,6 +78,14 @@ __host__ __device__ __forceinline__ int gcp_cdiv(int a, int b) { return (a + b -
 __host__ __device__ __forceinline__ int gcp_odd(int x) { return x | 1; }
 
 // ---- derived shape constants of one GCP2 block, shared by host packing code and kernels ---------------------
+// Arithmetic of the big products of the wave-per-tile chain kernels (scalar_out forward, its adjoint): 1 (default) = two fp16 terms per
+// operand, three MFMAs per product block (gcp_f16x2.h: 3 * 2^-22 |a b|); 0 (-DGCP_ARITH_F16X2=0) = three bf16 terms, six MFMAs
+// (gcp_bf16x3.h: 3 * 2^-24 |a b|), the form of rounds 3 - 5.  Compile-time: the packed weight images differ.
+#ifndef GCP_ARITH_F16X2
+#define GCP_ARITH_F16X2 1
+#endif
+#define GCP_W6_TERMS (GCP_ARITH_F16X2 ? 2 : 3)
+
 struct GcpShape {
     int si, vi, so, vo, H, nf;  // nf = 9 frame scalars or 0
     int K;    // merged width  = si (+ H + nf when vi > 0)
@@ -100,6 +108,8 @@ struct GcpShape {
     // v_mfma_f32_32x32x16_bf16, for the chain backward kernel's fp32-exact product on the bf16 matrix pipe (gcp_bf16x3.h):
     // [slab j < 2 NTG][tile uu < NKT of the (padded) merged axis][term][64 lanes][4 dwords of two bf16]; 0 floats when the block
     // cannot run in that kernel
+    // (round 6, GCP_ARITH_F16X2, the default: B6 and F6 hold TWO fp16 terms of 2^GCP_F16_WEXP w instead -- gcp_f16x2.h, three MFMAs
+    // per product block; `GCP_W6_TERMS` terms per element either way.  The gate image C6 stays three bf16 terms.)
     int NKT;
     int64_t offB6;
     // F6 / C6: the same three-term bf16 images of the forward scalar_out weights over a register-resident state
@@ -146,9 +156,9 @@ __host__ __device__ inline GcpShape gcp_shape(int si, int vi, int so, int vo, in
     // in tile NTS, as the chain backward kernel walks it; identical to the raw axis when si is a multiple of 32)
     s.NKT = s.NTS + gcp_cdiv(s.H + s.nf, 32);
     const bool chainable = s.NG == 1 && si == so && vi == vo && vi > 0 && (si & 3) == 0 && s.NTS == s.NTG && s.NKT == s.NTG + 1;
-    s.offF6 = s.offB6 + (chainable ? (int64_t)2 * s.NTG * s.NKT * 3 * 256 : 0);
+    s.offF6 = s.offB6 + (chainable ? (int64_t)2 * s.NTG * s.NKT * GCP_W6_TERMS * 256 : 0);
     const bool fwd6 = s.NG == 1 && s.NTG >= 2 && s.NTS == s.NTG && s.GT == 1 && vi > 0 && vo > 0;
-    s.offC6 = s.offF6 + (fwd6 ? (int64_t)2 * s.NTG * s.NTG * 3 * 256 : 0);
+    s.offC6 = s.offF6 + (fwd6 ? (int64_t)2 * s.NTG * s.NTG * GCP_W6_TERMS * 256 : 0);
     s.total = s.offC6 + (fwd6 ? (int64_t)2 * s.NTG * 3 * 256 : 0);
     return s;
 }

@@ -19,6 +19,7 @@
 #include "tile_io.h"
 #include "vec_mfma.h"
 #include "gcp_bf16x3.h"
+#include "gcp_f16x2.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -301,6 +302,9 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 
     gcp_stamp(p.stamps, p.stamp_cap, 0, lane);
     f32x16 dyr[NTG];
+    // (two-term fp16 form of step E, gcp_f16x2.h: d(s) stays multiplied by the power of two the last step E gave it -- dyr = true d(s) /
+    // dsc_inv, per lane = per row --; step D and the final store fold the inverse into a factor they apply anyway)
+    [[maybe_unused]] float dsc_inv = 1.f;
     float sg[NV];  // sigmoid(gate) of the current block: channel crow(r, hi) of row e
     unsigned sm[NTG / 2 > 0 ? NTG / 2 : 1];  // SGN: sign words of the current block's s_pre (bit 16 t + r = register r of tile t)
     // ---- prologue: everything the LAST block needs, plus the incoming gradients, in one memory round trip ----------
@@ -539,14 +543,15 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #else
         constexpr bool E_PRE = SGN && B6;
 #endif
-        gcp_u32x4 EA0[3], EA1[3], EA2[3];
+        constexpr int NTM = GCP_W6_TERMS;  // terms per weight element of the B6 image (two fp16 / three bf16: common.h)
+        gcp_u32x4 EA0[NTM], EA1[NTM], EA2[NTM];
         if constexpr (E_PRE) {
             const float* wq0 = it.pack + S.offB6 + (int64_t)lane * 4;
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
+            for (int tm = 0; tm < NTM; ++tm) {
                 EA0[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + tm * 256);
-                EA1[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + 768 + tm * 256);
-                EA2[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + 2 * 768 + tm * 256);
+                EA1[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + NTM * 256 + tm * 256);
+                EA2[tm] = *reinterpret_cast<const gcp_u32x4*>(wq0 + 2 * NTM * 256 + tm * 256);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -629,11 +634,11 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                     float d;
                     if constexpr (SGN) {
                         const bool pos = ((sm[(16 * t + r) >> 5] >> ((16 * t + r) & 31)) & 1u) != 0;
-                        d = dyr[t][r] * (pos ? 1.f : ns_s);
+                        d = dyr[t][r] * (pos ? dsc_inv : ns_s * dsc_inv);
                         if (scalar_gate) d += (pos ? 1.f : ns_v) * gacc[r];
                     } else {
                         const float sp = spr[t][r];
-                        d = dyr[t][r] * gcp_dactf<PWL>(it.act_s, ns_s, slope, sp);
+                        d = (dyr[t][r] * dsc_inv) * gcp_dactf<PWL>(it.act_s, ns_s, slope, sp);
                         if (scalar_gate) d += gcp_dactf<PWL>(it.act_v, ns_v, slope, sp) * gacc[r];
                     }
                     spr[t][r] = row_ok ? d : 0.f;
@@ -720,15 +725,36 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
 #else
             constexpr int ENB = 3;
 #endif
-            gcp_u32x4 A0[3], A1[3], A2[3], A3[3];
-            auto ld = [&](gcp_u32x4(&a)[3], int sg) {
-                const float* q = wq + (int64_t)(sg < NST ? sg : NST - 1) * 768;
+            gcp_u32x4 A0[NTM], A1[NTM], A2[NTM], A3[NTM];
+            auto ld = [&](gcp_u32x4(&a)[NTM], int sg) {
+                const float* q = wq + (int64_t)(sg < NST ? sg : NST - 1) * (NTM * 256);
 #pragma unroll
-                for (int tm = 0; tm < 3; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
+                for (int tm = 0; tm < NTM; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
             };
+#if GCP_ARITH_F16X2
+            // two fp16 terms (gcp_f16x2.h): this lane pair's ds_pre row scaled by 2^pa into fp16's range; d(s) -- which the products are
+            // added to -- by 2^(pa + GCP_F16_WEXP) for the duration of the stages (exact both ways)
+            float e_sc, e_isc;
+            {
+                float m = 0.f;
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(spr[t][r]));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const int pa = gcp_f16_row_exp(m);
+                e_sc = gcp_exp2i(pa); e_isc = gcp_exp2i(-(pa + GCP_F16_WEXP));
+                const float up = gcp_exp2i(pa + GCP_F16_WEXP) * dsc_inv;  // (from the previous block's scale to this one's: exact)
+                dsc_inv = e_isc;
+#pragma unroll
+                for (int t = 0; t < NTG; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dyr[t][r] *= up;
+            }
+#endif
             if constexpr (E_PRE) {
 #pragma unroll
-                for (int tm = 0; tm < 3; ++tm) { A0[tm] = EA0[tm]; A1[tm] = EA1[tm]; A2[tm] = EA2[tm]; }
+                for (int tm = 0; tm < NTM; ++tm) { A0[tm] = EA0[tm]; A1[tm] = EA1[tm]; A2[tm] = EA2[tm]; }
             } else {
                 ld(A0, 0);
                 ld(A1, 1);
@@ -736,7 +762,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
             }
             if constexpr (ENB == 4) ld(A3, 3);
             __builtin_amdgcn_sched_barrier(0);
-            gcp_u32x4 bh, bm, bl;
+            [[maybe_unused]] gcp_u32x4 bh, bm, bl;
 #pragma unroll
             for (int sg = 0; sg < NST; ++sg) {
                 const int j = sg / NKT, uu = sg % NKT;
@@ -744,12 +770,21 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                     float x[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[i] = spr[j / 2][8 * (j % 2) + i];
+#if GCP_ARITH_F16X2
+                    gcp_f16x2_split8(x, e_sc, bh, bl);
+#else
                     gcp_bf16x3_split8(x, bh, bm, bl);
+#endif
                 }
-                gcp_u32x4(&a)[3] = ENB == 4 ? ((sg % 4 == 0) ? A0 : ((sg % 4 == 1) ? A1 : ((sg % 4 == 2) ? A2 : A3)))
-                                             : ((sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2));
+                gcp_u32x4(&a)[NTM] = ENB == 4 ? ((sg % 4 == 0) ? A0 : ((sg % 4 == 1) ? A1 : ((sg % 4 == 2) ? A2 : A3)))
+                                               : ((sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2));
+#if GCP_ARITH_F16X2
+                if (uu < NTG) dyr[uu < NTG ? uu : 0] = gcp_mfma_f16x3(a, bh, bl, dyr[uu < NTG ? uu : 0]);
+                else accx = gcp_mfma_f16x3(a, bh, bl, accx);
+#else
                 if (uu < NTG) dyr[uu < NTG ? uu : 0] = gcp_mfma_bf16x6(a, bh, bm, bl, dyr[uu < NTG ? uu : 0]);
                 else accx = gcp_mfma_bf16x6(a, bh, bm, bl, accx);
+#endif
                 if ((GCP_CB_X & 1) == 0 && sg + ENB < NST) ld(a, sg + ENB);
                 if constexpr (STORE_LATE) {
                     if (sg == NST - ENB) request_f();  // (the first fragment buffer has retired)
@@ -762,6 +797,10 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
                 __builtin_amdgcn_sched_barrier(0);
                 store_ds_pre();
             }
+#if GCP_ARITH_F16X2
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accx[r] *= e_isc;  // (d(s) keeps its factor: dsc_inv)
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int x = gcp_crow(r, hi);
@@ -784,7 +823,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_bwd_kernel(ChainBwdPar
         if (stamp_here) gcp_stamp(p.stamps, p.stamp_cap, 4, lane);
         CB_LAUNDER();
 
-        if (k == k_lo) gcp_store_acc_rows_half_dense<NTG, PAD>(p.d_s_in, so, r0, rows, dyr, stage, lane);  // d(s) leaves the chip (or waits for the second half)
+        if (k == k_lo) gcp_store_acc_rows_half_dense<NTG, PAD>(p.d_s_in, so, r0, rows, dyr, stage, lane, dsc_inv);  // d(s) leaves the chip (or waits for the second half)
         gcp_wave_lds_sync();  // dext is visible; the first partial-sum pass is done with xt
 
         // ---- F. adjoint of the vector prologue: d[vh | vf] = Wu^T dvu + (norm and frame-scalar terms), d(V) += Wdf^T d[vh | vf] ---

@@ -18,6 +18,7 @@
 #include "tile_io.h"
 #include "vec_mfma.h"
 #include "gcp_bf16x3.h"
+#include "gcp_f16x2.h"
 
 // GCP_CF_X: measurement builds whose RESULTS ARE WRONG (tools/cf_variants.sh): bits remove one cost each so that its share of the
 // launch time can be read under real contention.  1: scalar_out's fragments loaded once; 2: no s_pre store; 4: no s_out store;
@@ -332,10 +333,23 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
         for (int r = 0; r < 16; ++r) { gacc[r] = 0.f; gwa[r] = 0.f; }
         if constexpr (HEAD) load_bias();
         gcp_mask_acc_layout<NT>(so, 0, hi, true, vec_so && ((reinterpret_cast<uintptr_t>(it.b_scalar) & 15) == 0), bias);
+        // F6 with two fp16 terms (gcp_f16x2.h): the state row of this lane pair scaled by 2^pa into fp16's range, the accumulators by
+        // 2^(pa + GCP_F16_WEXP) while the state products are added (the bias enters scaled -- exact --, the inverse follows the stages)
+        float xsc = 1.f, acc_sc = 1.f, acc_isc = 1.f;
+        if constexpr (F6 && GCP_ARITH_F16X2) {
+            float m = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(xs[t][r]));
+            m = fmaxf(m, __shfl_xor(m, 32));  // (the other half of the row's columns)
+            const int pa = gcp_f16_row_exp(m);
+            xsc = gcp_exp2i(pa); acc_sc = gcp_exp2i(pa + GCP_F16_WEXP); acc_isc = gcp_exp2i(-(pa + GCP_F16_WEXP));
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = head ? acc[t][r] + bias[t][r] : bias[t][r];
+            for (int r = 0; r < 16; ++r) acc[t][r] = head ? acc[t][r] + bias[t][r] : bias[t][r] * acc_sc;
 #ifdef GCP_FWD_FINE
         if (ci == n_blocks - 1) gcp_stamp(p.stamps, p.stamp_cap, 3, lane);
 #endif
@@ -367,19 +381,19 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
             if constexpr (F6) {
                 // 2 NT slabs of K = 16 (eight state registers each, split once per slab) x NT output tiles; one stage = three
                 // 16-byte weight fragments per lane and six MFMAs, fragments requested three stages ahead
-                constexpr int NSTG = 2 * NT * NT;
+                constexpr int NSTG = 2 * NT * NT, NTM = GCP_W6_TERMS;
                 const float* wq = it.pack + S.offF6 + (int64_t)lane * 4;
-                gcp_u32x4 A0[3], A1[3], A2[3];
-                auto ld6 = [&](gcp_u32x4(&a)[3], int sg) {
-                    const float* q = wq + (int64_t)(sg < NSTG ? sg : NSTG - 1) * 768;
+                gcp_u32x4 A0[NTM], A1[NTM], A2[NTM];
+                auto ld6 = [&](gcp_u32x4(&a)[NTM], int sg) {
+                    const float* q = wq + (int64_t)(sg < NSTG ? sg : NSTG - 1) * (NTM * 256);
 #pragma unroll
-                    for (int tm = 0; tm < 3; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
+                    for (int tm = 0; tm < NTM; ++tm) a[tm] = *reinterpret_cast<const gcp_u32x4*>(q + tm * 256);
                 };
                 ld6(A0, 0);
                 ld6(A1, 1);
                 ld6(A2, 2);
                 __builtin_amdgcn_sched_barrier(0);
-                gcp_u32x4 bh, bm, bl;
+                [[maybe_unused]] gcp_u32x4 bh, bm, bl;
 #pragma unroll
                 for (int sg = 0; sg < NSTG; ++sg) {
                     const int j2 = sg / NT, t = sg % NT;
@@ -387,12 +401,28 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                         float x[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) x[i] = xs[j2 / 2][8 * (j2 % 2) + i];
+#if GCP_ARITH_F16X2
+                        gcp_f16x2_split8(x, xsc, bh, bl);
+#else
                         gcp_bf16x3_split8(x, bh, bm, bl);
+#endif
                     }
-                    gcp_u32x4(&a)[3] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
-                    if constexpr ((GCP_CF_X & 128) == 0) acc[t] = gcp_mfma_bf16x6(a, bh, bm, bl, acc[t]);
+                    gcp_u32x4(&a)[NTM] = (sg % 3 == 0) ? A0 : ((sg % 3 == 1) ? A1 : A2);
+                    if constexpr ((GCP_CF_X & 128) == 0) {
+#if GCP_ARITH_F16X2
+                        acc[t] = gcp_mfma_f16x3(a, bh, bl, acc[t]);
+#else
+                        acc[t] = gcp_mfma_bf16x6(a, bh, bm, bl, acc[t]);
+#endif
+                    }
                     if ((GCP_CF_X & 1) == 0 && sg + 3 < NSTG) ld6(a, sg + 3);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (GCP_ARITH_F16X2) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] *= acc_isc;
                 }
             } else if (!head) {
             WF<NT> A0[U], A1[U], A2[U];
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(GCP_WAVE, 2) void gcp2_chain_fwd_kernel(typename Ch
                 float x[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = gcp_actf<PWL>(it.act_v, ns_v, slope, acc[j2 / 2][8 * (j2 % 2) + i]);
-                gcp_u32x4 bh, bm, bl;
+                [[maybe_unused]] gcp_u32x4 bh, bm, bl;
                 gcp_bf16x3_split8(x, bh, bm, bl);
                 gacc = gcp_mfma_bf16x6(g, bh, bm, bl, gacc);
                 if (j2 + 2 < 2 * NT) {

@@ -21,6 +21,7 @@
 #include "tile_io.h"
 #include "vec_mfma.h"
 #include "gcp_bf16x3.h"
+#include "gcp_f16x2.h"
 
 int gcp2_chain_fwd_registers(int rows, const float* s0, const float* v0, const float* frames, int n,
                              const gcp2_chain_item_t* items, hipStream_t st);
@@ -598,7 +599,8 @@ __device__ __forceinline__ void pack_gcp2_element(const gcp2_weights_t& w, const
         int64_t x = i - (gate ? S.offC6 : S.offF6);
         const int d = x % 4; x /= 4;
         const int lane = x % 64; x /= 64;
-        const int term = x % 3; x /= 3;
+        const int nterm = gate ? 3 : GCP_W6_TERMS;  // (F6: two fp16 terms by default, gcp_f16x2.h; the gate image: three bf16 terms)
+        const int term = x % nterm; x /= nterm;
         const int t = gate ? 0 : (int)(x % S.NTG);
         const int j = (int)(gate ? x : x / S.NTG);
         const int orow = 32 * t + (lane & 31);  // output column of scalar_out / gate channel
@@ -609,14 +611,14 @@ __device__ __forceinline__ void pack_gcp2_element(const gcp2_weights_t& w, const
             float wv = 0.f;
             if (gate) { if (w.w_gate && orow < S.vo && k < S.so) wv = w.w_gate[(int64_t)orow * S.so + k]; }
             else if (orow < S.so && k < S.si) wv = w.w_scalar[(int64_t)orow * S.K + k];
-            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+            bits |= ((!gate && GCP_ARITH_F16X2) ? gcp_f16x2_wterm(wv, term) : gcp_bf16x3_term(wv, term)) << (16 * h2);
         }
         val = __uint_as_float(bits);
     } else if (i >= S.offB6) {  // B6: backward-data weights as three bf16 terms, [slab][tile of K][term][64][4 x 2 bf16] (gcp_bf16x3.h)
         int64_t x = i - S.offB6;
         const int d = x % 4; x /= 4;
         const int lane = x % 64; x /= 64;
-        const int term = x % 3; x /= 3;
+        const int term = x % GCP_W6_TERMS; x /= GCP_W6_TERMS;
         const int uu = x % S.NKT;
         const int j = (int)(x / S.NKT);
         const int kp = 32 * uu + (lane & 31);  // padded merged axis -> column of w_scalar: scalars, then (from tile NTS on) the rest
@@ -626,7 +628,7 @@ __device__ __forceinline__ void pack_gcp2_element(const gcp2_weights_t& w, const
             const int r = 8 * (j & 1) + 2 * d + h2;  // accumulator register of tile j / 2 that is element 2 d + h2 of the slab
             const int c = 32 * (j >> 1) + gcp_crow(r, lane >> 5);
             const float wv = (c < S.so && k < S.K) ? w.w_scalar[(int64_t)c * S.K + k] : 0.f;
-            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+            bits |= (GCP_ARITH_F16X2 ? gcp_f16x2_wterm(wv, term) : gcp_bf16x3_term(wv, term)) << (16 * h2);
         }
         val = __uint_as_float(bits);
     } else if (i >= S.offVA) {  // V: the small vector Linears as MFMA A fragments (vec_mfma.h), all [step][64]

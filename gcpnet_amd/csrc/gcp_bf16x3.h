@@ -53,6 +53,12 @@ __device__ __forceinline__ f32x16 gcp_mfma_bf16(gcp_u32x4 a, gcp_u32x4 b, f32x16
 
 // c += (ah + am + al) (bh + bm + bl), the six kept products, small terms first
 __device__ __forceinline__ f32x16 gcp_mfma_bf16x6(const gcp_u32x4 (&a)[3], gcp_u32x4 bh, gcp_u32x4 bm, gcp_u32x4 bl, f32x16 c) {
+#ifdef GCP_X3_PROBE  // (measurement build: three of the six products -- what halving the matrix work is worth to a launch; results imprecise)
+    c = gcp_mfma_bf16(a[1], bh, c);
+    c = gcp_mfma_bf16(a[0], bm, c);
+    c = gcp_mfma_bf16(a[0], bh, c);
+    return c;
+#endif
     c = gcp_mfma_bf16(a[2], bh, c);
     c = gcp_mfma_bf16(a[0], bl, c);
     c = gcp_mfma_bf16(a[1], bm, c);

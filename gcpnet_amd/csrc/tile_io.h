@@ -420,7 +420,7 @@ __device__ __forceinline__ void gcp_store_acc_rows_dense(float* __restrict__ dst
 // PAD: ld (a multiple of 4) may be less than 32 NT -- the 16-byte pieces past column ld are dropped (one lane test per piece).
 template <int NT, bool PAD = false>
 __device__ __forceinline__ void gcp_store_acc_rows_half_dense(float* __restrict__ dst, int ld, int r0, int rows, const f32x16 (&acc)[NT],
-                                                              float* stage, int lane) {
+                                                              float* stage, int lane, float scale = 1.f) {  // (scale: per lane = per row)
     const int e = lane & 31, hi = lane >> 5;
     const int sub = lane >> 2, c4 = 4 * (lane & 3);
     const bool full = r0 + 32 <= rows;  // wave-uniform
@@ -436,7 +436,8 @@ __device__ __forceinline__ void gcp_store_acc_rows_half_dense(float* __restrict_
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
                     *reinterpret_cast<float4*>(stage + e * 20 + 8 * q + 4 * hi) =
-                        make_float4(acc[t][8 * h + 4 * q], acc[t][8 * h + 4 * q + 1], acc[t][8 * h + 4 * q + 2], acc[t][8 * h + 4 * q + 3]);
+                        make_float4(acc[t][8 * h + 4 * q] * scale, acc[t][8 * h + 4 * q + 1] * scale, acc[t][8 * h + 4 * q + 2] * scale,
+                                    acc[t][8 * h + 4 * q + 3] * scale);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const float4 w0 = *reinterpret_cast<const float4*>(stage + sub * 20 + c4);
                 const float4 w1 = *reinterpret_cast<const float4*>(stage + (16 + sub) * 20 + c4);
