@@ -39,12 +39,12 @@ def test_host_only_entry_points():
     assert lib.gcpnet_debug_knobs_compiled() == 0  # the shipped build carries no result-changing measurement knob
     assert lib.gcpnet_tn_splits(0, 1, 1) == 2
     assert lib.gcpnet_tn_splits(160000, 0, 0) == 126 and lib.gcpnet_tn_splits(10000, 512, 145) == 106  # (by rows only: 96 rows per split)
-    # packed image of a chainable block: the fp32 sections + the three-term bf16 sections B6 / F6 / C6 (csrc/gcp_bf16x3.h):
-    # (128,16,H=4): NTG = 4, NKT = 5 -> 2*4*5*768 + 2*4*4*768 + 2*4*768 floats on top
+    # packed image of a chainable block: the fp32 sections + B6 / F6 as TWO fp16 terms (csrc/gcp_f16x2.h) + the gate image C6 as three
+    # bf16 terms (csrc/gcp_bf16x3.h): (128,16,H=4): NTG = 4, NKT = 5 -> 2*4*5*512 + 2*4*4*512 + 2*4*768 floats on top
     base = lambda si, vi, so, vo, H: lib.gcpnet_gcp2_pack_floats(si, vi, so, vo, H, 1)
     S = 128
     fp32_part = (1 * 72 * 64 * 4) + (2 * 64 * 64 * 4) + (1 * 64 * 64) + (8 * 1 * 64 * 4) + (4 * 16 * 64 * 4) + (8 + 4 + 8 + 4) * 64
-    assert base(S, 16, S, 16, 4) == fp32_part + (2 * 4 * 5 + 2 * 4 * 4 + 2 * 4) * 768
+    assert base(S, 16, S, 16, 4) == fp32_part + (2 * 4 * 5 + 2 * 4 * 4) * 512 + 2 * 4 * 768
     # which residual chains the register-resident forward kernel takes (ops asks before preferring it to the workgroup kernel)
     ok = lib.gcpnet_gcp2_chain_forward_registers_ok
     assert ok(128, 16, 128, 16, 4, 1) == 1 and ok(64, 16, 64, 16, 4, 1) == 1 and ok(100, 16, 100, 16, 4, 1) == 1
