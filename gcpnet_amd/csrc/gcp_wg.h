@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "gcp_bf16x3.h"
+#include "gcp_f16x2.h"
 
 // GCPNET_DEBUG_UNSUPPORTED=1: the host entry points of the workgroup kernels say on stderr WHY a launch was refused (the caller
 // then takes the wave-per-tile kernels: a routing question one otherwise answers by reading profiles)
@@ -70,9 +71,10 @@ __host__ __device__ inline WgShape wg_shape(int si, int vi, int so, int vo, int 
     s.offA2 = s.offG1 + (s.gated ? (int64_t)s.GM * 4 * s.NT * 256 : 0);
     s.offG2 = s.offA2 + (int64_t)s.NKT * 4 * s.NT * 256;
     s.offA2b = s.offG2 + (s.gated ? (int64_t)s.NT * s.VG * 256 : 0);
-    s.offA1b = s.offA2b + (int64_t)s.NKT * 2 * s.NT * 3 * 256;
+    // (GCP_W6_TERMS terms per element: two fp16 terms by default -- gcp_f16x2.h --, three bf16 terms with -DGCP_ARITH_F16X2=0)
+    s.offA1b = s.offA2b + (int64_t)s.NKT * 2 * s.NT * GCP_W6_TERMS * 256;
     s.NSLf = gcp_cdiv(s.KG, 2);
-    s.total = s.offA1b + (int64_t)s.NT * s.NSLf * 3 * 256;
+    s.total = s.offA1b + (int64_t)s.NT * s.NSLf * GCP_W6_TERMS * 256;
     return s;
 }
 

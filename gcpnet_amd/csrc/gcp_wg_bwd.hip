@@ -494,6 +494,11 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 DVU[prow * US + 3 * o + 0] = d0; DVU[prow * US + 3 * o + 1] = d1; DVU[prow * US + 3 * o + 2] = d2;
             }
         }
+#if GCP_ARITH_F16X2
+        // (two-term fp16 form of P4: the per-row maxima of ds_pre that P3 collects -- 32 words behind the operand planes, zeroed here:
+        // P4 of the tile before is behind a barrier, P3 of this one in front of the next)
+        if (B6 && tid < 32) reinterpret_cast<unsigned*>(DS)[2 * NT * (GCP_W6_TERMS * 256) + tid] = 0u;
+#endif
         wg_barrier();
         if constexpr (!FUSED) {
             if (gated && p.dgate) wg_tile_store<NTH>(p.dgate + (int64_t)r0 * VOP, DG, DGS, VOP, nvalid, tid, wg_aligned16(p.dgate), DM(mg_vop));
@@ -523,16 +528,17 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
 #else
         constexpr bool P4_PRE = B6;
 #endif
-        gcp_u32x4 pre0[3], pre1[3], pre2[3], pre3[3];
+        constexpr int NTM = GCP_W6_TERMS, SLAB = NTM * 64;  // terms per element of the operand planes / weight image; 16-byte entries per slab
+        gcp_u32x4 pre0[NTM], pre1[NTM], pre2[NTM], pre3[NTM];
         if constexpr (P4_PRE) {
             const int NFT0 = split ? NKT - 1 : NKT, NSL0 = 2 * NT;
-            const gcp_u32x4* q0 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)min(w, NFT0 - 1) * NSL0 * 192 + lane;
+            const gcp_u32x4* q0 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)min(w, NFT0 - 1) * NSL0 * SLAB + lane;
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
+            for (int tm = 0; tm < NTM; ++tm) {
                 pre0[tm] = q0[tm * 64];
-                pre1[tm] = q0[(int64_t)min(1, NSL0 - 1) * 192 + tm * 64];
-                pre2[tm] = q0[(int64_t)min(2, NSL0 - 1) * 192 + tm * 64];
-                pre3[tm] = q0[(int64_t)min(3, NSL0 - 1) * 192 + tm * 64];
+                pre1[tm] = q0[(int64_t)min(1, NSL0 - 1) * SLAB + tm * 64];
+                pre2[tm] = q0[(int64_t)min(2, NSL0 - 1) * SLAB + tm * 64];
+                pre3[tm] = q0[(int64_t)min(3, NSL0 - 1) * SLAB + tm * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -577,7 +583,23 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 }
             }
             if constexpr (B6) {  // the tile's two K = 16 slabs: eight registers each, split here, once for every wave's P4
-                gcp_u32x4* pl = reinterpret_cast<gcp_u32x4*>(DS) + (int64_t)(2 * ot) * 192 + lane;
+                gcp_u32x4* pl = reinterpret_cast<gcp_u32x4*>(DS) + (int64_t)(2 * ot) * SLAB + lane;
+#if GCP_ARITH_F16X2
+                // two fp16 terms (gcp_f16x2.h) need the ROW's largest |ds_pre| over all of so -- the other waves' tiles too: this tile's
+                // share goes to rmax[e] (LDS, behind the planes), the values wait as fp32 in the lane's own 64 bytes of the planes and
+                // are split behind the barrier that ends P3
+                float m = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(dsp[i]));
+                atomicMax(reinterpret_cast<unsigned*>(DS) + 2 * NT * (GCP_W6_TERMS * 256) + e, __float_as_uint(m));
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+                        const f32x4 v = {dsp[8 * jh + 4 * tm], dsp[8 * jh + 4 * tm + 1], dsp[8 * jh + 4 * tm + 2], dsp[8 * jh + 4 * tm + 3]};
+                        *reinterpret_cast<f32x4*>(pl + jh * SLAB + tm * 64) = v;
+                    }
+#else
 #pragma unroll
                 for (int jh = 0; jh < 2; ++jh) {
                     float x8[8];
@@ -587,6 +609,7 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                     gcp_bf16x3_split8(x8, th, tm, tl);
                     pl[jh * 192] = th; pl[jh * 192 + 64] = tm; pl[jh * 192 + 128] = tl;
                 }
+#endif
             }
             if (GCP_WG_X & 128) {
             } else if (p.ds_pre && (p.tb & 8)) {  // tile-blocked operand of gcpnet_tn_gemm: straight from the registers (zeros in the rows past the end)
@@ -661,6 +684,27 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
             }
         }
         wg_barrier();
+#if GCP_ARITH_F16X2
+        [[maybe_unused]] float p4_isc = 1.f;  // 2^-(pa + GCP_F16_WEXP) of this lane's row: what P4's sums are multiplied by
+        if constexpr (B6) {
+            const float rm = __uint_as_float(reinterpret_cast<const unsigned*>(DS)[2 * NT * (GCP_W6_TERMS * 256) + e]);
+            const int pa = gcp_f16_row_exp(rm);
+            const float sc = gcp_exp2i(pa);
+            p4_isc = gcp_exp2i(-(pa + GCP_F16_WEXP));
+            for (int t = t_lo; t < t_lo + tpp && w + NW * t < NT; ++t) {  // (the wave's own tiles, its lanes' own 64 bytes: no other reader yet)
+                gcp_u32x4* pl = reinterpret_cast<gcp_u32x4*>(DS) + (int64_t)(2 * (w + NW * t)) * SLAB + lane;
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(pl + jh * SLAB), v1 = *reinterpret_cast<const f32x4*>(pl + jh * SLAB + 64);
+                    const float x8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    gcp_u32x4 th, tl;
+                    gcp_f16x2_split8(x8, sc, th, tl);
+                    pl[jh * SLAB] = th; pl[jh * SLAB + 64] = tl;
+                }
+            }
+            wg_barrier();
+        }
+#endif
 
         stamp(4);
         WG_LAUNDER();
@@ -683,39 +727,55 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 }
                 if constexpr (B6) {
                     const int NSL = 2 * NT;  // slabs of the reduction over so
-                    const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)ktc[0] * NSL * 192 + lane;
+                    const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)ktc[0] * NSL * SLAB + lane;
                     const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(DS) + lane;
-                    auto lda = [&](gcp_u32x4(&a)[3], int sj) {
+                    auto lda = [&](gcp_u32x4(&a)[NTM], int sj) {
 #ifdef GCP_WG_EXP1  // (measurement build, wrong results: every slab's fragments from slabs 0 / 1 of tile 0 -- 6 KB, L1-resident)
-                        const gcp_u32x4* q = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + lane + (int64_t)(sj & 1) * 192;
+                        const gcp_u32x4* q = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + lane + (int64_t)(sj & 1) * SLAB;
 #else
-                        const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSL - 1) * 192;
+                        const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSL - 1) * SLAB;
 #endif
-                        a[0] = q[0]; a[1] = q[64]; a[2] = q[128];
+#pragma unroll
+                        for (int tm = 0; tm < NTM; ++tm) a[tm] = q[64 * tm];
                     };
-                    gcp_u32x4 a0[3], a1[3], a2[3], a3[3];
+                    gcp_u32x4 a0[NTM], a1[NTM], a2[NTM], a3[NTM];
                     if constexpr (P4_PRE) {
 #pragma unroll
-                        for (int tm = 0; tm < 3; ++tm) { a0[tm] = pre0[tm]; a1[tm] = pre1[tm]; a2[tm] = pre2[tm]; a3[tm] = pre3[tm]; }
+                        for (int tm = 0; tm < NTM; ++tm) { a0[tm] = pre0[tm]; a1[tm] = pre1[tm]; a2[tm] = pre2[tm]; a3[tm] = pre3[tm]; }
                     } else {
                         lda(a0, 0); lda(a1, 1); lda(a2, 2); lda(a3, 3);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     for (int sj = 0; sj < NSL; sj += 4) {  // (NSL = 2 NT; a trailing pair is guarded)
+#if GCP_ARITH_F16X2
 #define WG_B6_STEP(A, S)                                                                                       \
     if ((S) < NSL) {                                                                                           \
-        const gcp_u32x4* qb = pb6 + (int64_t)(S) * 192;                                                        \
+        const gcp_u32x4* qb = pb6 + (int64_t)(S) * SLAB;                                                       \
+        const gcp_u32x4 bh = qb[0], bl = qb[64];                                                               \
+        if constexpr ((GCP_WG_X & 256) == 0) acc2[0] = gcp_mfma_f16x3(A, bh, bl, acc2[0]);                     \
+        lda(A, (S) + 4);                                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define WG_B6_STEP(A, S)                                                                                       \
+    if ((S) < NSL) {                                                                                           \
+        const gcp_u32x4* qb = pb6 + (int64_t)(S) * SLAB;                                                       \
         const gcp_u32x4 bh = qb[0], bm = qb[64], bl = qb[128];                                                 \
         if constexpr ((GCP_WG_X & 256) == 0) acc2[0] = gcp_mfma_bf16x6(A, bh, bm, bl, acc2[0]);                \
         lda(A, (S) + 4);                                                                                       \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
+#endif
                         WG_B6_STEP(a0, sj)
                         WG_B6_STEP(a1, sj + 1)
                         WG_B6_STEP(a2, sj + 2)
                         WG_B6_STEP(a3, sj + 3)
 #undef WG_B6_STEP
                     }
+#if GCP_ARITH_F16X2
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[0][r] *= p4_isc;
+#endif
                 } else {
                 constexpr int U = KT == 1 ? 4 : 1;
                 const float* pa = p.pk + p.offA2 + (int64_t)lane * 4;
@@ -790,14 +850,23 @@ __global__ __launch_bounds__(64 * NW, (FN > 0 && FN <= 2 && NW == 4) ? 3 : 2) vo
                 const float* db = DS + e * DSS + 4 * hi;
                 if constexpr (B6) {
                     const int NSL = 2 * NT, ss = gcp_cdiv(NSL, NW), s_lo = w * ss, s_hi = min(NSL, s_lo + ss);
-                    const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)kt * NSL * 192 + lane;
+                    const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(p.pk + p.offA2b) + (int64_t)kt * NSL * SLAB + lane;
                     const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(DS) + lane;
                     for (int sj = s_lo; sj < s_hi; ++sj) {
-                        const gcp_u32x4* qa = pa6 + (int64_t)sj * 192;
-                        const gcp_u32x4* qb = pb6 + (int64_t)sj * 192;
+                        const gcp_u32x4* qa = pa6 + (int64_t)sj * SLAB;
+                        const gcp_u32x4* qb = pb6 + (int64_t)sj * SLAB;
+#if GCP_ARITH_F16X2
+                        const gcp_u32x4 a6[2] = {qa[0], qa[64]};
+                        acc3 = gcp_mfma_f16x3(a6, qb[0], qb[64], acc3);
+#else
                         const gcp_u32x4 a6[3] = {qa[0], qa[64], qa[128]};
                         acc3 = gcp_mfma_bf16x6(a6, qb[0], qb[64], qb[128], acc3);
+#endif
                     }
+#if GCP_ARITH_F16X2
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc3[r] *= p4_isc;
+#endif
                 } else
                 for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
                     f32x4 a[4], bb[4];

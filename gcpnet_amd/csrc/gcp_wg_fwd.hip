@@ -328,6 +328,11 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
                 X[r * KS + K + c] = 0.f;
             }
         }
+#if GCP_ARITH_F16X2
+        // (two-term fp16 form: the largest magnitude of every row of X, collected after B1 -- zeroed here, behind B3 of the block before,
+        // whose readers are done.  32 words behind the operand planes: the planes use two thirds of their 768 floats per slab)
+        if (B6 && tid < 32) reinterpret_cast<unsigned*>(lds + DM(o_xp))[gcp_cdiv(KG, 2) * (GCP_W6_TERMS * 256) + tid] = 0u;
+#endif
         stamp(1);
         wg_barrier();  // B1
         if constexpr (B6) {
@@ -335,6 +340,19 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
             // slab's planes (lane = 32 (group & 1) + row: consecutive threads write consecutive 16-byte pieces)
             const int NG2 = 2 * gcp_cdiv(KG, 2);
             gcp_u32x4* XP = reinterpret_cast<gcp_u32x4*>(lds + DM(o_xp));
+#if GCP_ARITH_F16X2
+            // gcp_f16x2.h: a power-of-two scale per ROW of X (constant along the summed columns), from the row's largest magnitude
+            unsigned* rmax = reinterpret_cast<unsigned*>(lds + DM(o_xp)) + gcp_cdiv(KG, 2) * (GCP_W6_TERMS * 256);
+            for (int u = tid; u < 32 * KG; u += NTH) {
+                const int r = u & 31, g = u >> 5;
+                const float* xr = X + r * KS + 8 * g;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi4 = *reinterpret_cast<const f32x4*>(xr + 4);
+                const float m = fmaxf(fmaxf(fmaxf(fabsf(lo[0]), fabsf(lo[1])), fmaxf(fabsf(lo[2]), fabsf(lo[3]))),
+                                      fmaxf(fmaxf(fabsf(hi4[0]), fabsf(hi4[1])), fmaxf(fabsf(hi4[2]), fabsf(hi4[3]))));
+                atomicMax(rmax + r, __float_as_uint(m));  // (non-negative floats order like their bit patterns)
+            }
+            wg_barrier();
+#endif
             for (int u = tid; u < 32 * NG2; u += NTH) {
                 const int r = u & 31, g = u >> 5;
                 const bool in = g < KG;
@@ -342,10 +360,16 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi4 = *reinterpret_cast<const f32x4*>(xr + 4);
                 const float x8[8] = {in ? lo[0] : 0.f, in ? lo[1] : 0.f, in ? lo[2] : 0.f, in ? lo[3] : 0.f,
                                      in ? hi4[0] : 0.f, in ? hi4[1] : 0.f, in ? hi4[2] : 0.f, in ? hi4[3] : 0.f};
+                gcp_u32x4* q = XP + (g >> 1) * (GCP_W6_TERMS * 64) + 32 * (g & 1) + r;
+#if GCP_ARITH_F16X2
+                gcp_u32x4 th, tl;
+                gcp_f16x2_split8(x8, gcp_exp2i(gcp_f16_row_exp(__uint_as_float(rmax[r]))), th, tl);
+                q[0] = th; q[64] = tl;
+#else
                 gcp_u32x4 th, tm, tl;
                 gcp_bf16x3_split8(x8, th, tm, tl);
-                gcp_u32x4* q = XP + (g >> 1) * 192 + 32 * (g & 1) + r;
                 q[0] = th; q[64] = tm; q[128] = tl;
+#endif
             }
             wg_barrier();
         }
@@ -383,13 +407,15 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
             int nb_;
             if constexpr (B6) {
                 const int NSLf = gcp_cdiv(KG, 2);
-                const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(B.pk + B.offA1b) + (int64_t)otc[0] * NSLf * 192 + lane;
+                constexpr int NTM = GCP_W6_TERMS, SLAB = NTM * 64;  // 16-byte entries per slab: [term][64 lanes]
+                const gcp_u32x4* pa6 = reinterpret_cast<const gcp_u32x4*>(B.pk + B.offA1b) + (int64_t)otc[0] * NSLf * SLAB + lane;
                 const gcp_u32x4* pb6 = reinterpret_cast<const gcp_u32x4*>(lds + DM(o_xp)) + lane;
-                auto lda = [&](gcp_u32x4(&a)[3], int sj) {
-                    const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSLf - 1) * 192;
-                    a[0] = q[0]; a[1] = q[64]; a[2] = q[128];
+                auto lda = [&](gcp_u32x4(&a)[NTM], int sj) {
+                    const gcp_u32x4* q = pa6 + (int64_t)min(sj, NSLf - 1) * SLAB;
+#pragma unroll
+                    for (int tm = 0; tm < NTM; ++tm) a[tm] = q[64 * tm];
                 };
-                gcp_u32x4 f0[3], f1[3], f2[3], f3[3];
+                gcp_u32x4 f0[NTM], f1[NTM], f2[NTM], f3[NTM];
                 lda(f0, 0); lda(f1, 1); lda(f2, 2); lda(f3, 3);
                 if (scalar_gate) {  // the gate Linear's four fragments for this wave's columns arrive under the reduction
                     const float* pkG = B.pk + B.offG1 + (int64_t)lane * 4;
@@ -399,20 +425,39 @@ __global__ __launch_bounds__(64 * NW, (G2 ? 1 : (NW == 4 ? 3 : 2))) void gcp_wg_
                 nb_ = 0;  // (the gate Linear below takes its fragments from a0)
                 __builtin_amdgcn_sched_barrier(0);
                 for (int sj = 0; sj < NSLf; sj += 4) {
+#if GCP_ARITH_F16X2
 #define WG_B6_STEP(A, S)                                                                                       \
     if ((S) < NSLf) {                                                                                          \
-        const gcp_u32x4* qb = pb6 + (int64_t)(S) * 192;                                                        \
+        const gcp_u32x4* qb = pb6 + (int64_t)(S) * SLAB;                                                       \
+        const gcp_u32x4 bh = qb[0], bl = qb[64];                                                               \
+        acc[0] = gcp_mfma_f16x3(A, bh, bl, acc[0]);                                                            \
+        lda(A, (S) + 4);                                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define WG_B6_STEP(A, S)                                                                                       \
+    if ((S) < NSLf) {                                                                                          \
+        const gcp_u32x4* qb = pb6 + (int64_t)(S) * SLAB;                                                       \
         const gcp_u32x4 bh = qb[0], bm = qb[64], bl = qb[128];                                                 \
         acc[0] = gcp_mfma_bf16x6(A, bh, bm, bl, acc[0]);                                                       \
         lda(A, (S) + 4);                                                                                       \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
+#endif
                     WG_B6_STEP(f0, sj)
                     WG_B6_STEP(f1, sj + 1)
                     WG_B6_STEP(f2, sj + 2)
                     WG_B6_STEP(f3, sj + 3)
 #undef WG_B6_STEP
                 }
+#if GCP_ARITH_F16X2
+                {   // back from 2^(pa + GCP_F16_WEXP): this lane's accumulators are all row e's
+                    const unsigned* rmax = reinterpret_cast<const unsigned*>(lds + DM(o_xp)) + NSLf * (GCP_W6_TERMS * 256);
+                    const float isc = gcp_exp2i(-(gcp_f16_row_exp(__uint_as_float(rmax[e])) + GCP_F16_WEXP));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][r] *= isc;
+                }
+#endif
             } else {
                 const float* pkA = B.pk + (int64_t)lane * 4;
                 const float* pkG = B.pk + B.offG1 + (int64_t)lane * 4;
@@ -743,19 +788,19 @@ __device__ __forceinline__ void wg_pack_element(const WgShape& S, const WgPackVi
         if (o < S.vo && c < S.so) v = Wg[(int64_t)o * S.so + c];
     } else if (idx >= S.offA1b) {
         int64_t blk = (idx - S.offA1b) >> 8;  // (ot, slab, term)
-        const int term = (int)(blk % 3); blk /= 3;
+        const int term = (int)(blk % GCP_W6_TERMS); blk /= GCP_W6_TERMS;
         const int ot = (int)(blk / S.NSLf), j = (int)(blk - (int64_t)ot * S.NSLf);
         const int r = 32 * ot + m;
         unsigned bits = 0;
         for (int h2 = 0; h2 < 2; ++h2) {
             const int c = 16 * j + 8 * hi + 2 * i + h2;
             const float wv = (r < S.so && c < S.K) ? wg_view_at(view, r, c) : 0.f;
-            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+            bits |= (GCP_ARITH_F16X2 ? gcp_f16x2_wterm(wv, term) : gcp_bf16x3_term(wv, term)) << (16 * h2);
         }
         v = __uint_as_float(bits);
     } else if (idx >= S.offA2b) {
         int64_t blk = (idx - S.offA2b) >> 8;  // (kt, slab, term)
-        const int term = (int)(blk % 3); blk /= 3;
+        const int term = (int)(blk % GCP_W6_TERMS); blk /= GCP_W6_TERMS;
         const int NSL = 2 * S.NT;
         const int kt = (int)(blk / NSL), j = (int)(blk - (int64_t)kt * NSL);
         const int c = 32 * kt + m;
@@ -764,7 +809,7 @@ __device__ __forceinline__ void wg_pack_element(const WgShape& S, const WgPackVi
             const int ip = 2 * i + h2;  // element of the lane's eight
             const int r = 32 * (j >> 1) + 16 * (j & 1) + 8 * (ip >> 2) + 4 * hi + (ip & 3);
             const float wv = (r < S.so && c < S.K) ? wg_view_at(view, r, c) : 0.f;
-            bits |= gcp_bf16x3_term(wv, term) << (16 * h2);
+            bits |= (GCP_ARITH_F16X2 ? gcp_f16x2_wterm(wv, term) : gcp_bf16x3_term(wv, term)) << (16 * h2);
         }
         v = __uint_as_float(bits);
     } else if (idx < S.offG2) {
