@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "gcp_bf16x3.h"
+#include "gcp_f16x2.h"
 
 namespace {
 
@@ -541,6 +542,33 @@ __global__ __launch_bounds__(256) void tn_gemm_dma_kernel(TnArgs a) {
 // row ONCE.  Row gathers and activations on load stay with the kernels above (stream_ok).
 constexpr int TS_RK = 16;
 
+// Arithmetic of the pipelined kernels: 1 (default, with GCP_ARITH_F16X2) = two fp16 terms per operand element and three MFMAs per
+// product block (gcp_f16x2.h) instead of three bf16 terms and six.  The summed index here is the ROW, so the power-of-two scale of an
+// operand must be constant down a column: every 32-column fragment carries a RUNNING exponent, owned by the wave that loads it --
+// set from the first non-zero chunk's largest magnitude (with GCP_TN_HEAD bits of headroom) and lowered when a later chunk would
+// overflow fp16 --, published with the chunk's planes; a wave whose accumulators were scaled with an older exponent multiplies them by
+// the (exact) power of two in between.  The partial sums leave multiplied by 2^-(ea + eb).  Elements far below their fragment's running
+// maximum lose relative precision exactly as in gcp_f16x2.h; the result stays within 3 * 2^-22 of sum |a b| + N 2^-38 max|a| max|b|.
+#ifndef GCP_TN_F16X2
+#define GCP_TN_F16X2 GCP_ARITH_F16X2
+#endif
+#define GCP_TN_HEAD 2
+constexpr int TP_UNSET = 1000;  // exponent of a fragment that has only seen zeros
+
+// largest value of the wave (v >= 0), wave-uniform
+__device__ __forceinline__ float tp_wave_max(float v) {
+#define TP_DPP_MAX(ctrl, rmask)                                                                                                   \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xf, false)))
+    TP_DPP_MAX(0x111, 0xf);  // row_shr:1
+    TP_DPP_MAX(0x112, 0xf);  // row_shr:2
+    TP_DPP_MAX(0x114, 0xf);  // row_shr:4
+    TP_DPP_MAX(0x118, 0xf);  // row_shr:8   -> lane 15 of every row of 16: the row's maximum
+    TP_DPP_MAX(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+    TP_DPP_MAX(0x143, 0xc);  // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's maximum
+#undef TP_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 struct TpLane {
     const float* base;  // column of this lane in row 0 of its segment (tile-blocked: its piece + element); a valid address for every kind
     int ld;             // floats per row; tile-blocked: padded width
@@ -567,18 +595,20 @@ __device__ __forceinline__ int64_t tp_row_offset(const TpLane& L, int64_t r) { r
 
 // NBUF: plane buffers.  2: passes and product groups of a chunk interleave, one barrier per chunk.  1: products, barrier, passes,
 // barrier -- half the LDS and fewer registers (no second set of B fragments): three workgroups per CU instead of two.
-template <int NW, int MT, int NT, int UT, int NBUF = 2>
+template <int NW, int MT, int NT, int UT, int NBUF = 2, bool F16 = GCP_TN_F16X2 && NW == 8>
 struct TpCfg {
     static constexpr int NTH = 64 * NW, AT = MT * NW, BM = 32 * AT, BN = 32 * NT;
-    static constexpr int PLANES = (AT + NT) * 3 * 256;  // floats per buffer: [fragment][term][64 lanes][4 dwords]
-    static constexpr int LDS_FLOATS = NBUF * PLANES;
+    static constexpr int PLANES = (AT + NT) * (F16 ? 2 : 3) * 256;  // floats per buffer: [fragment][term][64 lanes][4 dwords]
+    static constexpr int NFR = AT + NT;                            // fragments (32-column tiles of A, then of B) per chunk
+    // (two-term form: behind the planes, per buffer, the fragments' exponents of the chunk + the chunk index of the last change)
+    static constexpr int LDS_FLOATS = NBUF * PLANES + (F16 ? NBUF * (NFR + 1) : 0);
     static constexpr int APASS = MT, BPASS = (NT + NW - 1) / NW, NPASS = APASS + BPASS;  // fragment-lanes per thread and chunk
     static constexpr int NG = (NT + UT - 1) / UT;                                          // product groups per chunk
 };
 
-template <int NW, int MT, int NT, int UT, int NBUF = 2>
+template <int NW, int MT, int NT, int UT, int NBUF = 2, bool F16 = GCP_TN_F16X2 && NW == 8>
 __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn_pipe_kernel(TnArgs a) {
-    using C = TpCfg<NW, MT, NT, UT, NBUF>;
+    using C = TpCfg<NW, MT, NT, UT, NBUF, F16>;
     constexpr int AT = C::AT, BM = C::BM, BN = C::BN, NPASS = C::NPASS, APASS = C::APASS, NG = C::NG;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -606,6 +636,8 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
     const int my_n = __builtin_amdgcn_readfirstlane((mg < mgroups && g < ntiles) ? (ntiles - g + G - 1) / G : 0);
     gcp_u32x4* const planes = reinterpret_cast<gcp_u32x4*>(lds);
     constexpr int PL4 = C::PLANES / 4;  // 16-byte entries per buffer
+    constexpr int NTM = F16 ? 2 : 3;
+    [[maybe_unused]] int* const pexp = reinterpret_cast<int*>(lds + NBUF * C::PLANES);  // [buf][NFR + 1]: exponents, then the change mark
     if (a.stamps && tid == 0 && (long long)blockIdx.x < a.stamp_cap) {
         unsigned long long* sp = a.stamps + (long long)blockIdx.x * GCP_MAX_STAMPS;
         sp[0] = __builtin_amdgcn_s_memtime();
@@ -629,6 +661,9 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
         ptr[ps] = L[ps].base + tp_row_offset(L[ps], (int64_t)min(split, max(full_chunks - 1, 0)) * TS_RK + 8 * hi);
     }
     float x[NPASS][8];
+    [[maybe_unused]] int pe[NPASS];  // (two-term form) running exponent of the pass's fragment: wave-uniform
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) pe[ps] = TP_UNSET;
     int issued = 0;  // chunks requested so far (all passes of a chunk advance together; the pointer stops at the split's last chunk)
     auto load_pass = [&](int ps) {
         // (the LAST pass is real for one wave only when the B tiles do not divide by the waves -- the ninth / fifth tile: the others
@@ -646,7 +681,7 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
             for (int ps = 0; ps < NPASS; ++ps) ptr[ps] += (int64_t)(P.splits * TS_RK) * L[ps].ld;  // (tile-blocked: splits / 2 tiles of 32 ld floats)
         }
     };
-    auto split_pass = [&](int ps, int buf, int nvalid) {  // nvalid: valid rows of this lane's eight (8 inside the loop)
+    auto split_pass = [&](int ps, int buf, int nvalid, [[maybe_unused]] int chunk) {  // nvalid: valid rows of this lane's eight (8 inside the loop); chunk: index the planes belong to
         if (!on[ps]) return;  // (wave-uniform)
         const int kind = L[ps].kind & 3;
         if (__builtin_amdgcn_ballot_w64(kind != 0)) {  // (wave-uniform) a tile with the ones column or padding in it
@@ -657,11 +692,38 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
 #pragma unroll
             for (int q = 0; q < 8; ++q) x[ps][q] = q < nvalid ? x[ps][q] : 0.f;
         }
+        if constexpr (F16) {
+        float mx = fmaxf(fmaxf(fmaxf(fabsf(x[ps][0]), fabsf(x[ps][1])), fmaxf(fabsf(x[ps][2]), fabsf(x[ps][3]))),
+                         fmaxf(fmaxf(fabsf(x[ps][4]), fabsf(x[ps][5])), fmaxf(fabsf(x[ps][6]), fabsf(x[ps][7]))));
+        mx = tp_wave_max(mx);
+        const int eb_ = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        int* const ex = pexp + (buf & (NBUF - 1)) * (C::NFR + 1);
+        if (eb_ != 0) {  // (wave-uniform; zero / subnormal chunks leave the exponent alone)
+            const int pn = min(max(14 + 127 - eb_, -100), 100);  // brings the chunk's maximum into [2^14, 2^15)
+            if (pn < pe[ps]) {  // the first data of the fragment, or more than the running exponent can hold: lower it, with headroom
+                pe[ps] = pn - GCP_TN_HEAD;
+                if (lane == 0) ex[C::NFR] = chunk + 1;  // (several waves may write the same mark)
+            }
+        }
+        const int pe_eff = pe[ps] == TP_UNSET ? 0 : pe[ps];
+        if (lane == 0) ex[frag[ps]] = pe_eff;
+        gcp_u32x4 th, tl3;
+        gcp_f16x2_split8(x[ps], gcp_exp2i(pe_eff), th, tl3);
+        gcp_u32x4* dst = planes + (buf & (NBUF - 1)) * PL4 + (frag[ps] * NTM) * 64 + lane;
+        dst[0] = th; dst[64] = tl3;
+        } else {
         gcp_u32x4 th, tm, tl3;
         gcp_bf16x3_split8(x[ps], th, tm, tl3);
         gcp_u32x4* dst = planes + (buf & (NBUF - 1)) * PL4 + (frag[ps] * 3) * 64 + lane;
         dst[0] = th; dst[64] = tm; dst[128] = tl3;
+        }
     };
+    // (two-term form) exponents the wave's accumulators carry: ea for its MT tiles of A, eb for its tiles g, g + G, ... of B
+    [[maybe_unused]] int ea[MT], eb[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ea[m] = 0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) eb[i] = 0;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -671,39 +733,90 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // the six kept products, small terms first
-    auto read_b = [&](const gcp_u32x4* pl, int i0, gcp_u32x4 (&bt)[UT][3]) {
+    // the kept products, small terms first: three of two fp16 terms (lh, hl, hh: gcp_f16x2.h) or six of three bf16 terms
+    constexpr int NPR = F16 ? 3 : 6;
+    constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, TB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
+    auto read_b = [&](const gcp_u32x4* pl, int i0, gcp_u32x4 (&bt)[UT][NTM]) {
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
-            const gcp_u32x4* pb = pl + ((AT + min(g + G * min(i0 + u, NT - 1), ntiles - 1)) * 3) * 64 + lane;
-            bt[u][0] = pb[0]; bt[u][1] = pb[64]; bt[u][2] = pb[128];
+            const gcp_u32x4* pb = pl + ((AT + min(g + G * min(i0 + u, NT - 1), ntiles - 1)) * NTM) * 64 + lane;
+#pragma unroll
+            for (int tm = 0; tm < NTM; ++tm) bt[u][tm] = pb[64 * tm];
         }
     };
-    auto read_a = [&](const gcp_u32x4* pl, gcp_u32x4 (&a3)[MT][3]) {
+    auto read_a = [&](const gcp_u32x4* pl, gcp_u32x4 (&a3)[MT][NTM]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const gcp_u32x4* pa = pl + (min(mg * MT + m, mtiles - 1) * 3) * 64 + lane;
-            a3[m][0] = pa[0]; a3[m][1] = pa[64]; a3[m][2] = pa[128];
+            const gcp_u32x4* pa = pl + (min(mg * MT + m, mtiles - 1) * NTM) * 64 + lane;
+#pragma unroll
+            for (int tm = 0; tm < NTM; ++tm) a3[m][tm] = pa[64 * tm];
         }
     };
-    auto mul_group = [&](int k, const gcp_u32x4 (&a3)[MT][3], const gcp_u32x4 (&bt)[UT][3]) {
+    auto mfma_t = [&](gcp_u32x4 av, gcp_u32x4 bv, f32x16 c) -> f32x16 {
+        if constexpr (F16) {
+        return gcp_mfma_f16(av, bv, c);
+        } else {
+        return gcp_mfma_bf16(av, bv, c);
+        }
+    };
+    auto mul_group = [&](int k, const gcp_u32x4 (&a3)[MT][NTM], const gcp_u32x4 (&bt)[UT][NTM]) {
         if (k * UT < my_n) {  // (wave-uniform)
 #pragma unroll
-            for (int p = 0; p < 6; ++p)
+            for (int p = 0; p < NPR; ++p)
 #pragma unroll
                 for (int u = 0; u < UT; ++u)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        if (k * UT + u < NT) acc[m][k * UT + u] = gcp_mfma_bf16(a3[m][TA[p]], bt[u][TB[p]], acc[m][k * UT + u]);  // (tiles past my_n: computed on a valid fragment, never stored)
+                        if (k * UT + u < NT) acc[m][k * UT + u] = mfma_t(a3[m][TA[p]], bt[u][TB[p]], acc[m][k * UT + u]);  // (tiles past my_n: computed on a valid fragment, never stored)
+        }
+    };
+    // (two-term form) a chunk whose planes carry a change mark: the exponents of this wave's fragments again, and every accumulator
+    // tile scaled with an older one multiplied by the exact power of two in between
+    [[maybe_unused]] auto rescale = [&](int buf, int chunk) {
+        if constexpr (F16) {
+        const int* ex = pexp + (buf & (NBUF - 1)) * (C::NFR + 1);
+        if (__builtin_amdgcn_readfirstlane(ex[C::NFR]) != chunk + 1) return;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int na = __builtin_amdgcn_readfirstlane(ex[min(mg * MT + m, mtiles - 1)]);
+            if (na != ea[m]) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][i][r] = __builtin_ldexpf(acc[m][i][r], na - ea[m]);
+                ea[m] = na;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int nb = __builtin_amdgcn_readfirstlane(ex[AT + min(g + G * i, ntiles - 1)]);
+            if (nb != eb[i]) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][i][r] = __builtin_ldexpf(acc[m][i][r], nb - eb[i]);
+                eb[i] = nb;
+            }
+        }
         }
     };
 
     // One tile with ONE set of B fragment registers: the products are ordered so that a term's registers retire early (bl after the
     // first product, bm after the third) and take the next tile's term at once -- the LDS latency of the next tile's fragments is
     // spent under this tile's remaining MFMAs without a second register set (UT == 1; the sums still run small terms first)
-    auto mul_rot = [&](int k, const gcp_u32x4 (&a3)[MT][3], gcp_u32x4 (&bt)[3], const gcp_u32x4* pl, bool more) {
+    auto mul_rot = [&](int k, const gcp_u32x4 (&a3)[MT][NTM], gcp_u32x4 (&bt)[NTM], const gcp_u32x4* pl, bool more) {
         if (k < my_n) {  // (wave-uniform)
-            const gcp_u32x4* pn = pl + ((AT + min(g + G * min(k + 1, NT - 1), ntiles - 1)) * 3) * 64 + lane;
+            const gcp_u32x4* pn = pl + ((AT + min(g + G * min(k + 1, NT - 1), ntiles - 1)) * NTM) * 64 + lane;
+            if constexpr (F16) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_f16(a3[m][0], bt[1], acc[m][k]);
+            if (more) { bt[1] = pn[64]; __builtin_amdgcn_sched_barrier(0); }  // (pinned, as below)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_f16(a3[m][1], bt[0], acc[m][k]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_f16(a3[m][0], bt[0], acc[m][k]);
+            if (more) bt[0] = pn[0];
+            } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][0], bt[2], acc[m][k]);
             if (more) { bt[2] = pn[128]; __builtin_amdgcn_sched_barrier(0); }  // (pinned: hipcc otherwise sinks the request behind the tile's last product)
@@ -719,17 +832,22 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][k] = gcp_mfma_bf16(a3[m][0], bt[0], acc[m][k]);
             if (more) bt[0] = pn[0];
+            }
         }
     };
 
     // prologue: chunk 0 requested, split into planes[0]; chunk 1 requested
+    if constexpr (F16) {
+    if (tid < NBUF) pexp[tid * (C::NFR + 1) + C::NFR] = 0;  // no change mark yet
+    __syncthreads();
+    }
     if (nchunks > 0) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) load_pass(ps);
         advance();
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            split_pass(ps, 0, 8);
+            split_pass(ps, 0, 8, 0);
             load_pass(ps);
         }
         advance();
@@ -739,7 +857,8 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
     for (int c = 0; c < nchunks; ++c) {
         const gcp_u32x4* pl = planes + (c & (NBUF - 1)) * PL4;
         constexpr bool DBUF = NBUF == 2 && NT * MT <= 5;  // two sets of B fragments only where the registers are there (the wide form holds 144 accumulators)
-        gcp_u32x4 a3[MT][3], bt[DBUF ? 2 : 1][UT][3];
+        gcp_u32x4 a3[MT][NTM], bt[DBUF ? 2 : 1][UT][NTM];
+        rescale(c, c);
         read_a(pl, a3);
         read_b(pl, 0, bt[0]);
 #pragma unroll
@@ -749,7 +868,7 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
                 for (int ps = 0; ps < NPASS; ++ps) {  // passes whose turn it is: pass ps runs ahead of product group (ps NG) / NPASS
                     if ((ps * NG) / NPASS == k) {
                         TN_T_MARK(3);
-                        if (c + 1 < nchunks) split_pass(ps, (c + 1) & 1, 8);
+                        if (c + 1 < nchunks) split_pass(ps, (c + 1) & 1, 8, c + 1);
                         TN_T_MARK(0);
                         load_pass(ps);  // chunk c + 2 (unconditional -- past the end: the split's last chunk once more, dropped)
                         if (ps == NPASS - 1) advance();
@@ -772,7 +891,7 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
-                if (c + 1 < nchunks) split_pass(ps, 0, 8);
+                if (c + 1 < nchunks) split_pass(ps, 0, 8, c + 1);
                 load_pass(ps);
             }
             advance();
@@ -787,10 +906,11 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
         for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) x[ps][q] = L[ps].base[tp_row_offset(L[ps], min(r0 + q, r_last))];
-            split_pass(ps, 0, P.rows - r0);
+            split_pass(ps, 0, P.rows - r0, nchunks);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        gcp_u32x4 a3[MT][3], bt[UT][3];
+        gcp_u32x4 a3[MT][NTM], bt[UT][NTM];
+        rescale(0, nchunks);
         read_a(planes, a3);
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
@@ -810,7 +930,11 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int mm = m0 + 32 * (mg * MT + m) + gcp_crow(r, hi);
+                            if constexpr (F16) {
+                            if (mm < M && n < N) part[(int64_t)mm * N + n] = __builtin_ldexpf(acc[m][i][r], -(ea[m] + eb[i]));
+                            } else {
                             if (mm < M && n < N) part[(int64_t)mm * N + n] = acc[m][i][r];
+                            }
                         }
                     }
                 }
