@@ -26,7 +26,9 @@ cpu_baseline = the oracle (pure PyTorch on the host cores) on the same stack, we
 other_configs = (default run, one GPU) the model-step configurations c1 / c4 / c3, eager and as a hipGraph replay: median ms/step
             and edges/s each; c5_single_gpu = 10 steps at configs[4] size.  Every BASELINE configuration that fits one GPU is thus in
             the one JSON line.  aggregate_product_path = the aggregation as the product launches it (two reductions).
-roofline.peak_bf16x6_equiv = the ceiling of the bf16 matrix pipe for fp32 products computed as six bf16 MFMAs (2 500 / 6 TFLOP/s).
+roofline.peak_f16x3_equiv = the ceiling of the 16-bit matrix pipe for fp32 products computed as three fp16 MFMAs (2 500 / 3 TFLOP/s: the
+            arithmetic of the big products since round 6, csrc/gcp_f16x2.h); peak_bf16x6_equiv = the same for the six-product bf16 form
+            of rounds 3 - 5 (2 500 / 6), kept for comparison with the earlier lines.
 --dry-run-world N = no timing: the N-rank bookkeeping of `--shard graph` on one GPU (nodes / edges / halo per rank, MB per layer).
 """
 import argparse
@@ -47,6 +49,8 @@ PEAK_HBM_GBS = 8000.0
 # peak (2 500 TFLOP/s) / 6 is the ceiling of THAT pipe in fp32-equivalent FLOPs -- reported next to the fp32 MFMA peak, which stays
 # `roofline.peak` (the kernels mix both forms)
 PEAK_BF16X6_EQUIV_TFLOPS = 2500.0 / 6.0
+# round 6: two fp16 terms per operand, three MFMAs per product block (csrc/gcp_f16x2.h) -- the pipe's ceiling for that form
+PEAK_F16X3_EQUIV_TFLOPS = 2500.0 / 3.0
 
 
 def parse():
@@ -700,7 +704,8 @@ def c5_kernel_roofline(G, ops, rows, sdim, vdim, iters=10):
     return {"kernel": f"gcp_wg_bwd_kernel: backward (data path) of one residual message GCP ({sdim},{vdim})->({sdim},{vdim}) on {rows} rows, "
                       "28 launches per 4-layer configs[4] step",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-            "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "median_launch_ms": t * 1e3,
+            "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "frac_of_f16x3_equiv": achieved / PEAK_F16X3_EQUIV_TFLOPS,
+            "median_launch_ms": t * 1e3,
             "layout": "tile-blocked s_pre / state gradient / ds_pre, as inside the chain" if tb else "row-major",
             "row_major_launch_ms": t_rows, "flop_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes, "algorithmic_hbm_gbs": nbytes / t / 1e9,
@@ -839,14 +844,17 @@ def main():
                 "kernel": f"{dom} on the {kr['n_blocks']}-block residual message chain (s,V)->(s,V) of one layer, E rows",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "peak_bf16x6_equiv": PEAK_BF16X6_EQUIV_TFLOPS,
-                "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS, "traffic": pmc_traffic(dom),
+                "frac_of_bf16x6_equiv": achieved / PEAK_BF16X6_EQUIV_TFLOPS,
+                "peak_f16x3_equiv": PEAK_F16X3_EQUIV_TFLOPS, "frac_of_f16x3_equiv": achieved / PEAK_F16X3_EQUIV_TFLOPS,
+                "traffic": pmc_traffic(dom),
                 "traffic_source": PMC_FILE if pmc_traffic(dom) is not None else None,
                 "traffic_note": (_pmc_file().get(dom + "_parts") or {}).get("note"),
-                "arithmetic": ("fp32 results; the large products of the chain kernels (W^T ds_pre backward, scalar_out and the gate Linear "
-                               "forward; at (256,32) scalar_out / W^T ds_pre of the workgroup kernels) run on the bf16 matrix pipe with both "
-                               "operands split into three bf16 terms and six products kept, fp32 accumulation (error <= 3*2^-24 of "
-                               "sum|a b|: csrc/gcp_bf16x3.h, tests/test_bf16x3.py); every other product is v_mfma_f32_32x32x2_f32. "
-                               "`peak` stays the fp32 MFMA peak"),
+                "arithmetic": ("fp32 results; the large products of the chain kernels (scalar_out forward, W^T ds_pre backward; at (256,32) the "
+                               "same two in the workgroup kernels and the 256 x 288 weight-gradient GEMM) run on the fp16 matrix pipe with both "
+                               "operands split into two fp16 terms under exact power-of-two scales and three products kept, fp32 "
+                               "accumulation (error <= 3*2^-22 of sum|a b|: csrc/gcp_f16x2.h, tests/test_f16x2.py, tests/test_bf16x3.py); "
+                               "the gate Linear and the 128 x 160 GEMM form keep three bf16 terms / six products (3*2^-24: csrc/gcp_bf16x3.h); "
+                               "every other product is v_mfma_f32_32x32x2_f32.  `peak` stays the fp32 MFMA peak"),
                 "mfma_busy_frac_pmc": pmc_mfma_busy(dom),
                 "median_launch_ms": times[dom] * 1e3, "flop_per_launch": kr["flops"][dom],
                 "algorithmic_hbm_gbs": kbytes[dom] / times[dom] / 1e9,
