@@ -122,6 +122,18 @@ class GCP2(nn.Module):
         return VMODE_SELF_GATE if self.act_v is not None else VMODE_NONE
 
     def _weights(self):
+        # (straight from the registries: nn.Module.__getattr__ costs ~0.3 us per hop and this runs for every block of every step --
+        # 40 calls x 12 lookups per configs[1] step, which is host-bound)
+        mods = self._modules
+        so = mods["scalar_out"]._parameters
+        if "weight" in so:
+            def w(name):
+                m = mods.get(name)
+                return None if m is None else m._parameters.get("weight")
+            gate = mods.get("vector_out_scale")
+            gp = None if gate is None else gate._parameters
+            return (so["weight"], so.get("bias"), w("vector_down"), w("vector_down_frames"), w("vector_up"),
+                    None if gp is None else gp.get("weight"), None if gp is None else gp.get("bias"))
         g = lambda name: getattr(self, name).weight if hasattr(self, name) else None
         gate = getattr(self, "vector_out_scale", None)
         return (self.scalar_out.weight, self.scalar_out.bias, g("vector_down"), g("vector_down_frames"), g("vector_up"),
