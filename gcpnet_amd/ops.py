@@ -1244,7 +1244,10 @@ class _UseCell:
 # id(weight) -> its cell, held WEAKLY: the autograd contexts that counted a use own the cell, so it lives exactly as long as a graph
 # that uses the weight does and nothing ever has to clear the table (a clear that landed between two uses of one weight in one graph
 # -- an auxiliary backward in the middle of a forward -- made both Functions see a count of 1: ADVICE round 3)
-_weight_uses = weakref.WeakValueDictionary()
+# (a plain dict of weakref.ref objects without callbacks: WeakValueDictionary's Python-level __setitem__ / removal callback cost 0.5 ms
+# of a host-bound configs[1] step for 280 weights; dead references are simply overwritten -- the table is bounded by the number of
+# distinct weight addresses, and `cell.t is t` rejects a recycled id)
+_weight_uses: dict = {}
 
 
 def _note_uses(weights) -> list:
@@ -1259,10 +1262,11 @@ def _note_uses(weights) -> list:
     for t in weights:
         if t is None:
             continue
-        cell = _weight_uses.get(id(t))
+        r = _weight_uses.get(id(t))
+        cell = r() if r is not None else None
         if cell is None or cell.t is not t:
             cell = _UseCell(t)
-            _weight_uses[id(t)] = cell
+            _weight_uses[id(t)] = weakref.ref(cell)
         cell.n += 1
         cells.append(cell)
     return cells

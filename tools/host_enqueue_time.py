@@ -20,6 +20,10 @@ wl = (bench.build_layer_workload if cfg in ("c2", "c5") else bench.build_model_w
 for _ in range(5):
     wl["step"]()
 torch.cuda.synchronize()
+if os.environ.get("HOST_GC_OFF"):  # (as bench.py times its steps: one collection before, none inside)
+    import gc
+    gc.collect()
+    gc.disable()
 stamps = []
 t0 = time.perf_counter()
 for _ in range(steps):
