@@ -544,15 +544,17 @@ constexpr int TS_RK = 16;
 
 // Arithmetic of the pipelined kernels: 1 (default, with GCP_ARITH_F16X2) = two fp16 terms per operand element and three MFMAs per
 // product block (gcp_f16x2.h) instead of three bf16 terms and six.  The summed index here is the ROW, so the power-of-two scale of an
-// operand must be constant down a column: every 32-column fragment carries a RUNNING exponent, owned by the wave that loads it --
-// set from the first non-zero chunk's largest magnitude (with GCP_TN_HEAD bits of headroom) and lowered when a later chunk would
-// overflow fp16 --, published with the chunk's planes; a wave whose accumulators were scaled with an older exponent multiplies them by
-// the (exact) power of two in between.  The partial sums leave multiplied by 2^-(ea + eb).  Elements far below their fragment's running
-// maximum lose relative precision exactly as in gcp_f16x2.h; the result stays within 3 * 2^-22 of sum |a b| + N 2^-38 max|a| max|b|.
+// operand must be constant down a column WHILE products are added with it: every 32-column fragment carries a CURRENT exponent, owned
+// by the wave that loads it -- set from the first non-zero chunk's largest magnitude (with GCP_TN_HEAD bits of headroom), lowered when a
+// later chunk would overflow fp16, raised again when the data falls more than 2^GCP_TN_WINDOW below it --, published with the chunk's
+// planes; a wave whose accumulators were scaled with another exponent multiplies them by the (exact) power of two in between, in
+// either direction.  The partial sums leave multiplied by 2^-(ea + eb).  Elements far below the maximum of their 16-row x 32-column
+// chunk lose relative precision exactly as in gcp_f16x2.h; the result stays within 3 * 2^-22 of sum |a b| + 2^-38 x (chunk maxima).
 #ifndef GCP_TN_F16X2
 #define GCP_TN_F16X2 GCP_ARITH_F16X2
 #endif
 #define GCP_TN_HEAD 2
+#define GCP_TN_WINDOW 8
 constexpr int TP_UNSET = 1000;  // exponent of a fragment that has only seen zeros
 
 // largest value of the wave (v >= 0), wave-uniform
@@ -700,7 +702,10 @@ __global__ __launch_bounds__(64 * NW, NW == 5 ? 2 : (NBUF == 1 ? 3 : 2)) void tn
         int* const ex = pexp + (buf & (NBUF - 1)) * (C::NFR + 1);
         if (eb_ != 0) {  // (wave-uniform; zero / subnormal chunks leave the exponent alone)
             const int pn = min(max(14 + 127 - eb_, -100), 100);  // brings the chunk's maximum into [2^14, 2^15)
-            if (pn < pe[ps]) {  // the first data of the fragment, or more than the running exponent can hold: lower it, with headroom
+            // the first data of the fragment, or more than the current exponent can hold (lower it, with headroom), or a chunk more than
+            // 2^GCP_TN_WINDOW below what it was chosen for (raise it again: a spike in one row must not cost the rows behind it their
+            // second term) -- either way the consumers rescale their accumulator tiles by an exact power of two
+            if (pn < pe[ps] || pn > pe[ps] + GCP_TN_HEAD + GCP_TN_WINDOW) {
                 pe[ps] = pn - GCP_TN_HEAD;
                 if (lane == 0) ex[C::NFR] = chunk + 1;  // (several waves may write the same mark)
             }
@@ -1169,6 +1174,13 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
         narrow.block_start[narrow.n] = nblocks; wide.block_start[wide.n] = wblocks; rest.block_start[rest.n] = rblocks_;
         mid.block_start[mid.n] = mblocks;
         constexpr size_t n_lds = (size_t)Narrow::LDS_FLOATS * sizeof(float), w_lds = (size_t)Wide::LDS_FLOATS * sizeof(float);
+        // GCPNET_TN_F16=0 (read per call): the 256 x 288 form with three bf16 terms and six products again -- for data whose magnitudes
+        // span more than ~2^15 INSIDE a 32-column fragment over a row split, where the shared running exponent of the two-term form costs
+        // the small columns bits (tests/test_tn_gemm.py, `spikes`)
+        using Wide6 = TpCfg<8, 1, 9, 1, 2, false>;
+        constexpr size_t w6_lds = (size_t)Wide6::LDS_FLOATS * sizeof(float);
+        const char* f16_env = getenv("GCPNET_TN_F16");
+        const bool wide_f16 = GCP_TN_F16X2 && !(f16_env && f16_env[0] == '0');
         // (the attribute is per device: one flag per device ordinal, written once under a mutex)
         static std::mutex tp_mu;
         static bool tp_configured_dev[64] = {};
@@ -1180,11 +1192,14 @@ extern "C" int gcpnet_tn_gemm(int n_problems, const gcp_tn_problem_t* problems, 
             hipError_t err = hipFuncSetAttribute((const void*)tn_pipe_kernel<4, 1, 5, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_lds);
             if (err == hipSuccess)
                 err = hipFuncSetAttribute((const void*)tn_pipe_kernel<8, 1, 9, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_lds);
+            if (err == hipSuccess && GCP_TN_F16X2)
+                err = hipFuncSetAttribute((const void*)tn_pipe_kernel<8, 1, 9, 1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w6_lds);
             if (err != hipSuccess) return (int)err;
             tp_configured = true;
         }
         if (wide.n) {
-            hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1>), dim3(wblocks), dim3(Wide::NTH), w_lds, st, wide);
+            if (wide_f16 || !GCP_TN_F16X2) hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1>), dim3(wblocks), dim3(Wide::NTH), w_lds, st, wide);
+            else hipLaunchKernelGGL((tn_pipe_kernel<8, 1, 9, 1, 2, false>), dim3(wblocks), dim3(Wide::NTH), w6_lds, st, wide);
             GCP_HIP_CHECK_LAUNCH();
         }
         if (mid.n) {  // (30 KB of LDS: below the default limit, no attribute)

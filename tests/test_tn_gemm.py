@@ -193,3 +193,52 @@ def test_tn_two_gradients_from_one_product(rows, so, vo, mid, monkeypatch):
     bad = TnProblem.from_buffer_copy(pr)
     bad.out_b = None
     assert lib.gcpnet_tn_gemm(1, C.byref(bad), None) != 0, "m_split without a second destination is refused"
+
+
+@pytest.mark.parametrize("pattern", ["growing", "shrinking", "zeros-first", "spikes-2^12", "spikes-2^25", "spikes-2^25-bf16"])
+def test_wide_form_running_exponents_follow_the_data(pattern, monkeypatch):
+    """The 256 x 288 form multiplies two-term fp16 operands under a RUNNING power-of-two exponent per 32-column fragment (tn_gemm.hip,
+    GCP_TN_F16X2): set by the first non-zero 16-row chunk, lowered -- with the accumulator tiles rescaled -- when a later chunk would
+    overflow.  Row magnitudes that grow by 2^60 over the rows (a rescale every few chunks), shrink by as much (the exponent stays: small
+    rows lose relative precision only), start with all-zero chunks (unset -> set), or spike in single rows of single columns: each
+    against float64, error relative to sum |a b| per output (the bound of gcp_f16x2.h; 2e-6 leaves room for the fp32 accumulation of
+    40 000 rows).  The limit of a shared exponent, stated and held here: a spike of 2^25 in ONE element costs the other elements of its
+    16-row x 32-column chunk their low bits (the exponent comes back up behind it) -- invisible in a sum over 40 000 rows UNLESS the
+    same row also carries a spike in the other operand, which multiplies exactly those coarsened elements: the `spikes-2^25` case puts
+    both spikes in the same rows and the affected outputs keep ~8 bits (bound 2^-7 of sum |a b|); spikes of 2^12 stay at round-off.
+    GCPNET_TN_F16=0 selects the six-product bf16 form, which has fp32's exponent range and no such coupling at all."""
+    from gcpnet_amd import ops
+
+    rows, M, N = 40000, 256, 284
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(rows, M, generator=g)
+    b = torch.randn(rows, N, generator=g)
+    t = torch.linspace(0, 1, rows)[:, None]
+    bound = 2e-6
+    if pattern == "growing":
+        a = a * torch.exp2(60 * t - 30)
+        b = b * torch.exp2(40 * t - 20)
+    elif pattern == "shrinking":
+        a = a * torch.exp2(30 - 60 * t)
+        b = b * torch.exp2(-20 * t)
+    elif pattern == "zeros-first":
+        a[:4096] = 0
+        b[:1000] = 0
+        a[:, 40:72] = 0          # a fragment that never sees data
+    else:
+        k = 12 if "2^12" in pattern else 25
+        idx = torch.randint(0, rows, (200,), generator=g)
+        a[idx, torch.randint(0, M, (200,), generator=g)] *= 2.0 ** k
+        b[idx, torch.randint(0, N, (200,), generator=g)] *= 2.0 ** (k - 7)
+        if pattern.endswith("bf16"):
+            monkeypatch.setenv("GCPNET_TN_F16", "0")
+        elif k == 25:
+            bound = 2.0 ** -7
+    want = a.double().t() @ b.double()
+    scale = a.double().abs().t() @ b.double().abs()
+    got = ops._tn_weight_grad(a.cuda(), b.cuda()).cpu().double()
+    assert torch.isfinite(got).all()
+    ok = scale > 0
+    err = ((got - want).abs()[ok] / scale[ok]).max().item()
+    assert err <= bound, f"{pattern}: {err:.3e} of sum |a b|"
+    assert torch.equal(got[~ok], torch.zeros_like(got[~ok]))
