@@ -437,6 +437,23 @@ def invalidate_packs() -> None:
     _PACK_EPOCH += 1
 
 
+F16_WEIGHT_LIMIT = 65504.0 / 64.0  # |w| above this saturates in the two-term fp16 weight images (csrc/gcp_f16x2.h: 2^6 w must fit fp16)
+
+
+def check_weight_range(module: torch.nn.Module) -> float:
+    """The largest |w| over the `scalar_out` weights of a model's GCP blocks; raises GcpnetHipError if one is outside what the
+    two-term fp16 images hold (|w| < 1023.5: the pack kernels SATURATE beyond it -- finite, but wrong -- because they cannot report).
+    Not on any hot path (one reduction and one host read per call): for a trainer's sanity hooks, after loading a checkpoint."""
+    worst = 0.0
+    for name, p in module.named_parameters():
+        if name.endswith("scalar_out.weight") or ".scalar_out." in name and name.endswith(".weight"):
+            worst = max(worst, float(p.detach().abs().max()))
+    if not worst < F16_WEIGHT_LIMIT:  # (also catches NaN)
+        raise _lib.GcpnetHipError(f"scalar_out weight magnitude {worst:.4g} is outside the two-term fp16 weight images' range "
+                                  f"(< {F16_WEIGHT_LIMIT:.1f}); build with -DGCP_ARITH_F16X2=0 for the bf16 form")
+    return worst
+
+
 def _pack(spec: Gcp2Spec, w) -> Tensor:
     lib = _lib.load()
     w = _dense_weights(spec, w)

@@ -154,3 +154,17 @@ def test_row_scales_follow_rows_of_very_different_magnitude(dims):
         e16 = (f16[k] - ref[k]).abs().amax(1) / row_scale
         worst = (e16 - 16 * e32).max().item()
         assert worst <= 1e-5, f"{k}: a row is {worst:.3e} (of its own scale) further from float64 than 16 x the fp32-MFMA form's distance"
+
+
+def test_check_weight_range_reports_weights_the_fp16_images_cannot_hold():
+    import torch
+
+    import gcpnet_amd as G
+    from gcpnet_amd import _lib
+
+    m = G.GCP2((16, 4), (16, 4), nonlinearities=("relu", None), bottleneck=4)
+    assert 0 < G.check_weight_range(m) < 10
+    with torch.no_grad():
+        m.scalar_out.weight[0, 0] = 2000.0
+    with pytest.raises(_lib.GcpnetHipError):
+        G.check_weight_range(m)
